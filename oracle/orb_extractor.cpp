@@ -102,7 +102,12 @@ float ic_angle(const Image8& image, float ptx, float pty, const std::vector<int>
 void orb_descriptor(const KeyPoint& kpt, const Image8& img, const int8_t* pat, uint8_t* desc) {
     const float factorPI = (float)(M_PI / 180.f);
     float angle = (float)kpt.angle * factorPI;
-    float a = (float)std::cos(angle), b = (float)std::sin(angle);      // float overloads = cosf/sinf
+    // Reference: (float)cos(angle), (float)sin(angle) on a float = libm cosf/sinf. glibc's cosf/sinf
+    // are NOT correctly rounded (they differ from the nearest float for 0.04% / 0.1% of the floats in
+    // [0, 2pi], measured exhaustively), so the reference's own result depends on its libm build.
+    // Deliberate deviation (SURVEY.md §7 hard part 2): a and b are the correctly rounded values,
+    // obtained as double cos/sin rounded once to float.
+    float a = (float)std::cos((double)angle), b = (float)std::sin((double)angle);
     const uint8_t* center = img.row(cvRound(kpt.y)) + cvRound(kpt.x);
     const int step = img.w;
     for (int i = 0; i < 32; ++i) {

@@ -1,0 +1,141 @@
+"""-m gpu parity tests of the HIP extractor against the CPU oracle, stage by stage and end to end,
+all through the C ABI (include/viorb.h). Bit-exact: this is integer/byte/index work plus float ops
+that are individually rounded the same way on both sides."""
+import os
+import numpy as np
+import pytest
+import viorb_amd
+from viorb_amd.synth import make_image, warp_image
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+CASES = {                      # name: (seed, w, h, nfeatures)
+    "euroc0": (0, 752, 480, 1000),
+    "euroc1": (1, 752, 480, 1000),
+    "kitti": (100, 1241, 376, 2000),
+    "synth720p": (1000, 1280, 720, 1500),
+    "small": (5, 160, 120, 300),
+    "odd": (9, 333, 257, 400),
+}
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    if viorb_amd.lib().viorb_device_count() < 1:
+        pytest.fail("no HIP device visible: -m gpu tests need the MI355X (and never fall back)")
+    return True
+
+
+def run_pair(oracle, seed, w, h, nf, **kw):
+    img = make_image(seed, w, h)
+    ex = viorb_amd.ORBextractor(nf, 1.2, 8, 20, 7)
+    kps, desc = ex(img)
+    ox = oracle.Extractor(nf, 1.2, 8, 20, 7)
+    okps, odesc = ox(img)
+    return img, ex, kps, desc, ox, okps, odesc
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_stage_parity(gpu, oracle, name):
+    seed, w, h, nf = CASES[name]
+    img, ex, kps, desc, ox, okps, odesc = run_pair(oracle, seed, w, h, nf)
+    # a2 pyramid
+    for l in range(8):
+        np.testing.assert_array_equal(ex.level(l), ox.level(l), err_msg="pyramid level %d" % l)
+    # a3 FAST candidates, order included
+    for l in range(8):
+        oc = ox.level_keypoints(l, candidates=True)
+        gc = ex.debug_level_points(l, kept=False)
+        want = np.stack([oc["x"], oc["y"], oc["response"]], 1).astype(np.int32).reshape(-1, 3)
+        np.testing.assert_array_equal(gc, want, err_msg="FAST candidates level %d" % l)
+    # a4 quadtree
+    for l in range(8):
+        ok = ox.level_keypoints(l)
+        gk = ex.debug_level_points(l, kept=True)
+        want = np.stack([ok["x"], ok["y"], ok["response"]], 1).astype(np.int32).reshape(-1, 3)
+        np.testing.assert_array_equal(gk, want, err_msg="quadtree level %d" % l)
+    # a6 blur (the oracle only blurs levels that have keypoints, like the reference)
+    for l in range(8):
+        ob = ox.level(l, blurred=True)
+        if ob is not None:
+            np.testing.assert_array_equal(ex.level(l, blurred=True), ob, err_msg="blur level %d" % l)
+    # a5 + a7 + a8 final records
+    assert len(kps) == len(okps)
+    for f in ("x", "y", "size", "response", "octave", "class_id"):
+        np.testing.assert_array_equal(kps[f], okps[f], err_msg=f)
+    np.testing.assert_array_equal(kps["angle"], okps["angle"], err_msg="orientation (fastAtan2 of integer moments)")
+    np.testing.assert_array_equal(desc, odesc)
+
+
+def test_golden_fixtures(gpu):
+    for name in sorted(os.listdir(GOLD)):
+        if not name.startswith("extract_"):
+            continue
+        g = np.load(os.path.join(GOLD, name))
+        ex = viorb_amd.ORBextractor(int(g["nfeat"]), 1.2, 8, 20, 7)
+        k, d = ex(make_image(int(g["seed"]), int(g["w"]), int(g["h"])))
+        np.testing.assert_array_equal(k, g["kps"], err_msg=name)
+        np.testing.assert_array_equal(d, g["desc"], err_msg=name)
+
+
+def test_batched_device_api_matches_single(gpu, oracle):
+    import torch
+    B = 5
+    imgs = np.stack([make_image(20 + b) for b in range(B)])
+    ex = viorb_amd.ORBextractor(1000, 1.2, 8, 20, 7, max_batch=8)
+    t = torch.from_numpy(imgs).cuda()
+    ex.extract_batch_device(t)
+    torch.cuda.synchronize()
+    ox = oracle.Extractor(1000, 1.2, 8, 20, 7)
+    for b in range(B):
+        k, d = ex.download(b)
+        ok, od = ox(imgs[b])
+        np.testing.assert_array_equal(k, ok)
+        np.testing.assert_array_equal(d, od)
+    # second call on the same handle, fewer images, non-default stream, strided rows
+    pad = torch.zeros((3, 480, 800), dtype=torch.uint8, device="cuda")
+    pad[:, :, :752] = t[:3]
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    ex.extract_batch_device(pad[:, :, :752], stream=s)
+    s.synchronize()
+    for b in range(3):
+        k, d = ex.download(b)
+        ok, od = ox(imgs[b])
+        np.testing.assert_array_equal(k, ok)
+        np.testing.assert_array_equal(d, od)
+
+
+def test_edge_inputs(gpu, oracle):
+    ex = viorb_amd.ORBextractor(300, 1.2, 8, 20, 7)
+    k, d = ex(np.full((120, 160), 77, np.uint8))               # textureless: zero keypoints everywhere
+    assert len(k) == 0 and d.shape == (0, 32)
+    rng = np.random.default_rng(1)
+    noise = rng.integers(0, 256, (240, 320), dtype=np.uint8)     # maximal corner density
+    ex2 = viorb_amd.ORBextractor(500, 1.2, 8, 20, 7)
+    k, d = ex2(noise)
+    ok, od = oracle.Extractor(500, 1.2, 8, 20, 7)(noise)
+    np.testing.assert_array_equal(k, ok)
+    np.testing.assert_array_equal(d, od)
+    # image size change on the same handle re-configures
+    k, d = ex2(make_image(3, 400, 300))
+    ok, od = oracle.Extractor(500, 1.2, 8, 20, 7)(make_image(3, 400, 300))
+    np.testing.assert_array_equal(k, ok)
+    np.testing.assert_array_equal(d, od)
+
+
+def test_properties_full_size(gpu):
+    """Size-independent checks at the bench configuration: determinism, bounds, and that a warped view
+    of the same scene re-detects most features with small Hamming distance."""
+    img = make_image(77)
+    ex = viorb_amd.ORBextractor(1000, 1.2, 8, 20, 7)
+    k1, d1 = ex(img)
+    k2, d2 = ex(img)
+    np.testing.assert_array_equal(k1, k2)
+    np.testing.assert_array_equal(d1, d2)
+    assert 900 <= len(k1) <= 1016 and (np.diff(k1["octave"]) >= 0).all()
+    assert (k1["x"] >= 19).all() and (k1["x"] <= 752 - 19).all() and (k1["y"] >= 19).all() and (k1["y"] <= 480 - 19).all()
+    kw, dw = ex(warp_image(img, 3.0, -2.0, 1.0, seed=3))
+    bits = np.unpackbits(d1[:, None, :] ^ dw[None, :, :], axis=2).sum(axis=2)
+    assert (bits.min(axis=1) <= 50).mean() > 0.5

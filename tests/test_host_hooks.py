@@ -1,0 +1,129 @@
+"""CPU tests of the product's host-side code (no GPU): the C ABI exports what include/viorb.h
+declares, and the host formulations that the kernels mirror agree with the oracle."""
+import ctypes as C
+import os
+import re
+import numpy as np
+import pytest
+import viorb_amd
+from viorb_amd import capi
+from viorb_amd.extractor import octree_host
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    txt = open(os.path.join(ROOT, "include", "viorb.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(viorb_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    L = viorb_amd.lib()
+    names = declared_functions()
+    assert len(names) >= 15
+    for n in names:
+        assert hasattr(L, n), "include/viorb.h declares %s but libviorb_hip.so does not export it" % n
+        assert n in capi.SIGNATURES, "capi.py has no ctypes signature for %s" % n
+    assert L.viorb_abi_version() == 1
+    assert isinstance(L.viorb_last_error(), bytes)
+
+
+def test_no_cpu_fallback_without_gpu():
+    L = viorb_amd.lib()
+    if L.viorb_device_count() > 0:
+        pytest.skip("GPU present")
+    ex = viorb_amd.ORBextractor()
+    with pytest.raises(viorb_amd.ViorbError) as e:
+        ex(np.zeros((480, 752), np.uint8))
+    assert e.value.code == capi.ERR_NO_DEVICE
+    k, d = ex(np.zeros((0, 0), np.uint8))                   # empty image: silent, like the reference
+    assert len(k) == 0 and d.shape == (0, 32)
+
+
+def test_create_argument_errors():
+    L = viorb_amd.lib()
+    h = C.c_void_p()
+    bad = capi.ExtractorParams(1000, 1.2, 0, 20, 7)
+    assert L.viorb_extractor_create(C.byref(bad), 1, 0, C.byref(h)) == capi.ERR_INVALID_ARG
+    assert b"nlevels" in L.viorb_last_error()
+    ok = capi.ExtractorParams(1000, 1.2, 8, 20, 7)
+    assert L.viorb_extractor_create(C.byref(ok), 0, 0, C.byref(h)) == capi.ERR_INVALID_ARG
+
+
+def test_tables_match_oracle(oracle):
+    for nf, sf, nl in ((1000, 1.2, 8), (2000, 1.2, 8), (1500, 1.2, 8), (500, 1.5, 5)):
+        t = viorb_amd.ORBextractor(nf, sf, nl, 20, 7).tables()
+        o = oracle.Extractor(nf, sf, nl, 20, 7).tables()
+        for k in ("scale", "inv_scale", "sigma2", "inv_sigma2", "quota"):
+            np.testing.assert_array_equal(t[k], o[k])
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_octree_arrays_equal_list_oracle(oracle, seed):
+    """The flat-array quadtree (what k_octree mirrors) returns the same keypoints, in the same order,
+    as the std::list restatement of the reference, over many sizes and quotas."""
+    rng = np.random.default_rng(seed)
+    W, H = [(720, 448), (1209, 344), (595, 368), (178, 102), (1248, 688), (331, 199)][seed]
+    for n, N in ((1, 10), (2, 1), (50, 217), (300, 60), (1800, 217), (2500, 434), (1200, 87), (4000, 326), (700, 699)):
+        n = min(n, W * H // 4)
+        xy = rng.choice(W * H, n, replace=False)
+        keys = np.zeros(n, oracle.KP_DTYPE)
+        keys["x"], keys["y"] = xy % W, xy // W
+        keys["response"] = rng.integers(7, 60 if seed % 2 else 255, n)      # many response ties when narrow
+        want = oracle.distribute_octree(keys, 16, 16 + W, 16, 16 + H, N)
+        got = octree_host(np.stack([keys["x"], keys["y"], keys["response"]], 1).astype(np.int32), W, H, N)
+        np.testing.assert_array_equal(got[:, 0], want["x"].astype(np.int32))
+        np.testing.assert_array_equal(got[:, 1], want["y"].astype(np.int32))
+        np.testing.assert_array_equal(got[:, 2], want["response"].astype(np.int32))
+
+
+def test_octree_clustered_points(oracle):
+    """Dense clusters force long single-child chains and the largest-first phase with many size ties."""
+    rng = np.random.default_rng(42)
+    W, H = 720, 448
+    pts = set()
+    for _ in range(25):
+        cx, cy = rng.integers(20, W - 20), rng.integers(20, H - 20)
+        for _ in range(80):
+            pts.add((int(np.clip(cx + rng.integers(-9, 10), 0, W - 1)), int(np.clip(cy + rng.integers(-9, 10), 0, H - 1))))
+    pts = np.array(sorted(pts, key=lambda p: (p[1], p[0])), np.int32)
+    keys = np.zeros(len(pts), oracle.KP_DTYPE)
+    keys["x"], keys["y"] = pts[:, 0], pts[:, 1]
+    keys["response"] = rng.integers(7, 30, len(pts))
+    for N in (30, 100, 217, 600):
+        want = oracle.distribute_octree(keys, 16, 16 + W, 16, 16 + H, N)
+        got = octree_host(np.stack([keys["x"], keys["y"], keys["response"]], 1).astype(np.int32), W, H, N)
+        np.testing.assert_array_equal(got, np.stack([want["x"], want["y"], want["response"]], 1).astype(np.int32))
+
+
+def test_octree_on_real_candidates(oracle):
+    from viorb_amd.synth import make_image
+    ex = oracle.Extractor(1000, 1.2, 8, 20, 7)
+    ex(make_image(3))
+    quota = ex.tables()["quota"]
+    for l in range(8):
+        cand = ex.level_keypoints(l, candidates=True)
+        h, w = ex.level(l).shape
+        want = ex.level_keypoints(l)
+        got = octree_host(np.stack([cand["x"], cand["y"], cand["response"]], 1).astype(np.int32), w - 32, h - 32, int(quota[l]))
+        np.testing.assert_array_equal(got[:, 0] + 16, want["x"].astype(np.int32))
+        np.testing.assert_array_equal(got[:, 1] + 16, want["y"].astype(np.int32))
+
+
+def test_device_math_host_build(oracle):
+    """orb_math.h compiled for the host: fast_atan2 is bit-identical to the oracle's, sincos_f32 is the
+    correctly rounded float of the double-precision value (what the oracle's descriptor uses)."""
+    L = viorb_amd.lib()
+    rng = np.random.default_rng(5)
+    for _ in range(5000):
+        y, x = (int(v) for v in rng.integers(-200000, 200000, 2))
+        assert L.viorb_debug_fast_atan2(y, x) == oracle.fast_atan2(y, x)
+    ang = np.concatenate([rng.uniform(0, 360, 200000), np.arange(0, 360, 0.25), [0, 30, 45, 60, 90, 180, 270, 359.99997]]).astype(np.float32)
+    rad = (ang * np.float32(np.pi / np.float32(180.0))).astype(np.float32)
+    s, c = C.c_float(), C.c_float()
+    want_s = np.sin(rad.astype(np.float64)).astype(np.float32)
+    want_c = np.cos(rad.astype(np.float64)).astype(np.float32)
+    for i in range(0, len(rad), 7):
+        L.viorb_debug_sincos(float(rad[i]), C.byref(s), C.byref(c))
+        assert s.value == want_s[i] and c.value == want_c[i]

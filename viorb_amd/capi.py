@@ -1,0 +1,81 @@
+"""ctypes declarations of include/viorb.h (kept 1:1 with the header; tests/test_capi_symbols.py checks
+that every declared entry point is exported)."""
+import ctypes as C
+import os
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "libviorb_hip.so")
+
+KP_DTYPE = np.dtype([("x", "f4"), ("y", "f4"), ("size", "f4"), ("angle", "f4"),
+                     ("response", "f4"), ("octave", "i4"), ("class_id", "i4")])
+
+VIORB_OK, ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_CAPACITY, ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5
+
+
+class ViorbError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("viorb error %d: %s" % (code, msg))
+        self.code = code
+
+
+class ExtractorParams(C.Structure):
+    _fields_ = [("nfeatures", C.c_int32), ("scale_factor", C.c_float), ("nlevels", C.c_int32),
+                ("ini_th_fast", C.c_int32), ("min_th_fast", C.c_int32)]
+
+
+vp, i32, f32, sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+PP = C.POINTER
+# name -> (restype, argtypes); mirrors include/viorb.h
+SIGNATURES = {
+    "viorb_abi_version": (i32, []),
+    "viorb_last_error": (C.c_char_p, []),
+    "viorb_device_count": (i32, []),
+    "viorb_extractor_create": (i32, [PP(ExtractorParams), i32, i32, PP(vp)]),
+    "viorb_extractor_destroy": (i32, [vp]),
+    "viorb_extractor_tables": (i32, [vp, vp, vp, vp, vp, vp]),
+    "viorb_extractor_max_keypoints": (i32, [vp, PP(i32)]),
+    "viorb_extract": (i32, [vp, vp, i32, i32, i32, vp, vp, i32, PP(i32)]),
+    "viorb_extract_batch_device": (i32, [vp, vp, i32, i32, i32, i32, sz, vp]),
+    "viorb_extractor_results_device": (i32, [vp, PP(vp), PP(vp), PP(vp), PP(vp), PP(i32)]),
+    "viorb_extractor_download": (i32, [vp, i32, vp, vp, i32, PP(i32)]),
+    "viorb_extractor_level_device": (i32, [vp, i32, i32, i32, PP(vp), PP(i32), PP(i32), PP(i32)]),
+    "viorb_extractor_level_download": (i32, [vp, i32, i32, i32, vp, PP(i32), PP(i32)]),
+    "viorb_extractor_debug_level_points": (i32, [vp, i32, i32, i32, vp, i32, PP(i32)]),
+    "viorb_debug_octree_host": (i32, [vp, i32, i32, i32, i32, vp, i32, PP(i32)]),
+    "viorb_debug_fast_atan2": (f32, [f32, f32]),
+    "viorb_debug_sincos": (None, [f32, PP(f32), PP(f32)]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load libviorb_hip.so. Raises (never falls back) when it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise ImportError("%s not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(hipcc, gfx950). viorb_amd has no CPU fallback." % SO_PATH)
+        L = C.CDLL(SO_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != VIORB_OK:
+        raise ViorbError(rc, lib().viorb_last_error().decode())
+    return rc
+
+
+def ptr(a):
+    """void* of a numpy array or a torch tensor (device or host)."""
+    if a is None:
+        return None
+    if isinstance(a, np.ndarray):
+        return a.ctypes.data_as(C.c_void_p)
+    return C.c_void_p(a.data_ptr())

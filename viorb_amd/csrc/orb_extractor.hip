@@ -1,0 +1,1150 @@
+// viorb_amd/csrc/orb_extractor.hip — MI355X (gfx950) ORB extractor: the HIP replacement for
+// ORB_SLAM2::ORBextractor (reference src/ORBextractor.cc). Batched by construction: every kernel
+// takes a batch of same-sized images (independent camera streams), all intermediate state stays in
+// HBM, nothing returns to the host between stages.
+//
+// Stage -> kernel map (reference lines in brackets):
+//   ComputePyramid [:1107-1132]            k_copy_level0 + k_resize (one launch per level, LDS-staged
+//                                          source tile, OpenCV 11-bit fixed-point bilinear)
+//   per-cell FAST, two thresholds [:765-830] k_fast_cells: one wavefront per 30-px cell, cell tile in
+//                                          LDS, score map in LDS, 3x3 NMS, ordered ballot compaction
+//   DistributeOctTree [:481-763]           k_octree: one wavefront per (image, level); stable 4-way
+//                                          segment partitions in LDS (see octree_arrays.h)
+//   GaussianBlur 7x7 s=2 [:1085-1086]      k_blur: separable, LDS tile, u16 intermediate
+//   IC_Angle + rBRIEF [:77-147]            k_orient_describe: one wavefront per keypoint, wave-reduced
+//                                          integer moments, 4 tests per lane, shuffle-packed bytes
+// No 19-px border is stored around the levels: nothing on this path reads it.
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdlib.h>
+#include <math.h>
+#include <vector>
+#include <string>
+#include <algorithm>
+#include "viorb_common.h"
+#include "orb_math.h"
+#include "octree_arrays.h"
+
+namespace viorb {
+
+static thread_local char g_err[512] = "";
+char* last_error_buf() { return g_err; }
+void set_error(const char* fmt, ...) {
+    va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof(g_err), fmt, ap); va_end(ap);
+}
+
+static const int8_t kPatternHost[1024] = {
+#include "orb_pattern.inc"
+};
+
+enum { MINB = 16, PATCH = 31, HALF_PATCH = 15, MAX_LEVELS = 16 };
+
+// ---------------------------------------------------------------------------------------------
+// Geometry shared by host and device
+// ---------------------------------------------------------------------------------------------
+struct LevelDev {
+    int w, h, stride;          // level size in px, row pitch in bytes (multiple of 64)
+    uint32_t plane_off;        // byte offset of the level inside one image's plane block
+    int cell_base, ncells;     // FAST cells of this level in the cell table
+    int quota;                 // mnFeaturesPerLevel
+    int oct_w, oct_h;          // maxBorder - minBorder
+    int n_ini;                 // quadtree roots
+    float hx;                  // root width
+    float scale;               // mvScaleFactor[l]
+    float kp_size;             // (float)(int)(31 * scale)
+    int xtab_off, ytab_off;    // resize tables (level >= 1): index of first entry
+    int kp_off;                // offset of this level inside the per-image level-keypoint buffer
+    int pad;
+};
+struct CellDesc {              // one FAST cell = sub-image [x0,x0+cw) x [y0,y0+ch) of its level
+    int16_t level, x0, y0, cw, ch, shx, shy, pad;
+};
+
+static inline int host_cv_round(double v) { return (int)nearbyint(v); }
+static inline int host_cv_floor(double v) { int i = host_cv_round(v); float d = (float)(v - i); return i - (d < 0); }
+static inline int host_cv_ceil(double v) { int i = host_cv_round(v); float d = (float)(i - v); return i + (d < 0); }
+static inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// ---------------------------------------------------------------------------------------------
+// Kernels
+// ---------------------------------------------------------------------------------------------
+
+// Level 0 = the input image re-pitched into the plane buffer.
+__global__ void k_copy_level0(const uint8_t* __restrict__ src, int w, int h, int sstride, size_t spitch,
+                              uint8_t* __restrict__ planes, size_t frame_bytes, int dstride) {
+    const int b = blockIdx.z;
+    const int y = blockIdx.y;
+    const int x = (blockIdx.x * blockDim.x + threadIdx.x) * 16;
+    if (x >= dstride) return;
+    const uint8_t* s = src + (size_t)b * spitch + (size_t)y * sstride;
+    uint8_t* d = planes + (size_t)b * frame_bytes + (size_t)y * dstride;
+    uint32_t v[4];
+    if (x + 16 <= w && ((((uintptr_t)(s + x)) & 15) == 0)) {
+        const uint4 q = *reinterpret_cast<const uint4*>(s + x);
+        v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            uint32_t acc = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                int xx = x + 4 * k + j;
+                uint32_t px = xx < w ? s[xx] : 0;
+                acc |= px << (8 * j);
+            }
+            v[k] = acc;
+        }
+    }
+    *reinterpret_cast<uint4*>(d + x) = make_uint4(v[0], v[1], v[2], v[3]);
+}
+
+// cv::resize(prev, cur, INTER_LINEAR) on 8U, OpenCV 2.4 fixed point (see oracle/cvprim.cpp for the
+// derivation): H = S[sx0]*a0 + S[sx1]*a1 (11-bit coefficients), out = (((b0*(H0>>4))>>16) +
+// ((b1*(H1>>4))>>16) + 2) >> 2. Tables are built on the host with OpenCV's double/float recipe.
+// Block = 64x16 output tile, 256 threads x 4 px; the source rectangle is staged in LDS as dwords.
+#define RS_TW 64
+#define RS_TH 16
+__global__ __launch_bounds__(256) void k_resize(uint8_t* __restrict__ planes, size_t frame_bytes,
+                                                const LevelDev* __restrict__ lv, int level,
+                                                const int2* __restrict__ xtab_all,
+                                                const int2* __restrict__ ytab_all, int lds_pitch_dw,
+                                                int lds_rows) {
+    extern __shared__ uint32_t s_tile[];
+    const LevelDev L = lv[level], P = lv[level - 1];
+    const int2* xtab = xtab_all + L.xtab_off;
+    const int2* ytab = ytab_all + L.ytab_off;
+    const uint8_t* src = planes + (size_t)blockIdx.z * frame_bytes + P.plane_off;
+    uint8_t* dst = planes + (size_t)blockIdx.z * frame_bytes + L.plane_off;
+    const int tx0 = blockIdx.x * RS_TW, ty0 = blockIdx.y * RS_TH;
+    const int tx1 = min(tx0 + RS_TW, L.w) - 1, ty1 = min(ty0 + RS_TH, L.h) - 1;
+    const int ys0 = ytab[ty0].x & 0xffff, ys1 = ytab[ty1].x >> 16;
+    const int xs0 = (xtab[tx0].x & 0xffff) & ~3, xs1 = xtab[tx1].x >> 16;
+    const int ndw = ((xs1 - xs0) >> 2) + 1, nrows = ys1 - ys0 + 1;
+    // host guarantees ndw <= lds_pitch_dw and nrows <= lds_rows
+    for (int i = threadIdx.x; i < nrows * lds_pitch_dw; i += 256) {
+        const int r = i / lds_pitch_dw, c = i - r * lds_pitch_dw;
+        if (c < ndw)
+            s_tile[i] = *reinterpret_cast<const uint32_t*>(src + (size_t)(ys0 + r) * P.stride + xs0 + 4 * c);
+    }
+    __syncthreads();
+    const uint8_t* t8 = reinterpret_cast<const uint8_t*>(s_tile);
+    const int r = threadIdx.x >> 4, xg = threadIdx.x & 15;
+    const int dy = ty0 + r;
+    if (dy >= L.h) return;
+    const int2 yt = ytab[dy];
+    const uint8_t* S0 = t8 + ((yt.x & 0xffff) - ys0) * (lds_pitch_dw * 4) - xs0;
+    const uint8_t* S1 = t8 + ((yt.x >> 16) - ys0) * (lds_pitch_dw * 4) - xs0;
+    const int b0 = yt.y & 0xffff, b1 = yt.y >> 16;
+    uint32_t packed = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int dx = min(tx0 + xg * 4 + j, L.w - 1);
+        const int2 xt = xtab[dx];
+        const int sx0 = xt.x & 0xffff, sx1 = xt.x >> 16, a0 = xt.y & 0xffff, a1 = xt.y >> 16;
+        const int h0 = S0[sx0] * a0 + S0[sx1] * a1;
+        const int h1 = S1[sx0] * a0 + S1[sx1] * a1;
+        const int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+        packed |= (uint32_t)(v & 0xff) << (8 * j);
+    }
+    const int dxw = tx0 + xg * 4;
+    if (dxw < L.stride) *reinterpret_cast<uint32_t*>(dst + (size_t)dy * L.stride + dxw) = packed;
+}
+
+// FAST-9-16 corner strength of the pixel at p (byte pointer into an LDS tile with `pitch` bytes per
+// row): max over the 16 arcs of 9 contiguous ring pixels of min(v - ring) and of min(ring - v),
+// minus 1 == cv::cornerScore<16>; the pixel is a FAST corner at threshold t iff strength >= t.
+__device__ __forceinline__ int fast_strength(const uint8_t* p, int pitch) {
+    const int v = p[0];
+    int d[16];
+    d[0] = v - p[3 * pitch];       d[1] = v - p[3 * pitch + 1];   d[2] = v - p[2 * pitch + 2];
+    d[3] = v - p[pitch + 3];       d[4] = v - p[3];               d[5] = v - p[-pitch + 3];
+    d[6] = v - p[-2 * pitch + 2];  d[7] = v - p[-3 * pitch + 1];  d[8] = v - p[-3 * pitch];
+    d[9] = v - p[-3 * pitch - 1];  d[10] = v - p[-2 * pitch - 2]; d[11] = v - p[-pitch - 3];
+    d[12] = v - p[-3];             d[13] = v - p[pitch - 3];      d[14] = v - p[2 * pitch - 2];
+    d[15] = v - p[3 * pitch - 1];
+    int lo2[16], hi2[16], lo4[16], hi4[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) { lo2[k] = min(d[k], d[(k + 1) & 15]); hi2[k] = max(d[k], d[(k + 1) & 15]); }
+#pragma unroll
+    for (int k = 0; k < 16; k++) { lo4[k] = min(lo2[k], lo2[(k + 2) & 15]); hi4[k] = max(hi2[k], hi2[(k + 2) & 15]); }
+    int a = -256, bq = 256;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const int lo9 = min(min(lo4[k], lo4[(k + 4) & 15]), d[(k + 8) & 15]);
+        const int hi9 = max(max(hi4[k], hi4[(k + 4) & 15]), d[(k + 8) & 15]);
+        a = max(a, lo9);
+        bq = min(bq, hi9);
+    }
+    return max(a, -bq) - 1;
+}
+
+// One wavefront per FAST cell (reference :789-828): load the (<= wCell+6)x(hCell+6) cell image into
+// LDS, compute every interior pixel's corner strength once, then run cv::FAST's 3x3 strict NMS at
+// iniThFAST and, only if that leaves the cell empty, again at minThFAST. Survivors are written in
+// row-major order (cv::FAST's output order) into the cell's slot as packed (x|y<<12|score<<24) with
+// the reference's j*wCell / i*hCell shift already applied.
+__global__ __launch_bounds__(64) void k_fast_cells(const uint8_t* __restrict__ planes, size_t frame_bytes,
+                                                   const LevelDev* __restrict__ lv,
+                                                   const CellDesc* __restrict__ cells, int ini_th, int min_th,
+                                                   uint32_t* __restrict__ slots, int slot_cap,
+                                                   int* __restrict__ cell_cnt, int ncells_total,
+                                                   int tile_pitch, int tile_rows, int score_bytes) {
+    extern __shared__ uint32_t s_mem[];
+    uint8_t* tile = reinterpret_cast<uint8_t*>(s_mem);
+    uint8_t* sc = tile + tile_pitch * tile_rows;
+    const int lane = threadIdx.x;
+    const CellDesc c = cells[blockIdx.x];
+    const LevelDev L = lv[c.level];
+    const uint8_t* img = planes + (size_t)blockIdx.y * frame_bytes + L.plane_off;
+    const int x0a = c.x0 & ~3, xoff = c.x0 - x0a;
+    const int ndw = ((c.x0 + c.cw - 1 - x0a) >> 2) + 1;
+    const int pitch_dw = tile_pitch >> 2;
+    for (int i = lane; i < c.ch * pitch_dw; i += 64) {
+        const int r = i / pitch_dw, q = i - r * pitch_dw;
+        if (q < ndw)
+            s_mem[i] = *reinterpret_cast<const uint32_t*>(img + (size_t)(c.y0 + r) * L.stride + x0a + 4 * q);
+    }
+    const int dw = c.cw - 6, dh = c.ch - 6;          // interior (detection) region
+    const int sp = dw + 2;                            // score map pitch, 1-px zero frame
+    for (int i = lane; i < (score_bytes >> 2); i += 64) reinterpret_cast<uint32_t*>(sc)[i] = 0;
+    __syncthreads();
+    uint32_t* my_slots = slots + ((size_t)blockIdx.y * ncells_total + blockIdx.x) * slot_cap;
+    int total = 0;
+    if (dw > 0 && dh > 0) {
+        const int npx = dw * dh;
+        for (int base = 0; base < npx; base += 64) {
+            const int p = base + lane;
+            if (p < npx) {
+                const int r = p / dw, q = p - r * dw;
+                int s = fast_strength(tile + (r + 3) * tile_pitch + xoff + q + 3, tile_pitch);
+                sc[(r + 1) * sp + q + 1] = (uint8_t)(s >= min_th ? s : 0);
+            }
+        }
+        __syncthreads();
+        for (int pass = 0; pass < 2 && total == 0; pass++) {
+            const int th = pass == 0 ? ini_th : min_th;
+            for (int base = 0; base < npx; base += 64) {
+                const int p = base + lane;
+                bool keep = false;
+                int r = 0, q = 0, s = 0;
+                if (p < npx) {
+                    r = p / dw; q = p - r * dw;
+                    const uint8_t* z = sc + (r + 1) * sp + q + 1;
+                    s = z[0];
+                    if (s >= th && s > 0) {
+                        keep = true;
+#pragma unroll
+                        for (int dy = -1; dy <= 1; dy++)
+#pragma unroll
+                            for (int dx = -1; dx <= 1; dx++) {
+                                if (dx == 0 && dy == 0) continue;
+                                const int nb = z[dy * sp + dx];
+                                keep = keep && (s > (nb >= th ? nb : 0));
+                            }
+                    }
+                }
+                const unsigned long long m = __ballot(keep);
+                if (keep) {
+                    const int pos = total + __popcll(m & ((1ull << lane) - 1ull));
+                    if (pos < slot_cap)
+                        my_slots[pos] = (uint32_t)(q + 3 + c.shx) | ((uint32_t)(r + 3 + c.shy) << 12) | ((uint32_t)s << 24);
+                }
+                total += __popcll(m);
+            }
+        }
+    }
+    if (lane == 0) cell_cnt[(size_t)blockIdx.y * ncells_total + blockIdx.x] = min(total, slot_cap);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Quadtree distribution: one wavefront per (level, image). Mirrors distribute_octree_arrays()
+// (octree_arrays.h) step for step; every control decision is wave-uniform.
+// ---------------------------------------------------------------------------------------------
+// single-wavefront workgroups: a workgroup barrier is one s_barrier and also orders LDS traffic
+#define WAVE_SYNC() __syncthreads()
+struct OctLds {
+    uint32_t* keys; uint16_t* perm0; uint16_t* perm1; OctNode* nd; uint32_t* sortb;
+};
+
+__device__ __forceinline__ unsigned long long lanemask_lt(int lane) { return (1ull << lane) - 1ull; }
+
+// Expand node i (DivideNode): stable 4-way partition of its key segment; children appended.
+__device__ __forceinline__ void oct_expand(const OctLds& S, int i, int lane, int& nn, int& live, int& n_to_expand) {
+    const OctNode p = S.nd[i];
+    const int mx = p.x0 + ((p.x1 - p.x0 + 1) >> 1), my = p.y0 + ((p.y1 - p.y0 + 1) >> 1);
+    const int sb = p.flags & OCT_BUF;
+    const uint16_t* src = sb ? S.perm1 : S.perm0;
+    uint16_t* dst = sb ? S.perm0 : S.perm1;
+    const int cnt = p.count, beg = p.begin;
+    int t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+    for (int o = 0; o < cnt; o += 64) {
+        const int idx = o + lane;
+        const bool valid = idx < cnt;
+        int c = -1;
+        if (valid) {
+            const uint32_t key = S.keys[src[beg + idx]];
+            c = ((int)(key & 0xfff) < mx ? 0 : 1) | ((int)((key >> 12) & 0xfff) < my ? 0 : 2);
+        }
+        t0 += __popcll(__ballot(c == 0)); t1 += __popcll(__ballot(c == 1));
+        t2 += __popcll(__ballot(c == 2)); t3 += __popcll(__ballot(c == 3));
+    }
+    const int s0 = beg, s1 = s0 + t0, s2 = s1 + t1, s3 = s2 + t2;
+    int r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+    for (int o = 0; o < cnt; o += 64) {
+        const int idx = o + lane;
+        const bool valid = idx < cnt;
+        int c = -1;
+        uint16_t id = 0;
+        if (valid) {
+            id = src[beg + idx];
+            const uint32_t key = S.keys[id];
+            c = ((int)(key & 0xfff) < mx ? 0 : 1) | ((int)((key >> 12) & 0xfff) < my ? 0 : 2);
+        }
+        const unsigned long long m0 = __ballot(c == 0), m1 = __ballot(c == 1), m2 = __ballot(c == 2), m3 = __ballot(c == 3);
+        const unsigned long long lt = lanemask_lt(lane);
+        if (c == 0) dst[s0 + r0 + __popcll(m0 & lt)] = id;
+        else if (c == 1) dst[s1 + r1 + __popcll(m1 & lt)] = id;
+        else if (c == 2) dst[s2 + r2 + __popcll(m2 & lt)] = id;
+        else if (c == 3) dst[s3 + r3 + __popcll(m3 & lt)] = id;
+        r0 += __popcll(m0); r1 += __popcll(m1); r2 += __popcll(m2); r3 += __popcll(m3);
+    }
+    // append the non-empty children in n1..n4 order (lane j builds child j)
+    const int tc[4] = {t0, t1, t2, t3};
+    const int sc4[4] = {s0, s1, s2, s3};
+    int off = 0;
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        if (tc[c] > 0) {
+            if (lane == 0) {
+                OctNode o;
+                o.x0 = (c & 1) ? (int16_t)mx : p.x0; o.x1 = (c & 1) ? p.x1 : (int16_t)mx;
+                o.y0 = (c & 2) ? (int16_t)my : p.y0; o.y1 = (c & 2) ? p.y1 : (int16_t)my;
+                o.begin = (uint16_t)sc4[c]; o.count = (uint16_t)tc[c];
+                o.flags = (uint16_t)((sb ^ 1) | (tc[c] == 1 ? OCT_NOMORE : 0)); o.pad = 0;
+                S.nd[nn + off] = o;
+            }
+            off++;
+            if (tc[c] > 1) n_to_expand++;
+        }
+    }
+    if (lane == 0) S.nd[i].flags = p.flags | OCT_DEAD;
+    nn += off;
+    live += off - 1;
+    WAVE_SYNC();
+}
+
+// Stable in-place removal of dead nodes; returns the new node count; first_new = new index of `upto`.
+__device__ __forceinline__ int oct_compact(const OctLds& S, int nn, int upto, int lane, int& first_new) {
+    int w = 0;
+    first_new = -1;
+    for (int base = 0; base < nn; base += 64) {
+        const int i = base + lane;
+        OctNode o; o.flags = OCT_DEAD;
+        if (i < nn) o = S.nd[i];
+        const bool alive = (i < nn) && !(o.flags & OCT_DEAD);
+        const unsigned long long m = __ballot(alive);
+        if (upto >= base && upto < base + 64) first_new = w + __popcll(m & lanemask_lt(upto - base));
+        WAVE_SYNC();
+        if (alive) S.nd[w + __popcll(m & lanemask_lt(lane))] = o;
+        w += __popcll(m);
+        WAVE_SYNC();
+    }
+    if (first_new < 0) first_new = w;
+    return w;
+}
+
+// Ascending bitonic sort of m (power of two) u32 keys in LDS by one wavefront.
+__device__ __forceinline__ void oct_sort(uint32_t* a, int m, int lane) {
+    for (int k = 2; k <= m; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = lane; t < (m >> 1); t += 64) {
+                const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));   // index with bit j clear
+                const int hi = lo | j;
+                const bool up = (lo & k) == 0;
+                const uint32_t x = a[lo], y = a[hi];
+                if ((x > y) == up) { a[lo] = y; a[hi] = x; }
+            }
+            WAVE_SYNC();
+        }
+}
+
+__global__ __launch_bounds__(64) void k_octree(const LevelDev* __restrict__ lv, const uint32_t* __restrict__ slots,
+                                               int slot_cap, const int* __restrict__ cell_cnt, int ncells_total,
+                                               uint32_t* __restrict__ lvl_kp, int kp_pitch, int* __restrict__ lvl_cnt,
+                                               int* __restrict__ lvl_ncand, int nlevels, int* __restrict__ status,
+                                               int ncap, int nodecap, int sortcap) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_oct[];
+    OctLds S;
+    S.keys = s_oct;
+    S.perm0 = reinterpret_cast<uint16_t*>(s_oct + ncap);
+    S.perm1 = S.perm0 + ncap;
+    S.nd = reinterpret_cast<OctNode*>(S.perm1 + ncap);
+    S.sortb = reinterpret_cast<uint32_t*>(S.nd + nodecap);
+    const int lane = threadIdx.x, level = blockIdx.x, b = blockIdx.y;
+    const LevelDev L = lv[level];
+    const int N = L.quota;
+    // ---- 1. gather candidates in the reference's push order (cell-major, row-major inside a cell)
+    int n = 0;
+    bool overflow = false;
+    {
+        const int* cc = cell_cnt + (size_t)b * ncells_total + L.cell_base;
+        const uint32_t* sl = slots + ((size_t)b * ncells_total + L.cell_base) * slot_cap;
+        for (int base = 0; base < L.ncells; base += 64) {
+            const int ci = base + lane;
+            const int cnt = ci < L.ncells ? cc[ci] : 0;
+            // inclusive wave scan of cnt
+            int incl = cnt;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const int v = __shfl_up(incl, d); if (lane >= d) incl += v; }
+            const int start = n + incl - cnt;
+            for (int k = 0; k < cnt; k++) {
+                const int pos = start + k;
+                if (pos < ncap) S.keys[pos] = sl[(size_t)ci * slot_cap + k];
+            }
+            n += __shfl(incl, 63);
+        }
+        if (n > ncap) { overflow = true; n = ncap; }
+    }
+    if (lane == 0) lvl_ncand[b * nlevels + level] = n;
+    WAVE_SYNC();
+    uint32_t* out = lvl_kp + (size_t)b * kp_pitch + L.kp_off;
+    if (n == 0 || L.n_ini < 1 || N < 1) {
+        if (lane == 0) { lvl_cnt[b * nlevels + level] = 0; if (overflow) status[b] = VIORB_ERR_CAPACITY; }
+        return;
+    }
+    // ---- 2. roots: stable counting sort by root index; array holds the roots back-to-front
+    int nn = 0, live = 0;
+    {
+        int begin = 0;
+        for (int r = 0; r < L.n_ini; r++) {
+            int cnt = 0;
+            for (int o = 0; o < n; o += 64) {
+                const int idx = o + lane;
+                bool mine = false;
+                if (idx < n) mine = ((int)((float)(S.keys[idx] & 0xfff) / L.hx)) == r;
+                const unsigned long long m = __ballot(mine);
+                if (mine) S.perm0[begin + cnt + __popcll(m & lanemask_lt(lane))] = (uint16_t)idx;
+                cnt += __popcll(m);
+            }
+            if (cnt > 0) {
+                if (lane == 0) {
+                    OctNode o;
+                    o.x0 = (int16_t)(int)(L.hx * (float)r); o.x1 = (int16_t)(int)(L.hx * (float)(r + 1));
+                    o.y0 = 0; o.y1 = (int16_t)L.oct_h;
+                    o.begin = (uint16_t)begin; o.count = (uint16_t)cnt;
+                    o.flags = (uint16_t)(cnt == 1 ? OCT_NOMORE : 0); o.pad = 0;
+                    S.nd[nn] = o;
+                }
+                nn++;
+            }
+            begin += cnt;
+        }
+        WAVE_SYNC();
+        // reverse the root array (list front = root 0 must be the LAST array element)
+        for (int i = lane; i < (nn >> 1); i += 64) {
+            const OctNode a = S.nd[i], z = S.nd[nn - 1 - i];
+            S.nd[i] = z; S.nd[nn - 1 - i] = a;
+        }
+        WAVE_SYNC();
+        live = nn;
+    }
+    // ---- 3. subdivision rounds
+    bool finish = false;
+    int guard = 0;
+    while (!finish && guard++ < 64) {
+        const int prev = live, nn0 = nn;
+        int n_to_expand = 0;
+        for (int i = nn0 - 1; i >= 0; i--) {
+            const int fl = S.nd[i].flags;
+            if (!(fl & (OCT_NOMORE | OCT_DEAD))) {
+                if (nn + 4 > nodecap) { overflow = true; finish = true; break; }
+                oct_expand(S, i, lane, nn, live, n_to_expand);
+            }
+        }
+        int first_new;
+        nn = oct_compact(S, nn, nn0, lane, first_new);
+        if (finish) break;
+        if (live >= N || live == prev) {
+            finish = true;
+        } else if (live + n_to_expand * 3 > N) {
+            int guard2 = 0;
+            while (!finish && guard2++ < 4096) {
+                const int prev2 = live;
+                // build (count<<16 | index) list of the nodes created in the previous round
+                int m = 0;
+                for (int base = first_new; base < nn; base += 64) {
+                    const int i = base + lane;
+                    bool want = false; uint32_t key = 0;
+                    if (i < nn) { const OctNode o = S.nd[i]; want = o.count > 1; key = ((uint32_t)o.count << 16) | (uint32_t)i; }
+                    const unsigned long long bm = __ballot(want);
+                    if (want) { const int pos = m + __popcll(bm & lanemask_lt(lane)); if (pos < sortcap) S.sortb[pos] = key; }
+                    m += __popcll(bm);
+                }
+                if (m > sortcap) { overflow = true; m = sortcap; }
+                int mp = 1; while (mp < m) mp <<= 1;
+                for (int i = m + lane; i < mp; i += 64) S.sortb[i] = 0;      // pad sorts to the front
+                WAVE_SYNC();
+                oct_sort(S.sortb, mp, lane);
+                const int nn1 = nn;
+                int dummy = 0;
+                for (int j = mp - 1; j >= mp - m; j--) {
+                    if (nn + 4 > nodecap) { overflow = true; finish = true; break; }
+                    oct_expand(S, (int)(S.sortb[j] & 0xffff), lane, nn, live, dummy);
+                    if (live >= N) break;
+                }
+                nn = oct_compact(S, nn, nn1, lane, first_new);
+                if (live >= N || live == prev2) finish = true;
+            }
+        }
+    }
+    // ---- 4. best response per node (first maximum), output in list order = array descending
+    for (int base = 0; base < nn; base += 64) {
+        const int i = base + lane;
+        if (i < nn) {
+            const OctNode o = S.nd[i];
+            const uint16_t* pm = (o.flags & OCT_BUF) ? S.perm1 : S.perm0;
+            uint32_t best = S.keys[pm[o.begin]];
+            for (int k = 1; k < o.count; k++) {
+                const uint32_t key = S.keys[pm[o.begin + k]];
+                if ((key >> 24) > (best >> 24)) best = key;
+            }
+            // level coordinates: + minBorder (reference :841-842)
+            out[nn - 1 - i] = (best & 0xff000000u) | ((((best >> 12) & 0xfff) + MINB) << 12) | ((best & 0xfff) + MINB);
+        }
+    }
+    if (lane == 0) {
+        lvl_cnt[b * nlevels + level] = nn;
+        if (overflow) status[b] = VIORB_ERR_CAPACITY;
+    }
+}
+
+// cv::GaussianBlur(7x7, sigma 2, BORDER_REFLECT_101) on 8U, OpenCV 2.4 integer path:
+// taps {18,34,49,55,49,34,18} (x256, sum 257) in both directions, (sum + 2^15) >> 16, saturated.
+// Block = 64x32 output tile; horizontal pass into a u16 LDS buffer (max 255*257 = 65535), vertical
+// pass out of it.
+#define BL_TW 64
+#define BL_TH 32
+__constant__ int c_gauss[7];
+__device__ __forceinline__ int reflect101(int p, int len) {
+    if (len == 1) return 0;
+    while (p < 0 || p >= len) p = p < 0 ? -p : 2 * (len - 1) - p;
+    return p;
+}
+__global__ __launch_bounds__(256) void k_blur(const uint8_t* __restrict__ planes, uint8_t* __restrict__ blur,
+                                              size_t frame_bytes, const LevelDev* __restrict__ lv,
+                                              const int4* __restrict__ tiles) {
+    __shared__ uint8_t s_in[(BL_TH + 6) * (BL_TW + 8)];
+    __shared__ uint16_t s_h[(BL_TH + 6) * BL_TW];
+    const int4 t = tiles[blockIdx.x];                 // level, tile x0, tile y0
+    const LevelDev L = lv[t.x];
+    const uint8_t* src = planes + (size_t)blockIdx.y * frame_bytes + L.plane_off;
+    uint8_t* dst = blur + (size_t)blockIdx.y * frame_bytes + L.plane_off;
+    const int x0 = t.y, y0 = t.z;
+    const int IW = BL_TW + 6, IP = BL_TW + 8;
+    for (int i = threadIdx.x; i < (BL_TH + 6) * IW; i += 256) {
+        const int r = i / IW, c = i - r * IW;
+        const int yy = reflect101(y0 + r - 3, L.h), xx = reflect101(x0 + c - 3, L.w);
+        s_in[r * IP + c] = src[(size_t)yy * L.stride + xx];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < (BL_TH + 6) * BL_TW; i += 256) {
+        const int r = i / BL_TW, c = i - r * BL_TW;
+        const uint8_t* p = s_in + r * IP + c;
+        int s = 0;
+#pragma unroll
+        for (int k = 0; k < 7; k++) s += c_gauss[k] * p[k];
+        s_h[i] = (uint16_t)s;
+    }
+    __syncthreads();
+    // 256 threads x 8 px: thread -> row (tid/8), 8-px group (tid%8)
+    const int r = threadIdx.x >> 3, g = threadIdx.x & 7;
+    const int y = y0 + r;
+    if (y >= L.h) return;
+    uint32_t w0 = 0, w1 = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int c = g * 8 + j;
+        int s = 0;
+#pragma unroll
+        for (int k = 0; k < 7; k++) s += c_gauss[k] * (int)s_h[(r + k) * BL_TW + c];
+        int v = (s + (1 << 15)) >> 16;
+        v = v > 255 ? 255 : v;
+        if (j < 4) w0 |= (uint32_t)v << (8 * j); else w1 |= (uint32_t)v << (8 * (j - 4));
+    }
+    const int xw = x0 + g * 8;
+    if (xw < L.stride) *reinterpret_cast<uint2*>(dst + (size_t)y * L.stride + xw) = make_uint2(w0, w1);
+}
+
+// One wavefront per keypoint: IC_Angle (reference :77-104) on the un-blurred level, then the
+// steered 256-bit BRIEF (reference :107-147) on the blurred level, then the cv::KeyPoint record
+// (reference :837-847, :1095-1101).
+__constant__ uint32_t c_pattern[256];                  // x0 | y0<<8 | x1<<16 | y1<<24 (int8 each)
+__constant__ int c_umax[16];
+__global__ __launch_bounds__(256) void k_orient_describe(const uint8_t* __restrict__ planes,
+                                                         const uint8_t* __restrict__ blur, size_t frame_bytes,
+                                                         const LevelDev* __restrict__ lv, int nlevels,
+                                                         const uint32_t* __restrict__ lvl_kp, int kp_pitch,
+                                                         const int* __restrict__ lvl_cnt,
+                                                         viorb_keypoint* __restrict__ out_kp,
+                                                         uint8_t* __restrict__ out_desc, int out_cap,
+                                                         int* __restrict__ out_cnt) {
+    const int lane = threadIdx.x & 63;
+    const int k = blockIdx.x * 4 + (threadIdx.x >> 6);       // keypoint slot inside the image
+    const int b = blockIdx.y;
+    const int* cnt = lvl_cnt + b * nlevels;
+    int level = -1, local = 0, total = 0;
+    for (int l = 0; l < nlevels; l++) {
+        const int c = cnt[l];
+        if (level < 0 && k < total + c) { level = l; local = k - total; }
+        total += c;
+    }
+    if (k == 0 && lane == 0) out_cnt[b] = min(total, out_cap);
+    if (level < 0 || k >= out_cap) return;
+    const LevelDev L = lv[level];
+    const uint32_t key = lvl_kp[(size_t)b * kp_pitch + L.kp_off + local];
+    const int cx = (int)(key & 0xfff), cy = (int)((key >> 12) & 0xfff), score = (int)(key >> 24);
+    // ---- orientation: integer moments over the circular patch, two rows per iteration
+    const uint8_t* img = planes + (size_t)b * frame_bytes + L.plane_off + (size_t)cy * L.stride + cx;
+    int m10 = 0, m01 = 0;
+    const int u = (lane & 31) - HALF_PATCH;
+#pragma unroll 4
+    for (int it = 0; it < 16; it++) {
+        const int v = -HALF_PATCH + 2 * it + (lane >> 5);
+        const int av = v < 0 ? -v : v;
+        if (av <= HALF_PATCH && (lane & 31) < PATCH) {
+            const int au = u < 0 ? -u : u;
+            if (au <= c_umax[av]) {
+                const int val = img[v * L.stride + u];
+                m10 += u * val;
+                m01 += v * val;
+            }
+        }
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) { m10 += __shfl_xor(m10, d); m01 += __shfl_xor(m01, d); }
+    const float angle = fast_atan2_deg((float)m01, (float)m10);
+    // ---- descriptor
+    const float factor_pi = (float)(3.14159265358979323846 / 180.f);
+    float sn, cs;
+    sincos_f32(angle * factor_pi, &sn, &cs);
+    const float a = cs, bb = sn;
+    const uint8_t* bim = blur + (size_t)b * frame_bytes + L.plane_off + (size_t)cy * L.stride + cx;
+    uint32_t nib = 0;
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        const uint32_t q = c_pattern[lane * 4 + t];
+        const float x0 = (float)(int8_t)(q & 0xff), y0 = (float)(int8_t)((q >> 8) & 0xff);
+        const float x1 = (float)(int8_t)((q >> 16) & 0xff), y1 = (float)(int8_t)(q >> 24);
+        const int r0 = round_half_even(x0 * bb + y0 * a), c0 = round_half_even(x0 * a - y0 * bb);
+        const int r1 = round_half_even(x1 * bb + y1 * a), c1 = round_half_even(x1 * a - y1 * bb);
+        const int t0 = bim[r0 * L.stride + c0], t1 = bim[r1 * L.stride + c1];
+        nib |= (uint32_t)(t0 < t1) << t;
+    }
+    // lane i holds bits 4i..4i+3: bytes from lane pairs, dwords from 8-lane groups
+    uint32_t byte = nib | (__shfl_down(nib, 1) << 4);
+    uint32_t word = byte | (__shfl_down(byte, 2) << 8) | (__shfl_down(byte, 4) << 16) | (__shfl_down(byte, 6) << 24);
+    const size_t o = (size_t)b * out_cap + k;
+    if ((lane & 7) == 0) reinterpret_cast<uint32_t*>(out_desc + o * 32)[lane >> 3] = word;
+    if (lane == 0) {
+        viorb_keypoint kp;
+        kp.x = level ? (float)cx * L.scale : (float)cx;
+        kp.y = level ? (float)cy * L.scale : (float)cy;
+        kp.size = L.kp_size; kp.angle = angle; kp.response = (float)score;
+        kp.octave = level; kp.class_id = -1;
+        out_kp[o] = kp;
+    }
+}
+
+} // namespace viorb
+
+// ---------------------------------------------------------------------------------------------
+// Host side: handle, geometry, launches, C ABI
+// ---------------------------------------------------------------------------------------------
+using namespace viorb;
+
+struct viorb_extractor {
+    viorb_extractor_params p;
+    int max_batch = 1, device = 0;
+    bool host_octree = false;
+    // ctor tables (reference :410-470)
+    std::vector<float> scale, inv_scale, sigma2, inv_sigma2;
+    std::vector<int> quota;
+    int umax[16];
+    // geometry for the current image size
+    int img_w = 0, img_h = 0;
+    std::vector<LevelDev> lv;
+    std::vector<CellDesc> cells;
+    std::vector<int4> blur_tiles;
+    size_t frame_bytes = 0;
+    int slot_cap = 0, kp_pitch = 0, out_cap = 0;
+    int fast_tile_pitch = 0, fast_tile_rows = 0, fast_score_bytes = 0;
+    int oct_ncap = 0, oct_nodecap = 0, oct_sortcap = 0;
+    std::vector<int> rs_pitch_dw, rs_rows;
+    // device memory
+    uint8_t *d_planes = nullptr, *d_blur = nullptr, *d_desc = nullptr, *d_stage = nullptr;
+    LevelDev* d_lv = nullptr; CellDesc* d_cells = nullptr; int4* d_blur_tiles = nullptr;
+    int2 *d_xtab = nullptr, *d_ytab = nullptr;
+    uint32_t *d_slots = nullptr, *d_lvl_kp = nullptr;
+    int *d_cell_cnt = nullptr, *d_lvl_cnt = nullptr, *d_lvl_ncand = nullptr, *d_count = nullptr, *d_status = nullptr;
+    viorb_keypoint* d_kps = nullptr;
+    size_t stage_bytes = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t last_stream = nullptr;
+    int last_batch = 0;
+    bool tables_uploaded = false;
+};
+
+static void free_device(viorb_extractor* h) {
+    void* ptrs[] = {h->d_planes, h->d_blur, h->d_desc, h->d_stage, h->d_lv, h->d_cells, h->d_blur_tiles, h->d_xtab,
+                    h->d_ytab, h->d_slots, h->d_lvl_kp, h->d_cell_cnt, h->d_lvl_cnt, h->d_lvl_ncand, h->d_count,
+                    h->d_status, h->d_kps};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    h->d_planes = h->d_blur = h->d_desc = h->d_stage = nullptr; h->d_lv = nullptr; h->d_cells = nullptr;
+    h->d_blur_tiles = nullptr; h->d_xtab = h->d_ytab = nullptr; h->d_slots = h->d_lvl_kp = nullptr;
+    h->d_cell_cnt = h->d_lvl_cnt = h->d_lvl_ncand = h->d_count = h->d_status = nullptr; h->d_kps = nullptr;
+    h->stage_bytes = 0;
+}
+
+// Build level geometry, FAST cell table, resize tables and buffers for a w x h image.
+static int configure(viorb_extractor* h, int w, int hgt) {
+    const int nl = h->p.nlevels;
+    free_device(h);
+    h->lv.assign(nl, LevelDev());
+    h->cells.clear(); h->blur_tiles.clear();
+    std::vector<int2> xtab, ytab;
+    h->rs_pitch_dw.assign(nl, 0); h->rs_rows.assign(nl, 0);
+    size_t off = 0;
+    int kp_off = 0, max_cw = 0, max_ch = 0;
+    for (int l = 0; l < nl; l++) {
+        LevelDev& L = h->lv[l];
+        const float s = h->inv_scale[l];
+        L.w = host_cv_round((double)((float)w * s));
+        L.h = host_cv_round((double)((float)hgt * s));
+        if (L.w < 1 || L.h < 1 || L.w > 4095 || L.h > 4095) { set_error("level %d size %dx%d unsupported", l, L.w, L.h); return VIORB_ERR_UNSUPPORTED; }
+        L.stride = (int)align_up(L.w, 64);
+        L.plane_off = (uint32_t)off;
+        off += align_up((size_t)L.stride * L.h, 256);
+        L.quota = h->quota[l];
+        L.scale = h->scale[l];
+        L.kp_size = (float)(int)(PATCH * h->scale[l]);
+        // FAST cell grid (reference :769-806)
+        const int maxBX = L.w - MINB, maxBY = L.h - MINB;
+        const float width = (float)(maxBX - MINB), height = (float)(maxBY - MINB);
+        L.oct_w = maxBX - MINB; L.oct_h = maxBY - MINB;
+        L.cell_base = (int)h->cells.size();
+        const int nCols = (int)(width / 30.f), nRows = (int)(height / 30.f);
+        if (nCols >= 1 && nRows >= 1) {
+            const int wCell = (int)ceilf(width / nCols), hCell = (int)ceilf(height / nRows);
+            for (int i = 0; i < nRows; i++) {
+                const float iniY = (float)(MINB + i * hCell);
+                float maxY = iniY + hCell + 6;
+                if (iniY >= maxBY - 3) continue;
+                if (maxY > maxBY) maxY = (float)maxBY;
+                for (int j = 0; j < nCols; j++) {
+                    const float iniX = (float)(MINB + j * wCell);
+                    float maxX = iniX + wCell + 6;
+                    if (iniX >= maxBX - 6) continue;
+                    if (maxX > maxBX) maxX = (float)maxBX;
+                    CellDesc c;
+                    c.level = (int16_t)l; c.x0 = (int16_t)iniX; c.y0 = (int16_t)iniY;
+                    c.cw = (int16_t)((int)maxX - (int)iniX); c.ch = (int16_t)((int)maxY - (int)iniY);
+                    c.shx = (int16_t)(j * wCell); c.shy = (int16_t)(i * hCell); c.pad = 0;
+                    if (c.cw < 7 || c.ch < 7) continue;            // cv::FAST finds nothing in such a sub-image
+                    h->cells.push_back(c);
+                    max_cw = std::max(max_cw, (int)c.cw); max_ch = std::max(max_ch, (int)c.ch);
+                }
+            }
+        }
+        L.ncells = (int)h->cells.size() - L.cell_base;
+        // quadtree roots (reference :542-545)
+        L.n_ini = (L.oct_h > 0 && L.oct_w > 0) ? (int)roundf((float)L.oct_w / (float)L.oct_h) : 0;
+        L.hx = L.n_ini > 0 ? (float)L.oct_w / (float)L.n_ini : 1.f;
+        // the first round splits every root unchecked (<= 4*n_ini nodes); afterwards <= quota + 2
+        L.kp_off = kp_off;
+        kp_off += std::max(L.quota, 4 * L.n_ini) + 4;
+        // resize tables from level l-1 (cv::resize INTER_LINEAR 8U, OpenCV 2.4 recipe)
+        L.xtab_off = (int)xtab.size(); L.ytab_off = (int)ytab.size();
+        if (l > 0) {
+            const int sw = h->lv[l - 1].w, sh = h->lv[l - 1].h;
+            const double inv_sx = (double)L.w / sw, inv_sy = (double)L.h / sh;
+            const double scale_x = 1. / inv_sx, scale_y = 1. / inv_sy;
+            for (int dx = 0; dx < L.w; dx++) {
+                float fx = (float)((dx + 0.5) * scale_x - 0.5);
+                int sx = host_cv_floor(fx);
+                fx -= sx;
+                if (sx < 0) { fx = 0; sx = 0; }
+                if (sx + 1 >= sw && sx >= sw - 1) { fx = 0; sx = sw - 1; }
+                const int a0 = clampi(host_cv_round((double)((1.f - fx) * 2048)), -32768, 32767);
+                const int a1 = clampi(host_cv_round((double)(fx * 2048)), -32768, 32767);
+                const int sx1 = std::min(sx + 1, sw - 1);
+                xtab.push_back(make_int2(sx | (sx1 << 16), (a0 & 0xffff) | (a1 << 16)));
+            }
+            for (int dy = 0; dy < L.h; dy++) {
+                float fy = (float)((dy + 0.5) * scale_y - 0.5);
+                int sy = host_cv_floor(fy);
+                fy -= sy;
+                const int b0 = clampi(host_cv_round((double)((1.f - fy) * 2048)), -32768, 32767);
+                const int b1 = clampi(host_cv_round((double)(fy * 2048)), -32768, 32767);
+                const int sy0 = clampi(sy, 0, sh - 1), sy1 = clampi(sy + 1, 0, sh - 1);
+                ytab.push_back(make_int2(sy0 | (sy1 << 16), (b0 & 0xffff) | (b1 << 16)));
+            }
+            // LDS extents of the worst 64x16 tile
+            int maxdw = 1, maxrows = 1;
+            const int2* xt = xtab.data() + L.xtab_off; const int2* yt = ytab.data() + L.ytab_off;
+            for (int tx = 0; tx < L.w; tx += RS_TW) {
+                const int x1 = std::min(tx + RS_TW, L.w) - 1;
+                const int xs0 = (xt[tx].x & 0xffff) & ~3, xs1 = xt[x1].x >> 16;
+                maxdw = std::max(maxdw, ((xs1 - xs0) >> 2) + 1);
+            }
+            for (int ty = 0; ty < L.h; ty += RS_TH) {
+                const int y1 = std::min(ty + RS_TH, L.h) - 1;
+                maxrows = std::max(maxrows, (yt[y1].x >> 16) - (yt[ty].x & 0xffff) + 1);
+            }
+            h->rs_pitch_dw[l] = maxdw; h->rs_rows[l] = maxrows;
+            if ((size_t)maxdw * maxrows * 4 > 60000) { set_error("resize tile does not fit LDS (scale factor too large)"); return VIORB_ERR_UNSUPPORTED; }
+        }
+        for (int ty = 0; ty < L.h; ty += BL_TH)
+            for (int tx = 0; tx < L.w; tx += BL_TW) h->blur_tiles.push_back(make_int4(l, tx, ty, 0));
+    }
+    h->frame_bytes = align_up(off, 256);
+    h->kp_pitch = kp_off;
+    int cap = 0; for (int l = 0; l < nl; l++) cap += h->quota[l] + 2;
+    h->out_cap = cap;
+    const int ncells = (int)h->cells.size();
+    if (ncells == 0) { set_error("image %dx%d too small for a FAST cell grid", w, hgt); return VIORB_ERR_UNSUPPORTED; }
+    // FAST LDS: tile rows x pitch (dword aligned start => up to 3 extra bytes) + score map
+    h->fast_tile_pitch = (int)align_up(max_cw + 3, 4) + 4;
+    h->fast_tile_rows = max_ch;
+    h->fast_score_bytes = (int)align_up((size_t)(max_cw - 6 + 2) * (max_ch - 6 + 2), 4);
+    h->slot_cap = ((max_cw - 6 + 1) / 2) * ((max_ch - 6 + 1) / 2);       // independent set of the king's graph
+    // quadtree capacities
+    int maxq = 1; for (int l = 0; l < nl; l++) maxq = std::max(maxq, h->quota[l]);
+    h->oct_ncap = 8192;
+    h->oct_nodecap = 5 * maxq + 64;
+    int sc = 1; while (sc < maxq + 8) sc <<= 1;
+    h->oct_sortcap = sc;
+    const size_t oct_lds = (size_t)h->oct_ncap * 4 + (size_t)h->oct_ncap * 4 + (size_t)h->oct_nodecap * sizeof(OctNode) + (size_t)sc * 4;
+    if (oct_lds > 160 * 1024 || h->oct_nodecap > 65535) { set_error("nfeatures too large for the LDS quadtree (%zu B)", oct_lds); return VIORB_ERR_UNSUPPORTED; }
+
+    const size_t B = (size_t)h->max_batch;
+    VIORB_HIP_TRY(hipMalloc(&h->d_planes, B * h->frame_bytes));
+    VIORB_HIP_TRY(hipMalloc(&h->d_blur, B * h->frame_bytes));
+    VIORB_HIP_TRY(hipMalloc(&h->d_lv, sizeof(LevelDev) * nl));
+    VIORB_HIP_TRY(hipMalloc(&h->d_cells, sizeof(CellDesc) * ncells));
+    VIORB_HIP_TRY(hipMalloc(&h->d_blur_tiles, sizeof(int4) * h->blur_tiles.size()));
+    VIORB_HIP_TRY(hipMalloc(&h->d_xtab, sizeof(int2) * std::max<size_t>(xtab.size(), 1)));
+    VIORB_HIP_TRY(hipMalloc(&h->d_ytab, sizeof(int2) * std::max<size_t>(ytab.size(), 1)));
+    VIORB_HIP_TRY(hipMalloc(&h->d_slots, B * ncells * h->slot_cap * sizeof(uint32_t)));
+    VIORB_HIP_TRY(hipMalloc(&h->d_cell_cnt, B * ncells * sizeof(int)));
+    VIORB_HIP_TRY(hipMalloc(&h->d_lvl_kp, B * h->kp_pitch * sizeof(uint32_t)));
+    VIORB_HIP_TRY(hipMalloc(&h->d_lvl_cnt, B * nl * sizeof(int)));
+    VIORB_HIP_TRY(hipMalloc(&h->d_lvl_ncand, B * nl * sizeof(int)));
+    VIORB_HIP_TRY(hipMalloc(&h->d_kps, B * h->out_cap * sizeof(viorb_keypoint)));
+    VIORB_HIP_TRY(hipMalloc(&h->d_desc, B * h->out_cap * 32));
+    VIORB_HIP_TRY(hipMalloc(&h->d_count, B * sizeof(int)));
+    VIORB_HIP_TRY(hipMalloc(&h->d_status, B * sizeof(int)));
+    VIORB_HIP_TRY(hipMemset(h->d_planes, 0, B * h->frame_bytes));
+    VIORB_HIP_TRY(hipMemset(h->d_blur, 0, B * h->frame_bytes));
+    VIORB_HIP_TRY(hipMemset(h->d_count, 0, B * sizeof(int)));
+    VIORB_HIP_TRY(hipMemset(h->d_status, 0, B * sizeof(int)));
+    VIORB_HIP_TRY(hipMemset(h->d_lvl_cnt, 0, B * nl * sizeof(int)));
+    VIORB_HIP_TRY(hipMemcpy(h->d_lv, h->lv.data(), sizeof(LevelDev) * nl, hipMemcpyHostToDevice));
+    VIORB_HIP_TRY(hipMemcpy(h->d_cells, h->cells.data(), sizeof(CellDesc) * ncells, hipMemcpyHostToDevice));
+    VIORB_HIP_TRY(hipMemcpy(h->d_blur_tiles, h->blur_tiles.data(), sizeof(int4) * h->blur_tiles.size(), hipMemcpyHostToDevice));
+    if (!xtab.empty()) VIORB_HIP_TRY(hipMemcpy(h->d_xtab, xtab.data(), sizeof(int2) * xtab.size(), hipMemcpyHostToDevice));
+    if (!ytab.empty()) VIORB_HIP_TRY(hipMemcpy(h->d_ytab, ytab.data(), sizeof(int2) * ytab.size(), hipMemcpyHostToDevice));
+    if (!h->tables_uploaded) {
+        int g[7];
+        {   // getGaussianKernel(7, 2, CV_32F) -> convertTo(CV_32S, 256)  (OpenCV 2.4)
+            float cf[7]; double sum = 0; const double s2 = -0.5 / (2.0 * 2.0);
+            for (int i = 0; i < 7; i++) { double x = i - 3.0; cf[i] = (float)exp(s2 * x * x); sum += cf[i]; }
+            sum = 1. / sum;
+            for (int i = 0; i < 7; i++) { cf[i] = (float)(cf[i] * sum); g[i] = host_cv_round((double)(cf[i] * 256.f)); }
+        }
+        uint32_t pat[256];
+        for (int i = 0; i < 256; i++)
+            pat[i] = (uint32_t)(uint8_t)kPatternHost[4 * i] | ((uint32_t)(uint8_t)kPatternHost[4 * i + 1] << 8) |
+                     ((uint32_t)(uint8_t)kPatternHost[4 * i + 2] << 16) | ((uint32_t)(uint8_t)kPatternHost[4 * i + 3] << 24);
+        VIORB_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_gauss), g, sizeof(g)));
+        VIORB_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_pattern), pat, sizeof(pat)));
+        VIORB_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_umax), h->umax, sizeof(int) * 16));
+        h->tables_uploaded = true;
+    }
+    h->img_w = w; h->img_h = hgt;
+    return VIORB_OK;
+}
+
+static int launch_all(viorb_extractor* h, const uint8_t* d_images, int batch, int stride, size_t pitch, hipStream_t st) {
+    const int nl = h->p.nlevels;
+    const int ncells = (int)h->cells.size();
+    const LevelDev& L0 = h->lv[0];
+    VIORB_HIP_TRY(hipMemsetAsync(h->d_status, 0, sizeof(int) * batch, st));
+    {
+        dim3 grid((L0.stride / 16 + 63) / 64, L0.h, batch);
+        hipLaunchKernelGGL(k_copy_level0, grid, dim3(64), 0, st, d_images, L0.w, L0.h, stride, pitch, h->d_planes, h->frame_bytes, L0.stride);
+    }
+    for (int l = 1; l < nl; l++) {
+        const LevelDev& L = h->lv[l];
+        dim3 grid((L.w + RS_TW - 1) / RS_TW, (L.h + RS_TH - 1) / RS_TH, batch);
+        const size_t lds = (size_t)h->rs_pitch_dw[l] * h->rs_rows[l] * 4;
+        hipLaunchKernelGGL(k_resize, grid, dim3(256), lds, st, h->d_planes, h->frame_bytes, h->d_lv, l, h->d_xtab, h->d_ytab,
+                           h->rs_pitch_dw[l], h->rs_rows[l]);
+    }
+    {
+        const size_t lds = (size_t)h->fast_tile_pitch * h->fast_tile_rows + h->fast_score_bytes;
+        hipLaunchKernelGGL(k_fast_cells, dim3(ncells, batch), dim3(64), lds, st, h->d_planes, h->frame_bytes, h->d_lv, h->d_cells,
+                           h->p.ini_th_fast, h->p.min_th_fast, h->d_slots, h->slot_cap, h->d_cell_cnt, ncells,
+                           h->fast_tile_pitch, h->fast_tile_rows, h->fast_score_bytes);
+    }
+    if (!h->host_octree) {
+        const size_t lds = (size_t)h->oct_ncap * 8 + (size_t)h->oct_nodecap * sizeof(OctNode) + (size_t)h->oct_sortcap * 4;
+        hipLaunchKernelGGL(k_octree, dim3(nl, batch), dim3(64), lds, st, h->d_lv, h->d_slots, h->slot_cap, h->d_cell_cnt, ncells,
+                           h->d_lvl_kp, h->kp_pitch, h->d_lvl_cnt, h->d_lvl_ncand, nl, h->d_status, h->oct_ncap, h->oct_nodecap,
+                           h->oct_sortcap);
+    } else {
+        // host stage (VIORB_OCTREE=host): download cell slots, run the array formulation on the CPU
+        VIORB_HIP_TRY(hipStreamSynchronize(st));
+        std::vector<int> cc((size_t)batch * ncells);
+        std::vector<uint32_t> sl((size_t)batch * ncells * h->slot_cap);
+        VIORB_HIP_TRY(hipMemcpy(cc.data(), h->d_cell_cnt, cc.size() * sizeof(int), hipMemcpyDeviceToHost));
+        VIORB_HIP_TRY(hipMemcpy(sl.data(), h->d_slots, sl.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        std::vector<uint32_t> kp((size_t)batch * h->kp_pitch, 0);
+        std::vector<int> lc((size_t)batch * nl, 0), nc((size_t)batch * nl, 0);
+        for (int b = 0; b < batch; b++)
+            for (int l = 0; l < nl; l++) {
+                const LevelDev& L = h->lv[l];
+                std::vector<uint32_t> keys;
+                for (int c = 0; c < L.ncells; c++) {
+                    const size_t ci = (size_t)b * ncells + L.cell_base + c;
+                    for (int k = 0; k < cc[ci]; k++) keys.push_back(sl[ci * h->slot_cap + k]);
+                }
+                nc[b * nl + l] = (int)keys.size();
+                std::vector<uint32_t> r = distribute_octree_arrays(keys, L.oct_w, L.oct_h, L.quota);
+                const int m = std::min((int)r.size(), L.quota + 4);
+                for (int k = 0; k < m; k++)
+                    kp[(size_t)b * h->kp_pitch + L.kp_off + k] = (r[k] & 0xff000000u) | ((((r[k] >> 12) & 0xfff) + MINB) << 12) | ((r[k] & 0xfff) + MINB);
+                lc[b * nl + l] = m;
+            }
+        VIORB_HIP_TRY(hipMemcpy(h->d_lvl_kp, kp.data(), kp.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        VIORB_HIP_TRY(hipMemcpy(h->d_lvl_cnt, lc.data(), lc.size() * sizeof(int), hipMemcpyHostToDevice));
+        VIORB_HIP_TRY(hipMemcpy(h->d_lvl_ncand, nc.data(), nc.size() * sizeof(int), hipMemcpyHostToDevice));
+    }
+    hipLaunchKernelGGL(k_blur, dim3((unsigned)h->blur_tiles.size(), batch), dim3(256), 0, st, h->d_planes, h->d_blur, h->frame_bytes,
+                       h->d_lv, h->d_blur_tiles);
+    hipLaunchKernelGGL(k_orient_describe, dim3((h->out_cap + 3) / 4, batch), dim3(256), 0, st, h->d_planes, h->d_blur, h->frame_bytes,
+                       h->d_lv, nl, h->d_lvl_kp, h->kp_pitch, h->d_lvl_cnt, h->d_kps, h->d_desc, h->out_cap, h->d_count);
+    VIORB_HIP_TRY(hipGetLastError());
+    h->last_stream = st; h->last_batch = batch;
+    return VIORB_OK;
+}
+
+extern "C" {
+
+int viorb_abi_version(void) { return 1; }
+const char* viorb_last_error(void) { return viorb::last_error_buf(); }
+int viorb_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int viorb_extractor_create(const viorb_extractor_params* params, int max_batch, int device, viorb_extractor** out) {
+    VIORB_REQUIRE(params && out, "null params/out");
+    VIORB_REQUIRE(params->nlevels >= 1 && params->nlevels <= MAX_LEVELS, "nlevels must be 1..16");
+    VIORB_REQUIRE(params->nfeatures >= 1 && params->scale_factor > 1.0f, "nfeatures >= 1, scale_factor > 1");
+    VIORB_REQUIRE(max_batch >= 1, "max_batch >= 1");
+    viorb_extractor* h = new viorb_extractor();
+    h->p = *params; h->max_batch = max_batch; h->device = device;
+    const char* e = getenv("VIORB_OCTREE");
+    h->host_octree = e && std::string(e) == "host";
+    const int nl = params->nlevels;
+    // reference :415-445 (scaleFactor is held in a double member there; float*double -> float)
+    const double sf = (double)params->scale_factor;
+    h->scale.resize(nl); h->sigma2.resize(nl); h->inv_scale.resize(nl); h->inv_sigma2.resize(nl); h->quota.resize(nl);
+    h->scale[0] = 1.f; h->sigma2[0] = 1.f;
+    for (int i = 1; i < nl; i++) { h->scale[i] = (float)(h->scale[i - 1] * sf); h->sigma2[i] = h->scale[i] * h->scale[i]; }
+    for (int i = 0; i < nl; i++) { h->inv_scale[i] = 1.0f / h->scale[i]; h->inv_sigma2[i] = 1.0f / h->sigma2[i]; }
+    const float factor = (float)(1.0f / sf);
+    float nd = params->nfeatures * (1 - factor) / (1 - (float)pow((double)factor, (double)nl));
+    int sum = 0;
+    for (int l = 0; l < nl - 1; l++) { h->quota[l] = host_cv_round(nd); sum += h->quota[l]; nd *= factor; }
+    h->quota[nl - 1] = std::max(params->nfeatures - sum, 0);
+    // umax (reference :452-469)
+    {
+        int v, v0, vmax = host_cv_floor(HALF_PATCH * sqrtf(2.f) / 2 + 1), vmin = host_cv_ceil(HALF_PATCH * sqrtf(2.f) / 2);
+        const double hp2 = HALF_PATCH * HALF_PATCH;
+        for (v = 0; v < 16; v++) h->umax[v] = 0;
+        for (v = 0; v <= vmax; ++v) h->umax[v] = host_cv_round(sqrt(hp2 - v * v));
+        for (v = HALF_PATCH, v0 = 0; v >= vmin; --v) { while (h->umax[v0] == h->umax[v0 + 1]) ++v0; h->umax[v] = v0; ++v0; }
+    }
+    *out = h;
+    return VIORB_OK;
+}
+
+int viorb_extractor_destroy(viorb_extractor* h) {
+    if (!h) return VIORB_OK;
+    if (h->d_planes) { (void)hipSetDevice(h->device); free_device(h); }
+    if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+    delete h;
+    return VIORB_OK;
+}
+
+int viorb_extractor_tables(const viorb_extractor* h, float* scale, float* inv_scale, float* sigma2, float* inv_sigma2,
+                           int32_t* fpl) {
+    VIORB_REQUIRE(h, "null handle");
+    for (int i = 0; i < h->p.nlevels; i++) {
+        if (scale) scale[i] = h->scale[i];
+        if (inv_scale) inv_scale[i] = h->inv_scale[i];
+        if (sigma2) sigma2[i] = h->sigma2[i];
+        if (inv_sigma2) inv_sigma2[i] = h->inv_sigma2[i];
+        if (fpl) fpl[i] = h->quota[i];
+    }
+    return VIORB_OK;
+}
+
+int viorb_extractor_max_keypoints(const viorb_extractor* h, int* cap) {
+    VIORB_REQUIRE(h && cap, "null handle/cap");
+    int c = 0; for (int l = 0; l < h->p.nlevels; l++) c += h->quota[l] + 2;
+    *cap = c;
+    return VIORB_OK;
+}
+
+static int ensure_device(viorb_extractor* h, int w, int hgt) {
+    if (viorb_device_count() < 1) { set_error("no HIP device: libviorb_hip has no CPU fallback"); return VIORB_ERR_NO_DEVICE; }
+    VIORB_HIP_TRY(hipSetDevice(h->device));
+    if (w != h->img_w || hgt != h->img_h || !h->d_planes) {
+        int rc = configure(h, w, hgt);
+        if (rc != VIORB_OK) { h->img_w = h->img_h = 0; return rc; }
+    }
+    return VIORB_OK;
+}
+
+int viorb_extract_batch_device(viorb_extractor* h, const uint8_t* d_images, int batch, int width, int height, int stride,
+                               size_t pitch, void* stream) {
+    VIORB_REQUIRE(h && d_images, "null handle/images");
+    VIORB_REQUIRE(batch >= 1 && batch <= h->max_batch, "batch out of range");
+    VIORB_REQUIRE(width > 0 && height > 0 && stride >= width, "bad image geometry");
+    int rc = ensure_device(h, width, height);
+    if (rc != VIORB_OK) return rc;
+    return launch_all(h, d_images, batch, stride, pitch, (hipStream_t)stream);
+}
+
+int viorb_extractor_results_device(const viorb_extractor* h, const viorb_keypoint** d_kps, const uint8_t** d_desc,
+                                   const int32_t** d_count, const int32_t** d_status, int* cap) {
+    VIORB_REQUIRE(h && h->d_kps, "no results yet");
+    if (d_kps) *d_kps = h->d_kps;
+    if (d_desc) *d_desc = h->d_desc;
+    if (d_count) *d_count = h->d_count;
+    if (d_status) *d_status = h->d_status;
+    if (cap) *cap = h->out_cap;
+    return VIORB_OK;
+}
+
+int viorb_extractor_download(viorb_extractor* h, int b, viorb_keypoint* kps, uint8_t* desc, int cap, int* n) {
+    VIORB_REQUIRE(h && h->d_kps && n, "no results yet");
+    VIORB_REQUIRE(b >= 0 && b < h->last_batch, "image index out of range");
+    VIORB_HIP_TRY(hipSetDevice(h->device));
+    VIORB_HIP_TRY(hipStreamSynchronize(h->last_stream));
+    int cnt = 0, st = 0;
+    VIORB_HIP_TRY(hipMemcpy(&cnt, h->d_count + b, sizeof(int), hipMemcpyDeviceToHost));
+    VIORB_HIP_TRY(hipMemcpy(&st, h->d_status + b, sizeof(int), hipMemcpyDeviceToHost));
+    *n = cnt;
+    const int m = std::min(cnt, cap);
+    if (m > 0 && kps) VIORB_HIP_TRY(hipMemcpy(kps, h->d_kps + (size_t)b * h->out_cap, sizeof(viorb_keypoint) * m, hipMemcpyDeviceToHost));
+    if (m > 0 && desc) VIORB_HIP_TRY(hipMemcpy(desc, h->d_desc + (size_t)b * h->out_cap * 32, (size_t)32 * m, hipMemcpyDeviceToHost));
+    if (st != VIORB_OK) { set_error("internal candidate/node capacity exceeded for image %d", b); return st; }
+    if (cnt > cap) { set_error("caller capacity %d < %d keypoints", cap, cnt); return VIORB_ERR_CAPACITY; }
+    return VIORB_OK;
+}
+
+int viorb_extract(viorb_extractor* h, const uint8_t* img, int width, int height, int stride, viorb_keypoint* kps,
+                  uint8_t* desc, int cap, int* n) {
+    VIORB_REQUIRE(h && n, "null handle/n");
+    *n = 0;
+    if (!img || width <= 0 || height <= 0) return VIORB_OK;       // reference :1046-1047
+    VIORB_REQUIRE(stride >= width, "stride < width");
+    int rc = ensure_device(h, width, height);
+    if (rc != VIORB_OK) return rc;
+    if (!h->own_stream) VIORB_HIP_TRY(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
+    const size_t bytes = (size_t)stride * height;
+    if (h->stage_bytes < bytes) {
+        if (h->d_stage) (void)hipFree(h->d_stage);
+        h->d_stage = nullptr; h->stage_bytes = 0;
+        VIORB_HIP_TRY(hipMalloc(&h->d_stage, bytes));
+        h->stage_bytes = bytes;
+    }
+    VIORB_HIP_TRY(hipMemcpyAsync(h->d_stage, img, bytes, hipMemcpyHostToDevice, h->own_stream));
+    rc = launch_all(h, h->d_stage, 1, stride, bytes, h->own_stream);
+    if (rc != VIORB_OK) return rc;
+    return viorb_extractor_download(h, 0, kps, desc, cap, n);
+}
+
+int viorb_extractor_level_device(const viorb_extractor* h, int b, int level, int blurred, const uint8_t** d_ptr, int* width,
+                                 int* height, int* stride) {
+    VIORB_REQUIRE(h && h->d_planes, "no pyramid yet");
+    VIORB_REQUIRE(level >= 0 && level < h->p.nlevels && b >= 0 && b < h->max_batch, "level/image out of range");
+    const LevelDev& L = h->lv[level];
+    if (d_ptr) *d_ptr = (blurred ? h->d_blur : h->d_planes) + (size_t)b * h->frame_bytes + L.plane_off;
+    if (width) *width = L.w;
+    if (height) *height = L.h;
+    if (stride) *stride = L.stride;
+    return VIORB_OK;
+}
+
+int viorb_extractor_level_download(viorb_extractor* h, int b, int level, int blurred, uint8_t* dst, int* width, int* height) {
+    const uint8_t* p = nullptr; int w = 0, hh = 0, s = 0;
+    int rc = viorb_extractor_level_device(h, b, level, blurred, &p, &w, &hh, &s);
+    if (rc != VIORB_OK) return rc;
+    VIORB_HIP_TRY(hipSetDevice(h->device));
+    VIORB_HIP_TRY(hipStreamSynchronize(h->last_stream));
+    if (dst) VIORB_HIP_TRY(hipMemcpy2D(dst, w, p, s, w, hh, hipMemcpyDeviceToHost));
+    if (width) *width = w;
+    if (height) *height = hh;
+    return VIORB_OK;
+}
+
+int viorb_extractor_debug_level_points(viorb_extractor* h, int b, int level, int which, int32_t* xyr, int cap, int* n) {
+    VIORB_REQUIRE(h && h->d_planes && n, "no results yet");
+    VIORB_REQUIRE(level >= 0 && level < h->p.nlevels && b >= 0 && b < h->last_batch, "level/image out of range");
+    VIORB_HIP_TRY(hipSetDevice(h->device));
+    VIORB_HIP_TRY(hipStreamSynchronize(h->last_stream));
+    const LevelDev& L = h->lv[level];
+    const int ncells = (int)h->cells.size();
+    std::vector<uint32_t> keys;
+    if (which == 0) {
+        std::vector<int> cc(L.ncells);
+        std::vector<uint32_t> sl((size_t)L.ncells * h->slot_cap);
+        if (L.ncells > 0) {
+            VIORB_HIP_TRY(hipMemcpy(cc.data(), h->d_cell_cnt + (size_t)b * ncells + L.cell_base, sizeof(int) * L.ncells, hipMemcpyDeviceToHost));
+            VIORB_HIP_TRY(hipMemcpy(sl.data(), h->d_slots + ((size_t)b * ncells + L.cell_base) * h->slot_cap, sl.size() * 4, hipMemcpyDeviceToHost));
+        }
+        for (int c = 0; c < L.ncells; c++)
+            for (int k = 0; k < cc[c]; k++) keys.push_back(sl[(size_t)c * h->slot_cap + k]);
+    } else {
+        int cnt = 0;
+        VIORB_HIP_TRY(hipMemcpy(&cnt, h->d_lvl_cnt + b * h->p.nlevels + level, sizeof(int), hipMemcpyDeviceToHost));
+        keys.resize(cnt);
+        if (cnt > 0) VIORB_HIP_TRY(hipMemcpy(keys.data(), h->d_lvl_kp + (size_t)b * h->kp_pitch + L.kp_off, sizeof(uint32_t) * cnt, hipMemcpyDeviceToHost));
+    }
+    *n = (int)keys.size();
+    for (int i = 0; i < (int)keys.size() && i < cap; i++) {
+        xyr[3 * i] = (int)(keys[i] & 0xfff); xyr[3 * i + 1] = (int)((keys[i] >> 12) & 0xfff); xyr[3 * i + 2] = (int)(keys[i] >> 24);
+    }
+    return VIORB_OK;
+}
+
+// Host-only test hooks (no GPU needed): the array formulation of the quadtree and the scalar math
+// used by the kernels, so the CPU test-suite can compare them with the oracle.
+int viorb_debug_octree_host(const uint32_t* keys, int n, int width, int height, int N, uint32_t* out, int cap, int* nout) {
+    VIORB_REQUIRE(keys && out && nout && n >= 0 && n <= 65535, "bad arguments");
+    std::vector<uint32_t> k(keys, keys + n);
+    std::vector<uint32_t> r = distribute_octree_arrays(k, width, height, N);
+    *nout = (int)r.size();
+    for (int i = 0; i < (int)r.size() && i < cap; i++) out[i] = r[i];
+    return VIORB_OK;
+}
+float viorb_debug_fast_atan2(float y, float x) { return fast_atan2_deg(y, x); }
+void viorb_debug_sincos(float r, float* s, float* c) { sincos_f32(r, s, c); }
+
+} // extern "C"

@@ -1,0 +1,32 @@
+// viorb_amd/csrc/viorb_common.h — error plumbing shared by the C-ABI translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+#include "../../include/viorb.h"
+
+namespace viorb {
+
+// thread-local last-error text (viorb_last_error())
+char* last_error_buf();
+void set_error(const char* fmt, ...);
+
+} // namespace viorb
+
+#define VIORB_HIP_TRY(expr)                                                                   \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess) {                                                               \
+            viorb::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, \
+                             __LINE__);                                                       \
+            return VIORB_ERR_HIP;                                                             \
+        }                                                                                     \
+    } while (0)
+
+#define VIORB_REQUIRE(cond, msg)                      \
+    do {                                              \
+        if (!(cond)) {                                \
+            viorb::set_error("invalid argument: %s", msg); \
+            return VIORB_ERR_INVALID_ARG;             \
+        }                                             \
+    } while (0)
