@@ -57,6 +57,14 @@ def lib():
         if not os.path.exists(SO_PATH):
             raise ImportError("%s not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
                               "(hipcc, gfx950). viorb_amd has no CPU fallback." % SO_PATH)
+        # One HIP runtime per process: PyTorch ships its own libamdhip64 (same SONAME as /opt/rocm's).
+        # If torch is going to be used in this process it must be loaded FIRST so that libviorb_hip.so
+        # binds to the runtime already in memory; loading ours first makes torch open a second runtime
+        # that then sees no GPU. C/C++ callers without torch are unaffected.
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
         L = C.CDLL(SO_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)

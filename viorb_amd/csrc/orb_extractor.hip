@@ -824,8 +824,15 @@ static int configure(viorb_extractor* h, int w, int hgt) {
     h->oct_nodecap = 5 * maxq + 64;
     int sc = 1; while (sc < maxq + 8) sc <<= 1;
     h->oct_sortcap = sc;
-    const size_t oct_lds = (size_t)h->oct_ncap * 4 + (size_t)h->oct_ncap * 4 + (size_t)h->oct_nodecap * sizeof(OctNode) + (size_t)sc * 4;
+    size_t oct_lds = (size_t)h->oct_ncap * 8 + (size_t)h->oct_nodecap * sizeof(OctNode) + (size_t)sc * 4;
     if (oct_lds > 160 * 1024 || h->oct_nodecap > 65535) { set_error("nfeatures too large for the LDS quadtree (%zu B)", oct_lds); return VIORB_ERR_UNSUPPORTED; }
+    if (oct_lds > 64 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_octree), hipFuncAttributeMaxDynamicSharedMemorySize, (int)oct_lds) != hipSuccess) {
+        (void)hipGetLastError();
+        h->oct_ncap = 4096;                              // stay inside the default 64 KiB dynamic-LDS window
+        oct_lds = (size_t)h->oct_ncap * 8 + (size_t)h->oct_nodecap * sizeof(OctNode) + (size_t)sc * 4;
+        if (oct_lds > 64 * 1024) { set_error("quadtree LDS (%zu B) exceeds the dynamic-LDS limit", oct_lds); return VIORB_ERR_UNSUPPORTED; }
+    }
 
     const size_t B = (size_t)h->max_batch;
     VIORB_HIP_TRY(hipMalloc(&h->d_planes, B * h->frame_bytes));
