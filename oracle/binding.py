@@ -154,3 +154,132 @@ def distribute_octree(keys, minX, maxX, minY, maxY, N):
     out = np.zeros(len(keys) + 8, KP_DTYPE)
     n = lib().ora_distribute_octree(_p(keys), len(keys), minX, maxX, minY, maxY, N, _p(out), len(out))
     return out[:n].copy()
+
+
+# ==================================================================================================
+# Visual-inertial part (oracle/vio.{h,cpp}); flat float64 layouts documented in oracle_capi.cpp
+# ==================================================================================================
+NS_LEN, PREINT_LEN, CAM_LEN = 22, 142, 16
+_vio_ready = False
+
+
+def _vio():
+    global _vio_ready
+    L = lib()
+    if not _vio_ready:
+        vp, i, d = C.c_void_p, C.c_int, C.c_double
+        L.ora_preintegrate.argtypes = [vp, i, vp, vp, d, d, vp]
+        L.ora_preint_update.argtypes = [vp, vp, vp, d]
+        L.ora_update_ns.argtypes = [vp, vp, vp]
+        L.ora_ns_inc_pvr.argtypes = [vp, vp]
+        L.ora_so3_exp.argtypes = [vp, vp]
+        L.ora_so3_log.argtypes = [vp, vp]
+        L.ora_so3_matrix.argtypes = [vp, vp]
+        L.ora_so3_from_matrix.argtypes = [vp, vp]
+        L.ora_jacobian_r.argtypes = [vp, vp, i]
+        L.ora_edge_pvr.argtypes = [vp] * 9
+        L.ora_edge_proj.argtypes = [vp] * 5
+        L.ora_edge_prior.argtypes = [vp] * 6
+        L.ora_pose_opt_vi_kf.argtypes = [vp, vp, vp, vp, vp, vp, i, i, vp, vp, vp, vp, vp, i]
+        L.ora_pose_opt_vi_frame.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i, vp, i, i, vp, vp, vp, vp, vp, vp, vp, i]
+        _vio_ready = True
+    return L
+
+
+def _f64(a, n=None):
+    a = np.ascontiguousarray(a, np.float64)
+    if n is not None:
+        assert a.size == n, (a.size, n)
+    return a
+
+
+def preintegrate(samples, bg, ba, t_last, t_cur):
+    """samples: [n,7] = gyro3, acc3, t. Returns preint[142]."""
+    s = _f64(samples).reshape(-1, 7)
+    out = np.zeros(PREINT_LEN)
+    _vio().ora_preintegrate(_p(s), len(s), _p(_f64(bg, 3)), _p(_f64(ba, 3)), float(t_last), float(t_cur), _p(out))
+    return out
+
+
+def preint_update(preint, omega, acc, dt):
+    p = _f64(preint, PREINT_LEN).copy()
+    _vio().ora_preint_update(_p(p), _p(_f64(omega, 3)), _p(_f64(acc, 3)), float(dt))
+    return p
+
+
+def update_ns(ns, preint, gw):
+    n = _f64(ns, NS_LEN).copy()
+    _vio().ora_update_ns(_p(n), _p(_f64(preint, PREINT_LEN)), _p(_f64(gw, 3)))
+    return n
+
+
+def ns_inc_pvr(ns, u9):
+    n = _f64(ns, NS_LEN).copy()
+    _vio().ora_ns_inc_pvr(_p(n), _p(_f64(u9, 9)))
+    return n
+
+
+def so3_exp(w):
+    q = np.zeros(4); _vio().ora_so3_exp(_p(_f64(w, 3)), _p(q)); return q
+
+
+def so3_log(q):
+    w = np.zeros(3); _vio().ora_so3_log(_p(_f64(q, 4)), _p(w)); return w
+
+
+def so3_matrix(q):
+    R = np.zeros(9); _vio().ora_so3_matrix(_p(_f64(q, 4)), _p(R)); return R.reshape(3, 3)
+
+
+def so3_from_matrix(R):
+    q = np.zeros(4); _vio().ora_so3_from_matrix(_p(_f64(R, 9)), _p(q)); return q
+
+
+def jacobian_r(w, inverse=False):
+    J = np.zeros(9); _vio().ora_jacobian_r(_p(_f64(w, 3)), _p(J), int(inverse)); return J.reshape(3, 3)
+
+
+def edge_pvr(ni, nj, nb, preint, gw, jac=True):
+    e, Ji, Jj, Jb = np.zeros(9), np.zeros(81), np.zeros(81), np.zeros(27)
+    _vio().ora_edge_pvr(_p(_f64(ni, 22)), _p(_f64(nj, 22)), _p(_f64(nb, 22)), _p(_f64(preint, 142)), _p(_f64(gw, 3)),
+                        _p(e), _p(Ji) if jac else None, _p(Jj), _p(Jb))
+    return e, Ji.reshape(9, 9), Jj.reshape(9, 9), Jb.reshape(9, 3)
+
+
+def edge_proj(ns, cam, obs, jac=True):
+    e, J = np.zeros(2), np.zeros(18)
+    _vio().ora_edge_proj(_p(_f64(ns, 22)), _p(_f64(cam, 16)), _p(_f64(obs, 6)), _p(e), _p(J) if jac else None)
+    return e, J.reshape(2, 9)
+
+
+def edge_prior(pvr, bias, prior, jac=True):
+    e, Jp, Jb = np.zeros(12), np.zeros(108), np.zeros(36)
+    _vio().ora_edge_prior(_p(_f64(pvr, 22)), _p(_f64(bias, 22)), _p(_f64(prior, 22)), _p(e), _p(Jp) if jac else None, _p(Jb))
+    return e, Jp.reshape(12, 9), Jb.reshape(12, 3)
+
+
+def _result(ns, ns_last, oc, ol, marg, info, trace):
+    return dict(ns=ns, ns_last=ns_last, outlier_cur=oc, outlier_last=ol, marg_cov_inv=marg.reshape(12, 12),
+                n_inliers=int(info[0]), final_chi2=float(info[1]), lm_iterations=int(info[2]),
+                chi2_trace=trace[:int(info[3])].copy())
+
+
+def pose_opt_vi_kf(cur, kf, preint, gw, cam, obs, marg=False):
+    """Optimizer::PoseOptimization(Frame*, KeyFrame*, ...) on the oracle. obs: [n,6] = Pw3,u,v,invSigma2."""
+    obs = _f64(obs).reshape(-1, 6)
+    ns, oc, mg, info, tr = np.zeros(22), np.zeros(max(len(obs), 1), np.uint8), np.zeros(144), np.zeros(4), np.zeros(64)
+    _vio().ora_pose_opt_vi_kf(_p(_f64(cur, 22)), _p(_f64(kf, 22)), _p(_f64(preint, 142)), _p(_f64(gw, 3)), _p(_f64(cam, 16)),
+                              _p(obs), len(obs), int(marg), _p(ns), _p(oc), _p(mg), _p(info), _p(tr), len(tr))
+    return _result(ns, None, oc[:len(obs)], None, mg, info, tr)
+
+
+def pose_opt_vi_frame(cur, last, prior, marg_cov_inv, preint, gw, cam, obs_cur, obs_last, marg=False):
+    """Optimizer::PoseOptimization(Frame*, Frame*, ...) on the oracle."""
+    oc_, ol_ = _f64(obs_cur).reshape(-1, 6), _f64(obs_last).reshape(-1, 6)
+    ns, nl = np.zeros(22), np.zeros(22)
+    oc, ol = np.zeros(max(len(oc_), 1), np.uint8), np.zeros(max(len(ol_), 1), np.uint8)
+    mg, info, tr = np.zeros(144), np.zeros(4), np.zeros(64)
+    _vio().ora_pose_opt_vi_frame(_p(_f64(cur, 22)), _p(_f64(last, 22)), _p(_f64(prior, 22)), _p(_f64(marg_cov_inv, 144)),
+                                 _p(_f64(preint, 142)), _p(_f64(gw, 3)), _p(_f64(cam, 16)), _p(oc_), len(oc_), _p(ol_), len(ol_),
+                                 int(marg), _p(ns), _p(nl), _p(oc), _p(ol), _p(mg), _p(info), _p(tr), len(tr))
+    return _result(ns, nl, oc[:len(oc_)], ol[:len(ol_)], mg, info, tr)

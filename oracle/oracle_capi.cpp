@@ -100,3 +100,109 @@ int ora_distribute_octree(const KeyPoint* keys, int n, int minX, int maxX, int m
 }
 
 } // extern "C"
+
+// =================================================================================================
+// Visual-inertial part (vio.h). Flat double layouts shared with include/viorb.h:
+//   navstate[22] = P3 V3 q4(x,y,z,w) bg3 ba3 dbg3 dba3
+//   preint[142]  = dP3 dV3 dR9 JPg9 JPa9 JVg9 JVa9 JRg9 cov81 dt        (matrices row-major)
+//   cam[16]      = fx fy cx cy Rbc9 Pbc3
+//   obs[n][6]    = Pw3 u v invSigma2
+// =================================================================================================
+#include "vio.h"
+namespace {
+V3 v3(const double* p) { return V3{p[0], p[1], p[2]}; }
+void put3(double* p, V3 v) { p[0] = v.x; p[1] = v.y; p[2] = v.z; }
+M3 m3(const double* p) { M3 m; for (int i = 0; i < 9; i++) m.m[i] = p[i]; return m; }
+void putm3(double* p, const M3& m) { for (int i = 0; i < 9; i++) p[i] = m.m[i]; }
+NavState ns_in(const double* p) {
+    NavState n; n.P = v3(p); n.V = v3(p + 3); n.R = SO3(Quat{p[6], p[7], p[8], p[9]});
+    n.bg = v3(p + 10); n.ba = v3(p + 13); n.dbg = v3(p + 16); n.dba = v3(p + 19); return n;
+}
+void ns_out(double* p, const NavState& n) {
+    put3(p, n.P); put3(p + 3, n.V); p[6] = n.R.q.x; p[7] = n.R.q.y; p[8] = n.R.q.z; p[9] = n.R.q.w;
+    put3(p + 10, n.bg); put3(p + 13, n.ba); put3(p + 16, n.dbg); put3(p + 19, n.dba);
+}
+Preint pre_in(const double* p) {
+    Preint M; M.dP = v3(p); M.dV = v3(p + 3); M.dR = m3(p + 6); M.JPg = m3(p + 15); M.JPa = m3(p + 24);
+    M.JVg = m3(p + 33); M.JVa = m3(p + 42); M.JRg = m3(p + 51);
+    for (int i = 0; i < 81; i++) M.cov.a[i] = p[60 + i];
+    M.dt = p[141]; return M;
+}
+void pre_out(double* p, const Preint& M) {
+    put3(p, M.dP); put3(p + 3, M.dV); putm3(p + 6, M.dR); putm3(p + 15, M.JPg); putm3(p + 24, M.JPa);
+    putm3(p + 33, M.JVg); putm3(p + 42, M.JVa); putm3(p + 51, M.JRg);
+    for (int i = 0; i < 81; i++) p[60 + i] = M.cov.a[i];
+    p[141] = M.dt;
+}
+Camera cam_in(const double* p) { Camera c; c.fx = p[0]; c.fy = p[1]; c.cx = p[2]; c.cy = p[3]; c.Rbc = m3(p + 4); c.Pbc = v3(p + 13); return c; }
+std::vector<Observation> obs_in(const double* p, int n) {
+    std::vector<Observation> o(n);
+    for (int i = 0; i < n; i++) { o[i].Pw = v3(p + 6 * i); o[i].u = p[6 * i + 3]; o[i].v = p[6 * i + 4]; o[i].inv_sigma2 = p[6 * i + 5]; }
+    return o;
+}
+void mat_out(double* p, const Mat& m) { for (size_t i = 0; i < m.a.size(); i++) p[i] = m.a[i]; }
+void result_out(const PoseOptResult& R, double* ns_cur, double* ns_last, uint8_t* oc, uint8_t* ol, double* marg144,
+                double* info4, double* trace, int trace_cap) {
+    ns_out(ns_cur, R.ns); if (ns_last) ns_out(ns_last, R.ns_last);
+    for (size_t i = 0; i < R.outlier_cur.size(); i++) oc[i] = R.outlier_cur[i];
+    if (ol) for (size_t i = 0; i < R.outlier_last.size(); i++) ol[i] = R.outlier_last[i];
+    if (marg144 && R.marg_cov_inv.r == 12) mat_out(marg144, R.marg_cov_inv);
+    info4[0] = R.n_inliers; info4[1] = R.final_chi2; info4[2] = R.lm_iterations; info4[3] = (double)R.chi2_trace.size();
+    for (int i = 0; i < (int)R.chi2_trace.size() && i < trace_cap; i++) trace[i] = R.chi2_trace[i];
+}
+} // namespace
+
+extern "C" {
+
+void ora_preintegrate(const double* samples7, int n, const double* bg, const double* ba, double t_last, double t_cur, double* out142) {
+    std::vector<ImuSample> s(n);
+    for (int i = 0; i < n; i++) { for (int k = 0; k < 3; k++) { s[i].g[k] = samples7[7 * i + k]; s[i].a[k] = samples7[7 * i + 3 + k]; } s[i].t = samples7[7 * i + 6]; }
+    Preint M; preintegrate(s.data(), n, v3(bg), v3(ba), t_last, t_cur, M);
+    pre_out(out142, M);
+}
+void ora_preint_update(double* preint142, const double* omega, const double* acc, double dt) {
+    Preint M = pre_in(preint142); M.update(v3(omega), v3(acc), dt); pre_out(preint142, M);
+}
+void ora_update_ns(double* ns22, const double* preint142, const double* gw) {
+    NavState n = ns_in(ns22); update_ns(n, pre_in(preint142), v3(gw)); ns_out(ns22, n);
+}
+void ora_ns_inc_pvr(double* ns22, const double* u9) { NavState n = ns_in(ns22); n.inc_small_pvr(u9); ns_out(ns22, n); }
+void ora_so3_exp(const double* w, double* q4) { SO3 r = SO3::exp(v3(w)); q4[0] = r.q.x; q4[1] = r.q.y; q4[2] = r.q.z; q4[3] = r.q.w; }
+void ora_so3_log(const double* q4, double* w) { put3(w, SO3(Quat{q4[0], q4[1], q4[2], q4[3]}).log()); }
+void ora_so3_matrix(const double* q4, double* R9) { putm3(R9, SO3(Quat{q4[0], q4[1], q4[2], q4[3]}).matrix()); }
+void ora_so3_from_matrix(const double* R9, double* q4) { SO3 r(m3(R9)); q4[0] = r.q.x; q4[1] = r.q.y; q4[2] = r.q.z; q4[3] = r.q.w; }
+void ora_jacobian_r(const double* w, double* J9, int inverse) { putm3(J9, inverse ? jacobian_r_inv(v3(w)) : jacobian_r(v3(w))); }
+
+void ora_edge_pvr(const double* i22, const double* j22, const double* b22, const double* preint142, const double* gw,
+                  double* e9, double* Ji81, double* Jj81, double* Jb27) {
+    NavState ni = ns_in(i22), nj = ns_in(j22), nb = ns_in(b22); Preint M = pre_in(preint142);
+    edge_pvr_error(ni, nj, nb, M, v3(gw), e9);
+    if (Ji81) { Mat Ji, Jj, Jb; edge_pvr_jacobians(ni, nj, nb, M, v3(gw), e9, Ji, Jj, Jb); mat_out(Ji81, Ji); mat_out(Jj81, Jj); mat_out(Jb27, Jb); }
+}
+void ora_edge_proj(const double* ns22, const double* cam16, const double* obs6, double* e2, double* J18) {
+    NavState n = ns_in(ns22); Camera c = cam_in(cam16); Observation o = obs_in(obs6, 1)[0];
+    edge_proj_error(n, c, o, e2);
+    if (J18) { Mat J; edge_proj_jacobian(n, c, o, J); mat_out(J18, J); }
+}
+void ora_edge_prior(const double* pvr22, const double* bias22, const double* prior22, double* e12, double* Jp108, double* Jb36) {
+    NavState p = ns_in(pvr22), b = ns_in(bias22), pr = ns_in(prior22);
+    edge_prior_error(p, b, pr, e12);
+    if (Jp108) { Mat Jp, Jb; edge_prior_jacobians(p, e12, Jp, Jb); mat_out(Jp108, Jp); mat_out(Jb36, Jb); }
+}
+void ora_pose_opt_vi_kf(const double* cur22, const double* kf22, const double* preint142, const double* gw, const double* cam16,
+                        const double* obs6, int n, int marg, double* out_ns22, uint8_t* outlier, double* marg144,
+                        double* info4, double* trace, int trace_cap) {
+    PoseOptResult R = pose_opt_vi_kf(ns_in(cur22), ns_in(kf22), pre_in(preint142), v3(gw), cam_in(cam16), obs_in(obs6, n), marg != 0);
+    result_out(R, out_ns22, nullptr, outlier, nullptr, marg144, info4, trace, trace_cap);
+}
+void ora_pose_opt_vi_frame(const double* cur22, const double* last22, const double* prior22, const double* margcovinv144,
+                           const double* preint142, const double* gw, const double* cam16, const double* obs_cur6, int ncur,
+                           const double* obs_last6, int nlast, int marg, double* out_ns22, double* out_last22,
+                           uint8_t* outlier_cur, uint8_t* outlier_last, double* marg144, double* info4, double* trace, int trace_cap) {
+    Mat mci(12, 12); for (int i = 0; i < 144; i++) mci.a[i] = margcovinv144[i];
+    PoseOptResult R = pose_opt_vi_frame(ns_in(cur22), ns_in(last22), ns_in(prior22), mci, pre_in(preint142), v3(gw), cam_in(cam16),
+                                        obs_in(obs_cur6, ncur), obs_in(obs_last6, nlast), marg != 0);
+    result_out(R, out_ns22, out_last22, outlier_cur, outlier_last, marg144, info4, trace, trace_cap);
+}
+
+} // extern "C"

@@ -1,0 +1,218 @@
+"""Pins the oracle's visual-inertial restatement (oracle/vio.cpp) with independent definitional checks:
+scipy rotations, central-difference Jacobians, brute-force integration, and an independent numpy/scipy
+re-optimisation of the final pose-optimisation objective."""
+import numpy as np
+import pytest
+from scipy.spatial.transform import Rotation
+from scipy.optimize import least_squares
+from viorb_amd.synth import make_vio_problem, GRAVITY_W
+
+
+def R_of(ns):
+    return Rotation.from_quat(ns[6:10]).as_matrix()
+
+
+def test_so3_exp_log_jacobians(oracle):
+    rng = np.random.default_rng(0)
+    for _ in range(200):
+        w = rng.normal(0, 1.0, 3) * rng.choice([1e-12, 1e-6, 0.1, 1.0])
+        q = oracle.so3_exp(w)
+        np.testing.assert_allclose(oracle.so3_matrix(q), Rotation.from_rotvec(w).as_matrix(), atol=1e-12)
+        if np.linalg.norm(w) < 3.0:
+            np.testing.assert_allclose(oracle.so3_log(q), w, atol=1e-9)
+        np.testing.assert_allclose(oracle.so3_matrix(oracle.so3_from_matrix(Rotation.from_rotvec(w).as_matrix())),
+                                   Rotation.from_rotvec(w).as_matrix(), atol=1e-12)
+    for _ in range(50):                       # Jr: Exp(w + d) ~ Exp(w) Exp(Jr d);  JrInv = Jr^-1
+        w = rng.normal(0, 0.7, 3)
+        Jr, Jri = oracle.jacobian_r(w), oracle.jacobian_r(w, inverse=True)
+        np.testing.assert_allclose(Jr @ Jri, np.eye(3), atol=1e-9)
+        d = rng.normal(0, 1e-6, 3)
+        lhs = Rotation.from_rotvec(w + d).as_matrix()
+        rhs = Rotation.from_rotvec(w).as_matrix() @ Rotation.from_rotvec(Jr @ d).as_matrix()
+        np.testing.assert_allclose(lhs, rhs, atol=1e-11)
+
+
+def test_preintegration_against_direct_integration(oracle):
+    """Delta R/V/P of Forster pre-integration == piecewise-constant integration of the same samples."""
+    p = make_vio_problem(3, n_imu=30)
+    bg, ba = p["ns_last"][10:13], p["ns_last"][13:16]
+    pre = oracle.preintegrate(p["imu"], bg, ba, p["t_last"], p["t_cur"])
+    ts = np.concatenate([[p["t_last"]], p["imu"][:, 6]])
+    seg = [(p["imu"][0], p["imu"][0, 6] - p["t_last"])]
+    for i in range(len(p["imu"])):
+        nxt = p["t_cur"] if i == len(p["imu"]) - 1 else p["imu"][i + 1, 6]
+        seg.append((p["imu"][i], nxt - p["imu"][i, 6]))
+    R, V, P, T = np.eye(3), np.zeros(3), np.zeros(3), 0.0
+    for s, dt in seg:
+        w, a = s[:3] - bg, s[3:6] - ba
+        P = P + V * dt + 0.5 * R @ a * dt * dt
+        V = V + R @ a * dt
+        R = R @ Rotation.from_rotvec(w * dt).as_matrix()
+        T += dt
+    assert abs(pre[141] - T) < 1e-12 and abs(T - (p["t_cur"] - p["t_last"])) < 1e-9
+    np.testing.assert_allclose(pre[:3], P, atol=1e-12)
+    np.testing.assert_allclose(pre[3:6], V, atol=1e-12)
+    np.testing.assert_allclose(pre[6:15].reshape(3, 3), R, atol=1e-12)
+    cov = pre[60:141].reshape(9, 9)
+    np.testing.assert_allclose(cov, cov.T, atol=1e-18)
+    assert np.linalg.eigvalsh(cov).min() > 0
+    # bias Jacobians: re-integrate with a perturbed bias, compare with the first-order correction
+    d = np.array([1e-5, -2e-5, 1.5e-5])
+    pre_a = oracle.preintegrate(p["imu"], bg, ba + d, p["t_last"], p["t_cur"])
+    np.testing.assert_allclose(pre_a[:3] - pre[:3], pre[24:33].reshape(3, 3) @ d, atol=1e-10)
+    np.testing.assert_allclose(pre_a[3:6] - pre[3:6], pre[42:51].reshape(3, 3) @ d, atol=1e-10)
+    pre_g = oracle.preintegrate(p["imu"], bg + d, ba, p["t_last"], p["t_cur"])
+    np.testing.assert_allclose(pre_g[:3] - pre[:3], pre[15:24].reshape(3, 3) @ d, atol=1e-9)
+    np.testing.assert_allclose(pre_g[3:6] - pre[3:6], pre[33:42].reshape(3, 3) @ d, atol=1e-9)
+    dR = pre[6:15].reshape(3, 3).T @ pre_g[6:15].reshape(3, 3)
+    np.testing.assert_allclose(Rotation.from_matrix(dR).as_rotvec(), pre[51:60].reshape(3, 3) @ d, atol=1e-9)
+
+
+def test_update_ns_predicts_ground_truth(oracle):
+    p = make_vio_problem(5)
+    pre = oracle.preintegrate(p["imu"], p["ns_last_true"][10:13], p["ns_last_true"][13:16], p["t_last"], p["t_cur"])
+    cur = oracle.update_ns(p["ns_last_true"], pre, p["gw"])
+    np.testing.assert_allclose(cur[:3], p["ns_cur_true"][:3], atol=2e-4)       # only IMU noise + discretisation
+    np.testing.assert_allclose(cur[3:6], p["ns_cur_true"][3:6], atol=5e-3)
+    np.testing.assert_allclose(R_of(cur), R_of(p["ns_cur_true"]), atol=5e-4)
+
+
+def numeric_jac(f, ns, dim, inc, eps=1e-6):
+    e0 = f(ns)
+    J = np.zeros((len(e0), dim))
+    for k in range(dim):
+        u = np.zeros(dim); u[k] = eps
+        J[:, k] = (f(inc(ns, u)) - f(inc(ns, -u))) / (2 * eps)
+    return J
+
+
+def inc_bias(ns, u):
+    n = ns.copy(); n[19:22] += u; return n
+
+
+def test_edge_jacobians_match_central_differences(oracle):
+    p = make_vio_problem(7)
+    pre = oracle.preintegrate(p["imu"], p["ns_last"][10:13], p["ns_last"][13:16], p["t_last"], p["t_cur"])
+    ni = p["ns_last"].copy(); ni[19:22] = [1e-3, -2e-3, 5e-4]
+    nj = oracle.update_ns(p["ns_last"], pre, p["gw"])
+    nj = oracle.ns_inc_pvr(nj, np.array([0.01, -0.02, 0.015, 0.03, 0.01, -0.02, 0.01, -0.008, 0.012]))
+    e, Ji, Jj, Jb = oracle.edge_pvr(ni, nj, ni, pre, p["gw"])
+    f = lambda a, b, c: oracle.edge_pvr(a, b, c, pre, p["gw"], jac=False)[0]
+    # rotation-residual rows are exact only to first order in the residual itself: loose tolerance there
+    np.testing.assert_allclose(Ji, numeric_jac(lambda n: f(n, nj, ni), ni, 9, oracle.ns_inc_pvr), atol=2e-3, rtol=1e-3)
+    np.testing.assert_allclose(Jj, numeric_jac(lambda n: f(ni, n, ni), nj, 9, oracle.ns_inc_pvr), atol=2e-3, rtol=1e-3)
+    np.testing.assert_allclose(Jb, numeric_jac(lambda n: f(ni, nj, n), ni, 3, inc_bias), atol=1e-6, rtol=1e-6)
+    for k in range(5):
+        e2, J = oracle.edge_proj(nj, p["cam"], p["obs_cur"][k])
+        Jn = numeric_jac(lambda n: oracle.edge_proj(n, p["cam"], p["obs_cur"][k], jac=False)[0], nj, 9, oracle.ns_inc_pvr)
+        np.testing.assert_allclose(J, Jn, atol=1e-4, rtol=1e-5)
+        assert np.abs(J[:, 3:6]).max() == 0                                   # velocity block is zero
+    prior = oracle.ns_inc_pvr(ni, np.array([0.02, 0.01, -0.01, 0.02, -0.03, 0.01, 0.004, -0.006, 0.003]))
+    e12, Jp, Jbb = oracle.edge_prior(ni, ni, prior)
+    np.testing.assert_allclose(Jp, numeric_jac(lambda n: oracle.edge_prior(n, ni, prior, jac=False)[0], ni, 9, oracle.ns_inc_pvr), atol=1e-5, rtol=1e-5)
+    np.testing.assert_allclose(Jbb, numeric_jac(lambda n: oracle.edge_prior(ni, n, prior, jac=False)[0], ni, 3, inc_bias), atol=1e-7)
+
+
+def test_pvr_residual_is_zero_on_noise_free_motion(oracle):
+    p = make_vio_problem(11)
+    pre = oracle.preintegrate(p["imu"], p["ns_last_true"][10:13], p["ns_last_true"][13:16], p["t_last"], p["t_cur"])
+    cur = oracle.update_ns(p["ns_last_true"], pre, p["gw"])
+    e = oracle.edge_pvr(p["ns_last_true"], cur, p["ns_last_true"], pre, p["gw"], jac=False)[0]
+    assert np.abs(e).max() < 1e-9
+
+
+def independent_kf_objective(p, pre, kf, inl):
+    """Final-round objective of PoseOptimization(Frame, KeyFrame): inlier reprojection chi2 (no kernel) +
+    Huber(IMU factor) + Huber(bias factor), written from the model definition with scipy rotations."""
+    cam = p["cam"]; fx, fy, cx, cy = cam[:4]; Rbc, Pbc = cam[4:13].reshape(3, 3), cam[13:16]
+    dT = pre[141]; dP, dV, dR = pre[:3], pre[3:6], pre[6:15].reshape(3, 3)
+    JPa, JVa = pre[24:33].reshape(3, 3), pre[42:51].reshape(3, 3)
+    cov = pre[60:141].reshape(9, 9)
+    info = np.linalg.inv(cov) + np.diag([1e2] * 3 + [1] * 3 + [1e2] * 3)
+    Li = np.linalg.cholesky(info)
+    Ri, Pi, Vi = R_of(kf), kf[:3], kf[3:6]
+    obs = p["obs_cur"][inl]
+
+    def huber_sqrt(chi2, delta):          # residual r with r^2 = rho(chi2)
+        return np.sqrt(chi2) if chi2 <= delta * delta else np.sqrt(2 * np.sqrt(chi2) * delta - delta * delta)
+
+    def unpack(x, base):
+        P = base[:3] + R_of(base) @ x[:3]; V = base[3:6] + x[3:6]
+        R = R_of(base) @ Rotation.from_rotvec(x[6:9]).as_matrix()
+        dba = base[19:22] + x[9:12]
+        return P, V, R, dba
+
+    def residuals(x, base):
+        P, V, R, dba = unpack(x, base)
+        Pc = (Rbc.T @ (R.T @ (obs[:, :3] - P).T)).T - Rbc.T @ Pbc
+        r = np.stack([obs[:, 3] - (fx * Pc[:, 0] / Pc[:, 2] + cx), obs[:, 4] - (fy * Pc[:, 1] / Pc[:, 2] + cy)], 1) * np.sqrt(obs[:, 5:6])
+        rP = Ri.T @ (P - Pi - Vi * dT - 0.5 * GRAVITY_W * dT * dT) - (dP + JPa @ kf[19:22])
+        rV = Ri.T @ (V - Vi - GRAVITY_W * dT) - (dV + JVa @ kf[19:22])
+        rR = Rotation.from_matrix(dR.T @ Ri.T @ R).as_rotvec()
+        e9 = np.concatenate([rP, rV, rR])
+        chi_imu = e9 @ info @ e9
+        w = Li.T @ e9
+        w = w / np.linalg.norm(w) * huber_sqrt(chi_imu, np.float32(np.sqrt(21.666))) if chi_imu > 0 else w
+        eb = (base[13:16] + dba) - (kf[13:16] + kf[19:22])
+        chi_b = eb @ eb / (5e-3 ** 2) / dT
+        wb = eb / (np.linalg.norm(eb) + 1e-300) * huber_sqrt(chi_b, np.float32(np.sqrt(16.812)))
+        return np.concatenate([r.ravel(), w, wb])
+    return residuals
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_pose_opt_kf_final_cost_is_the_optimum(oracle, seed):
+    p = make_vio_problem(seed)
+    kf = p["ns_last"]
+    pre = oracle.preintegrate(p["imu"], kf[10:13], kf[13:16], p["t_last"], p["t_cur"])
+    cur0 = oracle.update_ns(kf, pre, p["gw"])
+    r = oracle.pose_opt_vi_kf(cur0, kf, pre, p["gw"], p["cam"], p["obs_cur"], marg=True)
+    assert r["n_inliers"] == int((r["outlier_cur"] == 0).sum()) and 4 <= r["lm_iterations"] <= 40
+    # rounds 3 and 4 optimise different inlier sets; the LAST round used the classification made after round 3.
+    # Re-derive that set: an edge is an inlier of round 4 iff its chi2 at round 3's solution was <= 5.991; the
+    # final flags are the round-4 re-classification. Use the objective on the final flags' complement and check
+    # stationarity instead of exact set equality: the optimum of the final-flag objective must be within LM's
+    # stopping tolerance of the oracle's solution when both sets agree, which they do for these seeds.
+    inl = r["outlier_cur"] == 0
+    f = independent_kf_objective(p, pre, kf, inl)
+    x0 = np.zeros(12)
+    base = r["ns"].copy(); base[19:22] = r["ns"][19:22]
+    c_oracle = float((f(x0, base) ** 2).sum())
+    sol = least_squares(f, x0, args=(base,), method="lm", xtol=1e-14, ftol=1e-14, gtol=1e-14)
+    c_best = float((sol.fun ** 2).sum())
+    assert c_best <= c_oracle * (1 + 1e-12)
+    assert (c_oracle - c_best) / c_best < 2e-3           # g2o stops after 3 iterations with <0.1% gain each
+    assert np.abs(sol.x[:3]).max() < 2e-3 and np.abs(sol.x[6:9]).max() < 2e-3
+    # marginal information is symmetric positive definite and block diagonal (9 + 3)
+    M = r["marg_cov_inv"]
+    np.testing.assert_allclose(M, M.T, rtol=1e-6, atol=1e-6 * np.abs(M).max())
+    assert np.abs(M[:9, 9:]).max() == 0 and np.linalg.eigvalsh((M + M.T) / 2).min() > 0
+
+
+def test_pose_opt_frame_variant_recovers_truth_and_flags_outliers(oracle):
+    ok_pos, agree = [], []
+    for seed in range(4):
+        p = make_vio_problem(seed)
+        last = p["ns_last"]
+        pre = oracle.preintegrate(p["imu"], last[10:13], last[13:16], p["t_last"], p["t_cur"])
+        cur0 = oracle.update_ns(last, pre, p["gw"])
+        r = oracle.pose_opt_vi_frame(cur0, last, p["prior"], p["marg_cov_inv"], pre, p["gw"], p["cam"], p["obs_cur"], p["obs_last"], marg=True)
+        ok_pos.append(np.linalg.norm(r["ns"][:3] - p["ns_cur_true"][:3]))
+        agree.append((r["outlier_cur"].astype(bool) | ~p["outlier_cur_true"]).mean())   # every true outlier is flagged
+        assert np.all(np.diff(r["chi2_trace"][:5]) <= 1e-9)                              # LM never accepts an increase
+        M = r["marg_cov_inv"]
+        assert np.linalg.eigvalsh((M + M.T) / 2).min() > 0
+        assert r["n_inliers"] == int((r["outlier_cur"] == 0).sum())
+    assert max(ok_pos) < 0.01 and min(agree) > 0.99
+
+
+def test_pose_opt_degenerate_inputs(oracle):
+    p = make_vio_problem(2)
+    last = p["ns_last"]
+    pre = oracle.preintegrate(p["imu"], last[10:13], last[13:16], p["t_last"], p["t_cur"])
+    cur0 = oracle.update_ns(last, pre, p["gw"])
+    r = oracle.pose_opt_vi_kf(cur0, last, pre, p["gw"], p["cam"], p["obs_cur"][:2])
+    assert r["n_inliers"] == 0 and np.array_equal(r["ns"], cur0 * 0 + r["ns"])      # < 3 correspondences: returns 0
+    np.testing.assert_allclose(r["ns"][:10], cur0[:10], atol=1e-15)
+    r = oracle.pose_opt_vi_kf(cur0, last, pre, p["gw"], p["cam"], p["obs_cur"][:6])   # < 10 edges: one round only
+    assert r["lm_iterations"] <= 10

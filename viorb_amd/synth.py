@@ -61,3 +61,109 @@ def make_stream(seed, n_frames, w=752, h=480):
         dx += rng.uniform(-4, 4); dy += rng.uniform(-3, 3); roll += rng.uniform(-0.7, 0.7)
         dx, dy, roll = np.clip(dx, -10, 10), np.clip(dy, -10, 10), np.clip(roll, -3, 3)
     return frames, motions
+
+
+# ==================================================================================================
+# Synthetic visual-inertial problems: one "last frame -> current frame" step.
+# Flat layouts (shared with include/viorb.h):
+#   navstate[22] = P3 V3 q4(x,y,z,w) bg3 ba3 dbg3 dba3 ; cam[16] = fx fy cx cy Rbc9 Pbc3
+#   obs[n,6] = Pw3 u v invSigma2 ; imu[n,7] = gyro3 acc3 t
+# ==================================================================================================
+EUROC_TBC = np.array([[0.0148655429818, -0.999880929698, 0.00414029679422, -0.0216401454975],
+                      [0.999557249008, 0.0149672133247, 0.025715529948, -0.064676986768],
+                      [-0.0257744366974, 0.00375618835797, 0.999660727178, 0.00981073058949],
+                      [0.0, 0.0, 0.0, 1.0]])       # reference Examples/ROS/ORB_VIO/launch/euroc.yaml Camera.Tbc
+GRAVITY_W = np.array([0.0, 0.0, -9.81])
+
+
+def _rotvec_to_R(w):
+    th = np.linalg.norm(w)
+    if th < 1e-12:
+        return np.eye(3)
+    k = w / th
+    K = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+    return np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * K @ K
+
+
+def _R_to_quat(R):
+    from scipy.spatial.transform import Rotation
+    q = Rotation.from_matrix(R).as_quat()           # x, y, z, w
+    return q if q[3] >= 0 else -q
+
+
+def euroc_cam():
+    R = EUROC_TBC[:3, :3]
+    u, _, vt = np.linalg.svd(R)                     # yaml values are 12-digit: re-orthonormalise
+    R = u @ vt
+    return np.concatenate([[EUROC_K["fx"], EUROC_K["fy"], EUROC_K["cx"], EUROC_K["cy"]], R.ravel(), EUROC_TBC[:3, 3]])
+
+
+def navstate(P, V, R, bg=(0, 0, 0), ba=(0, 0, 0)):
+    return np.concatenate([P, V, _R_to_quat(R), bg, ba, np.zeros(3), np.zeros(3)]).astype(np.float64)
+
+
+def make_vio_problem(seed, n_points=300, outlier_frac=0.05, n_imu=10, w=752, h=480, pix_sigma=1.0):
+    """One tracking step with ground truth: last frame at t0, current frame at t0 + n_imu*5 ms."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    cam = euroc_cam()
+    fx, fy, cx, cy = cam[:4]
+    Rbc, Pbc = cam[4:13].reshape(3, 3), cam[13:16]
+    dt = 0.005
+    T = n_imu * dt
+    R0 = _rotvec_to_R(rng.normal(0, 0.4, 3))
+    P0 = rng.normal(0, 1.0, 3)
+    V0 = rng.normal(0, 0.5, 3)
+    omega = rng.normal(0, 0.1, 3)                   # body rate, constant over the step
+    a_w = rng.normal(0, 0.5, 3)                     # world acceleration, constant over the step
+    bg = rng.normal(0, 0.002, 3)
+    ba = rng.normal(0, 0.02, 3)
+    t0 = 100.0 + seed * 0.05
+    ts = t0 + dt * (np.arange(n_imu) + 0.3)         # IMU stamps are not aligned with the frame stamps
+    imu = np.zeros((n_imu, 7))
+    for k, t in enumerate(ts):
+        Rt = R0 @ _rotvec_to_R(omega * (t - t0))
+        imu[k, :3] = omega + bg + rng.normal(0, 1e-3, 3)
+        imu[k, 3:6] = Rt.T @ (a_w - GRAVITY_W) + ba + rng.normal(0, 1e-2, 3)
+        imu[k, 6] = t
+    t1 = t0 + T
+    R1 = R0 @ _rotvec_to_R(omega * T)
+    P1 = P0 + V0 * T + 0.5 * a_w * T * T
+    V1 = V0 + a_w * T
+
+    def project(Rwb, Pwb, Pw):
+        Pc = (Rbc.T @ (Rwb.T @ (Pw - Pwb).T)).T - Rbc.T @ Pbc
+        return np.stack([fx * Pc[:, 0] / Pc[:, 2] + cx, fy * Pc[:, 1] / Pc[:, 2] + cy], 1), Pc[:, 2]
+
+    # points seen from the current camera, then kept if also inside the last image
+    uv = np.stack([rng.uniform(20, w - 20, 4 * n_points), rng.uniform(20, h - 20, 4 * n_points)], 1)
+    z = rng.uniform(2, 10, len(uv))
+    Pc = np.stack([(uv[:, 0] - cx) / fx * z, (uv[:, 1] - cy) / fy * z, z], 1)
+    Pw = (R1 @ (Rbc @ (Pc + Rbc.T @ Pbc).T)).T + P1
+    uv0, z0 = project(R0, P0, Pw)
+    ok = (z0 > 0.5) & (uv0[:, 0] > 20) & (uv0[:, 0] < w - 20) & (uv0[:, 1] > 20) & (uv0[:, 1] < h - 20)
+    Pw, uv, uv0 = Pw[ok][:n_points], uv[ok][:n_points], uv0[ok][:n_points]
+    n = len(Pw)
+    octave = rng.integers(0, 8, n)
+    sig = (1.2 ** octave) * pix_sigma
+    inv_sigma2 = (1.0 / (np.float32(1.2) ** octave).astype(np.float32) ** 2).astype(np.float64)
+
+    def observe(uvt, salt):
+        r = np.random.Generator(np.random.PCG64(seed * 7 + salt))
+        o = uvt + r.normal(0, 1, uvt.shape) * sig[:, None]
+        bad = r.random(n) < outlier_frac
+        o[bad] += r.choice([-1, 1], (bad.sum(), 2)) * r.uniform(15, 25, (bad.sum(), 2))
+        return np.float32(o).astype(np.float64), bad                       # keypoints are float32 in the reference
+
+    oc, bad_c = observe(uv, 1)
+    ol, bad_l = observe(uv0, 2)
+    obs_cur = np.concatenate([Pw, oc, inv_sigma2[:, None]], 1)
+    obs_last = np.concatenate([Pw, ol, inv_sigma2[:, None]], 1)
+    ns_last_true = navstate(P0, V0, R0, bg, ba)
+    ns_cur_true = navstate(P1, V1, R1, bg, ba)
+    # what tracking would hold: last state slightly off, bias estimate slightly off
+    ns_last = navstate(P0 + rng.normal(0, 0.01, 3), V0 + rng.normal(0, 0.02, 3), R0 @ _rotvec_to_R(rng.normal(0, 0.003, 3)),
+                       bg + rng.normal(0, 2e-4, 3), ba + rng.normal(0, 5e-3, 3))
+    prior_info = np.diag(np.concatenate([np.full(3, 1e4), np.full(3, 1e3), np.full(3, 1e5), np.full(3, 1e3)]))
+    return dict(cam=cam, gw=GRAVITY_W.copy(), imu=imu, t_last=t0, t_cur=t1, ns_last=ns_last, ns_last_true=ns_last_true,
+                ns_cur_true=ns_cur_true, obs_cur=obs_cur, obs_last=obs_last, outlier_cur_true=bad_c, outlier_last_true=bad_l,
+                prior=ns_last.copy(), marg_cov_inv=prior_info, octave=octave)
