@@ -283,3 +283,58 @@ def pose_opt_vi_frame(cur, last, prior, marg_cov_inv, preint, gw, cam, obs_cur, 
                                  _p(_f64(preint, 142)), _p(_f64(gw, 3)), _p(_f64(cam, 16)), _p(oc_), len(oc_), _p(ol_), len(ol_),
                                  int(marg), _p(ns), _p(nl), _p(oc), _p(ol), _p(mg), _p(info), _p(tr), len(tr))
     return _result(ns, nl, oc[:len(oc_)], ol[:len(ol_)], mg, info, tr)
+
+
+# ==================================================================================================
+# Matcher (oracle/orb_matcher.{h,cpp})
+# ==================================================================================================
+_match_ready = False
+
+
+def _match():
+    global _match_ready
+    L = lib()
+    if not _match_ready:
+        vp, i, f = C.c_void_p, C.c_int, C.c_float
+        L.ora_descriptor_distance.argtypes = [vp, vp]
+        L.ora_frame_grid.argtypes = [vp, i, f, f, f, f, vp, vp]
+        L.ora_features_in_area.argtypes = [vp, i, f, f, f, f, f, f, f, i, i, vp, i]
+        L.ora_search_by_projection_frame.argtypes = [vp, vp, i, vp, vp, vp, vp, i, vp, vp, vp, vp, vp, f, i, vp]
+        _match_ready = True
+    return L
+
+
+def descriptor_distance(a, b):
+    return _match().ora_descriptor_distance(_p(np.ascontiguousarray(a, np.uint8)), _p(np.ascontiguousarray(b, np.uint8)))
+
+
+def frame_grid(kps, bounds):
+    """CSR of Frame::mGrid in storage order [ix][iy]: (cell_start[64*48+1], cell_idx[nbinned])."""
+    kps = np.ascontiguousarray(kps, KP_DTYPE)
+    cs = np.zeros(64 * 48 + 1, np.int32)
+    ci = np.zeros(max(len(kps), 1), np.int32)
+    n = _match().ora_frame_grid(_p(kps), len(kps), *[float(b) for b in bounds], _p(cs), _p(ci))
+    return cs, ci[:n].copy()
+
+
+def features_in_area(kps, bounds, x, y, r, min_level=-1, max_level=-1):
+    kps = np.ascontiguousarray(kps, KP_DTYPE)
+    out = np.zeros(max(len(kps), 1), np.int32)
+    n = _match().ora_features_in_area(_p(kps), len(kps), *[float(b) for b in bounds], float(x), float(y), float(r),
+                                      int(min_level), int(max_level), _p(out), len(out))
+    return out[:n].copy()
+
+
+def search_by_projection_frame(cur_kps, cur_desc, bounds, pose12, intr4, scale_factors, last_flags, last_Pw, last_mp_desc,
+                               last_octave, last_angle, th, check_ori=True, cur_match=None):
+    """ORBmatcher::SearchByProjection(Cur, Last, th, mono). Returns (nmatches, cur_match[Ncur])."""
+    cur_kps = np.ascontiguousarray(cur_kps, KP_DTYPE)
+    n = len(cur_kps)
+    m = np.full(max(n, 1), -1, np.int32) if cur_match is None else np.ascontiguousarray(cur_match, np.int32).copy()
+    f32 = lambda a: np.ascontiguousarray(a, np.float32)
+    nm = _match().ora_search_by_projection_frame(
+        _p(cur_kps), _p(np.ascontiguousarray(cur_desc, np.uint8)), n, _p(f32(bounds)), _p(f32(pose12)), _p(f32(intr4)),
+        _p(f32(scale_factors)), len(last_flags), _p(np.ascontiguousarray(last_flags, np.uint8)), _p(f32(last_Pw)),
+        _p(np.ascontiguousarray(last_mp_desc, np.uint8)), _p(np.ascontiguousarray(last_octave, np.int32)), _p(f32(last_angle)),
+        float(th), int(check_ori), _p(m))
+    return nm, m[:n]

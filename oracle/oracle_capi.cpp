@@ -206,3 +206,50 @@ void ora_pose_opt_vi_frame(const double* cur22, const double* last22, const doub
 }
 
 } // extern "C"
+
+// =================================================================================================
+// Matcher (orb_matcher.h)
+// =================================================================================================
+#include "orb_matcher.h"
+extern "C" {
+int ora_descriptor_distance(const uint8_t* a, const uint8_t* b) { return descriptor_distance(a, b); }
+// Grid introspection: CSR of the 64x48 grid in the reference's storage order grid[ix][iy]
+// (cell index = ix*48 + iy): cell_start[64*48+1], cell_idx[N]. Returns number of keypoints binned.
+int ora_frame_grid(const KeyPoint* kps, int n, float minX, float maxX, float minY, float maxY, int* cell_start, int* cell_idx) {
+    FrameGrid g; g.build(kps, nullptr, n, minX, maxX, minY, maxY);
+    int pos = 0;
+    for (int ix = 0; ix < FRAME_GRID_COLS; ix++) for (int iy = 0; iy < FRAME_GRID_ROWS; iy++) {
+        cell_start[ix * FRAME_GRID_ROWS + iy] = pos;
+        for (int idx : g.grid[ix][iy]) cell_idx[pos++] = idx;
+    }
+    cell_start[FRAME_GRID_COLS * FRAME_GRID_ROWS] = pos;
+    return pos;
+}
+int ora_features_in_area(const KeyPoint* kps, int n, float minX, float maxX, float minY, float maxY, float x, float y, float r,
+                         int minLevel, int maxLevel, int* out, int cap) {
+    FrameGrid g; g.build(kps, nullptr, n, minX, maxX, minY, maxY);
+    std::vector<int> v = g.features_in_area(x, y, r, minLevel, maxLevel);
+    for (int i = 0; i < (int)v.size() && i < cap; i++) out[i] = v[i];
+    return (int)v.size();
+}
+// pose12 = Rcw (9, row-major) + tcw (3); intr = fx fy cx cy; bounds = minX maxX minY maxY.
+// last_flags[i] = bit0 has_point | bit1 outlier | bit2 has_observations.
+int ora_search_by_projection_frame(const KeyPoint* cur_kps, const uint8_t* cur_desc, int ncur, const float* bounds4,
+                                   const float* pose12, const float* intr4, const float* scale_factors,
+                                   int nlast, const uint8_t* last_flags, const float* last_Pw, const uint8_t* last_mp_desc,
+                                   const int* last_octave, const float* last_angle, float th, int check_ori, int* cur_match) {
+    FrameGrid g; g.build(cur_kps, cur_desc, ncur, bounds4[0], bounds4[1], bounds4[2], bounds4[3]);
+    PoseF T; for (int i = 0; i < 9; i++) T.Rcw[i] = pose12[i]; for (int i = 0; i < 3; i++) T.tcw[i] = pose12[9 + i];
+    T.fx = intr4[0]; T.fy = intr4[1]; T.cx = intr4[2]; T.cy = intr4[3];
+    std::vector<LastFramePoint> last(nlast);
+    for (int i = 0; i < nlast; i++) {
+        last[i].has_point = last_flags[i] & 1; last[i].outlier = (last_flags[i] >> 1) & 1; last[i].has_observations = (last_flags[i] >> 2) & 1;
+        for (int k = 0; k < 3; k++) last[i].Pw[k] = last_Pw[3 * i + k];
+        last[i].desc = last_mp_desc + (size_t)32 * i; last[i].octave = last_octave[i]; last[i].angle = last_angle[i];
+    }
+    std::vector<int> m(cur_match, cur_match + ncur);
+    int n = search_by_projection_frame(g, T, scale_factors, last, th, check_ori != 0, m);
+    for (int i = 0; i < ncur; i++) cur_match[i] = m[i];
+    return n;
+}
+} // extern "C"

@@ -167,3 +167,89 @@ def make_vio_problem(seed, n_points=300, outlier_frac=0.05, n_imu=10, w=752, h=4
     return dict(cam=cam, gw=GRAVITY_W.copy(), imu=imu, t_last=t0, t_cur=t1, ns_last=ns_last, ns_last_true=ns_last_true,
                 ns_cur_true=ns_cur_true, obs_cur=obs_cur, obs_last=obs_last, outlier_cur_true=bad_c, outlier_last_true=bad_l,
                 prior=ns_last.copy(), marg_cov_inv=prior_info, octave=octave)
+
+
+# ==================================================================================================
+# A full synthetic visual-inertial stream: a textured plane z = Z0 in the world frame (= the frame of
+# the reference camera that sees `base` exactly), a smooth 6-DoF body trajectory, perspective-correct
+# rendered frames, and IMU samples consistent with the trajectory.
+# ==================================================================================================
+PLANE_Z0 = 5.0
+GRAVITY_CAM_WORLD = np.array([0.0, 9.81, 0.0])       # world = reference camera frame, y points down
+
+
+def render_view(base, cam, Rcw, tcw, seed=0, noise=1.0):
+    """Image of the plane z = PLANE_Z0 (textured with `base` as seen from Tcw = I) from pose (Rcw, tcw)."""
+    h, w = base.shape
+    fx, fy, cx, cy = cam[:4]
+    v, u = np.mgrid[0:h, 0:w].astype(np.float64)
+    d = np.stack([(u - cx) / fx, (v - cy) / fy, np.ones_like(u)], -1) @ Rcw          # Rcw^T d, row-vector form
+    O = -Rcw.T @ tcw
+    s = (PLANE_Z0 - O[2]) / d[..., 2]
+    X = O[0] + s * d[..., 0]
+    Y = O[1] + s * d[..., 1]
+    ub = fx * X / PLANE_Z0 + cx
+    vb = fy * Y / PLANE_Z0 + cy
+    out = ndimage.map_coordinates(base.astype(np.float32), [vb, ub], order=1, mode="reflect")
+    if noise > 0:
+        out = out + np.random.Generator(np.random.PCG64(seed + 31337)).normal(0, noise, out.shape)
+    return np.clip(np.rint(out), 0, 255).astype(np.uint8)
+
+
+def cam_pose_from_navstate(ns, cam):
+    """(Rcw, tcw) in float64 from a NavState and Tbc — Frame::UpdatePoseFromNS, reference src/Frame.cc:88-105."""
+    from scipy.spatial.transform import Rotation
+    Rwb = Rotation.from_quat(ns[6:10]).as_matrix()
+    Rbc, Pbc = cam[4:13].reshape(3, 3), cam[13:16]
+    Rcw = (Rwb @ Rbc).T
+    Pwc = Rwb @ Pbc + ns[:3]
+    return Rcw, -Rcw @ Pwc
+
+
+def backproject_to_plane(uv, ns, cam):
+    """World points on the plane z = PLANE_Z0 seen at pixels uv [n,2] from NavState ns."""
+    Rcw, tcw = cam_pose_from_navstate(ns, cam)
+    fx, fy, cx, cy = cam[:4]
+    d = np.stack([(uv[:, 0] - cx) / fx, (uv[:, 1] - cy) / fy, np.ones(len(uv))], 1) @ Rcw
+    O = -Rcw.T @ tcw
+    s = (PLANE_Z0 - O[2]) / d[:, 2]
+    return O[None, :] + s[:, None] * d
+
+
+def make_vi_stream(seed, n_frames, w=752, h=480, n_imu=10, imu_dt=0.005):
+    """Returns dict(frames [n,h,w] u8, ns_true [n,22], imu list of [n_imu,7] per interval (imu[k] spans
+    frame k-1 -> k, imu[0] is None), t [n], cam[16], gw[3])."""
+    rng = np.random.Generator(np.random.PCG64(seed + 424243))
+    cam = euroc_cam()
+    Rbc, Pbc = cam[4:13].reshape(3, 3), cam[13:16]
+    base = make_image(seed, w, h)
+    # body pose such that the camera starts at Tcw = I:  Rwb = Rbc^T, Pwb = -Rwb Pbc
+    R = Rbc.T.copy(); P = -R @ Pbc
+    V = rng.normal(0, 0.3, 3) * np.array([1, 1, 0.2])
+    bg, ba = rng.normal(0, 0.002, 3), rng.normal(0, 0.02, 3)
+    T = n_imu * imu_dt
+    t = 50.0 + seed
+    frames, states, imus, ts = [], [], [None], []
+    for k in range(n_frames):
+        ns = navstate(P, V, R, bg, ba)
+        Rcw, tcw = cam_pose_from_navstate(ns, cam)
+        frames.append(base.copy() if k == 0 else render_view(base, cam, Rcw, tcw, seed=seed * 1009 + k))
+        states.append(ns); ts.append(t)
+        if k == n_frames - 1:
+            break
+        omega = rng.normal(0, 0.12, 3)
+        a_w = rng.normal(0, 0.8, 3) * np.array([1, 1, 0.3]) - 0.8 * V      # keeps the speed bounded
+        stamps = t + imu_dt * (np.arange(n_imu) + 0.3)
+        imu = np.zeros((n_imu, 7))
+        for j, tj in enumerate(stamps):
+            Rt = R @ _rotvec_to_R(omega * (tj - t))
+            imu[j, :3] = omega + bg + rng.normal(0, 1e-3, 3)
+            imu[j, 3:6] = Rt.T @ (a_w - GRAVITY_CAM_WORLD) + ba + rng.normal(0, 1e-2, 3)
+            imu[j, 6] = tj
+        imus.append(imu)
+        P = P + V * T + 0.5 * a_w * T * T
+        V = V + a_w * T
+        R = R @ _rotvec_to_R(omega * T)
+        t = t + T
+    return dict(frames=np.stack(frames), ns_true=np.stack(states), imu=imus, t=np.array(ts), cam=cam,
+                gw=GRAVITY_CAM_WORLD.copy(), base=base)
