@@ -124,6 +124,89 @@ int viorb_extractor_level_download(viorb_extractor* h, int b, int level, int blu
 int viorb_extractor_debug_level_points(viorb_extractor* h, int b, int level, int which, int32_t* xyr,
                                        int cap, int* n);
 
+/* ------------------------------------------------------------------------------------------------
+ * Per-frame tracking front-end behind the extractor — replaces, for B independent camera streams at a
+ * time, the calls Tracking::TrackWithIMU makes per frame (reference src/Tracking.cc:412-534):
+ *   Frame::AssignFeaturesToGrid            (src/Frame.cc:410-425)      viorb_frontend_grid_device
+ *   GetIMUPreIntSinceLastFrame + updateNS  (src/Frame.cc:41-110)       viorb_frontend_imu_predict_device
+ *   ORBmatcher::SearchByProjection(F,F)    (src/ORBmatcher.cc:1328)    viorb_frontend_search_projection_device
+ *   Optimizer::PoseOptimization (VI)       (src/Optimizer.cc:323,789)  viorb_frontend_pose_opt_device
+ * All arrays are device pointers, row b of every array belongs to stream b; `cap` is the per-stream
+ * keypoint capacity the handle was created with. Flat float64 layouts:
+ *   navstate[22] = P3 V3 q4(x,y,z,w) bg3 ba3 dbg3 dba3        (NavState, src/IMU/NavState.h)
+ *   preint[142]  = dP3 dV3 dR9 JPg9 JPa9 JVg9 JVa9 JRg9 cov81 dt  (IMUPreintegrator, row-major blocks)
+ *   cam[16]      = fx fy cx cy Rbc9 Pbc3                        (Frame intrinsics + ConfigParam Tbc)
+ *   imu[n][7]    = gyro3 acc3 t                                 (IMUData)
+ *   obs[k][6]    = Pw3 u v invSigma2                            (one EdgeNavStatePVRPointXYZOnlyPose)
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct viorb_frontend viorb_frontend;    /* opaque: scratch buffers for max_batch x cap */
+
+typedef struct viorb_frontend_config {
+    float   min_x, max_x, min_y, max_y;   /* Frame::mnMinX.. (image bounds after undistortion) */
+    float   fx, fy, cx, cy;               /* pinhole intrinsics (float, as Frame stores them) */
+    double  cam[16];                      /* fx fy cx cy Rbc9 Pbc3 in double for the solver */
+    double  gravity[3];                   /* gw */
+    float   scale_factors[16];            /* mvScaleFactors */
+    float   inv_level_sigma2[16];         /* mvInvLevelSigma2 */
+    int32_t nlevels;
+    int32_t check_orientation;            /* ORBmatcher(nnratio, checkOri) second argument */
+    double  gyr_meas_cov, acc_meas_cov;   /* IMUData::_gyrMeasCov / _accMeasCov diagonal; <= 0 selects */
+    double  acc_bias_rw2;                 /* the reference constants (src/IMU/imudata.cpp:31-41)       */
+} viorb_frontend_config;
+
+int viorb_frontend_create(const viorb_frontend_config* cfg, int max_batch, int cap, int device, viorb_frontend** out);
+int viorb_frontend_destroy(viorb_frontend* h);
+
+/* cell_start[b][64*48+1], cell_idx[b][cap]: CSR of Frame::mGrid in storage order cell = ix*48 + iy. */
+int viorb_frontend_grid_device(viorb_frontend* h, const viorb_keypoint* kps, const int32_t* count, int batch,
+                               int32_t* cell_start, int32_t* cell_idx, void* stream);
+
+/* Pre-integrate imu[b][n_imu][7] between t_last[b] and t_cur[b] with the biases of last_ns[b], predict
+ * the current NavState (Converter::updateNS) and the float camera pose pose12[b] = Rcw(9) tcw(3). */
+int viorb_frontend_imu_predict_device(viorb_frontend* h, const double* imu, int n_imu, const double* t_last,
+                                      const double* t_cur, const double* last_ns, int batch, double* preint,
+                                      double* cur_ns, float* pose12, void* stream);
+
+/* SearchByProjection(CurrentFrame, LastFrame, th, bMono = true). last_flags: bit0 map point present,
+ * bit1 outlier, bit2 the map point has observations. cur_match[b][i2] = index of the last-frame point
+ * given to current keypoint i2 or -1 (starts empty, as Tracking clears mvpMapPoints first);
+ * nmatches[b] = the function's return value; status[b] = VIORB_OK / VIORB_ERR_CAPACITY. */
+int viorb_frontend_search_projection_device(viorb_frontend* h, const viorb_keypoint* cur_kps, const uint8_t* cur_desc,
+                                            const int32_t* cur_count, const int32_t* cell_start, const int32_t* cell_idx,
+                                            const float* pose12, const viorb_keypoint* last_kps, const int32_t* last_count,
+                                            const uint8_t* last_flags, const float* last_Pw, const uint8_t* last_desc,
+                                            float th, int batch, int32_t* cur_match, int32_t* nmatches, int32_t* status,
+                                            void* stream);
+
+/* Edge construction of PoseOptimization: one observation per matched keypoint, in keypoint order.
+ * match[b][i] >= 0 selects point match_Pw[b][match[b][i]]. obs_index[b][k] = keypoint of obs k. */
+int viorb_frontend_build_observations_device(viorb_frontend* h, const viorb_keypoint* kps, const int32_t* count,
+                                             const int32_t* match, const float* match_Pw, int batch, double* obs,
+                                             int32_t* obs_index, int32_t* n_obs, void* stream);
+
+/* Optimizer::PoseOptimization with NavState edges. variant 0 = (Frame*, KeyFrame*): last is fixed, no
+ * prior edge, obs_last ignored; variant 1 = (Frame*, Frame*): last is free, prior edge from prior_ns /
+ * marg_cov_inv[b][144], reprojection edges of both frames. Outputs: out_ns (optimised current NavState),
+ * out_last_ns (may be NULL), outlier_cur[b][cap] / outlier_last (mvbOutlier per observation),
+ * info[b][4] = {return value nInitialCorrespondences - nBad, final robust chi2, LM iterations, 0},
+ * marg_out[b][144] = mMargCovInv when compute_marg != 0. */
+int viorb_frontend_pose_opt_device(viorb_frontend* h, int variant, int compute_marg, const double* cur_ns,
+                                   const double* last_ns, const double* prior_ns, const double* marg_cov_inv,
+                                   const double* preint, const double* obs_cur, const int32_t* n_cur,
+                                   const double* obs_last, const int32_t* n_last, int batch, double* out_ns,
+                                   double* out_last_ns, uint8_t* outlier_cur, uint8_t* outlier_last, double* marg_out,
+                                   double* info, void* stream);
+
+/* Host-buffer drop-ins for single calls (they stage through the device and include the PCIe copies). */
+int viorb_descriptor_distance(const uint8_t* a, const uint8_t* b);       /* ORBmatcher::DescriptorDistance */
+int viorb_preintegrate(const double* imu, int n_imu, const double bg[3], const double ba[3], double t_last,
+                       double t_cur, double* preint142);
+int viorb_pose_opt_vi(int variant, int compute_marg, const double cur_ns[22], const double last_ns[22],
+                      const double prior_ns[22], const double* marg_cov_inv144, const double preint[142],
+                      const double gw[3], const double cam[16], const double* obs_cur, int n_cur, const double* obs_last,
+                      int n_last, double out_ns[22], double out_last_ns[22], uint8_t* outlier_cur, uint8_t* outlier_last,
+                      double* marg_out144, double info[4]);
+
 /* Host-only test hooks (no GPU needed; used by the CPU test-suite to compare product host code with
  * the oracle): the flat-array formulation of DistributeOctTree that the device kernel mirrors
  * (keys packed x | y<<12 | score<<24, border-relative), and the scalar math shared with the kernels. */
@@ -131,6 +214,16 @@ int viorb_debug_octree_host(const uint32_t* keys, int n, int width, int height, 
                             int cap, int* nout);
 float viorb_debug_fast_atan2(float y, float x);
 void viorb_debug_sincos(float radians, float* s, float* c);
+/* vio_core.h (the FP64 edge/state functions the solver kernel uses) compiled for the host. J layouts:
+ * pvr edge 9x21 = [d/d i(P V Phi) | d/d j(P V Phi) | d/d bias_i acc]; proj edge 2x3 (dP) then 2x3 (dPhi);
+ * prior edge 12x12 = [d/d(P V Phi) | d/d bias acc]; small60 = dP3 dV3 dR9 JPg9 JPa9 JVg9 JVa9 JRg9. */
+void viorb_debug_pvr_edge(const double* i22, const double* j22, const double* b22, const double* preint142,
+                          const double* gw, double* e9, double* J189);
+void viorb_debug_proj_edge(const double* ns22, const double* cam16, const double* obs6, double* e2, double* J12);
+void viorb_debug_prior_edge(const double* pvr22, const double* bias22, const double* prior22, double* e12, double* J144);
+void viorb_debug_update_ns(const double* ns22, const double* preint142, const double* gw, const double* cam16,
+                           double* out22, float* pose12);
+void viorb_debug_preint_step(double* small60, const double* omega, const double* acc, double dt);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,236 @@
+"""-m gpu parity tests of the tracking front-end kernels (grid, IMU prediction, SearchByProjection, pose
+optimisation) against the CPU oracle, through the C ABI. Integer / index results bit-exact; FP64 solver
+results within the north-star tolerance (final cost 1e-5 relative)."""
+import numpy as np
+import pytest
+import viorb_amd
+from viorb_amd.synth import make_vi_stream, make_vio_problem, backproject_to_plane, cam_pose_from_navstate
+
+pytestmark = pytest.mark.gpu
+BOUNDS = (0.0, 752.0, 0.0, 480.0)
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    if viorb_amd.lib().viorb_device_count() < 1:
+        pytest.fail("no HIP device visible: -m gpu tests need the MI355X (and never fall back)")
+    import torch
+    return torch
+
+
+@pytest.fixture(scope="module")
+def streams(oracle):
+    """Three 2-frame streams with oracle features for both frames and map points for frame 0."""
+    out = []
+    ex = oracle.Extractor()
+    for seed in (1, 2, 3):
+        s = make_vi_stream(seed, 2)
+        k0, d0 = ex(s["frames"][0]); k1, d1 = ex(s["frames"][1])
+        Pw = backproject_to_plane(np.stack([k0["x"], k0["y"]], 1).astype(np.float64), s["ns_true"][0], s["cam"]).astype(np.float32)
+        rng = np.random.default_rng(seed)
+        flags = np.full(len(k0), 1 | 4, np.uint8)
+        flags[rng.random(len(k0)) < 0.2] = 0
+        flags[rng.random(len(k0)) < 0.05] |= 2
+        flags[rng.random(len(k0)) < 0.1] &= ~np.uint8(4)
+        out.append(dict(s=s, k0=k0, d0=d0, k1=k1, d1=d1, Pw=Pw, flags=flags, tables=ex.tables()))
+    return out
+
+
+def make_frontend(st, B, cap):
+    t = st["tables"]
+    return viorb_amd.Frontend(st["s"]["cam"], st["s"]["gw"], t["scale"], t["inv_sigma2"], BOUNDS, max_batch=B, cap=cap)
+
+
+def pad(torch, arrs, cap, dtype, tail=()):
+    out = np.zeros((len(arrs), cap) + tuple(tail), dtype)
+    for b, a in enumerate(arrs):
+        out[b, :len(a)] = a
+    return torch.from_numpy(out.view(np.uint8).reshape(out.shape + (-1,)) if dtype == viorb_amd.KP_DTYPE else out).cuda()
+
+
+def test_grid_matches_oracle(torch_cuda, oracle, streams):
+    torch = torch_cuda
+    B, cap = len(streams), 1016
+    fe = make_frontend(streams[0], B, cap)
+    kps = pad(torch, [s["k1"] for s in streams], cap, viorb_amd.KP_DTYPE)
+    cnt = torch.tensor([len(s["k1"]) for s in streams], dtype=torch.int32, device="cuda")
+    cs = torch.zeros((B, 3073), dtype=torch.int32, device="cuda"); ci = torch.zeros((B, cap), dtype=torch.int32, device="cuda")
+    fe.grid(kps.data_ptr(), cnt.data_ptr(), B, cs, ci)
+    torch.cuda.synchronize()
+    for b, s in enumerate(streams):
+        ocs, oci = oracle.frame_grid(s["k1"], BOUNDS)
+        np.testing.assert_array_equal(cs[b].cpu().numpy(), ocs)
+        np.testing.assert_array_equal(ci[b, :len(oci)].cpu().numpy(), oci)
+
+
+def test_imu_predict_matches_oracle(torch_cuda, oracle, streams):
+    torch = torch_cuda
+    B = len(streams)
+    fe = make_frontend(streams[0], B, 64)
+    imu = torch.from_numpy(np.stack([s["s"]["imu"][1] for s in streams])).cuda()
+    tl = torch.tensor([s["s"]["t"][0] for s in streams], dtype=torch.float64, device="cuda")
+    tc = torch.tensor([s["s"]["t"][1] for s in streams], dtype=torch.float64, device="cuda")
+    ns = torch.from_numpy(np.stack([s["s"]["ns_true"][0] for s in streams])).cuda()
+    pre = torch.zeros((B, 142), dtype=torch.float64, device="cuda"); cur = torch.zeros((B, 22), dtype=torch.float64, device="cuda")
+    pose = torch.zeros((B, 12), dtype=torch.float32, device="cuda")
+    fe.imu_predict(imu, tl, tc, ns, pre, cur, pose)
+    torch.cuda.synchronize()
+    for b, s in enumerate(streams):
+        st = s["s"]
+        opre = oracle.preintegrate(st["imu"][1], st["ns_true"][0][10:13], st["ns_true"][0][13:16], st["t"][0], st["t"][1])
+        np.testing.assert_allclose(pre[b].cpu().numpy()[:60], opre[:60], rtol=0, atol=1e-12)
+        np.testing.assert_allclose(pre[b].cpu().numpy()[60:141], opre[60:141], rtol=1e-9, atol=1e-18)
+        assert abs(pre[b, 141].item() - opre[141]) < 1e-14
+        ocur = oracle.update_ns(st["ns_true"][0], opre, st["gw"])
+        np.testing.assert_allclose(cur[b].cpu().numpy(), ocur, rtol=0, atol=1e-11)
+        Rcw, tcw = cam_pose_from_navstate(ocur, st["cam"])
+        np.testing.assert_allclose(pose[b].cpu().numpy()[:9].reshape(3, 3), Rcw, atol=2e-6)
+        np.testing.assert_allclose(pose[b].cpu().numpy()[9:], tcw, atol=2e-5)
+    # host drop-in
+    st = streams[0]["s"]
+    hp = viorb_amd.preintegrate(st["imu"][1], st["ns_true"][0][10:13], st["ns_true"][0][13:16], st["t"][0], st["t"][1])
+    np.testing.assert_allclose(hp[:60], oracle.preintegrate(st["imu"][1], st["ns_true"][0][10:13], st["ns_true"][0][13:16], st["t"][0], st["t"][1])[:60], atol=1e-12)
+
+
+@pytest.mark.parametrize("th", [15.0, 30.0, 7.0])
+def test_search_by_projection_matches_oracle(torch_cuda, oracle, streams, th):
+    torch = torch_cuda
+    B, cap = len(streams), 1016
+    fe = make_frontend(streams[0], B, cap)
+    ck = pad(torch, [s["k1"] for s in streams], cap, viorb_amd.KP_DTYPE)
+    cd = pad(torch, [s["d1"] for s in streams], cap, np.uint8, (32,))
+    cc = torch.tensor([len(s["k1"]) for s in streams], dtype=torch.int32, device="cuda")
+    lk = pad(torch, [s["k0"] for s in streams], cap, viorb_amd.KP_DTYPE)
+    ld = pad(torch, [s["d0"] for s in streams], cap, np.uint8, (32,))
+    lc = torch.tensor([len(s["k0"]) for s in streams], dtype=torch.int32, device="cuda")
+    lf = pad(torch, [s["flags"] for s in streams], cap, np.uint8)
+    lp = pad(torch, [s["Pw"] for s in streams], cap, np.float32, (3,))
+    poses = []
+    for s in streams:
+        Rcw, tcw = cam_pose_from_navstate(s["s"]["ns_true"][1], s["s"]["cam"])
+        poses.append(np.concatenate([Rcw.ravel(), tcw + (0.01 if th == 30 else 0.0)]).astype(np.float32))
+    pose = torch.from_numpy(np.stack(poses)).cuda()
+    cs = torch.zeros((B, 3073), dtype=torch.int32, device="cuda"); ci = torch.zeros((B, cap), dtype=torch.int32, device="cuda")
+    fe.grid(ck.data_ptr(), cc.data_ptr(), B, cs, ci)
+    match = torch.full((B, cap), -7, dtype=torch.int32, device="cuda")
+    nm = torch.zeros(B, dtype=torch.int32, device="cuda"); status = torch.zeros(B, dtype=torch.int32, device="cuda")
+    fe.search_projection(ck.data_ptr(), cd.data_ptr(), cc.data_ptr(), cs, ci, pose, lk.data_ptr(), lc.data_ptr(), lf, lp, ld.data_ptr(),
+                         th, B, match, nm, status)
+    torch.cuda.synchronize()
+    assert (status.cpu().numpy() == 0).all()
+    for b, s in enumerate(streams):
+        onm, om = oracle.search_by_projection_frame(s["k1"], s["d1"], BOUNDS, poses[b], s["s"]["cam"][:4], s["tables"]["scale"],
+                                                    s["flags"], s["Pw"], s["d0"], s["k0"]["octave"], s["k0"]["angle"], th)
+        assert nm[b].item() == onm
+        np.testing.assert_array_equal(match[b, :len(om)].cpu().numpy(), om)
+        assert (match[b, len(om):].cpu().numpy() == -1).all()
+        if th == 15.0:
+            assert onm > 250
+
+
+def _gpu_pose_opt(p, oracle, variant, marg):
+    last = p["ns_last"]
+    pre = oracle.preintegrate(p["imu"], last[10:13], last[13:16], p["t_last"], p["t_cur"])
+    cur0 = oracle.update_ns(last, pre, p["gw"])
+    if variant == 0:
+        o = oracle.pose_opt_vi_kf(cur0, last, pre, p["gw"], p["cam"], p["obs_cur"], marg=marg)
+        g = viorb_amd.PoseOptimization(cur0, last, pre, p["gw"], p["cam"], p["obs_cur"], last_is_keyframe=True, bComputeMarg=marg)
+    else:
+        o = oracle.pose_opt_vi_frame(cur0, last, p["prior"], p["marg_cov_inv"], pre, p["gw"], p["cam"], p["obs_cur"], p["obs_last"], marg=marg)
+        g = viorb_amd.PoseOptimization(cur0, last, pre, p["gw"], p["cam"], p["obs_cur"], p["obs_last"], p["prior"], p["marg_cov_inv"],
+                                       last_is_keyframe=False, bComputeMarg=marg)
+    return o, g
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_pose_optimisation_matches_oracle(torch_cuda, oracle, variant, seed):
+    p = make_vio_problem(seed, n_points=300 if seed < 3 else 600)
+    o, g = _gpu_pose_opt(p, oracle, variant, True)
+    assert abs(g["final_chi2"] - o["final_chi2"]) <= 1e-5 * abs(o["final_chi2"])          # north-star tolerance
+    assert g["n_inliers"] == o["n_inliers"]
+    np.testing.assert_array_equal(g["outlier_cur"], o["outlier_cur"])
+    if variant == 1:
+        np.testing.assert_array_equal(g["outlier_last"], o["outlier_last"])
+        np.testing.assert_allclose(g["ns_last"], o["ns_last"], rtol=0, atol=1e-7)
+    np.testing.assert_allclose(g["ns"], o["ns"], rtol=0, atol=1e-7)
+    assert g["lm_iterations"] == o["lm_iterations"]
+    M, Mo = g["marg_cov_inv"], o["marg_cov_inv"]
+    np.testing.assert_allclose(M, Mo, rtol=1e-4, atol=1e-6 * np.abs(Mo).max())
+
+
+def test_pose_optimisation_edge_cases(torch_cuda, oracle):
+    p = make_vio_problem(5)
+    last = p["ns_last"]
+    pre = oracle.preintegrate(p["imu"], last[10:13], last[13:16], p["t_last"], p["t_cur"])
+    cur0 = oracle.update_ns(last, pre, p["gw"])
+    g = viorb_amd.PoseOptimization(cur0, last, pre, p["gw"], p["cam"], p["obs_cur"][:2])       # < 3 correspondences -> 0
+    assert g["n_inliers"] == 0
+    np.testing.assert_allclose(g["ns"][:10], cur0[:10], atol=1e-15)
+    o = oracle.pose_opt_vi_kf(cur0, last, pre, p["gw"], p["cam"], p["obs_cur"][:6])            # < 10 edges: one round
+    g = viorb_amd.PoseOptimization(cur0, last, pre, p["gw"], p["cam"], p["obs_cur"][:6])
+    assert g["n_inliers"] == o["n_inliers"] and abs(g["final_chi2"] - o["final_chi2"]) <= 1e-5 * abs(o["final_chi2"]) + 1e-12
+    bad = p["obs_cur"].copy(); bad[::2, 3:5] += 60.0                                            # half the matches are gross outliers
+    o = oracle.pose_opt_vi_kf(cur0, last, pre, p["gw"], p["cam"], bad)
+    g = viorb_amd.PoseOptimization(cur0, last, pre, p["gw"], p["cam"], bad)
+    assert g["n_inliers"] == o["n_inliers"]
+    np.testing.assert_array_equal(g["outlier_cur"], o["outlier_cur"])
+
+
+def test_batched_pose_opt_and_observation_builder(torch_cuda, oracle, streams):
+    """Device-resident chain: build_observations -> pose_opt (Frame/Frame overload) for a batch of streams."""
+    torch = torch_cuda
+    B, cap = len(streams), 1016
+    fe = make_frontend(streams[0], B, cap)
+    ck = pad(torch, [s["k1"] for s in streams], cap, viorb_amd.KP_DTYPE)
+    cc = torch.tensor([len(s["k1"]) for s in streams], dtype=torch.int32, device="cuda")
+    lk = pad(torch, [s["k0"] for s in streams], cap, viorb_amd.KP_DTYPE)
+    lc = torch.tensor([len(s["k0"]) for s in streams], dtype=torch.int32, device="cuda")
+    lp = pad(torch, [s["Pw"] for s in streams], cap, np.float32, (3,))
+    matches, omatches = [], []
+    for s in streams:
+        Rcw, tcw = cam_pose_from_navstate(s["s"]["ns_true"][1], s["s"]["cam"])
+        pose = np.concatenate([Rcw.ravel(), tcw]).astype(np.float32)
+        nm, m = oracle.search_by_projection_frame(s["k1"], s["d1"], BOUNDS, pose, s["s"]["cam"][:4], s["tables"]["scale"], s["flags"],
+                                                  s["Pw"], s["d0"], s["k0"]["octave"], s["k0"]["angle"], 15.0)
+        matches.append(m)
+    cm = pad(torch, matches, cap, np.int32) - (pad(torch, [np.ones(len(m), np.int32) for m in matches], cap, np.int32) == 0).int()
+    lm = pad(torch, [np.where(s["flags"] & 1, np.arange(len(s["flags"])), -1).astype(np.int32) for s in streams], cap, np.int32) \
+        - (pad(torch, [np.ones(len(s["flags"]), np.int32) for s in streams], cap, np.int32) == 0).int()
+    obs_c = torch.zeros((B, cap, 6), dtype=torch.float64, device="cuda"); obs_l = torch.zeros_like(obs_c)
+    idx_c = torch.zeros((B, cap), dtype=torch.int32, device="cuda"); idx_l = torch.zeros_like(idx_c)
+    n_c = torch.zeros(B, dtype=torch.int32, device="cuda"); n_l = torch.zeros_like(n_c)
+    fe.build_observations(ck.data_ptr(), cc.data_ptr(), cm, lp, B, obs_c, idx_c, n_c)
+    fe.build_observations(lk.data_ptr(), lc.data_ptr(), lm, lp, B, obs_l, idx_l, n_l)
+    # NavStates: last = truth (slightly perturbed), cur = IMU prediction
+    last_ns = np.stack([s["s"]["ns_true"][0] for s in streams])
+    imu = torch.from_numpy(np.stack([s["s"]["imu"][1] for s in streams])).cuda()
+    tl = torch.tensor([s["s"]["t"][0] for s in streams], dtype=torch.float64, device="cuda")
+    tc = torch.tensor([s["s"]["t"][1] for s in streams], dtype=torch.float64, device="cuda")
+    lns = torch.from_numpy(last_ns).cuda()
+    pre = torch.zeros((B, 142), dtype=torch.float64, device="cuda"); cur = torch.zeros((B, 22), dtype=torch.float64, device="cuda")
+    pose = torch.zeros((B, 12), dtype=torch.float32, device="cuda")
+    fe.imu_predict(imu, tl, tc, lns, pre, cur, pose)
+    mci = torch.from_numpy(np.stack([np.eye(12) * 1e3] * B)).cuda()
+    out = torch.zeros((B, 22), dtype=torch.float64, device="cuda"); outl = torch.zeros_like(out)
+    fc = torch.zeros((B, cap), dtype=torch.uint8, device="cuda"); fl = torch.zeros_like(fc)
+    marg = torch.zeros((B, 144), dtype=torch.float64, device="cuda"); info = torch.zeros((B, 4), dtype=torch.float64, device="cuda")
+    fe.pose_opt(1, True, cur, lns, lns, mci, pre, obs_c, n_c, obs_l, n_l, B, out, outl, fc, fl, marg, info)
+    torch.cuda.synchronize()
+    for b, s in enumerate(streams):
+        m = matches[b]
+        sel = np.nonzero(m >= 0)[0]
+        want = np.concatenate([s["Pw"][m[sel]].astype(np.float64), np.stack([s["k1"]["x"][sel], s["k1"]["y"][sel]], 1).astype(np.float64),
+                               s["tables"]["inv_sigma2"][s["k1"]["octave"][sel]].astype(np.float64)[:, None]], 1)
+        assert n_c[b].item() == len(sel)
+        np.testing.assert_array_equal(idx_c[b, :len(sel)].cpu().numpy(), sel)
+        np.testing.assert_array_equal(obs_c[b, :len(sel)].cpu().numpy(), want)
+        ol_np = obs_l[b, :n_l[b].item()].cpu().numpy()
+        o = oracle.pose_opt_vi_frame(cur[b].cpu().numpy(), last_ns[b], last_ns[b], np.eye(12) * 1e3, pre[b].cpu().numpy(), s["s"]["gw"],
+                                     s["s"]["cam"], want, ol_np, marg=True)
+        gi = info[b].cpu().numpy()
+        assert int(gi[0]) == o["n_inliers"] and abs(gi[1] - o["final_chi2"]) <= 1e-5 * o["final_chi2"]
+        np.testing.assert_array_equal(fc[b, :len(sel)].cpu().numpy(), o["outlier_cur"])
+        np.testing.assert_allclose(out[b].cpu().numpy(), o["ns"], atol=1e-7)
+        # the optimised pose is close to the ground truth of the synthetic stream
+        assert np.linalg.norm(out[b].cpu().numpy()[:3] - s["s"]["ns_true"][1][:3]) < 0.02

@@ -127,3 +127,69 @@ def test_device_math_host_build(oracle):
     for i in range(0, len(rad), 7):
         L.viorb_debug_sincos(float(rad[i]), C.byref(s), C.byref(c))
         assert s.value == want_s[i] and c.value == want_c[i]
+
+
+# ---- vio_core.h (what the solver kernel evaluates) on the host vs the oracle ----------------------------
+def _vio_case(oracle, seed):
+    from viorb_amd.synth import make_vio_problem
+    p = make_vio_problem(seed)
+    pre = oracle.preintegrate(p["imu"], p["ns_last"][10:13], p["ns_last"][13:16], p["t_last"], p["t_cur"])
+    ni = p["ns_last"].copy(); ni[19:22] = [1e-3, -2e-3, 5e-4]
+    nj = oracle.update_ns(p["ns_last"], pre, p["gw"])
+    nj = oracle.ns_inc_pvr(nj, np.array([0.01, -0.02, 0.015, 0.03, 0.01, -0.02, 0.01, -0.008, 0.012]))
+    return p, pre, ni, nj
+
+
+@pytest.mark.parametrize("seed", [0, 3])
+def test_vio_core_edges_equal_oracle(oracle, seed):
+    L = viorb_amd.lib()
+    p, pre, ni, nj = _vio_case(oracle, seed)
+    P = lambda a: a.ctypes.data_as(C.c_void_p)
+    e, J = np.zeros(9), np.zeros(9 * 21)
+    L.viorb_debug_pvr_edge(P(ni), P(nj), P(ni), P(pre), P(p["gw"]), P(e), P(J))
+    oe, Ji, Jj, Jb = oracle.edge_pvr(ni, nj, ni, pre, p["gw"])
+    np.testing.assert_allclose(e, oe, rtol=0, atol=1e-12)
+    np.testing.assert_allclose(J.reshape(9, 21), np.hstack([Ji, Jj, Jb]), rtol=0, atol=1e-10)
+    for k in range(8):
+        e2, J12 = np.zeros(2), np.zeros(12)
+        ob = np.ascontiguousarray(p["obs_cur"][k])
+        L.viorb_debug_proj_edge(P(nj), P(p["cam"]), P(ob), P(e2), P(J12))
+        oe2, oJ = oracle.edge_proj(nj, p["cam"], ob)
+        np.testing.assert_allclose(e2, oe2, rtol=0, atol=1e-9)
+        np.testing.assert_allclose(J12[:6].reshape(2, 3), oJ[:, 0:3], rtol=1e-12, atol=1e-10)
+        np.testing.assert_allclose(J12[6:].reshape(2, 3), oJ[:, 6:9], rtol=1e-12, atol=1e-10)
+    prior = oracle.ns_inc_pvr(ni, np.array([0.02, 0.01, -0.01, 0.02, -0.03, 0.01, 0.004, -0.006, 0.003]))
+    e12, J144 = np.zeros(12), np.zeros(144)
+    L.viorb_debug_prior_edge(P(ni), P(ni), P(prior), P(e12), P(J144))
+    oe12, Jp, Jbb = oracle.edge_prior(ni, ni, prior)
+    np.testing.assert_allclose(e12, oe12, rtol=0, atol=1e-12)
+    np.testing.assert_allclose(J144.reshape(12, 12), np.hstack([Jp, Jbb]), rtol=0, atol=1e-12)
+
+
+def test_vio_core_preint_step_and_update_ns_equal_oracle(oracle):
+    L = viorb_amd.lib()
+    p, pre, ni, nj = _vio_case(oracle, 1)
+    P = lambda a: a.ctypes.data_as(C.c_void_p)
+    small = np.zeros(60); small[6] = small[10] = small[14] = 1
+    full = np.zeros(142); full[6] = full[10] = full[14] = 1
+    bg, ba = p["ns_last"][10:13], p["ns_last"][13:16]
+    for k in range(len(p["imu"])):
+        om = np.ascontiguousarray(p["imu"][k, :3] - bg); ac = np.ascontiguousarray(p["imu"][k, 3:6] - ba)
+        L.viorb_debug_preint_step(P(small), P(om), P(ac), 0.005)
+        full = oracle.preint_update(full, om, ac, 0.005)
+    np.testing.assert_allclose(small, full[:60], rtol=0, atol=1e-13)
+    out, pose = np.zeros(22), np.zeros(12, np.float32)
+    L.viorb_debug_update_ns(P(p["ns_last"]), P(pre), P(p["gw"]), P(p["cam"]), P(out), P(pose))
+    want = oracle.update_ns(p["ns_last"], pre, p["gw"])
+    np.testing.assert_allclose(out, want, rtol=0, atol=1e-12)
+    from viorb_amd.synth import cam_pose_from_navstate
+    Rcw, tcw = cam_pose_from_navstate(want, p["cam"])
+    np.testing.assert_allclose(pose[:9].reshape(3, 3), Rcw, atol=2e-6)
+    np.testing.assert_allclose(pose[9:], tcw, atol=2e-5)
+
+
+def test_descriptor_distance_host(oracle):
+    rng = np.random.default_rng(1)
+    for _ in range(100):
+        a, b = rng.integers(0, 256, 32, dtype=np.uint8), rng.integers(0, 256, 32, dtype=np.uint8)
+        assert viorb_amd.descriptor_distance(a, b) == oracle.descriptor_distance(a, b)

@@ -19,6 +19,15 @@ class ViorbError(RuntimeError):
         self.code = code
 
 
+class FrontendConfig(C.Structure):
+    _fields_ = [("min_x", C.c_float), ("max_x", C.c_float), ("min_y", C.c_float), ("max_y", C.c_float),
+                ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float),
+                ("cam", C.c_double * 16), ("gravity", C.c_double * 3),
+                ("scale_factors", C.c_float * 16), ("inv_level_sigma2", C.c_float * 16),
+                ("nlevels", C.c_int32), ("check_orientation", C.c_int32),
+                ("gyr_meas_cov", C.c_double), ("acc_meas_cov", C.c_double), ("acc_bias_rw2", C.c_double)]
+
+
 class ExtractorParams(C.Structure):
     _fields_ = [("nfeatures", C.c_int32), ("scale_factor", C.c_float), ("nlevels", C.c_int32),
                 ("ini_th_fast", C.c_int32), ("min_th_fast", C.c_int32)]
@@ -42,6 +51,21 @@ SIGNATURES = {
     "viorb_extractor_level_device": (i32, [vp, i32, i32, i32, PP(vp), PP(i32), PP(i32), PP(i32)]),
     "viorb_extractor_level_download": (i32, [vp, i32, i32, i32, vp, PP(i32), PP(i32)]),
     "viorb_extractor_debug_level_points": (i32, [vp, i32, i32, i32, vp, i32, PP(i32)]),
+    "viorb_frontend_create": (i32, [PP(FrontendConfig), i32, i32, i32, PP(vp)]),
+    "viorb_frontend_destroy": (i32, [vp]),
+    "viorb_frontend_grid_device": (i32, [vp, vp, vp, i32, vp, vp, vp]),
+    "viorb_frontend_imu_predict_device": (i32, [vp, vp, i32, vp, vp, vp, i32, vp, vp, vp, vp]),
+    "viorb_frontend_search_projection_device": (i32, [vp] * 12 + [f32, i32, vp, vp, vp, vp]),
+    "viorb_frontend_build_observations_device": (i32, [vp, vp, vp, vp, vp, i32, vp, vp, vp, vp]),
+    "viorb_frontend_pose_opt_device": (i32, [vp, i32, i32] + [vp] * 9 + [i32] + [vp] * 7),
+    "viorb_descriptor_distance": (i32, [vp, vp]),
+    "viorb_preintegrate": (i32, [vp, i32, vp, vp, C.c_double, C.c_double, vp]),
+    "viorb_pose_opt_vi": (i32, [i32, i32] + [vp] * 8 + [i32, vp, i32] + [vp] * 6),
+    "viorb_debug_pvr_edge": (None, [vp] * 7),
+    "viorb_debug_proj_edge": (None, [vp] * 5),
+    "viorb_debug_prior_edge": (None, [vp] * 5),
+    "viorb_debug_update_ns": (None, [vp] * 6),
+    "viorb_debug_preint_step": (None, [vp, vp, vp, C.c_double]),
     "viorb_debug_octree_host": (i32, [vp, i32, i32, i32, i32, vp, i32, PP(i32)]),
     "viorb_debug_fast_atan2": (f32, [f32, f32]),
     "viorb_debug_sincos": (None, [f32, PP(f32), PP(f32)]),

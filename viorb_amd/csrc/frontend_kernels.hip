@@ -1,0 +1,988 @@
+// viorb_amd/csrc/frontend_kernels.hip — the per-frame tracking kernels behind the extractor, batched
+// over independent camera streams (one workgroup per stream):
+//   k_frame_grid          Frame::AssignFeaturesToGrid            reference src/Frame.cc:410-425,562-572
+//   k_search_projection   ORBmatcher::SearchByProjection(F,F)    reference src/ORBmatcher.cc:1328-1471
+//   k_imu_predict         IMUPreintegrator::update xN, Converter::updateNS, Frame::UpdatePoseFromNS
+//                         reference src/IMU/IMUPreintegrator.cpp:86-153, src/Frame.cc:41-105
+//   k_build_observations  the edge-construction loops of PoseOptimization  src/Optimizer.cc:493-589
+//   k_pose_opt_vi         Optimizer::PoseOptimization(Frame*, KeyFrame*|Frame*, ...) with g2o's LM
+//                         reference src/Optimizer.cc:323-1112 + Thirdparty/g2o (see vio_core.h)
+#include <hip/hip_runtime.h>
+#include <vector>
+#include <algorithm>
+#include "viorb_common.h"
+#include "orb_math.h"
+#include "vio_core.h"
+
+namespace viorb {
+
+enum { GRID_COLS = 64, GRID_ROWS = 48, GRID_CELLS = GRID_COLS * GRID_ROWS, TH_HIGH = 100, HISTO_LENGTH = 30, CAND_CAP = 128 };
+
+// ---------------------------------------------------------------------------------------------
+// Frame grid as CSR. Cell index = ix*48 + iy (the reference's mGrid[ix][iy] storage order), entries
+// of a cell in keypoint-index order (push_back order). Built by sorting (cell << 16 | index).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void block_bitonic_sort(uint32_t* a, int m) {
+    for (int k = 2; k <= m; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = threadIdx.x; t < (m >> 1); t += blockDim.x) {
+                const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                const int hi = lo | j;
+                const bool up = (lo & k) == 0;
+                const uint32_t x = a[lo], y = a[hi];
+                if ((x > y) == up) { a[lo] = y; a[hi] = x; }
+            }
+            __syncthreads();
+        }
+}
+
+__global__ __launch_bounds__(256) void k_frame_grid(const viorb_keypoint* __restrict__ kps, const int* __restrict__ count, int cap,
+                                                    float minX, float minY, float wInv, float hInv,
+                                                    int* __restrict__ cell_start, int* __restrict__ cell_idx, int sort_n) {
+    extern __shared__ uint32_t s_keys[];
+    const int b = blockIdx.x;
+    const int n = min(count[b], cap);
+    const viorb_keypoint* kp = kps + (size_t)b * cap;
+    for (int i = threadIdx.x; i < sort_n; i += blockDim.x) {
+        uint32_t key = 0xffffffffu;
+        if (i < n) {
+            // PosInGrid: round() = half away from zero
+            const int px = (int)roundf((kp[i].x - minX) * wInv), py = (int)roundf((kp[i].y - minY) * hInv);
+            if (!(px < 0 || px >= GRID_COLS || py < 0 || py >= GRID_ROWS)) key = ((uint32_t)(px * GRID_ROWS + py) << 16) | (uint32_t)i;
+        }
+        s_keys[i] = key;
+    }
+    __syncthreads();
+    block_bitonic_sort(s_keys, sort_n);
+    int* cs = cell_start + (size_t)b * (GRID_CELLS + 1);
+    int* ci = cell_idx + (size_t)b * cap;
+    // entries: sorted position p holds keypoint (key & 0xffff) of cell (key >> 16)
+    for (int p = threadIdx.x; p < sort_n; p += blockDim.x) {
+        const uint32_t key = s_keys[p];
+        const int cell = key == 0xffffffffu ? GRID_CELLS : (int)(key >> 16);
+        if (key != 0xffffffffu && p < cap) ci[p] = (int)(key & 0xffff);
+        const int prev_cell = p == 0 ? -1 : (s_keys[p - 1] == 0xffffffffu ? GRID_CELLS : (int)(s_keys[p - 1] >> 16));
+        // every cell in (prev_cell, cell] starts at p
+        for (int c = prev_cell + 1; c <= cell && c <= GRID_CELLS; c++) cs[c] = p;
+        if (p == sort_n - 1) for (int c = cell + 1; c <= GRID_CELLS; c++) cs[c] = sort_n;   // only when all slots are real entries
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// SearchByProjection(CurrentFrame, LastFrame, th, mono)
+//   phase A (parallel over last-frame points): project, walk the grid window in the reference's
+//     order (ix outer, iy inner, insertion order inside a cell), store (candidate, Hamming) lists;
+//   phase B: the reference's greedy loop "for i in order: take the closest candidate not yet owned by
+//     a point with observations" is reproduced by a parallel fixed-point iteration — after k sweeps
+//     the choices of the first k points are final, sweeps stop when nothing changes;
+//   phase C: rotation histogram (the reference's factor 1/30 binning), three maxima, rejection.
+// last_flags: bit0 has map point, bit1 outlier, bit2 the point has observations.
+// ---------------------------------------------------------------------------------------------
+struct SearchArgs {
+    const viorb_keypoint* cur_kps; const uint8_t* cur_desc; const int* cur_count;
+    const int* cell_start; const int* cell_idx;
+    const float* pose12; const viorb_keypoint* last_kps; const int* last_count; const uint8_t* last_flags;
+    const float* last_Pw; const uint8_t* last_desc;
+    int* cur_match; int* nmatches; int* status;
+    uint32_t* cand;           // [B][cap][CAND_CAP] = dist<<16 | idx
+    int* cand_n;              // [B][cap]
+    int cap;
+    float minX, maxX, minY, maxY, wInv, hInv, fx, fy, cx, cy, th;
+    float scale[16];
+    int check_ori;
+};
+
+__global__ __launch_bounds__(256) void k_search_projection(SearchArgs A) {
+    extern __shared__ int s_i[];
+    const int b = blockIdx.x, cap = A.cap;
+    const int ncur = min(A.cur_count[b], cap), nlast = min(A.last_count[b], cap);
+    int* choice = s_i;                 // [cap] chosen current keypoint of last point i, or -1
+    int* taken = s_i + cap;            // [cap] per current keypoint: smallest i (with observations) that chose it
+    int* owner = s_i + 2 * cap;        // [cap] per current keypoint: largest i that chose it
+    int* rej = s_i + 3 * cap;          // [cap] per current keypoint: chosen by a point of a rejected bin
+    __shared__ int s_changed, s_hist[HISTO_LENGTH], s_keep[HISTO_LENGTH], s_nm, s_overflow;
+    const float* P = A.pose12 + (size_t)b * 12;
+    const viorb_keypoint* ck = A.cur_kps + (size_t)b * cap;
+    const viorb_keypoint* lk = A.last_kps + (size_t)b * cap;
+    const uint8_t* lf = A.last_flags + (size_t)b * cap;
+    const int* cs = A.cell_start + (size_t)b * (GRID_CELLS + 1);
+    const int* ci = A.cell_idx + (size_t)b * cap;
+    uint32_t* cand = A.cand + (size_t)b * cap * CAND_CAP;
+    int* cand_n = A.cand_n + (size_t)b * cap;
+    if (threadIdx.x == 0) { s_overflow = 0; s_nm = 0; }
+    for (int i = threadIdx.x; i < HISTO_LENGTH; i += blockDim.x) { s_hist[i] = 0; s_keep[i] = 0; }
+    __syncthreads();
+    // ---- phase A
+    for (int i = threadIdx.x; i < nlast; i += blockDim.x) {
+        int nc = 0;
+        const int fl = lf[i];
+        if ((fl & 1) && !(fl & 2)) {
+            const float* X = A.last_Pw + ((size_t)b * cap + i) * 3;
+            float pc[3];
+#pragma unroll
+            for (int r = 0; r < 3; r++) { const float t = P[3 * r] * X[0] + P[3 * r + 1] * X[1] + P[3 * r + 2] * X[2]; pc[r] = t + P[9 + r]; }
+            const float invz = 1.0f / pc[2];
+            const float u = A.fx * pc[0] * invz + A.cx, v = A.fy * pc[1] * invz + A.cy;
+            if (!(invz < 0) && !(u < A.minX || u > A.maxX) && !(v < A.minY || v > A.maxY)) {
+                const int oct = lk[i].octave;
+                const float radius = A.th * A.scale[oct];
+                const int minL = oct - 1, maxL = oct + 1;
+                const int x0 = max(0, (int)floorf((u - A.minX - radius) * A.wInv));
+                const int x1 = min((int)GRID_COLS - 1, (int)ceilf((u - A.minX + radius) * A.wInv));
+                const int y0 = max(0, (int)floorf((v - A.minY - radius) * A.hInv));
+                const int y1 = min((int)GRID_ROWS - 1, (int)ceilf((v - A.minY + radius) * A.hInv));
+                if (x0 < GRID_COLS && x1 >= 0 && y0 < GRID_ROWS && y1 >= 0) {
+                    const uint32_t* dl = reinterpret_cast<const uint32_t*>(A.last_desc + ((size_t)b * cap + i) * 32);
+                    uint32_t d0[8];
+#pragma unroll
+                    for (int k = 0; k < 8; k++) d0[k] = dl[k];
+                    const bool check_levels = (minL > 0) || (maxL >= 0);
+                    for (int ix = x0; ix <= x1; ix++)
+                        for (int iy = y0; iy <= y1; iy++) {
+                            const int c = ix * GRID_ROWS + iy;
+                            for (int p = cs[c]; p < cs[c + 1]; p++) {
+                                const int i2 = ci[p];
+                                const viorb_keypoint k2 = ck[i2];
+                                if (check_levels) { if (k2.octave < minL) continue; if (maxL >= 0 && k2.octave > maxL) continue; }
+                                if (!(fabsf(k2.x - u) < radius && fabsf(k2.y - v) < radius)) continue;
+                                const uint32_t* dc = reinterpret_cast<const uint32_t*>(A.cur_desc + ((size_t)b * cap + i2) * 32);
+                                int dist = 0;
+#pragma unroll
+                                for (int k = 0; k < 8; k++) dist += __popc(d0[k] ^ dc[k]);
+                                if (nc < CAND_CAP) cand[(size_t)i * CAND_CAP + nc] = ((uint32_t)dist << 16) | (uint32_t)i2;
+                                nc++;
+                            }
+                        }
+                }
+            }
+        }
+        if (nc > CAND_CAP) { nc = CAND_CAP; s_overflow = 1; }
+        cand_n[i] = nc;
+        choice[i] = -1;
+    }
+    __syncthreads();
+    // ---- phase B: fixed-point sweeps
+    for (int sweep = 0; sweep <= nlast; sweep++) {
+        for (int c = threadIdx.x; c < ncur; c += blockDim.x) taken[c] = 0x7fffffff;
+        if (threadIdx.x == 0) s_changed = 0;
+        __syncthreads();
+        for (int i = threadIdx.x; i < nlast; i += blockDim.x)
+            if (choice[i] >= 0 && (lf[i] & 4)) atomicMin(&taken[choice[i]], i);
+        __syncthreads();
+        for (int i = threadIdx.x; i < nlast; i += blockDim.x) {
+            const int nc = cand_n[i];
+            int best = 256, bidx = -1;
+            for (int k = 0; k < nc; k++) {
+                const uint32_t e = cand[(size_t)i * CAND_CAP + k];
+                const int i2 = (int)(e & 0xffff), dist = (int)(e >> 16);
+                if (taken[i2] < i) continue;                      // owned by an earlier point that has observations
+                if (dist < best) { best = dist; bidx = i2; }
+            }
+            const int nw = best <= TH_HIGH ? bidx : -1;
+            if (nw != choice[i]) { s_changed = 1; }
+            // write after all reads of this sweep: choices are read only through `taken`, built above
+            rej[i] = nw;                                           // stash; committed below
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < nlast; i += blockDim.x) choice[i] = rej[i];
+        __syncthreads();
+        if (!s_changed) break;
+    }
+    // ---- phase C: histogram, maxima, final ownership
+    for (int c = threadIdx.x; c < ncur; c += blockDim.x) { owner[c] = -1; rej[c] = 0; }
+    __syncthreads();
+    const float factor = 1.0f / HISTO_LENGTH;
+    for (int i = threadIdx.x; i < nlast; i += blockDim.x) {
+        const int c = choice[i];
+        if (c < 0) continue;
+        atomicMax(&owner[c], i);
+        atomicAdd(&s_nm, 1);
+        if (A.check_ori) {
+            float rot = lk[i].angle - ck[c].angle;
+            if (rot < 0.0f) rot += 360.0f;
+            int bin = (int)roundf(rot * factor);
+            if (bin == HISTO_LENGTH) bin = 0;
+            atomicAdd(&s_hist[bin], 1);
+        }
+    }
+    __syncthreads();
+    if (A.check_ori) {
+        if (threadIdx.x == 0) {            // ComputeThreeMaxima
+            int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
+            for (int i = 0; i < HISTO_LENGTH; i++) {
+                const int s = s_hist[i];
+                if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+                else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+                else if (s > max3) { max3 = s; ind3 = i; }
+            }
+            if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+            else if (max3 < 0.1f * (float)max1) { ind3 = -1; }
+            int removed = 0;
+            for (int i = 0; i < HISTO_LENGTH; i++) { const int keep = (i == ind1 || i == ind2 || i == ind3); s_keep[i] = keep; if (!keep) removed += s_hist[i]; }
+            s_nm -= removed;
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < nlast; i += blockDim.x) {
+            const int c = choice[i];
+            if (c < 0) continue;
+            float rot = lk[i].angle - ck[c].angle;
+            if (rot < 0.0f) rot += 360.0f;
+            int bin = (int)roundf(rot * factor);
+            if (bin == HISTO_LENGTH) bin = 0;
+            if (!s_keep[bin]) rej[c] = 1;
+        }
+        __syncthreads();
+    }
+    int* out = A.cur_match + (size_t)b * cap;
+    for (int c = threadIdx.x; c < cap; c += blockDim.x) out[c] = (c < ncur && !rej[c]) ? owner[c] : -1;
+    if (threadIdx.x == 0) { A.nmatches[b] = s_nm; if (s_overflow) A.status[b] = VIORB_ERR_CAPACITY; }
+}
+
+// ---------------------------------------------------------------------------------------------
+// IMU: pre-integrate the samples between two frames, predict the NavState, derive the float pose.
+// One workgroup (128 threads) per stream; the 9x9 covariance product is spread over 81 lanes, the
+// 3x3 state is carried redundantly by every lane.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(128) void k_imu_predict(const double* __restrict__ imu, int n_imu, const double* __restrict__ t_last,
+                                                     const double* __restrict__ t_cur, const double* __restrict__ last_ns,
+                                                     const double* __restrict__ gw3, const double* __restrict__ cam16,
+                                                     double gyr_cov, double acc_cov, double* __restrict__ preint_out,
+                                                     double* __restrict__ cur_ns, float* __restrict__ pose12) {
+    __shared__ double s_cov[81], s_tmp[81], s_A[81], s_N[81];
+    const int b = blockIdx.x, t = threadIdx.x;
+    const double* ns = last_ns + (size_t)b * 22;
+    const double* S = imu + (size_t)b * n_imu * 7;
+    const d3 bg = ld3(ns + 10), ba = ld3(ns + 13);
+    preint_small M;
+    M.dP = mk3(0, 0, 0); M.dV = mk3(0, 0, 0); M.dR = eye3();
+    M.JPg = zero3(); M.JPa = zero3(); M.JVg = zero3(); M.JVa = zero3(); M.JRg = zero3(); M.dt = 0;
+    if (t < 81) s_cov[t] = 0;
+    __syncthreads();
+    const int r = t / 9, c = t % 9;
+    for (int step = 0; step <= n_imu && n_imu > 0; step++) {
+        // step 0: first sample over [t_last, t_imu0]; step k>=1: sample k-1 until the next stamp / the frame
+        const int si = step == 0 ? 0 : step - 1;
+        double d;
+        if (step == 0) d = S[6] - t_last[b];
+        else d = (si == n_imu - 1 ? t_cur[b] : S[(si + 1) * 7 + 6]) - S[si * 7 + 6];
+        const d3 om = ld3(S + si * 7) - bg, ac = ld3(S + si * 7 + 3) - ba;
+        const preint_cov_blocks C = preint_step(M, om, ac, d);
+        if (t < 81) {
+            // A = I + blocks; N = Bg*Sg*Bg^T + Ca*Sa*Ca^T
+            double a = (r == c) ? 1.0 : 0.0;
+            if (r >= 6 && c >= 6) a = m33_at(C.A66, r - 6, c - 6);
+            else if (r >= 3 && r < 6 && c >= 6) a = m33_at(C.A36, r - 3, c - 6);
+            else if (r < 3 && c >= 6) a = m33_at(C.A06, r, c - 6);
+            else if (r < 3 && c >= 3 && c < 6) a = (r == c - 3) ? C.dt : 0.0;
+            s_A[t] = a;
+            double nn = 0;
+            if (r >= 6 && c >= 6) { for (int k = 0; k < 3; k++) nn += m33_at(C.Bg, r - 6, k) * m33_at(C.Bg, c - 6, k); nn *= gyr_cov; }
+            else if (r < 6 && c < 6) {
+                const m33& Cr = r < 3 ? C.Ca0 : C.Ca3; const m33& Cc = c < 3 ? C.Ca0 : C.Ca3;
+                for (int k = 0; k < 3; k++) nn += m33_at(Cr, r % 3, k) * m33_at(Cc, c % 3, k);
+                nn *= acc_cov;
+            }
+            s_N[t] = nn;
+        }
+        __syncthreads();
+        if (t < 81) { double s = 0; for (int k = 0; k < 9; k++) s += s_A[r * 9 + k] * s_cov[k * 9 + c]; s_tmp[t] = s; }
+        __syncthreads();
+        if (t < 81) { double s = 0; for (int k = 0; k < 9; k++) s += s_tmp[r * 9 + k] * s_A[c * 9 + k]; s_cov[t] = s + s_N[t]; }
+        __syncthreads();
+    }
+    double* po = preint_out + (size_t)b * 142;
+    if (t == 0) {
+        st3(po, M.dP); st3(po + 3, M.dV); stm(po + 6, M.dR); stm(po + 15, M.JPg); stm(po + 24, M.JPa);
+        stm(po + 33, M.JVg); stm(po + 42, M.JVa); stm(po + 51, M.JRg); po[141] = M.dt;
+        // SetInitialNavStateAndBias(last) + UpdateNavState + UpdatePoseFromNS
+        const pvr pred = update_ns(ld_pvr(ns), M.dP, M.dV, M.dR, M.dt, ld3(gw3));
+        double* co = cur_ns + (size_t)b * 22;
+        st_pvr(co, pred);
+        for (int k = 10; k < 16; k++) co[k] = ns[k];
+        for (int k = 16; k < 22; k++) co[k] = 0.0;
+        pose_from_navstate_f32(pred, cam16, pose12 + (size_t)b * 12);
+    }
+    if (t < 81) po[60 + t] = s_cov[t];
+}
+
+// Observations of the matched keypoints, compacted in keypoint order (the order of the reference's
+// edge-construction loop): obs[k] = Pw(3) u v invSigma2, obs_index[k] = keypoint index.
+__global__ __launch_bounds__(256) void k_build_observations(const viorb_keypoint* __restrict__ kps, const int* __restrict__ count,
+                                                            const int* __restrict__ match, const float* __restrict__ match_Pw,
+                                                            const float* __restrict__ inv_sigma2, int cap,
+                                                            double* __restrict__ obs, int* __restrict__ obs_index, int* __restrict__ n_obs) {
+    __shared__ int s_base;
+    const int b = blockIdx.x;
+    const int n = min(count[b], cap);
+    if (threadIdx.x == 0) s_base = 0;
+    __syncthreads();
+    for (int base = 0; base < n; base += blockDim.x) {
+        const int i = base + threadIdx.x;
+        const int m = i < n ? match[(size_t)b * cap + i] : -1;
+        const bool has = m >= 0;
+        // block-wide ordered compaction: wave ballots + wave offsets through LDS
+        __shared__ int s_wave[4];
+        const unsigned long long bm = __ballot(has);
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        if (lane == 0) s_wave[wv] = __popcll(bm);
+        __syncthreads();
+        int off = s_base;
+        for (int k = 0; k < wv; k++) off += s_wave[k];
+        if (has) {
+            const int pos = off + __popcll(bm & ((1ull << lane) - 1ull));
+            const viorb_keypoint kp = kps[(size_t)b * cap + i];
+            const float* X = match_Pw + ((size_t)b * cap + m) * 3;
+            double* o = obs + ((size_t)b * cap + pos) * 6;
+            o[0] = X[0]; o[1] = X[1]; o[2] = X[2]; o[3] = kp.x; o[4] = kp.y; o[5] = inv_sigma2[kp.octave];
+            obs_index[(size_t)b * cap + pos] = i;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) s_base += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) n_obs[b] = s_base;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Pose optimisation with NavState edges. One workgroup (256 threads) per problem.
+// Unknowns: x = [cur PVR(9) | cur bias(3) | last PVR(9) | last bias(3)] (n = 24) for the Frame/Frame
+// overload, x = [cur PVR(9) | cur bias(3)] (n = 12) for the Frame/KeyFrame overload (KF fixed).
+// ---------------------------------------------------------------------------------------------
+struct PoseOptArgs {
+    int variant;                 // 0: last is a fixed KeyFrame; 1: last is a free Frame (+ prior edge)
+    int compute_marg, cap;
+    const double *cur_ns, *last_ns, *prior_ns, *marg_cov_inv, *preint, *gw, *cam;
+    const double *obs_cur, *obs_last; const int *n_cur, *n_last;
+    double *out_ns, *out_last_ns, *marg_out, *info;
+    uint8_t *outlier_cur, *outlier_last;
+    double acc_bias_rw2;
+};
+
+struct PoseOptShared {
+    double H[24 * 24], L[24 * 24], b[24], x[24];
+    double J[12 * 24], OJ[12 * 24], e[12];
+    double info_pvr[81], info_prior[144];
+    double red[4 * 32];
+    double est[2][10], bias[2][3];          // PVR (P V q) and dBias_acc of cur / last
+    double bak[2][10], bakb[2][3];
+    double base_ba[2][3];                    // BiasAcc of cur / last (constant)
+    double scal[8];                          // 0 chi2, 1 lambda, 2 ni, 3 rho, 4 ok, 5 scale ...
+    int flag[4];
+};
+
+__device__ __forceinline__ double block_sum(double v, double* red) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[wv] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+// in-place Gauss-Jordan inverse of an n x n matrix in LDS/global (single thread), returns false if singular
+__device__ bool small_inverse(double* a, double* inv, int n) {
+    for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) inv[i * n + j] = (i == j) ? 1.0 : 0.0;
+    for (int col = 0; col < n; col++) {
+        int p = col; double best = fabs(a[col * n + col]);
+        for (int i = col + 1; i < n; i++) if (fabs(a[i * n + col]) > best) { best = fabs(a[i * n + col]); p = i; }
+        if (best == 0) return false;
+        if (p != col) for (int j = 0; j < n; j++) { double t = a[p * n + j]; a[p * n + j] = a[col * n + j]; a[col * n + j] = t; t = inv[p * n + j]; inv[p * n + j] = inv[col * n + j]; inv[col * n + j] = t; }
+        const double iv = 1.0 / a[col * n + col];
+        for (int j = 0; j < n; j++) { a[col * n + j] *= iv; inv[col * n + j] *= iv; }
+        for (int i = 0; i < n; i++) if (i != col) { const double f = a[i * n + col]; if (f == 0) continue; for (int j = 0; j < n; j++) { a[i * n + j] -= f * a[col * n + j]; inv[i * n + j] -= f * inv[col * n + j]; } }
+    }
+    return true;
+}
+
+// H += w * J^T Omega J, b -= w * J^T Omega e for one dense edge (J: m x nv row-major in S.J, map: column -> x index or -1)
+__device__ void add_dense_edge(PoseOptShared& S, int m, int nv, const double* Omega, double w, const int* map, int n) {
+    for (int i = threadIdx.x; i < m * nv; i += blockDim.x) {
+        const int r = i / nv, c = i - r * nv;
+        double s = 0;
+        for (int k = 0; k < m; k++) s += Omega[r * m + k] * S.J[k * nv + c];
+        S.OJ[i] = s;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nv * nv; i += blockDim.x) {
+        const int r = i / nv, c = i - r * nv;
+        if (map[r] < 0 || map[c] < 0) continue;
+        double s = 0;
+        for (int k = 0; k < m; k++) s += S.J[k * nv + r] * S.OJ[k * nv + c];
+        S.H[map[r] * n + map[c]] += w * s;
+    }
+    for (int r = threadIdx.x; r < nv; r += blockDim.x) {
+        if (map[r] < 0) continue;
+        double s = 0;
+        for (int k = 0; k < m; k++) s += S.OJ[k * nv + r] * S.e[k];
+        S.b[map[r]] -= w * s;
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ pvr sh_pvr(const double* p) { pvr s; s.P = ld3(p); s.V = ld3(p + 3); s.q = mkq(p[6], p[7], p[8], p[9]); return s; }
+__device__ __forceinline__ void sh_put(double* p, const pvr& s) { st3(p, s.P); st3(p + 3, s.V); p[6] = s.q.x; p[7] = s.q.y; p[8] = s.q.z; p[9] = s.q.w; }
+
+__global__ __launch_bounds__(256) void k_pose_opt_vi(PoseOptArgs A) {
+    __shared__ PoseOptShared S;
+    __shared__ int s_map21[21], s_map12[12], s_map6[6];
+    const int b = blockIdx.x, t = threadIdx.x, cap = A.cap;
+    const int variant = A.variant, n = variant ? 24 : 12;
+    const int ncur = min(A.n_cur[b], cap), nlast = variant ? min(A.n_last[b], cap) : 0;
+    const double* obs_c = A.obs_cur + (size_t)b * cap * 6;
+    const double* obs_l = A.obs_last ? A.obs_last + (size_t)b * cap * 6 : nullptr;
+    uint8_t* out_c = A.outlier_cur + (size_t)b * cap;
+    uint8_t* out_l = A.outlier_last ? A.outlier_last + (size_t)b * cap : nullptr;
+    const double* curns = A.cur_ns + (size_t)b * 22;
+    const double* lastns = A.last_ns + (size_t)b * 22;
+    const double* pre = A.preint + (size_t)b * 142;
+    const cam_t K = ld_cam(A.cam);
+    const d3 gw = ld3(A.gw);
+    const double d_mono = (double)(float)sqrt(5.991), d_pvr = (double)(float)sqrt(21.666), d_bias = (double)(float)sqrt(16.812),
+                 d_prior = (double)(float)sqrt(30.5779);
+    const double bias_info = 1.0 / A.acc_bias_rw2 / pre[141];
+    // ---- setup
+    for (int i = t; i < ncur; i += blockDim.x) out_c[i] = 0;
+    for (int i = t; i < nlast; i += blockDim.x) out_l[i] = 0;
+    if (t == 0) {
+        // information of the IMU factor: cov^-1 + diag(1e2,1,1e2) (x) I3
+        double tmp[81];
+        for (int i = 0; i < 81; i++) tmp[i] = pre[60 + i];
+        small_inverse(tmp, S.info_pvr, 9);
+        for (int k = 0; k < 3; k++) { S.info_pvr[k * 9 + k] += 1e2; S.info_pvr[(3 + k) * 9 + 3 + k] += 1; S.info_pvr[(6 + k) * 9 + 6 + k] += 1e2; }
+        if (variant) {
+            const double* mc = A.marg_cov_inv + (size_t)b * 144;
+            for (int i = 0; i < 144; i++) S.info_prior[i] = mc[i];
+            for (int k = 0; k < 3; k++) { S.info_prior[k * 12 + k] += 1e2; S.info_prior[(3 + k) * 12 + 3 + k] += 1; S.info_prior[(6 + k) * 12 + 6 + k] += 1e2; }
+        }
+        for (int k = 0; k < 3; k++) { S.base_ba[0][k] = curns[13 + k]; S.base_ba[1][k] = lastns[13 + k]; }
+        // column maps: IMU factor J = [i(9) | j(9) | bias_i(3)] with i = last, j = cur
+        for (int k = 0; k < 9; k++) { s_map21[k] = variant ? 12 + k : -1; s_map21[9 + k] = k; }
+        for (int k = 0; k < 3; k++) s_map21[18 + k] = variant ? 21 + k : -1;
+        for (int k = 0; k < 12; k++) s_map12[k] = 12 + k;              // prior: [last PVR | last bias]
+        for (int k = 0; k < 3; k++) { s_map6[k] = 9 + k; s_map6[3 + k] = variant ? 21 + k : -1; }   // bias edge: [cur | last]
+        S.flag[1] = 0;                                                   // lm iteration counter
+    }
+    __syncthreads();
+    if (ncur < 3) {                                                      // "if(nInitialCorrespondences<3) return 0"
+        if (t == 0) {
+            double* o = A.out_ns + (size_t)b * 22; for (int k = 0; k < 22; k++) o[k] = curns[k];
+            if (A.out_last_ns) { double* ol = A.out_last_ns + (size_t)b * 22; for (int k = 0; k < 22; k++) ol[k] = lastns[k]; }
+            double* inf = A.info + (size_t)b * 4; inf[0] = 0; inf[1] = 0; inf[2] = 0; inf[3] = 0;
+        }
+        return;
+    }
+    const int n_edges_total = ncur + nlast + (variant ? 3 : 2);
+    int kernel_on = 1;           // mono edges keep their Huber kernel until the end of round 3
+    int nbad = 0;
+
+    // robust chi2 of all active edges at the current estimate
+    auto eval_chi2 = [&]() -> double {
+        double acc = 0;
+        for (int side = 0; side < (variant ? 2 : 1); side++) {
+            const pvr s = sh_pvr(S.est[side]);
+            const m33 RT = tr(qmat(s.q));
+            const double* ob = side ? obs_l : obs_c; const uint8_t* ol = side ? out_l : out_c; const int ne = side ? nlast : ncur;
+            for (int i = t; i < ne; i += blockDim.x) {
+                if (ol[i]) continue;
+                double e[2];
+                proj_edge(K, RT, s.P, ld3(ob + 6 * i), ob[6 * i + 3], ob[6 * i + 4], false, e, nullptr, nullptr);
+                const double chi = ob[6 * i + 5] * (e[0] * e[0] + e[1] * e[1]);
+                double r0 = chi, r1 = 1;
+                if (kernel_on) huber(chi, d_mono, &r0, &r1);
+                acc += r0;
+            }
+        }
+        double tot = block_sum(acc, S.red);
+        if (t == 0) {
+            double e[12], r0, r1, chi;
+            const pvr sc = sh_pvr(S.est[0]), sl = sh_pvr(S.est[1]);
+            pvr_edge(sl, sc, ld3(lastns + 16), ld3(S.bias[1]), pre, gw, e, nullptr);
+            chi = 0; for (int i = 0; i < 9; i++) { double s = 0; for (int j = 0; j < 9; j++) s += S.info_pvr[i * 9 + j] * e[j]; chi += e[i] * s; }
+            huber(chi, d_pvr, &r0, &r1); tot += r0;
+            const d3 eb = (ld3(S.base_ba[0]) + ld3(S.bias[0])) - (ld3(S.base_ba[1]) + ld3(S.bias[1]));
+            huber(bias_info * dot3(eb, eb), d_bias, &r0, &r1); tot += r0;
+            if (variant) {
+                prior_edge(sl, ld3(S.base_ba[1]) + ld3(S.bias[1]), A.prior_ns + (size_t)b * 22, e, nullptr);
+                chi = 0; for (int i = 0; i < 12; i++) { double s = 0; for (int j = 0; j < 12; j++) s += S.info_prior[i * 12 + j] * e[j]; chi += e[i] * s; }
+                huber(chi, d_prior, &r0, &r1); tot += r0;
+            }
+            S.scal[0] = tot;
+        }
+        __syncthreads();
+        return S.scal[0];
+    };
+
+    // linearise every active edge at the current estimate: H, b
+    auto build_system = [&]() {
+        for (int i = t; i < n * n; i += blockDim.x) S.H[i] = 0;
+        for (int i = t; i < n; i += blockDim.x) S.b[i] = 0;
+        __syncthreads();
+        for (int side = 0; side < (variant ? 2 : 1); side++) {
+            const pvr s = sh_pvr(S.est[side]);
+            const m33 RT = tr(qmat(s.q));
+            const double* ob = side ? obs_l : obs_c; const uint8_t* ol = side ? out_l : out_c; const int ne = side ? nlast : ncur;
+            double a[27];
+#pragma unroll
+            for (int k = 0; k < 27; k++) a[k] = 0;
+            for (int i = t; i < ne; i += blockDim.x) {
+                if (ol[i]) continue;
+                double e[2], JP[6], JR[6];
+                proj_edge(K, RT, s.P, ld3(ob + 6 * i), ob[6 * i + 3], ob[6 * i + 4], true, e, JP, JR);
+                const double is2 = ob[6 * i + 5];
+                double r0, r1 = 1;
+                if (kernel_on) huber(is2 * (e[0] * e[0] + e[1] * e[1]), d_mono, &r0, &r1);
+                const double w = r1 * is2;
+                const double j0[6] = {JP[0], JP[1], JP[2], JR[0], JR[1], JR[2]}, j1[6] = {JP[3], JP[4], JP[5], JR[3], JR[4], JR[5]};
+                int k = 0;
+#pragma unroll
+                for (int r = 0; r < 6; r++)
+#pragma unroll
+                    for (int c = r; c < 6; c++) a[k++] += w * (j0[r] * j0[c] + j1[r] * j1[c]);
+#pragma unroll
+                for (int r = 0; r < 6; r++) a[21 + r] -= w * (j0[r] * e[0] + j1[r] * e[1]);
+            }
+            // reduce the 27 partials over the block, then scatter into H / b (P at 0..2, Phi at 6..8 of the vertex)
+#pragma unroll
+            for (int k = 0; k < 27; k++) {
+                double v = a[k];
+#pragma unroll
+                for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d);
+                if ((t & 63) == 0) S.red[(t >> 6) * 32 + k] = v;
+            }
+            __syncthreads();
+            if (t < 27) {
+                const double v = S.red[t] + S.red[32 + t] + S.red[64 + t] + S.red[96 + t];
+                const int base = side ? 12 : 0;
+                const int loc[6] = {0, 1, 2, 6, 7, 8};
+                if (t < 21) {
+                    int k = 0, rr = 0, cc = 0;
+                    for (int r = 0; r < 6; r++) for (int c = r; c < 6; c++) { if (k == t) { rr = r; cc = c; } k++; }
+                    S.H[(base + loc[rr]) * n + base + loc[cc]] += v;
+                    if (rr != cc) S.H[(base + loc[cc]) * n + base + loc[rr]] += v;
+                } else S.b[base + loc[t - 21]] += v;
+            }
+            __syncthreads();
+        }
+        // IMU factor
+        if (t == 0) {
+            const pvr sc = sh_pvr(S.est[0]), sl = sh_pvr(S.est[1]);
+            pvr_edge(sl, sc, ld3(lastns + 16), ld3(S.bias[1]), pre, gw, S.e, S.J);
+            double chi = 0; for (int i = 0; i < 9; i++) { double s = 0; for (int j = 0; j < 9; j++) s += S.info_pvr[i * 9 + j] * S.e[j]; chi += S.e[i] * s; }
+            double r0, r1; huber(chi, d_pvr, &r0, &r1); S.scal[6] = r1;
+        }
+        __syncthreads();
+        add_dense_edge(S, 9, 21, S.info_pvr, S.scal[6], s_map21, n);
+        // bias random-walk factor: e = (ba_j + dba_j) - (ba_i + dba_i), J_i = -I, J_j = +I (i = last, j = cur)
+        if (t == 0) {
+            const d3 eb = (ld3(S.base_ba[0]) + ld3(S.bias[0])) - (ld3(S.base_ba[1]) + ld3(S.bias[1]));
+            double r0, r1; huber(bias_info * dot3(eb, eb), d_bias, &r0, &r1);
+            const double w = r1 * bias_info; const double ev[3] = {eb.x, eb.y, eb.z};
+            for (int k = 0; k < 3; k++) {
+                const int jc = s_map6[k], ic = s_map6[3 + k];
+                S.H[jc * n + jc] += w; S.b[jc] -= w * ev[k];
+                if (ic >= 0) { S.H[ic * n + ic] += w; S.H[ic * n + jc] -= w; S.H[jc * n + ic] -= w; S.b[ic] += w * ev[k]; }
+            }
+        }
+        __syncthreads();
+        if (variant) {
+            if (t == 0) {
+                const pvr sl = sh_pvr(S.est[1]);
+                prior_edge(sl, ld3(S.base_ba[1]) + ld3(S.bias[1]), A.prior_ns + (size_t)b * 22, S.e, S.J);
+                double chi = 0; for (int i = 0; i < 12; i++) { double s = 0; for (int j = 0; j < 12; j++) s += S.info_prior[i * 12 + j] * S.e[j]; chi += S.e[i] * s; }
+                double r0, r1; huber(chi, d_prior, &r0, &r1); S.scal[6] = r1;
+            }
+            __syncthreads();
+            add_dense_edge(S, 12, 12, S.info_prior, S.scal[6], s_map12, n);
+        }
+    };
+
+    // (H + lambda I) x = b by Cholesky, columns distributed over lanes; S.flag[0] = success
+    auto solve = [&](double lambda) {
+        for (int i = t; i < n * n; i += blockDim.x) S.L[i] = S.H[i] + ((i / n == i % n) ? lambda : 0.0);
+        if (t == 0) S.flag[0] = 1;
+        __syncthreads();
+        for (int j = 0; j < n; j++) {
+            if (t == 0) {
+                double d = S.L[j * n + j];
+                for (int k = 0; k < j; k++) d -= S.L[j * n + k] * S.L[j * n + k];
+                if (!(d > 0) || !isfinite(d)) { S.flag[0] = 0; d = 1; }
+                S.L[j * n + j] = sqrt(d);
+            }
+            __syncthreads();
+            for (int i = j + 1 + t; i < n; i += blockDim.x) {
+                double s = S.L[i * n + j];
+                for (int k = 0; k < j; k++) s -= S.L[i * n + k] * S.L[j * n + k];
+                S.L[i * n + j] = s / S.L[j * n + j];
+            }
+            __syncthreads();
+        }
+        if (t == 0) {
+            double y[24];
+            for (int i = 0; i < n; i++) { double s = S.b[i]; for (int k = 0; k < i; k++) s -= S.L[i * n + k] * y[k]; y[i] = s / S.L[i * n + i]; }
+            for (int i = n - 1; i >= 0; i--) { double s = y[i]; for (int k = i + 1; k < n; k++) s -= S.L[k * n + i] * S.x[k]; S.x[i] = s / S.L[i * n + i]; }
+            if (!S.flag[0]) for (int i = 0; i < n; i++) S.x[i] = 0;
+        }
+        __syncthreads();
+    };
+
+    for (int round = 0; round < 4; round++) {
+        // reset the estimates to the frames' NavStates (Optimizer.cc:614-617 / :984-985)
+        if (t == 0) {
+            sh_put(S.est[0], ld_pvr(curns)); sh_put(S.est[1], ld_pvr(lastns));
+            for (int k = 0; k < 3; k++) { S.bias[0][k] = curns[19 + k]; S.bias[1][k] = lastns[19 + k]; }
+        }
+        __syncthreads();
+        // ---- optimize(10): g2o Levenberg
+        double lambda = 0, ni = 2; int nBadLM = 0;
+        for (int it = 0; it < 10; it++) {
+            double currentChi = eval_chi2();
+            const double iniChi = currentChi;
+            build_system();
+            if (it == 0) {
+                double mx = 0; for (int i = 0; i < n; i++) mx = fmax(fabs(S.H[i * n + i]), mx);
+                lambda = 1e-5 * mx; ni = 2; nBadLM = 0;
+            }
+            double rho = 0; int qmax = 0;
+            do {
+                if (t == 0) { for (int k = 0; k < 10; k++) { S.bak[0][k] = S.est[0][k]; S.bak[1][k] = S.est[1][k]; } for (int k = 0; k < 3; k++) { S.bakb[0][k] = S.bias[0][k]; S.bakb[1][k] = S.bias[1][k]; } }
+                solve(lambda);
+                const int ok2 = S.flag[0];
+                if (t == 0) {
+                    sh_put(S.est[0], inc_small_pvr(sh_pvr(S.est[0]), S.x));
+                    for (int k = 0; k < 3; k++) S.bias[0][k] += S.x[9 + k];
+                    if (variant) { sh_put(S.est[1], inc_small_pvr(sh_pvr(S.est[1]), S.x + 12)); for (int k = 0; k < 3; k++) S.bias[1][k] += S.x[21 + k]; }
+                }
+                __syncthreads();
+                double tempChi = eval_chi2();
+                if (!ok2) tempChi = 1.7976931348623157e308;
+                double scale = 0; for (int j = 0; j < n; j++) scale += S.x[j] * (lambda * S.x[j] + S.b[j]);
+                scale += 1e-3;
+                rho = (currentChi - tempChi) / scale;
+                if (rho > 0 && isfinite(tempChi)) {
+                    double alpha = 1. - pow(2 * rho - 1, 3);
+                    alpha = fmin(alpha, 2. / 3.);
+                    lambda *= fmax(1. / 3., alpha); ni = 2; currentChi = tempChi;
+                } else {
+                    lambda *= ni; ni *= 2;
+                    __syncthreads();
+                    if (t == 0) { for (int k = 0; k < 10; k++) { S.est[0][k] = S.bak[0][k]; S.est[1][k] = S.bak[1][k]; } for (int k = 0; k < 3; k++) { S.bias[0][k] = S.bakb[0][k]; S.bias[1][k] = S.bakb[1][k]; } }
+                }
+                __syncthreads();
+                qmax++;
+            } while (rho < 0 && qmax < 10);
+            if (t == 0) { S.flag[1]++; S.scal[7] = currentChi; }
+            if (qmax == 10 || rho == 0) break;
+            if ((iniChi - currentChi) * 1e3 < iniChi) nBadLM++; else nBadLM = 0;
+            if (nBadLM >= 3) break;
+        }
+        __syncthreads();
+        // ---- re-classify every mono edge by its chi2 at the new estimate (Optimizer.cc:622-688)
+        nbad = 0;
+        {
+            int bad_local = 0;
+            for (int side = 0; side < (variant ? 2 : 1); side++) {
+                const pvr s = sh_pvr(S.est[side]);
+                const m33 RT = tr(qmat(s.q));
+                const double* ob = side ? obs_l : obs_c; uint8_t* ol = side ? out_l : out_c; const int ne = side ? nlast : ncur;
+                for (int i = t; i < ne; i += blockDim.x) {
+                    double e[2];
+                    proj_edge(K, RT, s.P, ld3(ob + 6 * i), ob[6 * i + 3], ob[6 * i + 4], false, e, nullptr, nullptr);
+                    const float chi2 = (float)(ob[6 * i + 5] * (e[0] * e[0] + e[1] * e[1]));
+                    const int bad = chi2 > 5.991f;
+                    ol[i] = (uint8_t)bad;
+                    if (side == 0) bad_local += bad;
+                }
+            }
+            nbad = (int)(block_sum((double)bad_local, S.red) + 0.5);
+        }
+        if (round == 2) kernel_on = 0;
+        __syncthreads();
+        if (n_edges_total < 10) break;
+    }
+    // ---- outputs
+    if (t == 0) {
+        double* o = A.out_ns + (size_t)b * 22;
+        for (int k = 0; k < 10; k++) o[k] = S.est[0][k];
+        for (int k = 10; k < 19; k++) o[k] = curns[k];
+        for (int k = 0; k < 3; k++) o[19 + k] = S.bias[0][k];
+        if (A.out_last_ns) {
+            double* ol = A.out_last_ns + (size_t)b * 22;
+            for (int k = 0; k < 10; k++) ol[k] = variant ? S.est[1][k] : lastns[k];
+            for (int k = 10; k < 19; k++) ol[k] = lastns[k];
+            for (int k = 0; k < 3; k++) ol[19 + k] = variant ? S.bias[1][k] : lastns[19 + k];
+        }
+        double* inf = A.info + (size_t)b * 4;
+        inf[0] = ncur - nbad; inf[1] = S.scal[7]; inf[2] = S.flag[1]; inf[3] = 0;
+        if (A.compute_marg) {
+            // marginal covariance blocks of (cur PVR, cur bias) from the last linearised H (restored diagonal)
+            double* mo = A.marg_out + (size_t)b * 144;
+            for (int i = 0; i < n * n; i++) S.L[i] = S.H[i];
+            double* Hinv = S.H;                       // H is not needed any more
+            small_inverse(S.L, Hinv, n);
+            if (variant) {
+                for (int i = 0; i < 12; i++) for (int j = 0; j < 12; j++) S.L[i * 12 + j] = Hinv[i * n + j];
+                small_inverse(S.L, mo, 12);
+            } else {
+                double c9[81], i9[81], c3[9], i3[9];
+                for (int i = 0; i < 9; i++) for (int j = 0; j < 9; j++) c9[i * 9 + j] = Hinv[i * n + j];
+                for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) c3[i * 3 + j] = Hinv[(9 + i) * n + 9 + j];
+                small_inverse(c9, i9, 9); small_inverse(c3, i3, 3);
+                for (int i = 0; i < 144; i++) mo[i] = 0;
+                for (int i = 0; i < 9; i++) for (int j = 0; j < 9; j++) mo[i * 12 + j] = i9[i * 9 + j];
+                for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) mo[(9 + i) * 12 + 9 + j] = i3[i * 3 + j];
+            }
+        }
+    }
+}
+
+} // namespace viorb
+
+// ---------------------------------------------------------------------------------------------
+// Host side: handle, launches, C ABI
+// ---------------------------------------------------------------------------------------------
+using namespace viorb;
+
+struct viorb_frontend {
+    viorb_frontend_config cfg;
+    int max_batch = 0, cap = 0, device = 0, sort_n = 0;
+    float wInv = 0, hInv = 0;
+    uint32_t* d_cand = nullptr; int* d_cand_n = nullptr;
+    double *d_cam = nullptr, *d_gw = nullptr; float* d_inv_sigma2 = nullptr;
+};
+
+extern "C" {
+
+int viorb_frontend_create(const viorb_frontend_config* cfg, int max_batch, int cap, int device, viorb_frontend** out) {
+    VIORB_REQUIRE(cfg && out, "null cfg/out");
+    VIORB_REQUIRE(max_batch >= 1 && cap >= 1 && cap <= 32768, "max_batch >= 1, 1 <= cap <= 32768");
+    VIORB_REQUIRE(cfg->nlevels >= 1 && cfg->nlevels <= 16, "nlevels must be 1..16");
+    VIORB_REQUIRE(cfg->max_x > cfg->min_x && cfg->max_y > cfg->min_y, "empty image bounds");
+    if (viorb_device_count() < 1) { set_error("no HIP device: libviorb_hip has no CPU fallback"); return VIORB_ERR_NO_DEVICE; }
+    VIORB_HIP_TRY(hipSetDevice(device));
+    viorb_frontend* h = new viorb_frontend();
+    h->cfg = *cfg; h->max_batch = max_batch; h->cap = cap; h->device = device;
+    if (h->cfg.gyr_meas_cov <= 0) h->cfg.gyr_meas_cov = 2.0e-3 * 2.0e-3 * 200;     // reference src/IMU/imudata.cpp:36-37
+    if (h->cfg.acc_meas_cov <= 0) h->cfg.acc_meas_cov = 8.0e-3 * 8.0e-3 * 200;
+    if (h->cfg.acc_bias_rw2 <= 0) h->cfg.acc_bias_rw2 = 5e-3 * 5e-3;               // :32
+    // Frame.cc:184-185
+    h->wInv = static_cast<float>(GRID_COLS) / static_cast<float>(cfg->max_x - cfg->min_x);
+    h->hInv = static_cast<float>(GRID_ROWS) / static_cast<float>(cfg->max_y - cfg->min_y);
+    int s = 64; while (s < cap) s <<= 1;
+    h->sort_n = s;
+    VIORB_HIP_TRY(hipMalloc(&h->d_cand, (size_t)max_batch * cap * CAND_CAP * sizeof(uint32_t)));
+    VIORB_HIP_TRY(hipMalloc(&h->d_cand_n, (size_t)max_batch * cap * sizeof(int)));
+    VIORB_HIP_TRY(hipMalloc(&h->d_cam, 16 * sizeof(double)));
+    VIORB_HIP_TRY(hipMalloc(&h->d_gw, 3 * sizeof(double)));
+    VIORB_HIP_TRY(hipMalloc(&h->d_inv_sigma2, 16 * sizeof(float)));
+    VIORB_HIP_TRY(hipMemcpy(h->d_cam, cfg->cam, 16 * sizeof(double), hipMemcpyHostToDevice));
+    VIORB_HIP_TRY(hipMemcpy(h->d_gw, cfg->gravity, 3 * sizeof(double), hipMemcpyHostToDevice));
+    VIORB_HIP_TRY(hipMemcpy(h->d_inv_sigma2, cfg->inv_level_sigma2, 16 * sizeof(float), hipMemcpyHostToDevice));
+    *out = h;
+    return VIORB_OK;
+}
+
+int viorb_frontend_destroy(viorb_frontend* h) {
+    if (!h) return VIORB_OK;
+    (void)hipSetDevice(h->device);
+    if (h->d_cand) (void)hipFree(h->d_cand);
+    if (h->d_cand_n) (void)hipFree(h->d_cand_n);
+    if (h->d_cam) (void)hipFree(h->d_cam);
+    if (h->d_gw) (void)hipFree(h->d_gw);
+    if (h->d_inv_sigma2) (void)hipFree(h->d_inv_sigma2);
+    delete h;
+    return VIORB_OK;
+}
+
+#define FE_CHECK_BATCH(h, batch)                                                              \
+    VIORB_REQUIRE(h, "null handle");                                                          \
+    VIORB_REQUIRE((batch) >= 1 && (batch) <= (h)->max_batch, "batch out of range");           \
+    VIORB_HIP_TRY(hipSetDevice((h)->device))
+
+int viorb_frontend_grid_device(viorb_frontend* h, const viorb_keypoint* kps, const int32_t* count, int batch,
+                               int32_t* cell_start, int32_t* cell_idx, void* stream) {
+    FE_CHECK_BATCH(h, batch);
+    VIORB_REQUIRE(kps && count && cell_start && cell_idx, "null array");
+    hipLaunchKernelGGL(k_frame_grid, dim3(batch), dim3(256), (size_t)h->sort_n * 4, (hipStream_t)stream, kps, count, h->cap,
+                       h->cfg.min_x, h->cfg.min_y, h->wInv, h->hInv, cell_start, cell_idx, h->sort_n);
+    VIORB_HIP_TRY(hipGetLastError());
+    return VIORB_OK;
+}
+
+int viorb_frontend_imu_predict_device(viorb_frontend* h, const double* imu, int n_imu, const double* t_last, const double* t_cur,
+                                      const double* last_ns, int batch, double* preint, double* cur_ns, float* pose12, void* stream) {
+    FE_CHECK_BATCH(h, batch);
+    VIORB_REQUIRE(imu && t_last && t_cur && last_ns && preint && cur_ns && pose12 && n_imu >= 1, "null array / n_imu < 1");
+    hipLaunchKernelGGL(k_imu_predict, dim3(batch), dim3(128), 0, (hipStream_t)stream, imu, n_imu, t_last, t_cur, last_ns, h->d_gw,
+                       h->d_cam, h->cfg.gyr_meas_cov, h->cfg.acc_meas_cov, preint, cur_ns, pose12);
+    VIORB_HIP_TRY(hipGetLastError());
+    return VIORB_OK;
+}
+
+int viorb_frontend_search_projection_device(viorb_frontend* h, const viorb_keypoint* cur_kps, const uint8_t* cur_desc,
+                                            const int32_t* cur_count, const int32_t* cell_start, const int32_t* cell_idx,
+                                            const float* pose12, const viorb_keypoint* last_kps, const int32_t* last_count,
+                                            const uint8_t* last_flags, const float* last_Pw, const uint8_t* last_desc, float th,
+                                            int batch, int32_t* cur_match, int32_t* nmatches, int32_t* status, void* stream) {
+    FE_CHECK_BATCH(h, batch);
+    VIORB_REQUIRE(cur_kps && cur_desc && cur_count && cell_start && cell_idx && pose12 && last_kps && last_count && last_flags &&
+                  last_Pw && last_desc && cur_match && nmatches && status, "null array");
+    SearchArgs A;
+    A.cur_kps = cur_kps; A.cur_desc = cur_desc; A.cur_count = cur_count; A.cell_start = cell_start; A.cell_idx = cell_idx;
+    A.pose12 = pose12; A.last_kps = last_kps; A.last_count = last_count; A.last_flags = last_flags; A.last_Pw = last_Pw;
+    A.last_desc = last_desc; A.cur_match = cur_match; A.nmatches = nmatches; A.status = status;
+    A.cand = h->d_cand; A.cand_n = h->d_cand_n; A.cap = h->cap;
+    A.minX = h->cfg.min_x; A.maxX = h->cfg.max_x; A.minY = h->cfg.min_y; A.maxY = h->cfg.max_y; A.wInv = h->wInv; A.hInv = h->hInv;
+    A.fx = h->cfg.fx; A.fy = h->cfg.fy; A.cx = h->cfg.cx; A.cy = h->cfg.cy; A.th = th;
+    for (int i = 0; i < 16; i++) A.scale[i] = h->cfg.scale_factors[i];
+    A.check_ori = h->cfg.check_orientation;
+    VIORB_HIP_TRY(hipMemsetAsync(status, 0, sizeof(int32_t) * batch, (hipStream_t)stream));
+    hipLaunchKernelGGL(k_search_projection, dim3(batch), dim3(256), (size_t)h->cap * 4 * sizeof(int), (hipStream_t)stream, A);
+    VIORB_HIP_TRY(hipGetLastError());
+    return VIORB_OK;
+}
+
+int viorb_frontend_build_observations_device(viorb_frontend* h, const viorb_keypoint* kps, const int32_t* count, const int32_t* match,
+                                             const float* match_Pw, int batch, double* obs, int32_t* obs_index, int32_t* n_obs,
+                                             void* stream) {
+    FE_CHECK_BATCH(h, batch);
+    VIORB_REQUIRE(kps && count && match && match_Pw && obs && obs_index && n_obs, "null array");
+    hipLaunchKernelGGL(k_build_observations, dim3(batch), dim3(256), 0, (hipStream_t)stream, kps, count, match, match_Pw,
+                       h->d_inv_sigma2, h->cap, obs, obs_index, n_obs);
+    VIORB_HIP_TRY(hipGetLastError());
+    return VIORB_OK;
+}
+
+int viorb_frontend_pose_opt_device(viorb_frontend* h, int variant, int compute_marg, const double* cur_ns, const double* last_ns,
+                                   const double* prior_ns, const double* marg_cov_inv, const double* preint, const double* obs_cur,
+                                   const int32_t* n_cur, const double* obs_last, const int32_t* n_last, int batch, double* out_ns,
+                                   double* out_last_ns, uint8_t* outlier_cur, uint8_t* outlier_last, double* marg_out, double* info,
+                                   void* stream) {
+    FE_CHECK_BATCH(h, batch);
+    VIORB_REQUIRE(variant == 0 || variant == 1, "variant must be 0 (KeyFrame) or 1 (Frame)");
+    VIORB_REQUIRE(cur_ns && last_ns && preint && obs_cur && n_cur && out_ns && outlier_cur && info, "null array");
+    VIORB_REQUIRE(!variant || (prior_ns && marg_cov_inv && obs_last && n_last && outlier_last), "variant 1 needs prior and last-frame arrays");
+    VIORB_REQUIRE(!compute_marg || marg_out, "marg_out is NULL");
+    PoseOptArgs A;
+    A.variant = variant; A.compute_marg = compute_marg; A.cap = h->cap;
+    A.cur_ns = cur_ns; A.last_ns = last_ns; A.prior_ns = prior_ns; A.marg_cov_inv = marg_cov_inv; A.preint = preint;
+    A.gw = h->d_gw; A.cam = h->d_cam; A.obs_cur = obs_cur; A.obs_last = variant ? obs_last : nullptr; A.n_cur = n_cur; A.n_last = n_last;
+    A.out_ns = out_ns; A.out_last_ns = out_last_ns; A.marg_out = marg_out; A.info = info;
+    A.outlier_cur = outlier_cur; A.outlier_last = variant ? outlier_last : nullptr; A.acc_bias_rw2 = h->cfg.acc_bias_rw2;
+    hipLaunchKernelGGL(k_pose_opt_vi, dim3(batch), dim3(256), 0, (hipStream_t)stream, A);
+    VIORB_HIP_TRY(hipGetLastError());
+    return VIORB_OK;
+}
+
+// ---- host-buffer drop-ins ------------------------------------------------------------------------
+int viorb_descriptor_distance(const uint8_t* a, const uint8_t* b) {
+    uint32_t x[8], y[8];
+    memcpy(x, a, 32); memcpy(y, b, 32);
+    return hamming256(x, y);
+}
+
+} // extern "C"
+
+namespace {
+struct DevBuf {                      // RAII scratch for the host wrappers
+    std::vector<void*> ptrs;
+    ~DevBuf() { for (void* p : ptrs) (void)hipFree(p); }
+    template <class T> int up(T** d, const T* hsrc, size_t n) {
+        hipError_t e = hipMalloc((void**)d, std::max<size_t>(n, 1) * sizeof(T));
+        if (e != hipSuccess) { set_error("hipMalloc failed: %s", hipGetErrorString(e)); return VIORB_ERR_HIP; }
+        ptrs.push_back(*d);
+        if (hsrc && n) { e = hipMemcpy(*d, hsrc, n * sizeof(T), hipMemcpyHostToDevice); if (e != hipSuccess) { set_error("H2D failed: %s", hipGetErrorString(e)); return VIORB_ERR_HIP; } }
+        else if (n) { e = hipMemset(*d, 0, n * sizeof(T)); if (e != hipSuccess) { set_error("memset failed"); return VIORB_ERR_HIP; } }
+        return VIORB_OK;
+    }
+};
+#define FE_TRY(x) do { int _rc = (x); if (_rc != VIORB_OK) return _rc; } while (0)
+viorb_frontend_config default_cfg() {
+    viorb_frontend_config c; memset(&c, 0, sizeof(c));
+    c.min_x = 0; c.max_x = 752; c.min_y = 0; c.max_y = 480; c.nlevels = 8; c.check_orientation = 1;
+    float s = 1.f; for (int i = 0; i < 16; i++) { c.scale_factors[i] = s; c.inv_level_sigma2[i] = 1.f / (s * s); s *= 1.2f; }
+    return c;
+}
+} // namespace
+
+extern "C" {
+
+int viorb_preintegrate(const double* imu, int n_imu, const double bg[3], const double ba[3], double t_last, double t_cur, double* preint142) {
+    VIORB_REQUIRE(imu && bg && ba && preint142 && n_imu >= 1, "null array / n_imu < 1");
+    viorb_frontend_config c = default_cfg();
+    for (int i = 0; i < 9; i += 4) c.cam[4 + i] = 1;
+    viorb_frontend* h = nullptr;
+    FE_TRY(viorb_frontend_create(&c, 1, 64, 0, &h));
+    struct Guard { viorb_frontend* h; ~Guard() { viorb_frontend_destroy(h); } } g{h};
+    double ns[22]; memset(ns, 0, sizeof(ns)); ns[9] = 1; for (int k = 0; k < 3; k++) { ns[10 + k] = bg[k]; ns[13 + k] = ba[k]; }
+    DevBuf B; double *d_imu, *d_tl, *d_tc, *d_ns, *d_pre, *d_cur; float* d_pose;
+    FE_TRY(B.up(&d_imu, imu, (size_t)n_imu * 7)); FE_TRY(B.up(&d_tl, &t_last, 1)); FE_TRY(B.up(&d_tc, &t_cur, 1));
+    FE_TRY(B.up(&d_ns, ns, 22)); FE_TRY(B.up(&d_pre, (const double*)nullptr, 142)); FE_TRY(B.up(&d_cur, (const double*)nullptr, 22));
+    FE_TRY(B.up(&d_pose, (const float*)nullptr, 12));
+    FE_TRY(viorb_frontend_imu_predict_device(h, d_imu, n_imu, d_tl, d_tc, d_ns, 1, d_pre, d_cur, d_pose, nullptr));
+    VIORB_HIP_TRY(hipDeviceSynchronize());
+    VIORB_HIP_TRY(hipMemcpy(preint142, d_pre, 142 * sizeof(double), hipMemcpyDeviceToHost));
+    return VIORB_OK;
+}
+
+int viorb_pose_opt_vi(int variant, int compute_marg, const double cur_ns[22], const double last_ns[22], const double prior_ns[22],
+                      const double* marg_cov_inv144, const double preint[142], const double gw[3], const double cam[16],
+                      const double* obs_cur, int n_cur, const double* obs_last, int n_last, double out_ns[22], double out_last_ns[22],
+                      uint8_t* outlier_cur, uint8_t* outlier_last, double* marg_out144, double info[4]) {
+    VIORB_REQUIRE(cur_ns && last_ns && preint && gw && cam && out_ns && info && n_cur >= 0 && n_last >= 0, "null array");
+    VIORB_REQUIRE(n_cur == 0 || (obs_cur && outlier_cur), "obs_cur/outlier_cur NULL");
+    viorb_frontend_config c = default_cfg();
+    for (int i = 0; i < 16; i++) c.cam[i] = cam[i];
+    for (int i = 0; i < 3; i++) c.gravity[i] = gw[i];
+    const int cap = std::max(std::max(n_cur, n_last), 1);
+    viorb_frontend* h = nullptr;
+    FE_TRY(viorb_frontend_create(&c, 1, cap, 0, &h));
+    struct Guard { viorb_frontend* h; ~Guard() { viorb_frontend_destroy(h); } } g{h};
+    DevBuf B; double *d_cur, *d_last, *d_prior, *d_mci, *d_pre, *d_oc, *d_ol, *d_out, *d_outl, *d_marg, *d_info; int *d_nc, *d_nl; uint8_t *d_fc, *d_fl;
+    double zero22[22] = {0}, zero144[144] = {0};
+    FE_TRY(B.up(&d_cur, cur_ns, 22)); FE_TRY(B.up(&d_last, last_ns, 22)); FE_TRY(B.up(&d_prior, prior_ns ? prior_ns : zero22, 22));
+    FE_TRY(B.up(&d_mci, marg_cov_inv144 ? marg_cov_inv144 : zero144, 144)); FE_TRY(B.up(&d_pre, preint, 142));
+    FE_TRY(B.up(&d_oc, obs_cur, (size_t)n_cur * 6)); FE_TRY(B.up(&d_ol, obs_last, (size_t)n_last * 6));
+    FE_TRY(B.up(&d_out, (const double*)nullptr, 22)); FE_TRY(B.up(&d_outl, (const double*)nullptr, 22));
+    FE_TRY(B.up(&d_marg, (const double*)nullptr, 144)); FE_TRY(B.up(&d_info, (const double*)nullptr, 4));
+    FE_TRY(B.up(&d_nc, &n_cur, 1)); FE_TRY(B.up(&d_nl, &n_last, 1));
+    FE_TRY(B.up(&d_fc, (const uint8_t*)nullptr, cap)); FE_TRY(B.up(&d_fl, (const uint8_t*)nullptr, cap));
+    FE_TRY(viorb_frontend_pose_opt_device(h, variant, compute_marg, d_cur, d_last, d_prior, d_mci, d_pre, d_oc, d_nc, d_ol, d_nl, 1,
+                                          d_out, d_outl, d_fc, d_fl, d_marg, d_info, nullptr));
+    VIORB_HIP_TRY(hipDeviceSynchronize());
+    VIORB_HIP_TRY(hipMemcpy(out_ns, d_out, 22 * sizeof(double), hipMemcpyDeviceToHost));
+    if (out_last_ns) VIORB_HIP_TRY(hipMemcpy(out_last_ns, d_outl, 22 * sizeof(double), hipMemcpyDeviceToHost));
+    if (n_cur) VIORB_HIP_TRY(hipMemcpy(outlier_cur, d_fc, n_cur, hipMemcpyDeviceToHost));
+    if (n_last && outlier_last && variant) VIORB_HIP_TRY(hipMemcpy(outlier_last, d_fl, n_last, hipMemcpyDeviceToHost));
+    if (compute_marg && marg_out144) VIORB_HIP_TRY(hipMemcpy(marg_out144, d_marg, 144 * sizeof(double), hipMemcpyDeviceToHost));
+    VIORB_HIP_TRY(hipMemcpy(info, d_info, 4 * sizeof(double), hipMemcpyDeviceToHost));
+    return VIORB_OK;
+}
+
+// ---- host-only test hooks: vio_core.h compiled for the host ---------------------------------------
+void viorb_debug_pvr_edge(const double* i22, const double* j22, const double* b22, const double* preint142, const double* gw,
+                          double* e9, double* J189) {
+    pvr_edge(ld_pvr(i22), ld_pvr(j22), ld3(b22 + 16), ld3(b22 + 19), preint142, ld3(gw), e9, J189);
+}
+void viorb_debug_proj_edge(const double* ns22, const double* cam16, const double* obs6, double* e2, double* J12) {
+    const pvr s = ld_pvr(ns22); const cam_t K = ld_cam(cam16);
+    proj_edge(K, tr(qmat(s.q)), s.P, ld3(obs6), obs6[3], obs6[4], true, e2, J12, J12 + 6);
+}
+void viorb_debug_prior_edge(const double* pvr22, const double* bias22, const double* prior22, double* e12, double* J144) {
+    prior_edge(ld_pvr(pvr22), ld3(bias22 + 13) + ld3(bias22 + 19), prior22, e12, J144);
+}
+void viorb_debug_update_ns(const double* ns22, const double* preint142, const double* gw, const double* cam16, double* out22, float* pose12) {
+    const pvr r = update_ns(ld_pvr(ns22), ld3(preint142), ld3(preint142 + 3), ldm(preint142 + 6), preint142[141], ld3(gw));
+    for (int k = 0; k < 22; k++) out22[k] = ns22[k];
+    st_pvr(out22, r);
+    pose_from_navstate_f32(r, cam16, pose12);
+}
+void viorb_debug_preint_step(double* small60, const double* omega, const double* acc, double dt) {
+    preint_small M; M.dP = ld3(small60); M.dV = ld3(small60 + 3); M.dR = ldm(small60 + 6); M.JPg = ldm(small60 + 15); M.JPa = ldm(small60 + 24);
+    M.JVg = ldm(small60 + 33); M.JVa = ldm(small60 + 42); M.JRg = ldm(small60 + 51); M.dt = 0;
+    preint_step(M, ld3(omega), ld3(acc), dt);
+    st3(small60, M.dP); st3(small60 + 3, M.dV); stm(small60 + 6, M.dR); stm(small60 + 15, M.JPg); stm(small60 + 24, M.JPa);
+    stm(small60 + 33, M.JVg); stm(small60 + 42, M.JVa); stm(small60 + 51, M.JRg);
+}
+
+} // extern "C"

@@ -13,8 +13,8 @@
 //   * the largest-first phase sorts (count<<16 | array_index): the index tie-break is the node
 //     creation order (the reference compares heap pointers there, src/ORBextractor.cc:684 — the
 //     deterministic replacement documented in DESIGN.md).
-// This host version is used (a) by the CPU parity tests to validate the formulation against the
-// list-based oracle without a GPU, (b) as the selectable host stage VIORB_OCTREE=host.
+// This host version exists only behind the test hook viorb_debug_octree_host(): the CPU parity tests
+// validate the formulation against the list-based oracle without a GPU. The product never runs it.
 #pragma once
 #include <stdint.h>
 #include <vector>

@@ -666,7 +666,6 @@ using namespace viorb;
 struct viorb_extractor {
     viorb_extractor_params p;
     int max_batch = 1, device = 0;
-    bool host_octree = false;
     // ctor tables (reference :410-470)
     std::vector<float> scale, inv_scale, sigma2, inv_sigma2;
     std::vector<int> quota;
@@ -904,38 +903,11 @@ static int launch_all(viorb_extractor* h, const uint8_t* d_images, int batch, in
                            h->p.ini_th_fast, h->p.min_th_fast, h->d_slots, h->slot_cap, h->d_cell_cnt, ncells,
                            h->fast_tile_pitch, h->fast_tile_rows, h->fast_score_bytes);
     }
-    if (!h->host_octree) {
+    {
         const size_t lds = (size_t)h->oct_ncap * 8 + (size_t)h->oct_nodecap * sizeof(OctNode) + (size_t)h->oct_sortcap * 4;
         hipLaunchKernelGGL(k_octree, dim3(nl, batch), dim3(64), lds, st, h->d_lv, h->d_slots, h->slot_cap, h->d_cell_cnt, ncells,
                            h->d_lvl_kp, h->kp_pitch, h->d_lvl_cnt, h->d_lvl_ncand, nl, h->d_status, h->oct_ncap, h->oct_nodecap,
                            h->oct_sortcap);
-    } else {
-        // host stage (VIORB_OCTREE=host): download cell slots, run the array formulation on the CPU
-        VIORB_HIP_TRY(hipStreamSynchronize(st));
-        std::vector<int> cc((size_t)batch * ncells);
-        std::vector<uint32_t> sl((size_t)batch * ncells * h->slot_cap);
-        VIORB_HIP_TRY(hipMemcpy(cc.data(), h->d_cell_cnt, cc.size() * sizeof(int), hipMemcpyDeviceToHost));
-        VIORB_HIP_TRY(hipMemcpy(sl.data(), h->d_slots, sl.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
-        std::vector<uint32_t> kp((size_t)batch * h->kp_pitch, 0);
-        std::vector<int> lc((size_t)batch * nl, 0), nc((size_t)batch * nl, 0);
-        for (int b = 0; b < batch; b++)
-            for (int l = 0; l < nl; l++) {
-                const LevelDev& L = h->lv[l];
-                std::vector<uint32_t> keys;
-                for (int c = 0; c < L.ncells; c++) {
-                    const size_t ci = (size_t)b * ncells + L.cell_base + c;
-                    for (int k = 0; k < cc[ci]; k++) keys.push_back(sl[ci * h->slot_cap + k]);
-                }
-                nc[b * nl + l] = (int)keys.size();
-                std::vector<uint32_t> r = distribute_octree_arrays(keys, L.oct_w, L.oct_h, L.quota);
-                const int m = std::min((int)r.size(), L.quota + 4);
-                for (int k = 0; k < m; k++)
-                    kp[(size_t)b * h->kp_pitch + L.kp_off + k] = (r[k] & 0xff000000u) | ((((r[k] >> 12) & 0xfff) + MINB) << 12) | ((r[k] & 0xfff) + MINB);
-                lc[b * nl + l] = m;
-            }
-        VIORB_HIP_TRY(hipMemcpy(h->d_lvl_kp, kp.data(), kp.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-        VIORB_HIP_TRY(hipMemcpy(h->d_lvl_cnt, lc.data(), lc.size() * sizeof(int), hipMemcpyHostToDevice));
-        VIORB_HIP_TRY(hipMemcpy(h->d_lvl_ncand, nc.data(), nc.size() * sizeof(int), hipMemcpyHostToDevice));
     }
     hipLaunchKernelGGL(k_blur, dim3((unsigned)h->blur_tiles.size(), batch), dim3(256), 0, st, h->d_planes, h->d_blur, h->frame_bytes,
                        h->d_lv, h->d_blur_tiles);
@@ -963,8 +935,6 @@ int viorb_extractor_create(const viorb_extractor_params* params, int max_batch, 
     VIORB_REQUIRE(max_batch >= 1, "max_batch >= 1");
     viorb_extractor* h = new viorb_extractor();
     h->p = *params; h->max_batch = max_batch; h->device = device;
-    const char* e = getenv("VIORB_OCTREE");
-    h->host_octree = e && std::string(e) == "host";
     const int nl = params->nlevels;
     // reference :415-445 (scaleFactor is held in a double member there; float*double -> float)
     const double sf = (double)params->scale_factor;

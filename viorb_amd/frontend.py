@@ -1,0 +1,107 @@
+"""Python mirror of the per-frame tracking calls over the C ABI (include/viorb.h, "front-end" section):
+ORBmatcher::SearchByProjection(Frame, Frame), Frame grid, IMU pre-integration + NavState prediction and
+Optimizer::PoseOptimization with NavState edges. `Frontend` is the batched, device-resident form (torch
+tensors carry device memory only); the module-level functions are the host-buffer drop-ins."""
+import ctypes as C
+import numpy as np
+from . import capi
+from .capi import lib, check, ptr
+
+GRID_CELLS = 64 * 48
+
+
+def descriptor_distance(a, b):
+    """ORBmatcher::DescriptorDistance (reference src/ORBmatcher.cc:1648-1664)."""
+    return lib().viorb_descriptor_distance(ptr(np.ascontiguousarray(a, np.uint8)), ptr(np.ascontiguousarray(b, np.uint8)))
+
+
+def preintegrate(imu, bg, ba, t_last, t_cur):
+    """IMU pre-integration between two frames (Frame::ComputeIMUPreIntSinceLastFrame). Returns preint[142]."""
+    imu = np.ascontiguousarray(imu, np.float64).reshape(-1, 7)
+    out = np.zeros(142)
+    check(lib().viorb_preintegrate(ptr(imu), len(imu), ptr(np.ascontiguousarray(bg, np.float64)),
+                                   ptr(np.ascontiguousarray(ba, np.float64)), float(t_last), float(t_cur), ptr(out)))
+    return out
+
+
+def PoseOptimization(cur_ns, last_ns, preint, gw, cam, obs_cur, obs_last=None, prior_ns=None, marg_cov_inv=None,
+                     last_is_keyframe=True, bComputeMarg=False):
+    """Optimizer::PoseOptimization(Frame*, KeyFrame*|Frame*, imupreint, gw, bComputeMarg)
+    (reference src/Optimizer.cc:323-1112) with host buffers. Returns a dict like the oracle binding's."""
+    f = lambda a: np.ascontiguousarray(a, np.float64)
+    oc = f(obs_cur).reshape(-1, 6)
+    ol = f(obs_last).reshape(-1, 6) if obs_last is not None else np.zeros((0, 6))
+    variant = 0 if last_is_keyframe else 1
+    ns, nl, mg, info = np.zeros(22), np.zeros(22), np.zeros(144), np.zeros(4)
+    fc, fl = np.zeros(max(len(oc), 1), np.uint8), np.zeros(max(len(ol), 1), np.uint8)
+    check(lib().viorb_pose_opt_vi(variant, int(bComputeMarg), ptr(f(cur_ns)), ptr(f(last_ns)),
+                                  ptr(f(prior_ns)) if prior_ns is not None else None,
+                                  ptr(f(marg_cov_inv)) if marg_cov_inv is not None else None,
+                                  ptr(f(preint)), ptr(f(gw)), ptr(f(cam)), ptr(oc), len(oc), ptr(ol), len(ol),
+                                  ptr(ns), ptr(nl), ptr(fc), ptr(fl), ptr(mg), ptr(info)))
+    return dict(ns=ns, ns_last=nl, outlier_cur=fc[:len(oc)], outlier_last=fl[:len(ol)], marg_cov_inv=mg.reshape(12, 12),
+                n_inliers=int(info[0]), final_chi2=float(info[1]), lm_iterations=int(info[2]))
+
+
+class Frontend:
+    """Batched device-resident front-end: every method only enqueues kernels on the given torch stream."""
+
+    def __init__(self, cam, gw, scale_factors, inv_level_sigma2, bounds=(0.0, 752.0, 0.0, 480.0), max_batch=1, cap=1016,
+                 check_orientation=True, device=0):
+        self.L = lib()
+        cfg = capi.FrontendConfig()
+        cfg.min_x, cfg.max_x, cfg.min_y, cfg.max_y = [float(b) for b in bounds]
+        cfg.fx, cfg.fy, cfg.cx, cfg.cy = [float(np.float32(v)) for v in cam[:4]]
+        for i in range(16):
+            cfg.cam[i] = float(cam[i])
+        for i in range(3):
+            cfg.gravity[i] = float(gw[i])
+        nl = len(scale_factors)
+        for i in range(16):
+            cfg.scale_factors[i] = float(scale_factors[min(i, nl - 1)])
+            cfg.inv_level_sigma2[i] = float(inv_level_sigma2[min(i, nl - 1)])
+        cfg.nlevels = nl
+        cfg.check_orientation = int(check_orientation)
+        h = C.c_void_p()
+        check(self.L.viorb_frontend_create(C.byref(cfg), max_batch, cap, device, C.byref(h)))
+        self.h, self.cap, self.max_batch, self.cfg = h, cap, max_batch, cfg
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.viorb_frontend_destroy(self.h)
+            self.h = None
+
+    @staticmethod
+    def _st(stream):
+        import torch
+        st = stream if stream is not None else torch.cuda.current_stream()
+        return C.c_void_p(st.cuda_stream)
+
+    def grid(self, kps_ptr, count_ptr, batch, cell_start, cell_idx, stream=None):
+        check(self.L.viorb_frontend_grid_device(self.h, C.c_void_p(kps_ptr), C.c_void_p(count_ptr), batch, ptr(cell_start),
+                                                ptr(cell_idx), self._st(stream)))
+
+    def imu_predict(self, imu, t_last, t_cur, last_ns, preint, cur_ns, pose12, stream=None):
+        B, n = imu.shape[0], imu.shape[1]
+        check(self.L.viorb_frontend_imu_predict_device(self.h, ptr(imu), n, ptr(t_last), ptr(t_cur), ptr(last_ns), B, ptr(preint),
+                                                       ptr(cur_ns), ptr(pose12), self._st(stream)))
+
+    def search_projection(self, cur_kps_ptr, cur_desc_ptr, cur_count_ptr, cell_start, cell_idx, pose12, last_kps, last_count,
+                          last_flags, last_Pw, last_desc, th, batch, cur_match, nmatches, status, stream=None):
+        p = lambda a: a if isinstance(a, C.c_void_p) else (C.c_void_p(a) if isinstance(a, int) else ptr(a))
+        check(self.L.viorb_frontend_search_projection_device(
+            self.h, p(cur_kps_ptr), p(cur_desc_ptr), p(cur_count_ptr), ptr(cell_start), ptr(cell_idx), ptr(pose12), p(last_kps),
+            p(last_count), ptr(last_flags), ptr(last_Pw), p(last_desc), float(th), batch, ptr(cur_match), ptr(nmatches), ptr(status),
+            self._st(stream)))
+
+    def build_observations(self, kps_ptr, count_ptr, match, match_Pw, batch, obs, obs_index, n_obs, stream=None):
+        p = lambda a: a if isinstance(a, C.c_void_p) else (C.c_void_p(a) if isinstance(a, int) else ptr(a))
+        check(self.L.viorb_frontend_build_observations_device(self.h, p(kps_ptr), p(count_ptr), ptr(match), ptr(match_Pw), batch,
+                                                              ptr(obs), ptr(obs_index), ptr(n_obs), self._st(stream)))
+
+    def pose_opt(self, variant, compute_marg, cur_ns, last_ns, prior_ns, marg_cov_inv, preint, obs_cur, n_cur, obs_last, n_last,
+                 batch, out_ns, out_last_ns, outlier_cur, outlier_last, marg_out, info, stream=None):
+        check(self.L.viorb_frontend_pose_opt_device(
+            self.h, variant, int(compute_marg), ptr(cur_ns), ptr(last_ns), ptr(prior_ns), ptr(marg_cov_inv), ptr(preint), ptr(obs_cur),
+            ptr(n_cur), ptr(obs_last), ptr(n_last), batch, ptr(out_ns), ptr(out_last_ns), ptr(outlier_cur), ptr(outlier_last),
+            ptr(marg_out), ptr(info), self._st(stream)))
