@@ -1,0 +1,211 @@
+#!/usr/bin/env python3
+"""bench.py — frames/s of the per-frame visual-inertial front-end (ORB extract + SearchByProjection +
+IMU pre-integration + PoseOptimization) on MI355X, BASELINE.json's metric.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (N > 1)
+
+A "step" is one pass of the hot path over one batch of synthetic frames: one new 752x480 frame for each of
+the S independent mono-inertial streams a GPU owns (weak scaling: every rank owns S streams; no data-path
+collective, the only RCCL traffic is the frames/time reduction at the end). Inputs (images, IMU samples)
+are resident in HBM before the timed region. Rank 0 prints ONE JSON line; `roofline` is measured with HIP
+events around the dominant kernel inside the timed region, `cpu_baseline` times the CPU oracle (a port of
+the reference's path; the reference itself cannot be built here) on a bounded sample of the same streams.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+
+W_IMG, H_IMG, NFEAT, NLEVELS = 752, 480, 1000, 8
+N_FRAMES = 8                                  # frames per (periodic) synthetic stream
+P_PIXELS = 1117367                            # sum of level pixels, SURVEY.md §8 table (config E)
+HBM_PEAK_GBS = 8000.0                         # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+# algorithmic bytes per frame of each extractor kernel (B_ext = 4 P + K (709 + 961 + 60))
+ALGO_BYTES = {
+    "k_fast_cells": P_PIXELS,                                  # 1 P read by FAST
+    "k_blur": 2 * P_PIXELS,                                    # 1 P read + 1 P written
+    "k_resize": P_PIXELS - W_IMG * H_IMG,                      # levels 1..7 written (reads served from cache)
+    "k_copy_level0": W_IMG * H_IMG,                            # level-0 copy
+    "k_orient_describe": NFEAT * (709 + 961 + 60),             # patch + window + outputs per keypoint
+}
+
+
+def _gen_stream(seed):
+    from viorb_amd.synth import make_periodic_stream
+    s = make_periodic_stream(seed, N_FRAMES, W_IMG, H_IMG)
+    return dict(frames=s["frames"], imu=s["imu"], t=s["t"], ns_true=s["ns_true"], pose_true=s["pose_true"], period=s["period"],
+                cam=s["cam"], gw=s["gw"])
+
+
+def generate_streams(seeds):
+    """CPU-side synthetic data (before anything touches the GPU)."""
+    import multiprocessing as mp
+    nproc = max(1, min(len(seeds), (os.cpu_count() or 2) // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1"))), 16))
+    if nproc == 1:
+        return [_gen_stream(s) for s in seeds]
+    with mp.get_context("fork").Pool(nproc) as pool:
+        return pool.map(_gen_stream, seeds)
+
+
+def cpu_baseline(streams, budget_s=12.0, max_frames=150):
+    """The oracle (CPU port of the reference path) on one host core, same streams, same per-frame sequence."""
+    from oracle.harness import OracleTracker           # checker only; never on the product path
+    done, t_total = 0, 0.0
+    for s in streams:
+        tr = OracleTracker(s["cam"], s["gw"], W_IMG, H_IMG, NFEAT)
+        tr.bootstrap(s["frames"][0], s["pose_true"][0], s["t"][0], s["ns_true"][0], np.eye(12) * 1e3)
+        k = 1
+        while t_total < budget_s and done < max_frames:
+            j = k % N_FRAMES
+            t0 = time.perf_counter()
+            tr.step(s["frames"][j], s["imu"][j], s["t"][j] if j else s["period"], s["pose_true"][j], t_next_last=0.0 if j == 0 else None)
+            t_total += time.perf_counter() - t0
+            done += 1; k += 1
+            if k > 3 * N_FRAMES:
+                break
+        if t_total >= budget_s or done >= max_frames:
+            break
+    return done / t_total, done, t_total
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--streams", type=int, default=64, help="independent camera streams per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
+    S = args.streams
+
+    # ---- synthetic inputs on the CPU, then the GPU runtime --------------------------------------------
+    seeds = [1000 + rank * S + i for i in range(S)]
+    streams = generate_streams(seeds)
+    import torch
+    import torch.distributed as dist
+    import viorb_amd
+    from viorb_amd.tracker import BatchedTracker
+    if viorb_amd.lib().viorb_device_count() < 1:
+        raise SystemExit("bench.py needs a HIP device (viorb_amd has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)       # "nccl" is RCCL on ROCm
+    up = lambda a, dt=None: torch.from_numpy(np.ascontiguousarray(a)).to(dev) if dt is None else torch.from_numpy(np.ascontiguousarray(a)).to(dev, dt)
+    frames = up(np.stack([s["frames"] for s in streams], 1))                   # [F, S, h, w] u8
+    imu = up(np.stack([s["imu"] for s in streams], 1))                         # [F, S, n, 7] f64
+    t_frames = up(np.stack([s["t"] for s in streams], 1))                      # [F, S]
+    t_period = up(np.array([s["period"] for s in streams]))                    # [S]
+    pose_true = up(np.stack([s["pose_true"] for s in streams], 1))             # [F, S, 12] f64
+    ns_true = up(np.stack([s["ns_true"] for s in streams], 1))                 # [F, S, 22]
+    zeros_t = torch.zeros(S, dtype=torch.float64, device=dev)
+    mci0 = up(np.stack([np.eye(12).ravel() * 1e3] * S))
+    cam, gw = streams[0]["cam"], streams[0]["gw"]
+
+    tr = BatchedTracker(cam, gw, S, W_IMG, H_IMG, NFEAT, th=15.0, device=local_rank, compute_marg=True)
+    tr.bootstrap(frames[0], pose_true[0], t_frames[0], ns_true[0], mci0)
+
+    def run_step(k):
+        j = k % N_FRAMES
+        if j == 0:      # closing the loop: frame F == frame 0, its stamp is the period; next "last" stamp is 0
+            tr.step(frames[0], imu[0], t_period, pose_true[0], t_next_last=zeros_t)
+        else:
+            tr.step(frames[j], imu[j], t_frames[j], pose_true[j])
+
+    k = 1
+    for _ in range(args.warmup):
+        run_step(k); k += 1
+    torch.cuda.synchronize()
+    L = viorb_amd.lib()
+    L.viorb_profile_reset(); L.viorb_profile_enable(1)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run_step(k); k += 1
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    L.viorb_profile_enable(0)
+
+    # ---- sanity of the timed work (outside the timed region): every stream tracked its frame ------------
+    info = tr.info.cpu().numpy()
+    nm = tr.nmatches.cpu().numpy()
+    status_ok = bool((tr.status.cpu().numpy() == 0).all())
+    tracked = int((info[:, 0] >= 20).sum())
+
+    # ---- per-kernel HIP-event times ------------------------------------------------------------------------
+    import ctypes as C
+    names = C.create_string_buffer(4096); ms = (C.c_double * 64)(); calls = (C.c_int * 64)(); n = C.c_int()
+    L.viorb_profile_read(names, 4096, ms, calls, 64, C.byref(n))
+    prof = {nm_: (ms[i], calls[i]) for i, nm_ in enumerate(names.value.decode().split("\n")[:n.value])}
+    ext = {kname: v for kname, v in prof.items() if kname in ALGO_BYTES}
+    dom = max(ext, key=lambda kname: ext[kname][0]) if ext else None
+
+    # ---- reduce over ranks: total frames, max time ----------------------------------------------------------
+    frames_done = float(S * args.steps)
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        ff = torch.tensor([frames_done], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dist.all_reduce(ff, op=dist.ReduceOp.SUM)
+        elapsed, frames_done = tt.item(), ff.item()
+
+    if rank == 0:
+        roof = None
+        if dom:
+            tot_ms, ncalls = ext[dom]
+            launches_per_step = ncalls / args.steps
+            avg_s = tot_ms / ncalls * 1e-3
+            bytes_per_launch = ALGO_BYTES[dom] * S / launches_per_step
+            achieved = bytes_per_launch / avg_s / 1e9
+            ext_ms = sum(v[0] for v in ext.values())
+            ext_bytes = (4 * P_PIXELS + NFEAT * (709 + 961 + 60)) * S * args.steps
+            roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                    "avg_launch_us": round(avg_s * 1e6, 2), "algorithmic_bytes_per_launch": int(bytes_per_launch),
+                    "extractor_all_kernels_GBps": round(ext_bytes / (ext_ms * 1e-3) / 1e9, 2),
+                    "kernel_ms_per_step": {kname: round(v[0] / args.steps, 4) for kname, v in sorted(prof.items())}}
+        cpu = None
+        if not args.no_cpu_baseline:
+            fps, nfr, tsec = cpu_baseline(streams[:2])
+            cpu = {"value": round(fps, 3), "unit": "frames/s", "cores": 1, "kind": "port",
+                   "sample": "%d frames of the same synthetic streams, same extract+match+IMU+pose-opt sequence, oracle (C++ -O3) on 1 host thread, %.1f s"
+                             % (nfr, tsec)}
+        out = {
+            "metric": "frames/sec ORB extract+match+pose-opt, EuRoC 752x480, 1/2/4/8 GPUs",
+            "value": round(frames_done / elapsed, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "EuRoC-shaped synthetic mono-inertial streams 752x480, 8 levels, 1000 features: extract + "
+                                   "SearchByProjection(th=15) + IMU pre-integration (10 samples) + PoseOptimization(Frame,Frame,marg) per frame",
+                       "streams_per_gpu": S, "frames_per_step": S * world, "solver_dtype": "f64",
+                       "tracked_streams_last_step": tracked, "mean_matches_last_step": round(float(nm.mean()), 1),
+                       "mean_inliers_last_step": round(float(info[:, 0].mean()), 1), "status_ok": status_ok},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

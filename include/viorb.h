@@ -197,6 +197,22 @@ int viorb_frontend_pose_opt_device(viorb_frontend* h, int variant, int compute_m
                                    double* out_last_ns, uint8_t* outlier_cur, uint8_t* outlier_last, double* marg_out,
                                    double* info, void* stream);
 
+/* Workload support for bench.py / tests (no reference counterpart): map points of the synthetic plane
+ * world (viorb_amd/synth.py) for all keypoints of a frame; pose12 = Rcw(9) tcw(3) in double per stream.
+ * Writes Pw[b][cap][3] and flags[b][cap] = 1|4 (map point with observations), 0 beyond count[b]. */
+int viorb_synth_plane_points_device(viorb_frontend* h, const viorb_keypoint* kps, const int32_t* count,
+                                    const double* pose12, double z0, int batch, float* Pw, uint8_t* flags, void* stream);
+
+/* hipMemcpyAsync(device -> device) on `stream`, for callers that hold raw device addresses. */
+int viorb_memcpy_dtod_async(void* dst, const void* src, size_t bytes, void* stream);
+
+/* Per-kernel timing with HIP events recorded on the stream each kernel is launched on. Off by default.
+ * viorb_profile_read synchronises the device; names_buf gets the kernel names separated by newlines,
+ * total_ms[i] / calls[i] the summed duration and launch count of name i since the last reset. */
+int viorb_profile_enable(int on);
+int viorb_profile_reset(void);
+int viorb_profile_read(char* names_buf, int names_cap, double* total_ms, int* calls, int cap, int* n);
+
 /* Host-buffer drop-ins for single calls (they stage through the device and include the PCIe copies). */
 int viorb_descriptor_distance(const uint8_t* a, const uint8_t* b);       /* ORBmatcher::DescriptorDistance */
 int viorb_preintegrate(const double* imu, int n_imu, const double bg[3], const double ba[3], double t_last,

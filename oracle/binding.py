@@ -172,6 +172,8 @@ def _vio():
         L.ora_preint_update.argtypes = [vp, vp, vp, d]
         L.ora_update_ns.argtypes = [vp, vp, vp]
         L.ora_ns_inc_pvr.argtypes = [vp, vp]
+        L.ora_predict_navstate.argtypes = [vp, vp, vp, vp]
+        L.ora_pose_from_navstate.argtypes = [vp, vp, vp]
         L.ora_so3_exp.argtypes = [vp, vp]
         L.ora_so3_log.argtypes = [vp, vp]
         L.ora_so3_matrix.argtypes = [vp, vp]
@@ -211,6 +213,20 @@ def update_ns(ns, preint, gw):
     n = _f64(ns, NS_LEN).copy()
     _vio().ora_update_ns(_p(n), _p(_f64(preint, PREINT_LEN)), _p(_f64(gw, 3)))
     return n
+
+
+def predict_navstate(last_ns, preint, gw):
+    """PredictNavStateByIMU: SetInitialNavStateAndBias(last) + UpdateNavState."""
+    out = np.zeros(NS_LEN)
+    _vio().ora_predict_navstate(_p(_f64(last_ns, NS_LEN)), _p(_f64(preint, PREINT_LEN)), _p(_f64(gw, 3)), _p(out))
+    return out
+
+
+def pose_from_navstate(ns, cam):
+    """Frame::UpdatePoseFromNS -> float pose12 = Rcw(9) tcw(3)."""
+    out = np.zeros(12, np.float32)
+    _vio().ora_pose_from_navstate(_p(_f64(ns, NS_LEN)), _p(_f64(cam, CAM_LEN)), _p(out))
+    return out
 
 
 def ns_inc_pvr(ns, u9):

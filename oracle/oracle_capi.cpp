@@ -166,6 +166,12 @@ void ora_preint_update(double* preint142, const double* omega, const double* acc
 void ora_update_ns(double* ns22, const double* preint142, const double* gw) {
     NavState n = ns_in(ns22); update_ns(n, pre_in(preint142), v3(gw)); ns_out(ns22, n);
 }
+void ora_predict_navstate(const double* last22, const double* preint142, const double* gw, double* out22) {
+    ns_out(out22, predict_navstate(ns_in(last22), pre_in(preint142), v3(gw)));
+}
+void ora_pose_from_navstate(const double* ns22, const double* cam16, float* pose12) {
+    pose_from_navstate_f32(ns_in(ns22), cam_in(cam16), pose12);
+}
 void ora_ns_inc_pvr(double* ns22, const double* u9) { NavState n = ns_in(ns22); n.inc_small_pvr(u9); ns_out(ns22, n); }
 void ora_so3_exp(const double* w, double* q4) { SO3 r = SO3::exp(v3(w)); q4[0] = r.q.x; q4[1] = r.q.y; q4[2] = r.q.z; q4[3] = r.q.w; }
 void ora_so3_log(const double* q4, double* w) { put3(w, SO3(Quat{q4[0], q4[1], q4[2], q4[3]}).log()); }

@@ -82,6 +82,31 @@ void update_ns(NavState& ns, const Preint& p, V3 gw) {
     ns.P = Pwb; ns.V = Vwb; ns.R = SO3(Rwb);
 }
 
+NavState predict_navstate(const NavState& last, const Preint& p, V3 gw) {
+    NavState ns = last;
+    ns.bg = last.bg + last.dbg; ns.ba = last.ba + last.dba; ns.dbg = V3(); ns.dba = V3();
+    update_ns(ns, p, gw);
+    return ns;
+}
+
+void pose_from_navstate_f32(const NavState& ns, const Camera& cam, float* pose12) {
+    const M3 Rd = ns.R.matrix();
+    float Rwb[3][3], Rbc[3][3], Pbc[3] = {(float)cam.Pbc.x, (float)cam.Pbc.y, (float)cam.Pbc.z};
+    const float Pwb[3] = {(float)ns.P.x, (float)ns.P.y, (float)ns.P.z};
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { Rwb[i][j] = (float)Rd(i, j); Rbc[i][j] = (float)cam.Rbc(i, j); }
+    float Rwc[3][3], Pwc[3];
+    for (int i = 0; i < 3; i++) {
+        for (int j = 0; j < 3; j++) Rwc[i][j] = Rwb[i][0] * Rbc[0][j] + Rwb[i][1] * Rbc[1][j] + Rwb[i][2] * Rbc[2][j];   // (Rwb*Rbc)
+        const float t = Rwb[i][0] * Pbc[0] + Rwb[i][1] * Pbc[1] + Rwb[i][2] * Pbc[2];
+        Pwc[i] = (float)((double)t + (double)Pwb[i]);                                                                     // Rwb*Pbc + Pwb
+    }
+    for (int i = 0; i < 3; i++) {
+        for (int j = 0; j < 3; j++) pose12[3 * i + j] = Rwc[j][i];                                                        // .t()
+        const float t = Rwc[0][i] * Pwc[0] + Rwc[1][i] * Pwc[1] + Rwc[2][i] * Pwc[2];
+        pose12[9 + i] = -t;                                                                                               // -Rcw*Pwc
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Edges — reference src/IMU/g2otypes.{h,cpp}
 // ------------------------------------------------------------------------------------------------

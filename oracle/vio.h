@@ -46,8 +46,15 @@ struct NavState {
 };
 // Converter::updateNS, reference src/Converter.cc:27-49
 void update_ns(NavState& ns, const Preint& p, V3 gw);
+// Tracking::PredictNavStateByIMU (src/Tracking.cc:348-410): Frame::SetInitialNavStateAndBias(last)
+// (src/Frame.cc:117-125: bias += delta bias, delta = 0) followed by UpdateNavState.
+NavState predict_navstate(const NavState& last, const Preint& p, V3 gw);
 
 struct Camera { double fx, fy, cx, cy; M3 Rbc; V3 Pbc; };
+// Frame::UpdatePoseFromNS (reference src/Frame.cc:88-105) in the float arithmetic of its cv::Mat
+// expressions; pose12 = Rcw (row-major) then tcw. Same small-matrix gemm evaluation order as
+// transform_point() in orb_matcher.cpp (parity unpinned vs OpenCV).
+void pose_from_navstate_f32(const NavState& ns, const Camera& cam, float* pose12);
 
 struct Observation { V3 Pw; double u, v, inv_sigma2; };
 

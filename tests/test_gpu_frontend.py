@@ -70,19 +70,23 @@ def test_imu_predict_matches_oracle(torch_cuda, oracle, streams):
     imu = torch.from_numpy(np.stack([s["s"]["imu"][1] for s in streams])).cuda()
     tl = torch.tensor([s["s"]["t"][0] for s in streams], dtype=torch.float64, device="cuda")
     tc = torch.tensor([s["s"]["t"][1] for s in streams], dtype=torch.float64, device="cuda")
-    ns = torch.from_numpy(np.stack([s["s"]["ns_true"][0] for s in streams])).cuda()
+    last = np.stack([s["s"]["ns_true"][0] for s in streams]).copy()
+    last[:, 19:22] = [[2e-3, -1e-3, 5e-4]] * B                     # a non-zero delta bias on the last frame
+    ns = torch.from_numpy(last).cuda()
     pre = torch.zeros((B, 142), dtype=torch.float64, device="cuda"); cur = torch.zeros((B, 22), dtype=torch.float64, device="cuda")
     pose = torch.zeros((B, 12), dtype=torch.float32, device="cuda")
     fe.imu_predict(imu, tl, tc, ns, pre, cur, pose)
     torch.cuda.synchronize()
     for b, s in enumerate(streams):
-        st = s["s"]
+        st = dict(s["s"]); st["ns_true"] = [last[b]]
         opre = oracle.preintegrate(st["imu"][1], st["ns_true"][0][10:13], st["ns_true"][0][13:16], st["t"][0], st["t"][1])
         np.testing.assert_allclose(pre[b].cpu().numpy()[:60], opre[:60], rtol=0, atol=1e-12)
         np.testing.assert_allclose(pre[b].cpu().numpy()[60:141], opre[60:141], rtol=1e-9, atol=1e-18)
         assert abs(pre[b, 141].item() - opre[141]) < 1e-14
-        ocur = oracle.update_ns(st["ns_true"][0], opre, st["gw"])
+        ocur = oracle.predict_navstate(st["ns_true"][0], opre, st["gw"])
         np.testing.assert_allclose(cur[b].cpu().numpy(), ocur, rtol=0, atol=1e-11)
+        np.testing.assert_allclose(ocur[13:16], last[b, 13:16] + last[b, 19:22], atol=0)
+        assert (ocur[16:22] == 0).all()
         Rcw, tcw = cam_pose_from_navstate(ocur, st["cam"])
         np.testing.assert_allclose(pose[b].cpu().numpy()[:9].reshape(3, 3), Rcw, atol=2e-6)
         np.testing.assert_allclose(pose[b].cpu().numpy()[9:], tcw, atol=2e-5)

@@ -58,6 +58,11 @@ SIGNATURES = {
     "viorb_frontend_search_projection_device": (i32, [vp] * 12 + [f32, i32, vp, vp, vp, vp]),
     "viorb_frontend_build_observations_device": (i32, [vp, vp, vp, vp, vp, i32, vp, vp, vp, vp]),
     "viorb_frontend_pose_opt_device": (i32, [vp, i32, i32] + [vp] * 9 + [i32] + [vp] * 7),
+    "viorb_synth_plane_points_device": (i32, [vp, vp, vp, vp, C.c_double, i32, vp, vp, vp]),
+    "viorb_memcpy_dtod_async": (i32, [vp, vp, sz, vp]),
+    "viorb_profile_enable": (i32, [i32]),
+    "viorb_profile_reset": (i32, []),
+    "viorb_profile_read": (i32, [C.c_char_p, i32, vp, vp, i32, PP(i32)]),
     "viorb_descriptor_distance": (i32, [vp, vp]),
     "viorb_preintegrate": (i32, [vp, i32, vp, vp, C.c_double, C.c_double, vp]),
     "viorb_pose_opt_vi": (i32, [i32, i32] + [vp] * 8 + [i32, vp, i32] + [vp] * 6),

@@ -298,7 +298,8 @@ __global__ __launch_bounds__(128) void k_imu_predict(const double* __restrict__ 
         const pvr pred = update_ns(ld_pvr(ns), M.dP, M.dV, M.dR, M.dt, ld3(gw3));
         double* co = cur_ns + (size_t)b * 22;
         st_pvr(co, pred);
-        for (int k = 10; k < 16; k++) co[k] = ns[k];
+        // Frame::SetInitialNavStateAndBias (src/Frame.cc:117-125): bias <- bias + delta bias, delta <- 0
+        for (int k = 10; k < 16; k++) co[k] = ns[k] + ns[k + 6];
         for (int k = 16; k < 22; k++) co[k] = 0.0;
         pose_from_navstate_f32(pred, cam16, pose12 + (size_t)b * 12);
     }
@@ -341,6 +342,27 @@ __global__ __launch_bounds__(256) void k_build_observations(const viorb_keypoint
         __syncthreads();
     }
     if (threadIdx.x == 0) n_obs[b] = s_base;
+}
+
+// Workload support (not a reference function): map points for the keypoints of a frame of the
+// synthetic plane world of viorb_amd/synth.py — intersects the pixel ray with the plane z = z0 using
+// the given camera pose (Rcw, tcw) in double, writes float world points and flags = 1|4.
+__global__ void k_synth_plane_points(const viorb_keypoint* __restrict__ kps, const int* __restrict__ count, int cap,
+                                     const double* __restrict__ pose12, double fx, double fy, double cx, double cy, double z0,
+                                     float* __restrict__ Pw, uint8_t* __restrict__ flags) {
+    const int b = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cap) return;
+    const size_t o = (size_t)b * cap + i;
+    if (i >= count[b]) { flags[o] = 0; return; }
+    const double* T = pose12 + (size_t)b * 12;
+    const double dx = (kps[o].x - cx) / fx, dy = (kps[o].y - cy) / fy;
+    // ray direction Rcw^T d and camera centre -Rcw^T t
+    const double rx = T[0] * dx + T[3] * dy + T[6], ry = T[1] * dx + T[4] * dy + T[7], rz = T[2] * dx + T[5] * dy + T[8];
+    const double ox = -(T[0] * T[9] + T[3] * T[10] + T[6] * T[11]), oy = -(T[1] * T[9] + T[4] * T[10] + T[7] * T[11]),
+                 oz = -(T[2] * T[9] + T[5] * T[10] + T[8] * T[11]);
+    const double s = (z0 - oz) / rz;
+    Pw[3 * o] = (float)(ox + s * rx); Pw[3 * o + 1] = (float)(oy + s * ry); Pw[3 * o + 2] = (float)(oz + s * rz);
+    flags[o] = 1 | 4;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -803,6 +825,7 @@ int viorb_frontend_grid_device(viorb_frontend* h, const viorb_keypoint* kps, con
                                int32_t* cell_start, int32_t* cell_idx, void* stream) {
     FE_CHECK_BATCH(h, batch);
     VIORB_REQUIRE(kps && count && cell_start && cell_idx, "null array");
+    ProfScope ps("k_frame_grid", (hipStream_t)stream);
     hipLaunchKernelGGL(k_frame_grid, dim3(batch), dim3(256), (size_t)h->sort_n * 4, (hipStream_t)stream, kps, count, h->cap,
                        h->cfg.min_x, h->cfg.min_y, h->wInv, h->hInv, cell_start, cell_idx, h->sort_n);
     VIORB_HIP_TRY(hipGetLastError());
@@ -813,6 +836,7 @@ int viorb_frontend_imu_predict_device(viorb_frontend* h, const double* imu, int 
                                       const double* last_ns, int batch, double* preint, double* cur_ns, float* pose12, void* stream) {
     FE_CHECK_BATCH(h, batch);
     VIORB_REQUIRE(imu && t_last && t_cur && last_ns && preint && cur_ns && pose12 && n_imu >= 1, "null array / n_imu < 1");
+    ProfScope ps("k_imu_predict", (hipStream_t)stream);
     hipLaunchKernelGGL(k_imu_predict, dim3(batch), dim3(128), 0, (hipStream_t)stream, imu, n_imu, t_last, t_cur, last_ns, h->d_gw,
                        h->d_cam, h->cfg.gyr_meas_cov, h->cfg.acc_meas_cov, preint, cur_ns, pose12);
     VIORB_HIP_TRY(hipGetLastError());
@@ -837,6 +861,7 @@ int viorb_frontend_search_projection_device(viorb_frontend* h, const viorb_keypo
     for (int i = 0; i < 16; i++) A.scale[i] = h->cfg.scale_factors[i];
     A.check_ori = h->cfg.check_orientation;
     VIORB_HIP_TRY(hipMemsetAsync(status, 0, sizeof(int32_t) * batch, (hipStream_t)stream));
+    ProfScope ps("k_search_projection", (hipStream_t)stream);
     hipLaunchKernelGGL(k_search_projection, dim3(batch), dim3(256), (size_t)h->cap * 4 * sizeof(int), (hipStream_t)stream, A);
     VIORB_HIP_TRY(hipGetLastError());
     return VIORB_OK;
@@ -847,6 +872,7 @@ int viorb_frontend_build_observations_device(viorb_frontend* h, const viorb_keyp
                                              void* stream) {
     FE_CHECK_BATCH(h, batch);
     VIORB_REQUIRE(kps && count && match && match_Pw && obs && obs_index && n_obs, "null array");
+    ProfScope ps("k_build_observations", (hipStream_t)stream);
     hipLaunchKernelGGL(k_build_observations, dim3(batch), dim3(256), 0, (hipStream_t)stream, kps, count, match, match_Pw,
                        h->d_inv_sigma2, h->cap, obs, obs_index, n_obs);
     VIORB_HIP_TRY(hipGetLastError());
@@ -869,7 +895,19 @@ int viorb_frontend_pose_opt_device(viorb_frontend* h, int variant, int compute_m
     A.gw = h->d_gw; A.cam = h->d_cam; A.obs_cur = obs_cur; A.obs_last = variant ? obs_last : nullptr; A.n_cur = n_cur; A.n_last = n_last;
     A.out_ns = out_ns; A.out_last_ns = out_last_ns; A.marg_out = marg_out; A.info = info;
     A.outlier_cur = outlier_cur; A.outlier_last = variant ? outlier_last : nullptr; A.acc_bias_rw2 = h->cfg.acc_bias_rw2;
+    ProfScope ps("k_pose_opt_vi", (hipStream_t)stream);
     hipLaunchKernelGGL(k_pose_opt_vi, dim3(batch), dim3(256), 0, (hipStream_t)stream, A);
+    VIORB_HIP_TRY(hipGetLastError());
+    return VIORB_OK;
+}
+
+int viorb_synth_plane_points_device(viorb_frontend* h, const viorb_keypoint* kps, const int32_t* count, const double* pose12,
+                                    double z0, int batch, float* Pw, uint8_t* flags, void* stream) {
+    FE_CHECK_BATCH(h, batch);
+    VIORB_REQUIRE(kps && count && pose12 && Pw && flags, "null array");
+    ProfScope ps("k_synth_plane_points", (hipStream_t)stream);
+    hipLaunchKernelGGL(k_synth_plane_points, dim3((h->cap + 255) / 256, batch), dim3(256), 0, (hipStream_t)stream, kps, count, h->cap,
+                       pose12, h->cfg.cam[0], h->cfg.cam[1], h->cfg.cam[2], h->cfg.cam[3], z0, Pw, flags);
     VIORB_HIP_TRY(hipGetLastError());
     return VIORB_OK;
 }

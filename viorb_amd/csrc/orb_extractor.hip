@@ -33,6 +33,33 @@ void set_error(const char* fmt, ...) {
     va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof(g_err), fmt, ap); va_end(ap);
 }
 
+// ---- kernel profiler (process-wide, single-threaded use) ----------------------------------------
+namespace {
+struct ProfRec { hipEvent_t a, b; int slot; };
+struct Profiler {
+    bool enabled = false;
+    std::vector<std::string> names;
+    std::vector<ProfRec> recs;
+    size_t used = 0;
+} g_prof;
+}
+ProfScope::ProfScope(const char* name, hipStream_t s) : idx(-1), st(s) {
+    if (!g_prof.enabled) return;
+    if (g_prof.used >= g_prof.recs.size()) {
+        if (g_prof.recs.size() >= 16384) return;
+        ProfRec r; r.slot = -1;
+        if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
+        g_prof.recs.push_back(r);
+    }
+    int slot = -1;
+    for (size_t i = 0; i < g_prof.names.size(); i++) if (g_prof.names[i] == name) slot = (int)i;
+    if (slot < 0) { g_prof.names.push_back(name); slot = (int)g_prof.names.size() - 1; }
+    idx = (int)g_prof.used++;
+    g_prof.recs[idx].slot = slot;
+    (void)hipEventRecord(g_prof.recs[idx].a, st);
+}
+ProfScope::~ProfScope() { if (idx >= 0) (void)hipEventRecord(g_prof.recs[idx].b, st); }
+
 static const int8_t kPatternHost[1024] = {
 #include "orb_pattern.inc"
 };
@@ -888,31 +915,41 @@ static int launch_all(viorb_extractor* h, const uint8_t* d_images, int batch, in
     VIORB_HIP_TRY(hipMemsetAsync(h->d_status, 0, sizeof(int) * batch, st));
     {
         dim3 grid((L0.stride / 16 + 63) / 64, L0.h, batch);
+        ProfScope ps("k_copy_level0", st);
         hipLaunchKernelGGL(k_copy_level0, grid, dim3(64), 0, st, d_images, L0.w, L0.h, stride, pitch, h->d_planes, h->frame_bytes, L0.stride);
     }
     for (int l = 1; l < nl; l++) {
         const LevelDev& L = h->lv[l];
         dim3 grid((L.w + RS_TW - 1) / RS_TW, (L.h + RS_TH - 1) / RS_TH, batch);
         const size_t lds = (size_t)h->rs_pitch_dw[l] * h->rs_rows[l] * 4;
+        ProfScope ps("k_resize", st);
         hipLaunchKernelGGL(k_resize, grid, dim3(256), lds, st, h->d_planes, h->frame_bytes, h->d_lv, l, h->d_xtab, h->d_ytab,
                            h->rs_pitch_dw[l], h->rs_rows[l]);
     }
     {
         const size_t lds = (size_t)h->fast_tile_pitch * h->fast_tile_rows + h->fast_score_bytes;
+        ProfScope ps("k_fast_cells", st);
         hipLaunchKernelGGL(k_fast_cells, dim3(ncells, batch), dim3(64), lds, st, h->d_planes, h->frame_bytes, h->d_lv, h->d_cells,
                            h->p.ini_th_fast, h->p.min_th_fast, h->d_slots, h->slot_cap, h->d_cell_cnt, ncells,
                            h->fast_tile_pitch, h->fast_tile_rows, h->fast_score_bytes);
     }
     {
         const size_t lds = (size_t)h->oct_ncap * 8 + (size_t)h->oct_nodecap * sizeof(OctNode) + (size_t)h->oct_sortcap * 4;
+        ProfScope ps("k_octree", st);
         hipLaunchKernelGGL(k_octree, dim3(nl, batch), dim3(64), lds, st, h->d_lv, h->d_slots, h->slot_cap, h->d_cell_cnt, ncells,
                            h->d_lvl_kp, h->kp_pitch, h->d_lvl_cnt, h->d_lvl_ncand, nl, h->d_status, h->oct_ncap, h->oct_nodecap,
                            h->oct_sortcap);
     }
-    hipLaunchKernelGGL(k_blur, dim3((unsigned)h->blur_tiles.size(), batch), dim3(256), 0, st, h->d_planes, h->d_blur, h->frame_bytes,
-                       h->d_lv, h->d_blur_tiles);
-    hipLaunchKernelGGL(k_orient_describe, dim3((h->out_cap + 3) / 4, batch), dim3(256), 0, st, h->d_planes, h->d_blur, h->frame_bytes,
-                       h->d_lv, nl, h->d_lvl_kp, h->kp_pitch, h->d_lvl_cnt, h->d_kps, h->d_desc, h->out_cap, h->d_count);
+    {
+        ProfScope ps("k_blur", st);
+        hipLaunchKernelGGL(k_blur, dim3((unsigned)h->blur_tiles.size(), batch), dim3(256), 0, st, h->d_planes, h->d_blur, h->frame_bytes,
+                           h->d_lv, h->d_blur_tiles);
+    }
+    {
+        ProfScope ps("k_orient_describe", st);
+        hipLaunchKernelGGL(k_orient_describe, dim3((h->out_cap + 3) / 4, batch), dim3(256), 0, st, h->d_planes, h->d_blur, h->frame_bytes,
+                           h->d_lv, nl, h->d_lvl_kp, h->kp_pitch, h->d_lvl_cnt, h->d_kps, h->d_desc, h->out_cap, h->d_count);
+    }
     VIORB_HIP_TRY(hipGetLastError());
     h->last_stream = st; h->last_batch = batch;
     return VIORB_OK;
@@ -921,6 +958,40 @@ static int launch_all(viorb_extractor* h, const uint8_t* d_images, int batch, in
 extern "C" {
 
 int viorb_abi_version(void) { return 1; }
+
+int viorb_memcpy_dtod_async(void* dst, const void* src, size_t bytes, void* stream) {
+    VIORB_REQUIRE(dst && src, "null pointer");
+    VIORB_HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return VIORB_OK;
+}
+
+int viorb_profile_enable(int on) {
+    g_prof.enabled = on != 0;
+    return VIORB_OK;
+}
+int viorb_profile_reset(void) {
+    g_prof.used = 0;
+    return VIORB_OK;
+}
+// Synchronises the device and sums the recorded intervals per kernel name. names_buf receives the
+// names separated by '\n'.
+int viorb_profile_read(char* names_buf, int names_cap, double* total_ms, int* calls, int cap, int* n) {
+    VIORB_REQUIRE(names_buf && total_ms && calls && n, "null argument");
+    VIORB_HIP_TRY(hipDeviceSynchronize());
+    const int k = (int)g_prof.names.size();
+    *n = k;
+    std::string all;
+    for (int i = 0; i < k; i++) { all += g_prof.names[i]; all += '\n'; }
+    snprintf(names_buf, names_cap, "%s", all.c_str());
+    for (int i = 0; i < k && i < cap; i++) { total_ms[i] = 0; calls[i] = 0; }
+    for (size_t r = 0; r < g_prof.used; r++) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, g_prof.recs[r].a, g_prof.recs[r].b) != hipSuccess) continue;
+        const int slot = g_prof.recs[r].slot;
+        if (slot >= 0 && slot < cap) { total_ms[slot] += ms; calls[slot]++; }
+    }
+    return VIORB_OK;
+}
 const char* viorb_last_error(void) { return viorb::last_error_buf(); }
 int viorb_device_count(void) {
     int n = 0;

@@ -11,6 +11,15 @@ namespace viorb {
 char* last_error_buf();
 void set_error(const char* fmt, ...);
 
+// Optional per-kernel timing with HIP events recorded on the stream the kernel is launched on
+// (viorb_profile_* in include/viorb.h); used by bench.py for the roofline line. Off by default.
+struct ProfScope {
+    int idx;
+    hipStream_t st;
+    ProfScope(const char* name, hipStream_t s);
+    ~ProfScope();
+};
+
 } // namespace viorb
 
 #define VIORB_HIP_TRY(expr)                                                                   \

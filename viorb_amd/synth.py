@@ -253,3 +253,72 @@ def make_vi_stream(seed, n_frames, w=752, h=480, n_imu=10, imu_dt=0.005):
         t = t + T
     return dict(frames=np.stack(frames), ns_true=np.stack(states), imu=imus, t=np.array(ts), cam=cam,
                 gw=GRAVITY_CAM_WORLD.copy(), base=base)
+
+
+def make_periodic_stream(seed, n_frames=8, w=752, h=480, n_imu=10, imu_dt=0.005, nfeat_hint=None):
+    """A closed-loop mono-inertial stream: poses, velocities and images are periodic with period
+    n_frames * n_imu * imu_dt, so a tracker can run over it for any number of steps (frame k of the run is
+    frame k % n_frames of the stream; time keeps increasing). IMU samples come from the analytic trajectory.
+    Returns dict(frames [n,h,w], ns_true [n,22], pose_true [n,12] (Rcw,tcw double), imu [n,n_imu,7] with
+    imu[j] covering frame j-1 -> j (j = 0: frame n-1 -> n == 0) and stamps relative to the period start,
+    t [n] frame stamps in [0, T), period T, cam, gw)."""
+    rng = np.random.Generator(np.random.PCG64(seed + 987001))
+    cam = euroc_cam()
+    Rbc, Pbc = cam[4:13].reshape(3, 3), cam[13:16]
+    base = make_image(seed, w, h)
+    dtf = n_imu * imu_dt
+    T = n_frames * dtf
+    wp = 2 * np.pi / T
+    A = rng.uniform(0.02, 0.05, 3) * np.array([1, 1, 0.4]); phP = rng.uniform(0, 2 * np.pi, 3)
+    Th = np.deg2rad(rng.uniform(0.5, 1.5, 3)); phR = rng.uniform(0, 2 * np.pi, 3)
+    bg, ba = rng.normal(0, 0.002, 3), rng.normal(0, 0.02, 3)
+    R0 = Rbc.T.copy()                                    # camera starts near Tcw = I
+    P0 = -R0 @ Pbc
+
+    def traj(t):
+        P = P0 + A * np.sin(wp * t + phP)
+        V = A * wp * np.cos(wp * t + phP)
+        Acc = -A * wp * wp * np.sin(wp * t + phP)
+        th = Th * np.sin(wp * t + phR); thd = Th * wp * np.cos(wp * t + phR)
+        R = R0 @ _rotvec_to_R(th)
+        n = np.linalg.norm(th)
+        if n < 1e-9:
+            Jr = np.eye(3)
+        else:
+            k = th / n; K = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+            Jr = np.eye(3) - (1 - np.cos(n)) / n * K + (1 - np.sin(n) / n) * K @ K
+        return P, V, Acc, R, Jr @ thd
+
+    frames, states, poses, imus, ts = [], [], [], [], []
+    for j in range(n_frames):
+        t = j * dtf
+        P, V, _, R, _ = traj(t)
+        ns = navstate(P, V, R, bg, ba)
+        Rcw, tcw = cam_pose_from_navstate(ns, cam)
+        frames.append(render_view(base, cam, Rcw, tcw, seed=seed * 1013 + j))
+        states.append(ns); poses.append(np.concatenate([Rcw.ravel(), tcw])); ts.append(t)
+        # IMU between frame j-1 and j (j = 0 closes the loop: stamps in (T - dtf, T))
+        tstart = (j - 1) * dtf if j > 0 else T - dtf
+        imu = np.zeros((n_imu, 7))
+        for q in range(n_imu):
+            tq = tstart + imu_dt * (q + 0.3)
+            _, _, Acc, Rq, om = traj(tq)
+            imu[q, :3] = om + bg + rng.normal(0, 1e-3, 3)
+            imu[q, 3:6] = Rq.T @ (Acc - GRAVITY_CAM_WORLD) + ba + rng.normal(0, 1e-2, 3)
+            imu[q, 6] = tq
+        imus.append(imu)
+    return dict(frames=np.stack(frames), ns_true=np.stack(states), pose_true=np.stack(poses), imu=np.stack(imus), t=np.array(ts),
+                period=T, frame_dt=dtf, cam=cam, gw=GRAVITY_CAM_WORLD.copy(), base=base)
+
+
+def plane_points_f32(kps_xy, pose12_true, cam):
+    """numpy twin of viorb_synth_plane_points_device (same FP64 operation order, then float32)."""
+    T = np.asarray(pose12_true, np.float64)
+    fx, fy, cx, cy = cam[:4]
+    dx = (kps_xy[:, 0].astype(np.float64) - cx) / fx
+    dy = (kps_xy[:, 1].astype(np.float64) - cy) / fy
+    rx = T[0] * dx + T[3] * dy + T[6]; ry = T[1] * dx + T[4] * dy + T[7]; rz = T[2] * dx + T[5] * dy + T[8]
+    ox = -(T[0] * T[9] + T[3] * T[10] + T[6] * T[11]); oy = -(T[1] * T[9] + T[4] * T[10] + T[7] * T[11])
+    oz = -(T[2] * T[9] + T[5] * T[10] + T[8] * T[11])
+    s = (PLANE_Z0 - oz) / rz
+    return np.stack([ox + s * rx, oy + s * ry, oz + s * rz], 1).astype(np.float32)

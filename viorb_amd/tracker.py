@@ -1,0 +1,123 @@
+"""Batched per-frame tracking sequence on the device — the build's counterpart of the call order in
+Tracking::TrackWithIMU (reference src/Tracking.cc:412-534) for B independent mono-inertial streams:
+
+    extract -> AssignFeaturesToGrid -> IMU pre-integration + NavState prediction (PredictNavStateByIMU)
+            -> SearchByProjection(cur, last, th=15) -> PoseOptimization(cur, last frame, preint, gw, marg)
+
+Everything stays in HBM; the only host work per step is enqueueing kernels. Map maintenance (creating
+map points for the new last frame) is NOT part of the reference's per-frame path (LocalMapping does it);
+here it is supplied by the synthetic plane world of viorb_amd/synth.py through
+viorb_synth_plane_points_device, using the stream's ground-truth pose of that frame.
+torch tensors only carry device memory and the stream."""
+import ctypes as C
+import numpy as np
+from .capi import lib, check, ptr, KP_DTYPE
+from .extractor import ORBextractor
+from .frontend import Frontend
+from . import synth
+
+
+class BatchedTracker:
+    def __init__(self, cam, gw, batch, width=752, height=480, nfeatures=1000, th=15.0, device=0, compute_marg=True):
+        import torch
+        self.torch = torch
+        self.B, self.w, self.h, self.th = batch, width, height, float(th)
+        self.dev = torch.device("cuda", device)
+        self.ex = ORBextractor(nfeatures, 1.2, 8, 20, 7, max_batch=batch, device=device)
+        t = self.ex.tables()
+        self.cap = self.ex.cap
+        self.fe = Frontend(cam, gw, t["scale"], t["inv_sigma2"], (0.0, float(width), 0.0, float(height)), max_batch=batch,
+                           cap=self.cap, device=device)
+        self.cam = np.asarray(cam, np.float64)
+        self.compute_marg = compute_marg
+        B, cap = batch, self.cap
+        z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=self.dev)
+        # last-frame state
+        self.last_kps = z((B, cap, KP_DTYPE.itemsize), torch.uint8)
+        self.last_desc = z((B, cap, 32), torch.uint8)
+        self.last_count = z((B,), torch.int32)
+        self.last_flags = z((B, cap), torch.uint8)
+        self.last_Pw = z((B, cap, 3), torch.float32)
+        self.last_ns = z((B, 22), torch.float64)
+        self.prior_ns = z((B, 22), torch.float64)
+        self.marg_cov_inv = z((B, 144), torch.float64)
+        self.t_last = z((B,), torch.float64)
+        # per-step scratch / outputs
+        self.cell_start = z((B, 64 * 48 + 1), torch.int32)
+        self.cell_idx = z((B, cap), torch.int32)
+        self.preint = z((B, 142), torch.float64)
+        self.cur_ns = z((B, 22), torch.float64)
+        self.pose12 = z((B, 12), torch.float32)
+        self.cur_match = z((B, cap), torch.int32)
+        self.nmatches = z((B,), torch.int32)
+        self.status = z((B,), torch.int32)
+        self.obs_cur = z((B, cap, 6), torch.float64)
+        self.obs_last = z((B, cap, 6), torch.float64)
+        self.idx_cur = z((B, cap), torch.int32)
+        self.idx_last = z((B, cap), torch.int32)
+        self.n_cur = z((B,), torch.int32)
+        self.n_last = z((B,), torch.int32)
+        self.last_self = z((B, cap), torch.int32)          # identity where the last keypoint has a map point
+        self.out_ns = z((B, 22), torch.float64)
+        self.out_last_ns = z((B, 22), torch.float64)
+        self.outlier_cur = z((B, cap), torch.uint8)
+        self.outlier_last = z((B, cap), torch.uint8)
+        self.marg_out = z((B, 144), torch.float64)
+        self.info = z((B, 4), torch.float64)
+        self.iota = torch.arange(cap, dtype=torch.int32, device=self.dev)[None, :].expand(B, cap).contiguous()
+
+    # -- helpers ------------------------------------------------------------------------------------
+    def _cur_ptrs(self):
+        return self.ex.results_device()            # kps, desc, count, status, cap
+
+    def _roll(self, true_pose12, t_cur, ns_for_last, stream=None):
+        """Make the frame just processed the new last frame and give its keypoints map points."""
+        torch = self.torch
+        kps, desc, count, _, cap = self._cur_ptrs()
+        L = lib()
+        st = Frontend._st(stream)
+        nb = self.B * cap
+        for dst, src, nbytes in ((self.last_kps, kps, nb * KP_DTYPE.itemsize), (self.last_desc, desc, nb * 32), (self.last_count, count, self.B * 4)):
+            rc = _hip_memcpy_dtod_async(dst.data_ptr(), src, nbytes, st)
+            assert rc == 0
+        check(L.viorb_synth_plane_points_device(self.fe.h, C.c_void_p(self.last_kps.data_ptr()), C.c_void_p(self.last_count.data_ptr()),
+                                                ptr(true_pose12), synth.PLANE_Z0, self.B, ptr(self.last_Pw), ptr(self.last_flags), st))
+        self.last_ns.copy_(ns_for_last, non_blocking=True)
+        self.prior_ns.copy_(ns_for_last, non_blocking=True)
+        self.t_last.copy_(t_cur, non_blocking=True)
+        self.last_self.copy_(torch.where(self.last_flags > 0, self.iota, torch.full_like(self.iota, -1)))
+
+    def bootstrap(self, images, true_pose12, t0, ns0, marg_cov_inv):
+        """First frame of every stream: extract, adopt as last frame with ground-truth state."""
+        self.ex.extract_batch_device(images)
+        self.marg_cov_inv.copy_(marg_cov_inv)
+        self._roll(true_pose12, t0, ns0)
+
+    def step(self, images, imu, t_cur, true_pose12, chain_estimate=True, true_ns=None, t_next_last=None):
+        """One tracking step for all streams. images [B,h,w] u8, imu [B,n,7] f64, t_cur [B] f64,
+        true_pose12 [B,12] f64 (only used to create map points for the next step). t_next_last overrides the
+        stamp the frame gets as "last frame" (periodic streams: the loop-closing frame restarts at 0)."""
+        B = self.B
+        self.ex.extract_batch_device(images)
+        kps, desc, count, _, cap = self._cur_ptrs()
+        fe = self.fe
+        fe.grid(kps, count, B, self.cell_start, self.cell_idx)
+        fe.imu_predict(imu, self.t_last, t_cur, self.last_ns, self.preint, self.cur_ns, self.pose12)
+        fe.search_projection(kps, desc, count, self.cell_start, self.cell_idx, self.pose12, self.last_kps.data_ptr(),
+                             self.last_count.data_ptr(), self.last_flags, self.last_Pw, self.last_desc.data_ptr(), self.th, B,
+                             self.cur_match, self.nmatches, self.status)
+        fe.build_observations(kps, count, self.cur_match, self.last_Pw, B, self.obs_cur, self.idx_cur, self.n_cur)
+        fe.build_observations(self.last_kps.data_ptr(), self.last_count.data_ptr(), self.last_self, self.last_Pw, B, self.obs_last,
+                              self.idx_last, self.n_last)
+        fe.pose_opt(1, self.compute_marg, self.cur_ns, self.last_ns, self.prior_ns, self.marg_cov_inv, self.preint, self.obs_cur, self.n_cur,
+                    self.obs_last, self.n_last, B, self.out_ns, self.out_last_ns, self.outlier_cur, self.outlier_last, self.marg_out,
+                    self.info)
+        if self.compute_marg and chain_estimate:
+            self.marg_cov_inv.copy_(self.marg_out, non_blocking=True)
+        self._roll(true_pose12, t_cur if t_next_last is None else t_next_last, self.out_ns if chain_estimate else true_ns)
+
+
+def _hip_memcpy_dtod_async(dst, src, nbytes, stream):
+    """Device-to-device copy of raw device addresses on `stream`, through libviorb_hip's own HIP runtime binding
+    (dlopen-ing libamdhip64 by name from Python could load a second runtime next to torch's)."""
+    return lib().viorb_memcpy_dtod_async(C.c_void_p(dst), C.c_void_p(src), nbytes, stream)
