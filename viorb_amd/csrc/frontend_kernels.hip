@@ -381,65 +381,43 @@ struct PoseOptArgs {
 };
 
 struct PoseOptShared {
-    double H[24 * 24], L[24 * 24], b[24], x[24];
-    double J[12 * 24], OJ[12 * 24], e[12];
+    double H[24 * 24], Lm[24 * 24], b[24], x[24], y[24];
+    double J1[9 * 21], OJ1[9 * 21], e1[12];            // IMU factor
+    double J2[12 * 12], OJ2[12 * 12], e2[12];          // prior factor
+    double q[32];                                       // per-row terms of the quadratic forms
     double info_pvr[81], info_prior[144];
-    double red[4 * 32];
-    double est[2][10], bias[2][3];          // PVR (P V q) and dBias_acc of cur / last
+    double red[4][2][28];                               // per wave, per side: 21 H + 6 b + chi
+    double est[2][10], bias[2][3];                      // PVR (P V q) and dBias_acc of cur / last
     double bak[2][10], bakb[2][3];
-    double base_ba[2][3];                    // BiasAcc of cur / last (constant)
-    double scal[8];                          // 0 chi2, 1 lambda, 2 ni, 3 rho, 4 ok, 5 scale ...
+    double base_ba[2][3];                               // BiasAcc of cur / last (constant)
+    double sc[16];                                      // 0 chi total, 1 w_imu, 2 w_prior, 3 ok, 7 last chi
     int flag[4];
 };
 
-__device__ __forceinline__ double block_sum(double v, double* red) {
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d);
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    __syncthreads();
-    if (lane == 0) red[wv] = v;
-    __syncthreads();
-    return red[0] + red[1] + red[2] + red[3];
-}
+// single-wavefront LDS hand-offs: the LDS unit executes one wave's instructions in order, the fence only
+// stops the compiler from moving LDS accesses across the hand-off
+#define WAVE_LDS_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
 
-// in-place Gauss-Jordan inverse of an n x n matrix in LDS/global (single thread), returns false if singular
-__device__ bool small_inverse(double* a, double* inv, int n) {
-    for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) inv[i * n + j] = (i == j) ? 1.0 : 0.0;
-    for (int col = 0; col < n; col++) {
-        int p = col; double best = fabs(a[col * n + col]);
-        for (int i = col + 1; i < n; i++) if (fabs(a[i * n + col]) > best) { best = fabs(a[i * n + col]); p = i; }
-        if (best == 0) return false;
-        if (p != col) for (int j = 0; j < n; j++) { double t = a[p * n + j]; a[p * n + j] = a[col * n + j]; a[col * n + j] = t; t = inv[p * n + j]; inv[p * n + j] = inv[col * n + j]; inv[col * n + j] = t; }
-        const double iv = 1.0 / a[col * n + col];
-        for (int j = 0; j < n; j++) { a[col * n + j] *= iv; inv[col * n + j] *= iv; }
-        for (int i = 0; i < n; i++) if (i != col) { const double f = a[i * n + col]; if (f == 0) continue; for (int j = 0; j < n; j++) { a[i * n + j] -= f * a[col * n + j]; inv[i * n + j] -= f * inv[col * n + j]; } }
+// In-LDS right-looking Cholesky by ONE wavefront: eliminates the first `nsteps` columns of the n x n SPD
+// matrix M (row-major, lower triangle used and overwritten by L); the trailing (n-nsteps)^2 block is then
+// the Schur complement. Returns false (wave-uniform) on a non-positive pivot.
+__device__ bool wave_cholesky(double* M, int n, int nsteps, int lane) {
+    bool ok = true;
+    for (int j = 0; j < nsteps; j++) {
+        const double d = M[j * n + j];
+        if (!(d > 0) || !isfinite(d)) { ok = false; break; }
+        const double sd = sqrt(d);
+        const int i = j + lane;
+        if (i < n) M[i * n + j] = (i == j) ? sd : M[i * n + j] / sd;
+        WAVE_LDS_SYNC();
+        const int m = n - j - 1;
+        for (int idx = lane; idx < m * m; idx += 64) {
+            const int r = j + 1 + idx / m, c = j + 1 + idx % m;
+            if (c <= r) M[r * n + c] -= M[r * n + j] * M[c * n + j];
+        }
+        WAVE_LDS_SYNC();
     }
-    return true;
-}
-
-// H += w * J^T Omega J, b -= w * J^T Omega e for one dense edge (J: m x nv row-major in S.J, map: column -> x index or -1)
-__device__ void add_dense_edge(PoseOptShared& S, int m, int nv, const double* Omega, double w, const int* map, int n) {
-    for (int i = threadIdx.x; i < m * nv; i += blockDim.x) {
-        const int r = i / nv, c = i - r * nv;
-        double s = 0;
-        for (int k = 0; k < m; k++) s += Omega[r * m + k] * S.J[k * nv + c];
-        S.OJ[i] = s;
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < nv * nv; i += blockDim.x) {
-        const int r = i / nv, c = i - r * nv;
-        if (map[r] < 0 || map[c] < 0) continue;
-        double s = 0;
-        for (int k = 0; k < m; k++) s += S.J[k * nv + r] * S.OJ[k * nv + c];
-        S.H[map[r] * n + map[c]] += w * s;
-    }
-    for (int r = threadIdx.x; r < nv; r += blockDim.x) {
-        if (map[r] < 0) continue;
-        double s = 0;
-        for (int k = 0; k < m; k++) s += S.OJ[k * nv + r] * S.e[k];
-        S.b[map[r]] -= w * s;
-    }
-    __syncthreads();
+    return ok;
 }
 
 __device__ __forceinline__ pvr sh_pvr(const double* p) { pvr s; s.P = ld3(p); s.V = ld3(p + 3); s.q = mkq(p[6], p[7], p[8], p[9]); return s; }
@@ -447,8 +425,8 @@ __device__ __forceinline__ void sh_put(double* p, const pvr& s) { st3(p, s.P); s
 
 __global__ __launch_bounds__(256) void k_pose_opt_vi(PoseOptArgs A) {
     __shared__ PoseOptShared S;
-    __shared__ int s_map21[21], s_map12[12], s_map6[6];
-    const int b = blockIdx.x, t = threadIdx.x, cap = A.cap;
+    __shared__ int s_map21[21], s_map12[12];
+    const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6, cap = A.cap;
     const int variant = A.variant, n = variant ? 24 : 12;
     const int ncur = min(A.n_cur[b], cap), nlast = variant ? min(A.n_last[b], cap) : 0;
     const double* obs_c = A.obs_cur + (size_t)b * cap * 6;
@@ -458,32 +436,53 @@ __global__ __launch_bounds__(256) void k_pose_opt_vi(PoseOptArgs A) {
     const double* curns = A.cur_ns + (size_t)b * 22;
     const double* lastns = A.last_ns + (size_t)b * 22;
     const double* pre = A.preint + (size_t)b * 142;
+    const double* priorns = variant ? A.prior_ns + (size_t)b * 22 : nullptr;
     const cam_t K = ld_cam(A.cam);
     const d3 gw = ld3(A.gw);
+    const d3 last_dbg = ld3(lastns + 16);
     const double d_mono = (double)(float)sqrt(5.991), d_pvr = (double)(float)sqrt(21.666), d_bias = (double)(float)sqrt(16.812),
                  d_prior = (double)(float)sqrt(30.5779);
     const double bias_info = 1.0 / A.acc_bias_rw2 / pre[141];
     // ---- setup
     for (int i = t; i < ncur; i += blockDim.x) out_c[i] = 0;
     for (int i = t; i < nlast; i += blockDim.x) out_l[i] = 0;
-    if (t == 0) {
-        // information of the IMU factor: cov^-1 + diag(1e2,1,1e2) (x) I3
-        double tmp[81];
-        for (int i = 0; i < 81; i++) tmp[i] = pre[60 + i];
-        small_inverse(tmp, S.info_pvr, 9);
-        for (int k = 0; k < 3; k++) { S.info_pvr[k * 9 + k] += 1e2; S.info_pvr[(3 + k) * 9 + 3 + k] += 1; S.info_pvr[(6 + k) * 9 + 6 + k] += 1e2; }
-        if (variant) {
-            const double* mc = A.marg_cov_inv + (size_t)b * 144;
-            for (int i = 0; i < 144; i++) S.info_prior[i] = mc[i];
-            for (int k = 0; k < 3; k++) { S.info_prior[k * 12 + k] += 1e2; S.info_prior[(3 + k) * 12 + 3 + k] += 1; S.info_prior[(6 + k) * 12 + 6 + k] += 1e2; }
+    // information of the IMU factor: cov^-1 + diag(1e2,1,1e2) (x) I3, by Gauss-Jordan over all threads
+    {
+        double* a = S.Lm; double* inv = S.H;                  // scratch: [9x9 | 9x9]
+        for (int i = t; i < 81; i += blockDim.x) { a[i] = pre[60 + i]; inv[i] = (i / 9 == i % 9) ? 1.0 : 0.0; }
+        __syncthreads();
+        for (int col = 0; col < 9; col++) {
+            // the covariance is SPD: no pivoting needed. Barriers only in wave-uniform control flow.
+            const double piv = a[col * 9 + col];
+            __syncthreads();
+            if (t < 9) a[col * 9 + t] /= piv; else if (t >= 64 && t < 73) inv[col * 9 + t - 64] /= piv;
+            __syncthreads();
+            const int which = t / 81, el = t % 81, r = el / 9, c = el % 9;
+            double* M = which ? inv : a;
+            const double f = (t < 162) ? a[r * 9 + col] : 0.0;
+            __syncthreads();
+            if (t < 162 && r != col) M[r * 9 + c] -= f * M[col * 9 + c];
+            __syncthreads();
         }
+        for (int i = t; i < 81; i += blockDim.x) {
+            const int r = i / 9, c = i % 9;
+            S.info_pvr[i] = inv[i] + ((r == c) ? ((r < 3 || r >= 6) ? 1e2 : 1.0) : 0.0);
+        }
+    }
+    if (variant) {
+        const double* mc = A.marg_cov_inv + (size_t)b * 144;
+        for (int i = t; i < 144; i += blockDim.x) {
+            const int r = i / 12, c = i % 12;
+            S.info_prior[i] = mc[i] + ((r == c && r < 9) ? ((r < 3 || r >= 6) ? 1e2 : 1.0) : 0.0);
+        }
+    }
+    if (t == 0) {
         for (int k = 0; k < 3; k++) { S.base_ba[0][k] = curns[13 + k]; S.base_ba[1][k] = lastns[13 + k]; }
         // column maps: IMU factor J = [i(9) | j(9) | bias_i(3)] with i = last, j = cur
         for (int k = 0; k < 9; k++) { s_map21[k] = variant ? 12 + k : -1; s_map21[9 + k] = k; }
         for (int k = 0; k < 3; k++) s_map21[18 + k] = variant ? 21 + k : -1;
         for (int k = 0; k < 12; k++) s_map12[k] = 12 + k;              // prior: [last PVR | last bias]
-        for (int k = 0; k < 3; k++) { s_map6[k] = 9 + k; s_map6[3 + k] = variant ? 21 + k : -1; }   // bias edge: [cur | last]
-        S.flag[1] = 0;                                                   // lm iteration counter
+        S.flag[1] = 0;                                                   // LM iteration counter
     }
     __syncthreads();
     if (ncur < 3) {                                                      // "if(nInitialCorrespondences<3) return 0"
@@ -498,152 +497,155 @@ __global__ __launch_bounds__(256) void k_pose_opt_vi(PoseOptArgs A) {
     int kernel_on = 1;           // mono edges keep their Huber kernel until the end of round 3
     int nbad = 0;
 
-    // robust chi2 of all active edges at the current estimate
-    auto eval_chi2 = [&]() -> double {
-        double acc = 0;
-        for (int side = 0; side < (variant ? 2 : 1); side++) {
-            const pvr s = sh_pvr(S.est[side]);
-            const m33 RT = tr(qmat(s.q));
-            const double* ob = side ? obs_l : obs_c; const uint8_t* ol = side ? out_l : out_c; const int ne = side ? nlast : ncur;
-            for (int i = t; i < ne; i += blockDim.x) {
-                if (ol[i]) continue;
-                double e[2];
-                proj_edge(K, RT, s.P, ld3(ob + 6 * i), ob[6 * i + 3], ob[6 * i + 4], false, e, nullptr, nullptr);
-                const double chi = ob[6 * i + 5] * (e[0] * e[0] + e[1] * e[1]);
-                double r0 = chi, r1 = 1;
-                if (kernel_on) huber(chi, d_mono, &r0, &r1);
-                acc += r0;
-            }
+    // One pass over the active reprojection edges at the current estimate: robust chi2 and, when `lin`,
+    // the 6x6 (P, Phi) normal-equation blocks of both frames. Followed by the two dense factors (IMU on
+    // wave 0, prior on wave 1) and the bias factor. Leaves H, b (when lin) and the total robust chi2 in S.sc[0].
+    auto evaluate = [&](bool lin) -> double {
+        if (lin) {
+            for (int i = t; i < n * n; i += blockDim.x) S.H[i] = 0;
+            for (int i = t; i < n; i += blockDim.x) S.b[i] = 0;
         }
-        double tot = block_sum(acc, S.red);
+        // dense factors: residuals (+ Jacobians) by one lane of two different waves
         if (t == 0) {
-            double e[12], r0, r1, chi;
             const pvr sc = sh_pvr(S.est[0]), sl = sh_pvr(S.est[1]);
-            pvr_edge(sl, sc, ld3(lastns + 16), ld3(S.bias[1]), pre, gw, e, nullptr);
-            chi = 0; for (int i = 0; i < 9; i++) { double s = 0; for (int j = 0; j < 9; j++) s += S.info_pvr[i * 9 + j] * e[j]; chi += e[i] * s; }
-            huber(chi, d_pvr, &r0, &r1); tot += r0;
-            const d3 eb = (ld3(S.base_ba[0]) + ld3(S.bias[0])) - (ld3(S.base_ba[1]) + ld3(S.bias[1]));
-            huber(bias_info * dot3(eb, eb), d_bias, &r0, &r1); tot += r0;
-            if (variant) {
-                prior_edge(sl, ld3(S.base_ba[1]) + ld3(S.bias[1]), A.prior_ns + (size_t)b * 22, e, nullptr);
-                chi = 0; for (int i = 0; i < 12; i++) { double s = 0; for (int j = 0; j < 12; j++) s += S.info_prior[i * 12 + j] * e[j]; chi += e[i] * s; }
-                huber(chi, d_prior, &r0, &r1); tot += r0;
-            }
-            S.scal[0] = tot;
+            pvr_edge(sl, sc, last_dbg, ld3(S.bias[1]), pre, gw, S.e1, lin ? S.J1 : nullptr);
+        } else if (t == 64 && variant) {
+            const pvr sl = sh_pvr(S.est[1]);
+            prior_edge(sl, ld3(S.base_ba[1]) + ld3(S.bias[1]), priorns, S.e2, lin ? S.J2 : nullptr);
         }
-        __syncthreads();
-        return S.scal[0];
-    };
-
-    // linearise every active edge at the current estimate: H, b
-    auto build_system = [&]() {
-        for (int i = t; i < n * n; i += blockDim.x) S.H[i] = 0;
-        for (int i = t; i < n; i += blockDim.x) S.b[i] = 0;
-        __syncthreads();
         for (int side = 0; side < (variant ? 2 : 1); side++) {
             const pvr s = sh_pvr(S.est[side]);
             const m33 RT = tr(qmat(s.q));
             const double* ob = side ? obs_l : obs_c; const uint8_t* ol = side ? out_l : out_c; const int ne = side ? nlast : ncur;
-            double a[27];
+            double a[28];
 #pragma unroll
-            for (int k = 0; k < 27; k++) a[k] = 0;
+            for (int k = 0; k < 28; k++) a[k] = 0;
             for (int i = t; i < ne; i += blockDim.x) {
                 if (ol[i]) continue;
                 double e[2], JP[6], JR[6];
-                proj_edge(K, RT, s.P, ld3(ob + 6 * i), ob[6 * i + 3], ob[6 * i + 4], true, e, JP, JR);
+                proj_edge(K, RT, s.P, ld3(ob + 6 * i), ob[6 * i + 3], ob[6 * i + 4], lin, e, JP, JR);
                 const double is2 = ob[6 * i + 5];
-                double r0, r1 = 1;
-                if (kernel_on) huber(is2 * (e[0] * e[0] + e[1] * e[1]), d_mono, &r0, &r1);
-                const double w = r1 * is2;
-                const double j0[6] = {JP[0], JP[1], JP[2], JR[0], JR[1], JR[2]}, j1[6] = {JP[3], JP[4], JP[5], JR[3], JR[4], JR[5]};
-                int k = 0;
+                const double chi = is2 * (e[0] * e[0] + e[1] * e[1]);
+                double r0 = chi, r1 = 1;
+                if (kernel_on) huber(chi, d_mono, &r0, &r1);
+                a[27] += r0;
+                if (lin) {
+                    const double w = r1 * is2;
+                    const double j0[6] = {JP[0], JP[1], JP[2], JR[0], JR[1], JR[2]}, j1[6] = {JP[3], JP[4], JP[5], JR[3], JR[4], JR[5]};
+                    int k = 0;
 #pragma unroll
-                for (int r = 0; r < 6; r++)
+                    for (int r = 0; r < 6; r++)
 #pragma unroll
-                    for (int c = r; c < 6; c++) a[k++] += w * (j0[r] * j0[c] + j1[r] * j1[c]);
+                        for (int c = r; c < 6; c++) a[k++] += w * (j0[r] * j0[c] + j1[r] * j1[c]);
 #pragma unroll
-                for (int r = 0; r < 6; r++) a[21 + r] -= w * (j0[r] * e[0] + j1[r] * e[1]);
+                    for (int r = 0; r < 6; r++) a[21 + r] -= w * (j0[r] * e[0] + j1[r] * e[1]);
+                }
             }
-            // reduce the 27 partials over the block, then scatter into H / b (P at 0..2, Phi at 6..8 of the vertex)
 #pragma unroll
-            for (int k = 0; k < 27; k++) {
+            for (int k = 0; k < 28; k++) {
+                if (!lin && k < 27) continue;
                 double v = a[k];
 #pragma unroll
                 for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d);
-                if ((t & 63) == 0) S.red[(t >> 6) * 32 + k] = v;
+                if (lane == 0) S.red[wave][side][k] = v;
             }
-            __syncthreads();
-            if (t < 27) {
-                const double v = S.red[t] + S.red[32 + t] + S.red[64 + t] + S.red[96 + t];
+        }
+        __syncthreads();
+        // quadratic forms of the dense factors: q[r] = e_r * (Omega e)_r ; proj partials -> H, b
+        if (t < 9) { double s = 0; for (int c = 0; c < 9; c++) s += S.info_pvr[t * 9 + c] * S.e1[c]; S.q[t] = S.e1[t] * s; }
+        else if (t >= 64 && t < 76 && variant) { const int r = t - 64; double s = 0; for (int c = 0; c < 12; c++) s += S.info_prior[r * 12 + c] * S.e2[c]; S.q[12 + r] = S.e2[r] * s; }
+        else if (lin && t >= 128 && t < 128 + 54) {
+            const int side = (t - 128) / 27, k = (t - 128) % 27;
+            if (side == 0 || variant) {
+                const double v = S.red[0][side][k] + S.red[1][side][k] + S.red[2][side][k] + S.red[3][side][k];
                 const int base = side ? 12 : 0;
                 const int loc[6] = {0, 1, 2, 6, 7, 8};
-                if (t < 21) {
-                    int k = 0, rr = 0, cc = 0;
-                    for (int r = 0; r < 6; r++) for (int c = r; c < 6; c++) { if (k == t) { rr = r; cc = c; } k++; }
+                if (k < 21) {
+                    int kk = 0, rr = 0, cc = 0;
+                    for (int r = 0; r < 6; r++) for (int c = r; c < 6; c++) { if (kk == k) { rr = r; cc = c; } kk++; }
                     S.H[(base + loc[rr]) * n + base + loc[cc]] += v;
                     if (rr != cc) S.H[(base + loc[cc]) * n + base + loc[rr]] += v;
-                } else S.b[base + loc[t - 21]] += v;
+                } else S.b[base + loc[k - 21]] += v;
             }
-            __syncthreads();
-        }
-        // IMU factor
-        if (t == 0) {
-            const pvr sc = sh_pvr(S.est[0]), sl = sh_pvr(S.est[1]);
-            pvr_edge(sl, sc, ld3(lastns + 16), ld3(S.bias[1]), pre, gw, S.e, S.J);
-            double chi = 0; for (int i = 0; i < 9; i++) { double s = 0; for (int j = 0; j < 9; j++) s += S.info_pvr[i * 9 + j] * S.e[j]; chi += S.e[i] * s; }
-            double r0, r1; huber(chi, d_pvr, &r0, &r1); S.scal[6] = r1;
         }
         __syncthreads();
-        add_dense_edge(S, 9, 21, S.info_pvr, S.scal[6], s_map21, n);
-        // bias random-walk factor: e = (ba_j + dba_j) - (ba_i + dba_i), J_i = -I, J_j = +I (i = last, j = cur)
         if (t == 0) {
+            double tot = 0;
+            for (int w = 0; w < 4; w++) { tot += S.red[w][0][27]; if (variant) tot += S.red[w][1][27]; }
+            double chi = 0, r0, r1;
+            for (int i = 0; i < 9; i++) chi += S.q[i];
+            huber(chi, d_pvr, &r0, &r1); tot += r0; S.sc[1] = r1;
             const d3 eb = (ld3(S.base_ba[0]) + ld3(S.bias[0])) - (ld3(S.base_ba[1]) + ld3(S.bias[1]));
-            double r0, r1; huber(bias_info * dot3(eb, eb), d_bias, &r0, &r1);
-            const double w = r1 * bias_info; const double ev[3] = {eb.x, eb.y, eb.z};
-            for (int k = 0; k < 3; k++) {
-                const int jc = s_map6[k], ic = s_map6[3 + k];
-                S.H[jc * n + jc] += w; S.b[jc] -= w * ev[k];
-                if (ic >= 0) { S.H[ic * n + ic] += w; S.H[ic * n + jc] -= w; S.H[jc * n + ic] -= w; S.b[ic] += w * ev[k]; }
+            huber(bias_info * dot3(eb, eb), d_bias, &r0, &r1); tot += r0;
+            if (lin) {      // bias random-walk factor: J_i = -I (last), J_j = +I (cur)
+                const double w = r1 * bias_info; const double ev[3] = {eb.x, eb.y, eb.z};
+                for (int k = 0; k < 3; k++) {
+                    const int jc = 9 + k, ic = variant ? 21 + k : -1;
+                    S.H[jc * n + jc] += w; S.b[jc] -= w * ev[k];
+                    if (ic >= 0) { S.H[ic * n + ic] += w; S.H[ic * n + jc] -= w; S.H[jc * n + ic] -= w; S.b[ic] += w * ev[k]; }
+                }
+            }
+            if (variant) {
+                chi = 0; for (int i = 0; i < 12; i++) chi += S.q[12 + i];
+                huber(chi, d_prior, &r0, &r1); tot += r0; S.sc[2] = r1;
+            }
+            S.sc[0] = tot;
+        }
+        if (lin) {
+            // Omega*J of both dense factors
+            for (int i = t; i < 189 + (variant ? 144 : 0); i += blockDim.x) {
+                if (i < 189) { const int r = i / 21, c = i % 21; double s = 0; for (int k = 0; k < 9; k++) s += S.info_pvr[r * 9 + k] * S.J1[k * 21 + c]; S.OJ1[i] = s; }
+                else { const int ii = i - 189, r = ii / 12, c = ii % 12; double s = 0; for (int k = 0; k < 12; k++) s += S.info_prior[r * 12 + k] * S.J2[k * 12 + c]; S.OJ2[ii] = s; }
+            }
+            __syncthreads();
+            // H += w J^T (Omega J), b -= w (Omega J)^T e — one output element per thread; the two factors touch
+            // overlapping H entries (last-frame block), so they are applied one after the other
+            const double w1 = S.sc[1];
+            for (int i = t; i < 441 + 21; i += blockDim.x) {
+                if (i < 441) {
+                    const int r = i / 21, c = i % 21;
+                    if (s_map21[r] >= 0 && s_map21[c] >= 0) { double s = 0; for (int k = 0; k < 9; k++) s += S.J1[k * 21 + r] * S.OJ1[k * 21 + c]; S.H[s_map21[r] * n + s_map21[c]] += w1 * s; }
+                } else {
+                    const int r = i - 441;
+                    if (s_map21[r] >= 0) { double s = 0; for (int k = 0; k < 9; k++) s += S.OJ1[k * 21 + r] * S.e1[k]; S.b[s_map21[r]] -= w1 * s; }
+                }
+            }
+            __syncthreads();
+            if (variant) {
+                const double w2 = S.sc[2];
+                for (int i = t; i < 144 + 12; i += blockDim.x) {
+                    if (i < 144) { const int r = i / 12, c = i % 12; double s = 0; for (int k = 0; k < 12; k++) s += S.J2[k * 12 + r] * S.OJ2[k * 12 + c]; S.H[s_map12[r] * n + s_map12[c]] += w2 * s; }
+                    else { const int r = i - 144; double s = 0; for (int k = 0; k < 12; k++) s += S.OJ2[k * 12 + r] * S.e2[k]; S.b[s_map12[r]] -= w2 * s; }
+                }
             }
         }
         __syncthreads();
-        if (variant) {
-            if (t == 0) {
-                const pvr sl = sh_pvr(S.est[1]);
-                prior_edge(sl, ld3(S.base_ba[1]) + ld3(S.bias[1]), A.prior_ns + (size_t)b * 22, S.e, S.J);
-                double chi = 0; for (int i = 0; i < 12; i++) { double s = 0; for (int j = 0; j < 12; j++) s += S.info_prior[i * 12 + j] * S.e[j]; chi += S.e[i] * s; }
-                double r0, r1; huber(chi, d_prior, &r0, &r1); S.scal[6] = r1;
-            }
-            __syncthreads();
-            add_dense_edge(S, 12, 12, S.info_prior, S.scal[6], s_map12, n);
-        }
+        return S.sc[0];
     };
 
-    // (H + lambda I) x = b by Cholesky, columns distributed over lanes; S.flag[0] = success
+    // (H + lambda I) x = b on wave 0: in-LDS Cholesky, then lane-parallel substitutions. S.flag[0] = success.
     auto solve = [&](double lambda) {
-        for (int i = t; i < n * n; i += blockDim.x) S.L[i] = S.H[i] + ((i / n == i % n) ? lambda : 0.0);
-        if (t == 0) S.flag[0] = 1;
+        for (int i = t; i < n * n; i += blockDim.x) S.Lm[i] = S.H[i] + ((i / n == i % n) ? lambda : 0.0);
         __syncthreads();
-        for (int j = 0; j < n; j++) {
-            if (t == 0) {
-                double d = S.L[j * n + j];
-                for (int k = 0; k < j; k++) d -= S.L[j * n + k] * S.L[j * n + k];
-                if (!(d > 0) || !isfinite(d)) { S.flag[0] = 0; d = 1; }
-                S.L[j * n + j] = sqrt(d);
-            }
-            __syncthreads();
-            for (int i = j + 1 + t; i < n; i += blockDim.x) {
-                double s = S.L[i * n + j];
-                for (int k = 0; k < j; k++) s -= S.L[i * n + k] * S.L[j * n + k];
-                S.L[i * n + j] = s / S.L[j * n + j];
-            }
-            __syncthreads();
-        }
-        if (t == 0) {
-            double y[24];
-            for (int i = 0; i < n; i++) { double s = S.b[i]; for (int k = 0; k < i; k++) s -= S.L[i * n + k] * y[k]; y[i] = s / S.L[i * n + i]; }
-            for (int i = n - 1; i >= 0; i--) { double s = y[i]; for (int k = i + 1; k < n; k++) s -= S.L[k * n + i] * S.x[k]; S.x[i] = s / S.L[i * n + i]; }
-            if (!S.flag[0]) for (int i = 0; i < n; i++) S.x[i] = 0;
+        if (wave == 0) {
+            const bool ok = wave_cholesky(S.Lm, n, n, lane);
+            if (ok) {
+                // forward: L y = b
+                double acc = lane < n ? S.b[lane] : 0.0;
+                for (int j = 0; j < n; j++) {
+                    if (lane == j) S.y[j] = acc / S.Lm[j * n + j];
+                    WAVE_LDS_SYNC();
+                    if (lane > j && lane < n) acc -= S.Lm[lane * n + j] * S.y[j];
+                }
+                // backward: L^T x = y
+                acc = lane < n ? S.y[lane] : 0.0;
+                for (int j = n - 1; j >= 0; j--) {
+                    if (lane == j) S.x[j] = acc / S.Lm[j * n + j];
+                    WAVE_LDS_SYNC();
+                    if (lane < j) acc -= S.Lm[j * n + lane] * S.x[j];
+                }
+            } else if (lane < n) S.x[lane] = 0;
+            if (lane == 0) S.flag[0] = ok ? 1 : 0;
         }
         __syncthreads();
     };
@@ -658,25 +660,26 @@ __global__ __launch_bounds__(256) void k_pose_opt_vi(PoseOptArgs A) {
         // ---- optimize(10): g2o Levenberg
         double lambda = 0, ni = 2; int nBadLM = 0;
         for (int it = 0; it < 10; it++) {
-            double currentChi = eval_chi2();
+            double currentChi = evaluate(true);              // computeActiveErrors + activeRobustChi2 + buildSystem
             const double iniChi = currentChi;
-            build_system();
             if (it == 0) {
                 double mx = 0; for (int i = 0; i < n; i++) mx = fmax(fabs(S.H[i * n + i]), mx);
                 lambda = 1e-5 * mx; ni = 2; nBadLM = 0;
             }
             double rho = 0; int qmax = 0;
             do {
-                if (t == 0) { for (int k = 0; k < 10; k++) { S.bak[0][k] = S.est[0][k]; S.bak[1][k] = S.est[1][k]; } for (int k = 0; k < 3; k++) { S.bakb[0][k] = S.bias[0][k]; S.bakb[1][k] = S.bias[1][k]; } }
+                if (t < 20) S.bak[t / 10][t % 10] = S.est[t / 10][t % 10]; else if (t < 26) S.bakb[(t - 20) / 3][(t - 20) % 3] = S.bias[(t - 20) / 3][(t - 20) % 3];
                 solve(lambda);
                 const int ok2 = S.flag[0];
                 if (t == 0) {
                     sh_put(S.est[0], inc_small_pvr(sh_pvr(S.est[0]), S.x));
                     for (int k = 0; k < 3; k++) S.bias[0][k] += S.x[9 + k];
-                    if (variant) { sh_put(S.est[1], inc_small_pvr(sh_pvr(S.est[1]), S.x + 12)); for (int k = 0; k < 3; k++) S.bias[1][k] += S.x[21 + k]; }
+                } else if (t == 64 && variant) {
+                    sh_put(S.est[1], inc_small_pvr(sh_pvr(S.est[1]), S.x + 12));
+                    for (int k = 0; k < 3; k++) S.bias[1][k] += S.x[21 + k];
                 }
                 __syncthreads();
-                double tempChi = eval_chi2();
+                double tempChi = evaluate(false);
                 if (!ok2) tempChi = 1.7976931348623157e308;
                 double scale = 0; for (int j = 0; j < n; j++) scale += S.x[j] * (lambda * S.x[j] + S.b[j]);
                 scale += 1e-3;
@@ -687,20 +690,18 @@ __global__ __launch_bounds__(256) void k_pose_opt_vi(PoseOptArgs A) {
                     lambda *= fmax(1. / 3., alpha); ni = 2; currentChi = tempChi;
                 } else {
                     lambda *= ni; ni *= 2;
-                    __syncthreads();
-                    if (t == 0) { for (int k = 0; k < 10; k++) { S.est[0][k] = S.bak[0][k]; S.est[1][k] = S.bak[1][k]; } for (int k = 0; k < 3; k++) { S.bias[0][k] = S.bakb[0][k]; S.bias[1][k] = S.bakb[1][k]; } }
+                    if (t < 20) S.est[t / 10][t % 10] = S.bak[t / 10][t % 10]; else if (t < 26) S.bias[(t - 20) / 3][(t - 20) % 3] = S.bakb[(t - 20) / 3][(t - 20) % 3];
                 }
                 __syncthreads();
                 qmax++;
             } while (rho < 0 && qmax < 10);
-            if (t == 0) { S.flag[1]++; S.scal[7] = currentChi; }
+            if (t == 0) { S.flag[1]++; S.sc[7] = currentChi; }
             if (qmax == 10 || rho == 0) break;
             if ((iniChi - currentChi) * 1e3 < iniChi) nBadLM++; else nBadLM = 0;
             if (nBadLM >= 3) break;
         }
         __syncthreads();
         // ---- re-classify every mono edge by its chi2 at the new estimate (Optimizer.cc:622-688)
-        nbad = 0;
         {
             int bad_local = 0;
             for (int side = 0; side < (variant ? 2 : 1); side++) {
@@ -716,7 +717,14 @@ __global__ __launch_bounds__(256) void k_pose_opt_vi(PoseOptArgs A) {
                     if (side == 0) bad_local += bad;
                 }
             }
-            nbad = (int)(block_sum((double)bad_local, S.red) + 0.5);
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) bad_local += __shfl_xor(bad_local, d);
+            __syncthreads();
+            if (lane == 0) S.flag[2 + 0] = 0;
+            __syncthreads();
+            if (lane == 0) atomicAdd(&S.flag[2], bad_local);
+            __syncthreads();
+            nbad = S.flag[2];
         }
         if (round == 2) kernel_on = 0;
         __syncthreads();
@@ -735,24 +743,30 @@ __global__ __launch_bounds__(256) void k_pose_opt_vi(PoseOptArgs A) {
             for (int k = 0; k < 3; k++) ol[19 + k] = variant ? S.bias[1][k] : lastns[19 + k];
         }
         double* inf = A.info + (size_t)b * 4;
-        inf[0] = ncur - nbad; inf[1] = S.scal[7]; inf[2] = S.flag[1]; inf[3] = 0;
-        if (A.compute_marg) {
-            // marginal covariance blocks of (cur PVR, cur bias) from the last linearised H (restored diagonal)
-            double* mo = A.marg_out + (size_t)b * 144;
-            for (int i = 0; i < n * n; i++) S.L[i] = S.H[i];
-            double* Hinv = S.H;                       // H is not needed any more
-            small_inverse(S.L, Hinv, n);
-            if (variant) {
-                for (int i = 0; i < 12; i++) for (int j = 0; j < 12; j++) S.L[i * 12 + j] = Hinv[i * n + j];
-                small_inverse(S.L, mo, 12);
-            } else {
-                double c9[81], i9[81], c3[9], i3[9];
-                for (int i = 0; i < 9; i++) for (int j = 0; j < 9; j++) c9[i * 9 + j] = Hinv[i * n + j];
-                for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) c3[i * 3 + j] = Hinv[(9 + i) * n + 9 + j];
-                small_inverse(c9, i9, 9); small_inverse(c3, i3, 3);
-                for (int i = 0; i < 144; i++) mo[i] = 0;
-                for (int i = 0; i < 9; i++) for (int j = 0; j < 9; j++) mo[i * 12 + j] = i9[i * 9 + j];
-                for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) mo[(9 + i) * 12 + 9 + j] = i3[i * 3 + j];
+        inf[0] = ncur - nbad; inf[1] = S.sc[7]; inf[2] = S.flag[1]; inf[3] = 0;
+    }
+    if (A.compute_marg) {
+        // mMargCovInv from the last linearised H (diagonal restored). The reference inverts H, takes the blocks of
+        // (cur PVR, cur bias) and inverts again; inverse-of-a-block-of-the-inverse is the Schur complement of the
+        // other block, which falls out of a partial Cholesky with the last-frame block ordered first.
+        double* mo = A.marg_out + (size_t)b * 144;
+        if (variant) {
+            for (int i = t; i < 576; i += blockDim.x) {
+                const int r = i / 24, c = i % 24;
+                S.Lm[i] = S.H[((r + 12) % 24) * 24 + (c + 12) % 24];              // [last | cur] ordering
+            }
+            __syncthreads();
+            if (wave == 0) wave_cholesky(S.Lm, 24, 12, lane);
+            __syncthreads();
+            for (int i = t; i < 144; i += blockDim.x) {
+                const int r = i / 12, c = i % 12;
+                mo[i] = (c <= r) ? S.Lm[(12 + r) * 24 + 12 + c] : S.Lm[(12 + c) * 24 + 12 + r];
+            }
+        } else {
+            // H = diag(H_pp (9x9), H_bb (3x3)) exactly (no factor couples cur PVR and cur bias when the KF is fixed)
+            for (int i = t; i < 144; i += blockDim.x) {
+                const int r = i / 12, c = i % 12;
+                mo[i] = ((r < 9) == (c < 9)) ? S.H[r * 12 + c] : 0.0;
             }
         }
     }
