@@ -420,6 +420,60 @@ __device__ bool wave_cholesky(double* M, int n, int nsteps, int lane) {
     return ok;
 }
 
+__device__ __forceinline__ double readlane_d(double v, int l) {
+    union { double d; int i[2]; } u; u.d = v;
+    u.i[0] = __builtin_amdgcn_readlane(u.i[0], l); u.i[1] = __builtin_amdgcn_readlane(u.i[1], l);
+    return u.d;
+}
+// 1/sqrt(d) to full double precision: hardware estimate + two Newton steps
+__device__ __forceinline__ double rsqrt_nr(double d) {
+    double y = __builtin_amdgcn_rsq(d);
+    y = y * (1.5 - 0.5 * d * y * y);
+    y = y * (1.5 - 0.5 * d * y * y);
+    return y;
+}
+// Cholesky solve of (H + lambda I) x = b for ONE wavefront with lane i holding row i of the matrix in
+// registers (N <= 24, fully unrolled: pivots and column entries travel by v_readlane, no LDS in the
+// factorisation; L is transposed once through Lt for the back substitution). Entries above the diagonal
+// hold don't-care values that never reach a valid result. Returns false on a non-positive pivot.
+template <int N>
+__device__ bool wave_solve_reg(const double* __restrict__ H, const double* __restrict__ bvec, double lambda,
+                               double* __restrict__ Lt, double* __restrict__ x, int lane) {
+    const int li = lane < N ? lane : N - 1;
+    double a[N], invd[N];
+#pragma unroll
+    for (int c = 0; c < N; c++) a[c] = H[li * N + c] + ((c == li) ? lambda : 0.0);
+    double rhs = bvec[li];
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+        const double d = readlane_d(a[j], j);
+        ok = ok && (d > 0.0) && isfinite(d);
+        const double inv = rsqrt_nr(d);
+        invd[j] = inv;
+        const double lij = (lane == j) ? d * inv : a[j] * inv;
+        a[j] = lij;
+        const double yj = readlane_d(rhs, j) * inv;              // forward substitution rides along
+        if (lane == j) rhs = yj; else if (lane > j) rhs -= lij * yj;
+#pragma unroll
+        for (int k = j + 1; k < N; k++) a[k] -= lij * readlane_d(lij, k);
+    }
+#pragma unroll
+    for (int c = 0; c < N; c++) Lt[li * N + c] = a[c];
+    WAVE_LDS_SYNC();
+    double col[N];
+#pragma unroll
+    for (int j = 0; j < N; j++) col[j] = Lt[j * N + li];         // L[j][i]: column i of L
+    double acc = rhs;
+#pragma unroll
+    for (int j = N - 1; j >= 0; j--) {
+        const double xj = readlane_d(acc, j) * invd[j];
+        if (lane == j) acc = xj; else if (lane < j) acc -= col[j] * xj;
+    }
+    if (lane < N) x[lane] = acc;
+    return ok;
+}
+
 __device__ __forceinline__ pvr sh_pvr(const double* p) { pvr s; s.P = ld3(p); s.V = ld3(p + 3); s.q = mkq(p[6], p[7], p[8], p[9]); return s; }
 __device__ __forceinline__ void sh_put(double* p, const pvr& s) { st3(p, s.P); st3(p + 3, s.V); p[6] = s.q.x; p[7] = s.q.y; p[8] = s.q.z; p[9] = s.q.w; }
 
@@ -476,6 +530,8 @@ __global__ __launch_bounds__(256) void k_pose_opt_vi(PoseOptArgs A) {
             S.info_prior[i] = mc[i] + ((r == c && r < 9) ? ((r < 3 || r >= 6) ? 1e2 : 1.0) : 0.0);
         }
     }
+    for (int i = t; i < 189; i += blockDim.x) S.J1[i] = 0;          // the factors' Jacobians keep a static zero pattern
+    for (int i = t; i < 144; i += blockDim.x) S.J2[i] = 0;
     if (t == 0) {
         for (int k = 0; k < 3; k++) { S.base_ba[0][k] = curns[13 + k]; S.base_ba[1][k] = lastns[13 + k]; }
         // column maps: IMU factor J = [i(9) | j(9) | bias_i(3)] with i = last, j = cur
@@ -508,10 +564,10 @@ __global__ __launch_bounds__(256) void k_pose_opt_vi(PoseOptArgs A) {
         // dense factors: residuals (+ Jacobians) by one lane of two different waves
         if (t == 0) {
             const pvr sc = sh_pvr(S.est[0]), sl = sh_pvr(S.est[1]);
-            pvr_edge(sl, sc, last_dbg, ld3(S.bias[1]), pre, gw, S.e1, lin ? S.J1 : nullptr);
+            pvr_edge(sl, sc, last_dbg, ld3(S.bias[1]), pre, gw, S.e1, lin ? S.J1 : nullptr, false);
         } else if (t == 64 && variant) {
             const pvr sl = sh_pvr(S.est[1]);
-            prior_edge(sl, ld3(S.base_ba[1]) + ld3(S.bias[1]), priorns, S.e2, lin ? S.J2 : nullptr);
+            prior_edge(sl, ld3(S.base_ba[1]) + ld3(S.bias[1]), priorns, S.e2, lin ? S.J2 : nullptr, false);
         }
         for (int side = 0; side < (variant ? 2 : 1); side++) {
             const pvr s = sh_pvr(S.est[side]);
@@ -541,13 +597,33 @@ __global__ __launch_bounds__(256) void k_pose_opt_vi(PoseOptArgs A) {
                     for (int r = 0; r < 6; r++) a[21 + r] -= w * (j0[r] * e[0] + j1[r] * e[1]);
                 }
             }
+            if (lin) {
+                // transpose-reduce 32 padded values over the 64 lanes: 16+8+4+2+1 exchanges leave lane l with the
+                // wave total of value (l >> 1) & 31, one more exchange pairs the two copies
+                double v[32];
 #pragma unroll
-            for (int k = 0; k < 28; k++) {
-                if (!lin && k < 27) continue;
-                double v = a[k];
+                for (int k = 0; k < 28; k++) v[k] = a[k];
 #pragma unroll
-                for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d);
-                if (lane == 0) S.red[wave][side][k] = v;
+                for (int k = 28; k < 32; k++) v[k] = 0;
+#pragma unroll
+                for (int half = 16, bit = 32; half >= 1; half >>= 1, bit >>= 1) {
+                    const bool up = (lane & bit) != 0;
+#pragma unroll
+                    for (int i = 0; i < half; i++) {
+                        const double keep = up ? v[half + i] : v[i];
+                        const double send = up ? v[i] : v[half + i];
+                        v[i] = keep + __shfl_xor(send, bit);
+                    }
+                }
+                const double tot = v[0] + __shfl_xor(v[0], 1);
+                // lane bits 5..1 selected the upper half at steps 16,8,4,2,1 -> value index
+                const int idx = ((lane >> 5) & 1) * 16 + ((lane >> 4) & 1) * 8 + ((lane >> 3) & 1) * 4 + ((lane >> 2) & 1) * 2 + ((lane >> 1) & 1);
+                if ((lane & 1) == 0 && idx < 28) S.red[wave][side][idx] = tot;
+            } else {
+                double vv = a[27];
+#pragma unroll
+                for (int d = 32; d > 0; d >>= 1) vv += __shfl_xor(vv, d);
+                if (lane == 0) S.red[wave][side][27] = vv;
             }
         }
         __syncthreads();
@@ -623,28 +699,11 @@ __global__ __launch_bounds__(256) void k_pose_opt_vi(PoseOptArgs A) {
         return S.sc[0];
     };
 
-    // (H + lambda I) x = b on wave 0: in-LDS Cholesky, then lane-parallel substitutions. S.flag[0] = success.
+    // (H + lambda I) x = b on wave 0, matrix rows in registers (wave_solve_reg). S.flag[0] = success.
     auto solve = [&](double lambda) {
-        for (int i = t; i < n * n; i += blockDim.x) S.Lm[i] = S.H[i] + ((i / n == i % n) ? lambda : 0.0);
-        __syncthreads();
         if (wave == 0) {
-            const bool ok = wave_cholesky(S.Lm, n, n, lane);
-            if (ok) {
-                // forward: L y = b
-                double acc = lane < n ? S.b[lane] : 0.0;
-                for (int j = 0; j < n; j++) {
-                    if (lane == j) S.y[j] = acc / S.Lm[j * n + j];
-                    WAVE_LDS_SYNC();
-                    if (lane > j && lane < n) acc -= S.Lm[lane * n + j] * S.y[j];
-                }
-                // backward: L^T x = y
-                acc = lane < n ? S.y[lane] : 0.0;
-                for (int j = n - 1; j >= 0; j--) {
-                    if (lane == j) S.x[j] = acc / S.Lm[j * n + j];
-                    WAVE_LDS_SYNC();
-                    if (lane < j) acc -= S.Lm[j * n + lane] * S.x[j];
-                }
-            } else if (lane < n) S.x[lane] = 0;
+            const bool ok = variant ? wave_solve_reg<24>(S.H, S.b, lambda, S.Lm, S.x, lane) : wave_solve_reg<12>(S.H, S.b, lambda, S.Lm, S.x, lane);
+            if (!ok && lane < n) S.x[lane] = 0;
             if (lane == 0) S.flag[0] = ok ? 1 : 0;
         }
         __syncthreads();

@@ -197,11 +197,11 @@ VIO_HD cam_t ld_cam(const double* c) { cam_t k; k.fx = c[0]; k.fy = c[1]; k.cx =
 VIO_HD void proj_edge(const cam_t& k, const m33& RwbT, d3 Pwb, d3 Pw, double u, double v, bool jac, double* e, double* JP, double* JR) {
     const d3 Paux = mulv(k.Rcb, mulv(RwbT, Pw - Pwb));
     const d3 Pc = Paux - k.RcbPbc;
-    const double iz = 1.0 / Pc.z;
-    e[0] = u - (Pc.x / Pc.z * k.fx + k.cx);
-    e[1] = v - (Pc.y / Pc.z * k.fy + k.cy);
+    const double iz = 1.0 / Pc.z, xz = Pc.x * iz, yz = Pc.y * iz;
+    e[0] = u - (xz * k.fx + k.cx);
+    e[1] = v - (yz * k.fy + k.cy);
     if (!jac) return;
-    const double j00 = k.fx * iz, j02 = -Pc.x / Pc.z * k.fx * iz, j11 = k.fy * iz, j12 = -Pc.y / Pc.z * k.fy * iz;
+    const double j00 = k.fx * iz, j02 = -xz * k.fx * iz, j11 = k.fy * iz, j12 = -yz * k.fy * iz;
     const m33 HR = mul(hat3(Paux), k.Rcb);
     // JdPwb = Jpi * Rcb ; JdRwb = -Jpi * (hat(Paux) * Rcb)
     JP[0] = j00 * k.Rcb.a00 + j02 * k.Rcb.a20; JP[1] = j00 * k.Rcb.a01 + j02 * k.Rcb.a21; JP[2] = j00 * k.Rcb.a02 + j02 * k.Rcb.a22;
@@ -219,7 +219,8 @@ VIO_HD void huber(double e, double delta, double* rho0, double* rho1) {
 
 // ---- IMU factor (EdgeNavStatePVR): error e[9]; Jacobians written as dense row-major 9 x 21 =
 // [ d/d(i: P V Phi) | d/d(j: P V Phi) | d/d(bias_i acc) ]
-VIO_HD void pvr_edge(const pvr& si, const pvr& sj, d3 dbg_i, d3 dba_i, const double* preint, d3 gw, double* e, double* J /* 9*21 or null */) {
+VIO_HD void pvr_edge(const pvr& si, const pvr& sj, d3 dbg_i, d3 dba_i, const double* preint, d3 gw, double* e, double* J /* 9*21 or null */,
+                     bool zero_fill = true) {
     const d3 dP = ld3(preint), dV = ld3(preint + 3);
     const m33 dR = ldm(preint + 6), JPg = ldm(preint + 15), JPa = ldm(preint + 24), JVg = ldm(preint + 33), JVa = ldm(preint + 42), JRg = ldm(preint + 51);
     const double dT = preint[141], dT2 = dT * dT;
@@ -234,7 +235,7 @@ VIO_HD void pvr_edge(const pvr& si, const pvr& sj, d3 dbg_i, d3 dba_i, const dou
     const d3 rPhi = so3_log(rR);
     e[0] = rP.x; e[1] = rP.y; e[2] = rP.z; e[3] = rV.x; e[4] = rV.y; e[5] = rV.z; e[6] = rPhi.x; e[7] = rPhi.y; e[8] = rPhi.z;
     if (!J) return;
-    for (int i = 0; i < 9 * 21; i++) J[i] = 0;
+    if (zero_fill) for (int i = 0; i < 9 * 21; i++) J[i] = 0;
     const m33 Ri = qmat(si.q), Rj = qmat(sj.q), RiTm = tr(Ri), RjT = tr(Rj);
     const m33 JrInv = so3_jr_inv(rPhi);
     auto put = [&](int r0, int c0, const m33& B, double s) {
@@ -248,14 +249,14 @@ VIO_HD void pvr_edge(const pvr& si, const pvr& sj, d3 dbg_i, d3 dba_i, const dou
     put(0, 18, JPa, -1); put(3, 18, JVa, -1);
 }
 // ---- prior factor (EdgeNavStatePriorPVRBias, 12-D): J row-major 12 x 12 = [ d/d(P V Phi) | d/d(bias acc) ]
-VIO_HD void prior_edge(const pvr& s, d3 ba_plus_dba, const double* prior22, double* e, double* J /* 12*12 or null */) {
+VIO_HD void prior_edge(const pvr& s, d3 ba_plus_dba, const double* prior22, double* e, double* J /* 12*12 or null */, bool zero_fill = true) {
     const pvr pr = ld_pvr(prior22);
     const d3 eP = pr.P - s.P, eV = pr.V - s.V;
     const d3 eR = so3_log(so3_mul(qnorm(qconj(pr.q)), s.q));
     const d3 eB = (ld3(prior22 + 13) + ld3(prior22 + 19)) - ba_plus_dba;
     e[0] = eP.x; e[1] = eP.y; e[2] = eP.z; e[3] = eV.x; e[4] = eV.y; e[5] = eV.z; e[6] = eR.x; e[7] = eR.y; e[8] = eR.z; e[9] = eB.x; e[10] = eB.y; e[11] = eB.z;
     if (!J) return;
-    for (int i = 0; i < 144; i++) J[i] = 0;
+    if (zero_fill) for (int i = 0; i < 144; i++) J[i] = 0;
     const m33 R = qmat(s.q), Ji = so3_jr_inv(eR);
     const double rv[9] = {R.a00, R.a01, R.a02, R.a10, R.a11, R.a12, R.a20, R.a21, R.a22};
     const double jv[9] = {Ji.a00, Ji.a01, Ji.a02, Ji.a10, Ji.a11, Ji.a12, Ji.a20, Ji.a21, Ji.a22};
