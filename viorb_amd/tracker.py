@@ -4,7 +4,9 @@ Tracking::TrackWithIMU (reference src/Tracking.cc:412-534) for B independent mon
     extract -> AssignFeaturesToGrid -> IMU pre-integration + NavState prediction (PredictNavStateByIMU)
             -> SearchByProjection(cur, last, th=15) -> PoseOptimization(cur, last frame, preint, gw, marg)
 
-Everything stays in HBM; the only host work per step is enqueueing kernels. Map maintenance (creating
+Everything stays in HBM; the only host work per step is enqueueing kernels. Two HIP streams: extraction of
+frame k+1 (bandwidth/ALU-bound, fills the chip) overlaps the matching + pose solve of frame k (latency-bound,
+one workgroup per stream); two extractor handles alternate so frame k's keypoints stay valid meanwhile. Map maintenance (creating
 map points for the new last frame) is NOT part of the reference's per-frame path (LocalMapping does it);
 here it is supplied by the synthetic plane world of viorb_amd/synth.py through
 viorb_synth_plane_points_device, using the stream's ground-truth pose of that frame.
@@ -18,14 +20,21 @@ from . import synth
 
 
 class BatchedTracker:
-    def __init__(self, cam, gw, batch, width=752, height=480, nfeatures=1000, th=15.0, device=0, compute_marg=True):
+    def __init__(self, cam, gw, batch, width=752, height=480, nfeatures=1000, th=15.0, device=0, compute_marg=True, overlap=True):
         import torch
         self.torch = torch
         self.B, self.w, self.h, self.th = batch, width, height, float(th)
         self.dev = torch.device("cuda", device)
-        self.ex = ORBextractor(nfeatures, 1.2, 8, 20, 7, max_batch=batch, device=device)
+        self.exs = [ORBextractor(nfeatures, 1.2, 8, 20, 7, max_batch=batch, device=device) for _ in range(2 if overlap else 1)]
+        self.ex = self.exs[0]
         t = self.ex.tables()
         self.cap = self.ex.cap
+        self.overlap = overlap
+        self.s_ex = torch.cuda.Stream(device=self.dev) if overlap else None
+        self.s_tr = torch.cuda.Stream(device=self.dev) if overlap else None
+        self.ev_ex = [torch.cuda.Event() for _ in range(2)]
+        self.ev_tr = [None, None]
+        self.k = 0
         self.fe = Frontend(cam, gw, t["scale"], t["inv_sigma2"], (0.0, float(width), 0.0, float(height)), max_batch=batch,
                            cap=self.cap, device=device)
         self.cam = np.asarray(cam, np.float64)
@@ -71,7 +80,8 @@ class BatchedTracker:
         return self.ex.results_device()            # kps, desc, count, status, cap
 
     def _roll(self, true_pose12, t_cur, ns_for_last, stream=None):
-        """Make the frame just processed the new last frame and give its keypoints map points."""
+        """Make the frame just processed the new last frame and give its keypoints map points.
+        Runs on the current torch stream (the tracking stream when overlapping)."""
         torch = self.torch
         kps, desc, count, _, cap = self._cur_ptrs()
         L = lib()
@@ -89,16 +99,17 @@ class BatchedTracker:
 
     def bootstrap(self, images, true_pose12, t0, ns0, marg_cov_inv):
         """First frame of every stream: extract, adopt as last frame with ground-truth state."""
+        self.torch.cuda.synchronize()
+        self.ex = self.exs[0]
         self.ex.extract_batch_device(images)
         self.marg_cov_inv.copy_(marg_cov_inv)
         self._roll(true_pose12, t0, ns0)
+        self.torch.cuda.synchronize()
+        self.k = 0
+        self.ev_tr = [None, None]
 
-    def step(self, images, imu, t_cur, true_pose12, chain_estimate=True, true_ns=None, t_next_last=None):
-        """One tracking step for all streams. images [B,h,w] u8, imu [B,n,7] f64, t_cur [B] f64,
-        true_pose12 [B,12] f64 (only used to create map points for the next step). t_next_last overrides the
-        stamp the frame gets as "last frame" (periodic streams: the loop-closing frame restarts at 0)."""
+    def _track(self, imu, t_cur, true_pose12, chain_estimate, true_ns, t_next_last):
         B = self.B
-        self.ex.extract_batch_device(images)
         kps, desc, count, _, cap = self._cur_ptrs()
         fe = self.fe
         fe.grid(kps, count, B, self.cell_start, self.cell_idx)
@@ -115,6 +126,34 @@ class BatchedTracker:
         if self.compute_marg and chain_estimate:
             self.marg_cov_inv.copy_(self.marg_out, non_blocking=True)
         self._roll(true_pose12, t_cur if t_next_last is None else t_next_last, self.out_ns if chain_estimate else true_ns)
+
+    def step(self, images, imu, t_cur, true_pose12, chain_estimate=True, true_ns=None, t_next_last=None):
+        """One tracking step for all streams. images [B,h,w] u8, imu [B,n,7] f64, t_cur [B] f64,
+        true_pose12 [B,12] f64 (only used to create map points for the next step). t_next_last overrides the
+        stamp the frame gets as "last frame" (periodic streams: the loop-closing frame restarts at 0).
+        With overlap the call returns after enqueueing; results (info, nmatches, out_ns, ...) are those of this
+        step once the device is synchronised."""
+        torch = self.torch
+        if not self.overlap:
+            self.ex.extract_batch_device(images)
+            self._track(imu, t_cur, true_pose12, chain_estimate, true_ns, t_next_last)
+            return
+        slot = self.k % 2
+        ex = self.exs[slot]
+        cur = torch.cuda.current_stream(self.dev)
+        self.s_ex.wait_stream(cur)                       # inputs produced on the caller's stream
+        if self.ev_tr[slot] is not None:
+            self.s_ex.wait_event(self.ev_tr[slot])       # this handle's previous results have been consumed
+        ex.extract_batch_device(images, stream=self.s_ex)
+        self.ev_ex[slot].record(self.s_ex)
+        self.s_tr.wait_stream(cur)
+        self.s_tr.wait_event(self.ev_ex[slot])
+        self.ex = ex
+        with torch.cuda.stream(self.s_tr):
+            self._track(imu, t_cur, true_pose12, chain_estimate, true_ns, t_next_last)
+            ev = torch.cuda.Event(); ev.record(self.s_tr)
+            self.ev_tr[slot] = ev
+        self.k += 1
 
 
 def _hip_memcpy_dtod_async(dst, src, nbytes, stream):
