@@ -92,35 +92,58 @@ struct SearchArgs {
     int check_ori;
 };
 
+// LDS plan (dynamic, per workgroup): the current frame's grid (u16 CSR), keypoint x/y/octave/angle, the first
+// SLOT candidates of every last-frame point, and the four per-keypoint work arrays. Candidates beyond SLOT
+// spill to the global scratch list.
+#define SEARCH_SLOT 8
+__host__ __device__ inline size_t search_lds_bytes(int cap) {
+    return (size_t)(GRID_CELLS + 1) * 2 + 2 /*pad*/ + (size_t)cap * (2 + 8 + 4 + 1 + 3 /*pad to 4*/) + (size_t)cap * SEARCH_SLOT * 4 + (size_t)cap * 4 * 4 + 64;
+}
+
 __global__ __launch_bounds__(256) void k_search_projection(SearchArgs A) {
-    extern __shared__ int s_i[];
-    const int b = blockIdx.x, cap = A.cap;
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+    const int b = blockIdx.x, cap = A.cap, t = threadIdx.x, lane = t & 63;
     const int ncur = min(A.cur_count[b], cap), nlast = min(A.last_count[b], cap);
-    int* choice = s_i;                 // [cap] chosen current keypoint of last point i, or -1
-    int* taken = s_i + cap;            // [cap] per current keypoint: smallest i (with observations) that chose it
-    int* owner = s_i + 2 * cap;        // [cap] per current keypoint: largest i that chose it
-    int* rej = s_i + 3 * cap;          // [cap] per current keypoint: chosen by a point of a rejected bin
+    // carve LDS (4-byte aligned sections first)
+    uint32_t* slot = reinterpret_cast<uint32_t*>(s_raw);                 // [cap][SLOT] dist<<16 | idx
+    int* choice = reinterpret_cast<int*>(slot + (size_t)cap * SEARCH_SLOT);   // [cap] chosen current keypoint of last point i, or -1
+    int* taken = choice + cap;            // [cap] per current keypoint: smallest i (with observations) that chose it
+    int* owner = taken + cap;             // [cap] per current keypoint: largest i that chose it
+    int* rej = owner + cap;               // [cap] scratch / per current keypoint: chosen by a point of a rejected bin
+    float2* cxy = reinterpret_cast<float2*>(rej + cap);                  // [cap]
+    float* cang = reinterpret_cast<float*>(cxy + cap);                   // [cap]
+    uint16_t* cs = reinterpret_cast<uint16_t*>(cang + cap);              // [GRID_CELLS + 1] (+1 pad)
+    uint16_t* ci = cs + GRID_CELLS + 2;                                   // [cap]
+    uint8_t* coct = reinterpret_cast<uint8_t*>(ci + cap);                // [cap]
     __shared__ int s_changed, s_hist[HISTO_LENGTH], s_keep[HISTO_LENGTH], s_nm, s_overflow;
     const float* P = A.pose12 + (size_t)b * 12;
     const viorb_keypoint* ck = A.cur_kps + (size_t)b * cap;
     const viorb_keypoint* lk = A.last_kps + (size_t)b * cap;
     const uint8_t* lf = A.last_flags + (size_t)b * cap;
-    const int* cs = A.cell_start + (size_t)b * (GRID_CELLS + 1);
-    const int* ci = A.cell_idx + (size_t)b * cap;
     uint32_t* cand = A.cand + (size_t)b * cap * CAND_CAP;
     int* cand_n = A.cand_n + (size_t)b * cap;
-    if (threadIdx.x == 0) { s_overflow = 0; s_nm = 0; }
-    for (int i = threadIdx.x; i < HISTO_LENGTH; i += blockDim.x) { s_hist[i] = 0; s_keep[i] = 0; }
+    {
+        const int* gcs = A.cell_start + (size_t)b * (GRID_CELLS + 1);
+        const int* gci = A.cell_idx + (size_t)b * cap;
+        for (int i = t; i <= GRID_CELLS; i += blockDim.x) cs[i] = (uint16_t)gcs[i];
+        for (int i = t; i < ncur; i += blockDim.x) {
+            ci[i] = (uint16_t)gci[i];
+            const viorb_keypoint k = ck[i];
+            cxy[i] = make_float2(k.x, k.y); cang[i] = k.angle; coct[i] = (uint8_t)k.octave;
+        }
+    }
+    if (t == 0) { s_overflow = 0; s_nm = 0; }
+    for (int i = t; i < HISTO_LENGTH; i += blockDim.x) { s_hist[i] = 0; s_keep[i] = 0; }
     __syncthreads();
     // ---- phase A
-    for (int i = threadIdx.x; i < nlast; i += blockDim.x) {
+    for (int i = t; i < nlast; i += blockDim.x) {
         int nc = 0;
         const int fl = lf[i];
         if ((fl & 1) && !(fl & 2)) {
             const float* X = A.last_Pw + ((size_t)b * cap + i) * 3;
             float pc[3];
 #pragma unroll
-            for (int r = 0; r < 3; r++) { const float t = P[3 * r] * X[0] + P[3 * r + 1] * X[1] + P[3 * r + 2] * X[2]; pc[r] = t + P[9 + r]; }
+            for (int r = 0; r < 3; r++) { const float tt = P[3 * r] * X[0] + P[3 * r + 1] * X[1] + P[3 * r + 2] * X[2]; pc[r] = tt + P[9 + r]; }
             const float invz = 1.0f / pc[2];
             const float u = A.fx * pc[0] * invz + A.cx, v = A.fy * pc[1] * invz + A.cy;
             if (!(invz < 0) && !(u < A.minX || u > A.maxX) && !(v < A.minY || v > A.maxY)) {
@@ -132,27 +155,28 @@ __global__ __launch_bounds__(256) void k_search_projection(SearchArgs A) {
                 const int y0 = max(0, (int)floorf((v - A.minY - radius) * A.hInv));
                 const int y1 = min((int)GRID_ROWS - 1, (int)ceilf((v - A.minY + radius) * A.hInv));
                 if (x0 < GRID_COLS && x1 >= 0 && y0 < GRID_ROWS && y1 >= 0) {
-                    const uint32_t* dl = reinterpret_cast<const uint32_t*>(A.last_desc + ((size_t)b * cap + i) * 32);
-                    uint32_t d0[8];
-#pragma unroll
-                    for (int k = 0; k < 8; k++) d0[k] = dl[k];
+                    const uint4* dl = reinterpret_cast<const uint4*>(A.last_desc + ((size_t)b * cap + i) * 32);
+                    const uint4 da = dl[0], db = dl[1];
                     const bool check_levels = (minL > 0) || (maxL >= 0);
-                    for (int ix = x0; ix <= x1; ix++)
-                        for (int iy = y0; iy <= y1; iy++) {
-                            const int c = ix * GRID_ROWS + iy;
-                            for (int p = cs[c]; p < cs[c + 1]; p++) {
-                                const int i2 = ci[p];
-                                const viorb_keypoint k2 = ck[i2];
-                                if (check_levels) { if (k2.octave < minL) continue; if (maxL >= 0 && k2.octave > maxL) continue; }
-                                if (!(fabsf(k2.x - u) < radius && fabsf(k2.y - v) < radius)) continue;
-                                const uint32_t* dc = reinterpret_cast<const uint32_t*>(A.cur_desc + ((size_t)b * cap + i2) * 32);
-                                int dist = 0;
-#pragma unroll
-                                for (int k = 0; k < 8; k++) dist += __popc(d0[k] ^ dc[k]);
-                                if (nc < CAND_CAP) cand[(size_t)i * CAND_CAP + nc] = ((uint32_t)dist << 16) | (uint32_t)i2;
-                                nc++;
-                            }
+                    for (int ix = x0; ix <= x1; ix++) {
+                        // cells (ix, y0..y1) are contiguous in the CSR: one range per column
+                        const int pbeg = cs[ix * GRID_ROWS + y0], pend = cs[ix * GRID_ROWS + y1 + 1];
+                        for (int p = pbeg; p < pend; p++) {
+                            const int i2 = ci[p];
+                            const int o2 = coct[i2];
+                            if (check_levels) { if (o2 < minL) continue; if (maxL >= 0 && o2 > maxL) continue; }
+                            const float2 q = cxy[i2];
+                            if (!(fabsf(q.x - u) < radius && fabsf(q.y - v) < radius)) continue;
+                            const uint4* dc = reinterpret_cast<const uint4*>(A.cur_desc + ((size_t)b * cap + i2) * 32);
+                            const uint4 ea = dc[0], eb = dc[1];
+                            const int dist = __popc(da.x ^ ea.x) + __popc(da.y ^ ea.y) + __popc(da.z ^ ea.z) + __popc(da.w ^ ea.w) +
+                                             __popc(db.x ^ eb.x) + __popc(db.y ^ eb.y) + __popc(db.z ^ eb.z) + __popc(db.w ^ eb.w);
+                            const uint32_t e = ((uint32_t)dist << 16) | (uint32_t)i2;
+                            if (nc < SEARCH_SLOT) slot[(size_t)i * SEARCH_SLOT + nc] = e;
+                            else if (nc < CAND_CAP) cand[(size_t)i * CAND_CAP + nc] = e;
+                            nc++;
                         }
+                    }
                 }
             }
         }
@@ -163,57 +187,72 @@ __global__ __launch_bounds__(256) void k_search_projection(SearchArgs A) {
     __syncthreads();
     // ---- phase B: fixed-point sweeps
     for (int sweep = 0; sweep <= nlast; sweep++) {
-        for (int c = threadIdx.x; c < ncur; c += blockDim.x) taken[c] = 0x7fffffff;
-        if (threadIdx.x == 0) s_changed = 0;
+        for (int c = t; c < ncur; c += blockDim.x) taken[c] = 0x7fffffff;
+        if (t == 0) s_changed = 0;
         __syncthreads();
-        for (int i = threadIdx.x; i < nlast; i += blockDim.x)
+        for (int i = t; i < nlast; i += blockDim.x)
             if (choice[i] >= 0 && (lf[i] & 4)) atomicMin(&taken[choice[i]], i);
         __syncthreads();
-        for (int i = threadIdx.x; i < nlast; i += blockDim.x) {
+        bool changed = false;
+        for (int i = t; i < nlast; i += blockDim.x) {
             const int nc = cand_n[i];
             int best = 256, bidx = -1;
             for (int k = 0; k < nc; k++) {
-                const uint32_t e = cand[(size_t)i * CAND_CAP + k];
+                const uint32_t e = k < SEARCH_SLOT ? slot[(size_t)i * SEARCH_SLOT + k] : cand[(size_t)i * CAND_CAP + k];
                 const int i2 = (int)(e & 0xffff), dist = (int)(e >> 16);
                 if (taken[i2] < i) continue;                      // owned by an earlier point that has observations
                 if (dist < best) { best = dist; bidx = i2; }
             }
             const int nw = best <= TH_HIGH ? bidx : -1;
-            if (nw != choice[i]) { s_changed = 1; }
-            // write after all reads of this sweep: choices are read only through `taken`, built above
-            rej[i] = nw;                                           // stash; committed below
+            changed = changed || (nw != choice[i]);
+            rej[i] = nw;                                           // committed after every thread has read `taken`
         }
+        if (__any(changed) && lane == 0) s_changed = 1;
         __syncthreads();
-        for (int i = threadIdx.x; i < nlast; i += blockDim.x) choice[i] = rej[i];
+        for (int i = t; i < nlast; i += blockDim.x) choice[i] = rej[i];
         __syncthreads();
         if (!s_changed) break;
     }
     // ---- phase C: histogram, maxima, final ownership
-    for (int c = threadIdx.x; c < ncur; c += blockDim.x) { owner[c] = -1; rej[c] = 0; }
+    for (int c = t; c < ncur; c += blockDim.x) { owner[c] = -1; rej[c] = 0; }
     __syncthreads();
     const float factor = 1.0f / HISTO_LENGTH;
-    for (int i = threadIdx.x; i < nlast; i += blockDim.x) {
-        const int c = choice[i];
-        if (c < 0) continue;
-        atomicMax(&owner[c], i);
-        atomicAdd(&s_nm, 1);
-        if (A.check_ori) {
-            float rot = lk[i].angle - ck[c].angle;
-            if (rot < 0.0f) rot += 360.0f;
-            int bin = (int)roundf(rot * factor);
-            if (bin == HISTO_LENGTH) bin = 0;
-            atomicAdd(&s_hist[bin], 1);
+    {
+        int my_n = 0;
+        for (int i = t; i < nlast; i += blockDim.x) {
+            const int c = choice[i];
+            int bin = -1;
+            if (c >= 0) {
+                atomicMax(&owner[c], i);
+                my_n++;
+                if (A.check_ori) {
+                    float rot = lk[i].angle - cang[c];
+                    if (rot < 0.0f) rot += 360.0f;
+                    bin = (int)roundf(rot * factor);
+                    if (bin == HISTO_LENGTH) bin = 0;
+                }
+            }
+            taken[i] = bin;                                        // remember the bin of point i (taken[] is free now)
+            if (A.check_ori) {
+                // wave-aggregated histogram: one atomic per distinct bin per wave
+                for (int hb = 0; hb < 13; hb++) { const unsigned long long m = __ballot(bin == hb); if (m && lane == (int)__ffsll((long long)m) - 1) atomicAdd(&s_hist[hb], __popcll(m)); }
+                const unsigned long long mo = __ballot(bin > 12);   // bins above 12 cannot occur with factor 1/30; kept for safety
+                if (mo && bin > 12) atomicAdd(&s_hist[bin], 1);
+            }
         }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) my_n += __shfl_xor(my_n, d);
+        if (lane == 0) atomicAdd(&s_nm, my_n);
     }
     __syncthreads();
     if (A.check_ori) {
-        if (threadIdx.x == 0) {            // ComputeThreeMaxima
+        if (t == 0) {            // ComputeThreeMaxima
             int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
             for (int i = 0; i < HISTO_LENGTH; i++) {
-                const int s = s_hist[i];
-                if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
-                else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
-                else if (s > max3) { max3 = s; ind3 = i; }
+                const int sz = s_hist[i];
+                if (sz > max1) { max3 = max2; max2 = max1; max1 = sz; ind3 = ind2; ind2 = ind1; ind1 = i; }
+                else if (sz > max2) { max3 = max2; max2 = sz; ind3 = ind2; ind2 = i; }
+                else if (sz > max3) { max3 = sz; ind3 = i; }
             }
             if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
             else if (max3 < 0.1f * (float)max1) { ind3 = -1; }
@@ -222,20 +261,15 @@ __global__ __launch_bounds__(256) void k_search_projection(SearchArgs A) {
             s_nm -= removed;
         }
         __syncthreads();
-        for (int i = threadIdx.x; i < nlast; i += blockDim.x) {
+        for (int i = t; i < nlast; i += blockDim.x) {
             const int c = choice[i];
-            if (c < 0) continue;
-            float rot = lk[i].angle - ck[c].angle;
-            if (rot < 0.0f) rot += 360.0f;
-            int bin = (int)roundf(rot * factor);
-            if (bin == HISTO_LENGTH) bin = 0;
-            if (!s_keep[bin]) rej[c] = 1;
+            if (c >= 0 && !s_keep[taken[i]]) rej[c] = 1;
         }
         __syncthreads();
     }
     int* out = A.cur_match + (size_t)b * cap;
-    for (int c = threadIdx.x; c < cap; c += blockDim.x) out[c] = (c < ncur && !rej[c]) ? owner[c] : -1;
-    if (threadIdx.x == 0) { A.nmatches[b] = s_nm; if (s_overflow) A.status[b] = VIORB_ERR_CAPACITY; }
+    for (int c = t; c < cap; c += blockDim.x) out[c] = (c < ncur && !rej[c]) ? owner[c] : -1;
+    if (t == 0) { A.nmatches[b] = s_nm; if (s_overflow) A.status[b] = VIORB_ERR_CAPACITY; }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -865,6 +899,9 @@ int viorb_frontend_create(const viorb_frontend_config* cfg, int max_batch, int c
     h->hInv = static_cast<float>(GRID_ROWS) / static_cast<float>(cfg->max_y - cfg->min_y);
     int s = 64; while (s < cap) s <<= 1;
     h->sort_n = s;
+    if (search_lds_bytes(cap) > 160 * 1024) { delete h; set_error("cap %d needs %zu B of LDS for the projection search", cap, search_lds_bytes(cap)); return VIORB_ERR_UNSUPPORTED; }
+    if (search_lds_bytes(cap) > 64 * 1024)
+        VIORB_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_search_projection), hipFuncAttributeMaxDynamicSharedMemorySize, (int)search_lds_bytes(cap)));
     VIORB_HIP_TRY(hipMalloc(&h->d_cand, (size_t)max_batch * cap * CAND_CAP * sizeof(uint32_t)));
     VIORB_HIP_TRY(hipMalloc(&h->d_cand_n, (size_t)max_batch * cap * sizeof(int)));
     VIORB_HIP_TRY(hipMalloc(&h->d_cam, 16 * sizeof(double)));
@@ -935,7 +972,7 @@ int viorb_frontend_search_projection_device(viorb_frontend* h, const viorb_keypo
     A.check_ori = h->cfg.check_orientation;
     VIORB_HIP_TRY(hipMemsetAsync(status, 0, sizeof(int32_t) * batch, (hipStream_t)stream));
     ProfScope ps("k_search_projection", (hipStream_t)stream);
-    hipLaunchKernelGGL(k_search_projection, dim3(batch), dim3(256), (size_t)h->cap * 4 * sizeof(int), (hipStream_t)stream, A);
+    hipLaunchKernelGGL(k_search_projection, dim3(batch), dim3(256), search_lds_bytes(h->cap), (hipStream_t)stream, A);
     VIORB_HIP_TRY(hipGetLastError());
     return VIORB_OK;
 }
