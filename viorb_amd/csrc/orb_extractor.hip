@@ -207,19 +207,25 @@ __device__ __forceinline__ int fast_strength(const uint8_t* p, int pitch) {
 }
 
 // One wavefront per FAST cell (reference :789-828): load the (<= wCell+6)x(hCell+6) cell image into
-// LDS, compute every interior pixel's corner strength once, then run cv::FAST's 3x3 strict NMS at
-// iniThFAST and, only if that leaves the cell empty, again at minThFAST. Survivors are written in
-// row-major order (cv::FAST's output order) into the cell's slot as packed (x|y<<12|score<<24) with
-// the reference's j*wCell / i*hCell shift already applied.
+// LDS, then three ordered passes, each compacting its survivors with wave ballots so the next pass runs
+// on dense lanes and every list stays in row-major (cv::FAST output) order:
+//   1. necessary test on the 4 compass ring pixels (any 9-arc holds two ADJACENT compass pixels, so a
+//      corner at threshold t needs an adjacent compass pair both darker than v-t or both brighter than v+t);
+//   2. exact corner strength (cv::cornerScore<16>) of the survivors -> score map in LDS, list of corners;
+//   3. cv::FAST's strict 3x3 NMS at iniThFAST over the corner list and, only if that leaves the cell
+//      empty, again at minThFAST. Survivors go to the cell's slot as packed (x | y<<12 | score<<24) with
+//      the reference's j*wCell / i*hCell shift applied.
 __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t* __restrict__ planes, size_t frame_bytes,
                                                    const LevelDev* __restrict__ lv,
                                                    const CellDesc* __restrict__ cells, int ini_th, int min_th,
                                                    uint32_t* __restrict__ slots, int slot_cap,
                                                    int* __restrict__ cell_cnt, int ncells_total,
-                                                   int tile_pitch, int tile_rows, int score_bytes) {
+                                                   int tile_pitch, int tile_rows, int score_bytes, int list_cap) {
     extern __shared__ uint32_t s_mem[];
     uint8_t* tile = reinterpret_cast<uint8_t*>(s_mem);
     uint8_t* sc = tile + tile_pitch * tile_rows;
+    uint16_t* surv = reinterpret_cast<uint16_t*>(sc + score_bytes);     // [list_cap] (r << 8 | q) of pass-1 survivors
+    uint16_t* corn = surv + list_cap;                                    // [list_cap] corners (strength >= minTh)
     const int lane = threadIdx.x;
     const CellDesc c = cells[blockIdx.x];
     const LevelDev L = lv[c.level];
@@ -240,26 +246,58 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t* __restrict__ p
     int total = 0;
     if (dw > 0 && dh > 0) {
         const int npx = dw * dh;
-        for (int base = 0; base < npx; base += 64) {
-            const int p = base + lane;
-            if (p < npx) {
-                const int r = p / dw, q = p - r * dw;
-                int s = fast_strength(tile + (r + 3) * tile_pitch + xoff + q + 3, tile_pitch);
-                sc[(r + 1) * sp + q + 1] = (uint8_t)(s >= min_th ? s : 0);
+        const unsigned long long lt = (1ull << lane) - 1ull;
+        // ---- pass 1
+        int nsurv = 0;
+        {
+            const int step_r = 64 / dw, step_q = 64 - step_r * dw;
+            int r = lane / dw, q = lane - r * dw;
+            for (int base = 0; base < npx; base += 64) {
+                bool pass = false;
+                if (base + lane < npx) {
+                    const uint8_t* p = tile + (r + 3) * tile_pitch + xoff + q + 3;
+                    const int v = p[0];
+                    const int d0 = v - p[3 * tile_pitch], d4 = v - p[3], d8 = v - p[-3 * tile_pitch], d12 = v - p[-3];
+                    const int lo = min(min(max(d0, d4), max(d4, d8)), min(max(d8, d12), max(d12, d0)));   // some adjacent pair both < -t
+                    const int hi = max(max(min(d0, d4), min(d4, d8)), max(min(d8, d12), min(d12, d0)));   // some adjacent pair both >  t
+                    pass = (hi > min_th) || (lo < -min_th);
+                }
+                const unsigned long long m = __ballot(pass);
+                if (pass) surv[nsurv + __popcll(m & lt)] = (uint16_t)((r << 8) | q);
+                nsurv += __popcll(m);
+                r += step_r; q += step_q;
+                if (q >= dw) { q -= dw; r++; }
             }
         }
         __syncthreads();
+        // ---- pass 2
+        int ncorn = 0;
+        for (int base = 0; base < nsurv; base += 64) {
+            bool is_c = false;
+            uint16_t rq = 0;
+            if (base + lane < nsurv) {
+                rq = surv[base + lane];
+                const int r = rq >> 8, q = rq & 0xff;
+                const int s = fast_strength(tile + (r + 3) * tile_pitch + xoff + q + 3, tile_pitch);
+                if (s >= min_th) { is_c = true; sc[(r + 1) * sp + q + 1] = (uint8_t)s; }
+            }
+            const unsigned long long m = __ballot(is_c);
+            if (is_c) corn[ncorn + __popcll(m & lt)] = rq;
+            ncorn += __popcll(m);
+        }
+        __syncthreads();
+        // ---- pass 3
         for (int pass = 0; pass < 2 && total == 0; pass++) {
             const int th = pass == 0 ? ini_th : min_th;
-            for (int base = 0; base < npx; base += 64) {
-                const int p = base + lane;
+            for (int base = 0; base < ncorn; base += 64) {
                 bool keep = false;
                 int r = 0, q = 0, s = 0;
-                if (p < npx) {
-                    r = p / dw; q = p - r * dw;
+                if (base + lane < ncorn) {
+                    const uint16_t rq = corn[base + lane];
+                    r = rq >> 8; q = rq & 0xff;
                     const uint8_t* z = sc + (r + 1) * sp + q + 1;
                     s = z[0];
-                    if (s >= th && s > 0) {
+                    if (s >= th) {
                         keep = true;
 #pragma unroll
                         for (int dy = -1; dy <= 1; dy++)
@@ -273,7 +311,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t* __restrict__ p
                 }
                 const unsigned long long m = __ballot(keep);
                 if (keep) {
-                    const int pos = total + __popcll(m & ((1ull << lane) - 1ull));
+                    const int pos = total + __popcll(m & lt);
                     if (pos < slot_cap)
                         my_slots[pos] = (uint32_t)(q + 3 + c.shx) | ((uint32_t)(r + 3 + c.shy) << 12) | ((uint32_t)s << 24);
                 }
@@ -704,7 +742,7 @@ struct viorb_extractor {
     std::vector<int4> blur_tiles;
     size_t frame_bytes = 0;
     int slot_cap = 0, kp_pitch = 0, out_cap = 0;
-    int fast_tile_pitch = 0, fast_tile_rows = 0, fast_score_bytes = 0;
+    int fast_tile_pitch = 0, fast_tile_rows = 0, fast_score_bytes = 0, fast_list_cap = 0;
     int oct_ncap = 0, oct_nodecap = 0, oct_sortcap = 0;
     std::vector<int> rs_pitch_dw, rs_rows;
     // device memory
@@ -844,6 +882,8 @@ static int configure(viorb_extractor* h, int w, int hgt) {
     h->fast_tile_rows = max_ch;
     h->fast_score_bytes = (int)align_up((size_t)(max_cw - 6 + 2) * (max_ch - 6 + 2), 4);
     h->slot_cap = ((max_cw - 6 + 1) / 2) * ((max_ch - 6 + 1) / 2);       // independent set of the king's graph
+    h->fast_list_cap = (int)align_up((size_t)(max_cw - 6) * (max_ch - 6), 2);
+    if (max_cw - 6 > 255 || max_ch - 6 > 255) { set_error("FAST cell larger than 255 px"); return VIORB_ERR_UNSUPPORTED; }
     // quadtree capacities
     int maxq = 1; for (int l = 0; l < nl; l++) maxq = std::max(maxq, h->quota[l]);
     h->oct_ncap = 8192;
@@ -927,11 +967,11 @@ static int launch_all(viorb_extractor* h, const uint8_t* d_images, int batch, in
                            h->rs_pitch_dw[l], h->rs_rows[l]);
     }
     {
-        const size_t lds = (size_t)h->fast_tile_pitch * h->fast_tile_rows + h->fast_score_bytes;
+        const size_t lds = (size_t)h->fast_tile_pitch * h->fast_tile_rows + h->fast_score_bytes + (size_t)h->fast_list_cap * 4;
         ProfScope ps("k_fast_cells", st);
         hipLaunchKernelGGL(k_fast_cells, dim3(ncells, batch), dim3(64), lds, st, h->d_planes, h->frame_bytes, h->d_lv, h->d_cells,
                            h->p.ini_th_fast, h->p.min_th_fast, h->d_slots, h->slot_cap, h->d_cell_cnt, ncells,
-                           h->fast_tile_pitch, h->fast_tile_rows, h->fast_score_bytes);
+                           h->fast_tile_pitch, h->fast_tile_rows, h->fast_score_bytes, h->fast_list_cap);
     }
     {
         const size_t lds = (size_t)h->oct_ncap * 8 + (size_t)h->oct_nodecap * sizeof(OctNode) + (size_t)h->oct_sortcap * 4;
