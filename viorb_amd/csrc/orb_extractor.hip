@@ -586,10 +586,13 @@ __global__ __launch_bounds__(64) void k_octree(const LevelDev* __restrict__ lv, 
 
 // cv::GaussianBlur(7x7, sigma 2, BORDER_REFLECT_101) on 8U, OpenCV 2.4 integer path:
 // taps {18,34,49,55,49,34,18} (x256, sum 257) in both directions, (sum + 2^15) >> 16, saturated.
-// Block = 64x32 output tile; horizontal pass into a u16 LDS buffer (max 255*257 = 65535), vertical
-// pass out of it.
+// Block = 64x64 output tile, 256 threads. The input rectangle (70 rows x 72 bytes, 4-byte left apron) is
+// staged in LDS as dwords; the horizontal pass takes 4 outputs per work item with v_alignbyte + v_dot4
+// (7 byte taps = two 4-byte dot products) into a u16 buffer (max 255*257 = 65535); the vertical pass
+// computes 4 columns x 4 rows per thread and stores one dword per row.
 #define BL_TW 64
-#define BL_TH 32
+#define BL_TH 64
+#define BL_IPD 18                         // input pitch in dwords: bytes x0-4 .. x0+67
 __constant__ int c_gauss[7];
 __device__ __forceinline__ int reflect101(int p, int len) {
     if (len == 1) return 0;
@@ -599,46 +602,73 @@ __device__ __forceinline__ int reflect101(int p, int len) {
 __global__ __launch_bounds__(256) void k_blur(const uint8_t* __restrict__ planes, uint8_t* __restrict__ blur,
                                               size_t frame_bytes, const LevelDev* __restrict__ lv,
                                               const int4* __restrict__ tiles) {
-    __shared__ uint8_t s_in[(BL_TH + 6) * (BL_TW + 8)];
-    __shared__ uint16_t s_h[(BL_TH + 6) * BL_TW];
+    __shared__ uint32_t s_in[(BL_TH + 6) * BL_IPD];
+    __shared__ uint32_t s_h[(BL_TH + 6) * (BL_TW / 2)];      // u16 pairs
     const int4 t = tiles[blockIdx.x];                 // level, tile x0, tile y0
     const LevelDev L = lv[t.x];
     const uint8_t* src = planes + (size_t)blockIdx.y * frame_bytes + L.plane_off;
     uint8_t* dst = blur + (size_t)blockIdx.y * frame_bytes + L.plane_off;
     const int x0 = t.y, y0 = t.z;
-    const int IW = BL_TW + 6, IP = BL_TW + 8;
-    for (int i = threadIdx.x; i < (BL_TH + 6) * IW; i += 256) {
-        const int r = i / IW, c = i - r * IW;
-        const int yy = reflect101(y0 + r - 3, L.h), xx = reflect101(x0 + c - 3, L.w);
-        s_in[r * IP + c] = src[(size_t)yy * L.stride + xx];
+    for (int i = threadIdx.x; i < (BL_TH + 6) * BL_IPD; i += 256) {
+        const int r = i / BL_IPD, c = i - r * BL_IPD;
+        const int yy = reflect101(y0 + r - 3, L.h);
+        const int xb = x0 - 4 + 4 * c;
+        const uint8_t* row = src + (size_t)yy * L.stride;
+        uint32_t v;
+        if (xb >= 0 && xb + 3 < L.w) v = *reinterpret_cast<const uint32_t*>(row + xb);
+        else {
+            v = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) v |= (uint32_t)row[reflect101(xb + j, L.w)] << (8 * j);
+        }
+        s_in[i] = v;
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < (BL_TH + 6) * BL_TW; i += 256) {
-        const int r = i / BL_TW, c = i - r * BL_TW;
-        const uint8_t* p = s_in + r * IP + c;
-        int s = 0;
-#pragma unroll
-        for (int k = 0; k < 7; k++) s += c_gauss[k] * p[k];
-        s_h[i] = (uint16_t)s;
+    const uint32_t T0 = (uint32_t)c_gauss[0] | ((uint32_t)c_gauss[1] << 8) | ((uint32_t)c_gauss[2] << 16) | ((uint32_t)c_gauss[3] << 24);
+    const uint32_t T1 = (uint32_t)c_gauss[4] | ((uint32_t)c_gauss[5] << 8) | ((uint32_t)c_gauss[6] << 16);
+    for (int i = threadIdx.x; i < (BL_TH + 6) * (BL_TW / 4); i += 256) {
+        const int r = i / (BL_TW / 4), g = i - r * (BL_TW / 4);          // outputs x0 + 4g .. 4g+3 of row r
+        const uint32_t D0 = s_in[r * BL_IPD + g], D1 = s_in[r * BL_IPD + g + 1], D2 = s_in[r * BL_IPD + g + 2];
+        // output j: bytes (4g+1+j .. 4g+4+j) and (4g+5+j .. 4g+8+j) of the row's byte stream
+        const uint32_t h0 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(D1, D0, 1), T0, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(D2, D1, 1), T1, 0u, false), false);
+        const uint32_t h1 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(D1, D0, 2), T0, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(D2, D1, 2), T1, 0u, false), false);
+        const uint32_t h2 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(D1, D0, 3), T0, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(D2, D1, 3), T1, 0u, false), false);
+        const uint32_t h3 = __builtin_amdgcn_udot4(D1, T0, __builtin_amdgcn_udot4(D2, T1, 0u, false), false);
+        s_h[r * (BL_TW / 2) + 2 * g] = h0 | (h1 << 16);
+        s_h[r * (BL_TW / 2) + 2 * g + 1] = h2 | (h3 << 16);
     }
     __syncthreads();
-    // 256 threads x 8 px: thread -> row (tid/8), 8-px group (tid%8)
-    const int r = threadIdx.x >> 3, g = threadIdx.x & 7;
-    const int y = y0 + r;
-    if (y >= L.h) return;
-    uint32_t w0 = 0, w1 = 0;
+    // vertical: thread -> 4 columns (tx) x 4 rows (ty)
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int k0 = c_gauss[0], k1 = c_gauss[1], k2 = c_gauss[2], k3 = c_gauss[3];
+    int acc[4][4];
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
-        const int c = g * 8 + j;
-        int s = 0;
+    for (int a = 0; a < 4; a++)
 #pragma unroll
-        for (int k = 0; k < 7; k++) s += c_gauss[k] * (int)s_h[(r + k) * BL_TW + c];
-        int v = (s + (1 << 15)) >> 16;
-        v = v > 255 ? 255 : v;
-        if (j < 4) w0 |= (uint32_t)v << (8 * j); else w1 |= (uint32_t)v << (8 * (j - 4));
+        for (int c = 0; c < 4; c++) acc[a][c] = 1 << 15;
+#pragma unroll
+    for (int rr = 0; rr < 10; rr++) {
+        const uint32_t p0 = s_h[(4 * ty + rr) * (BL_TW / 2) + 2 * tx], p1 = s_h[(4 * ty + rr) * (BL_TW / 2) + 2 * tx + 1];
+        const int v[4] = {(int)(p0 & 0xffff), (int)(p0 >> 16), (int)(p1 & 0xffff), (int)(p1 >> 16)};
+#pragma unroll
+        for (int a = 0; a < 4; a++) {
+            const int j = rr - a;                      // tap index for output row a
+            if (j < 0 || j > 6) continue;
+            const int kj = (j == 0 || j == 6) ? k0 : (j == 1 || j == 5) ? k1 : (j == 2 || j == 4) ? k2 : k3;
+#pragma unroll
+            for (int c = 0; c < 4; c++) acc[a][c] += kj * v[c];
+        }
     }
-    const int xw = x0 + g * 8;
-    if (xw < L.stride) *reinterpret_cast<uint2*>(dst + (size_t)y * L.stride + xw) = make_uint2(w0, w1);
+#pragma unroll
+    for (int a = 0; a < 4; a++) {
+        const int y = y0 + 4 * ty + a;
+        if (y >= L.h) continue;
+        uint32_t w = 0;
+#pragma unroll
+        for (int c = 0; c < 4; c++) { int v = acc[a][c] >> 16; v = v > 255 ? 255 : v; w |= (uint32_t)v << (8 * c); }
+        const int xw = x0 + 4 * tx;
+        if (xw < L.stride) *reinterpret_cast<uint32_t*>(dst + (size_t)y * L.stride + xw) = w;
+    }
 }
 
 // One wavefront per keypoint: IC_Angle (reference :77-104) on the un-blurred level, then the
