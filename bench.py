@@ -81,7 +81,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--streams", type=int, default=64, help="independent camera streams per GPU")
+    ap.add_argument("--streams", type=int, default=256, help="independent camera streams per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -93,8 +93,8 @@ def main():
     S = args.streams
 
     # ---- synthetic inputs on the CPU, then the GPU runtime --------------------------------------------
-    seeds = [1000 + rank * S + i for i in range(S)]
-    streams = generate_streams(seeds)
+    from viorb_amd.distributed import stream_seeds, reduce_throughput, init as dist_init
+    streams = generate_streams(stream_seeds(rank, S))
     import torch
     import torch.distributed as dist
     import viorb_amd
@@ -104,8 +104,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)       # "nccl" is RCCL on ROCm
+        dist_init("nccl", dev)                               # "nccl" is RCCL on ROCm
     up = lambda a, dt=None: torch.from_numpy(np.ascontiguousarray(a)).to(dev) if dt is None else torch.from_numpy(np.ascontiguousarray(a)).to(dev, dt)
     frames = up(np.stack([s["frames"] for s in streams], 1))                   # [F, S, h, w] u8
     imu = up(np.stack([s["imu"] for s in streams], 1))                         # [F, S, n, 7] f64
@@ -161,13 +160,7 @@ def main():
     dom = max(ext, key=lambda kname: ext[kname][0]) if ext else None
 
     # ---- reduce over ranks: total frames, max time ----------------------------------------------------------
-    frames_done = float(S * args.steps)
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        ff = torch.tensor([frames_done], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dist.all_reduce(ff, op=dist.ReduceOp.SUM)
-        elapsed, frames_done = tt.item(), ff.item()
+    frames_done, elapsed = reduce_throughput(S * args.steps, elapsed, dev)
 
     if rank == 0:
         roof = None
@@ -186,7 +179,7 @@ def main():
                     "kernel_ms_per_step": {kname: round(v[0] / args.steps, 4) for kname, v in sorted(prof.items())}}
         cpu = None
         if not args.no_cpu_baseline:
-            fps, nfr, tsec = cpu_baseline(streams[:2])
+            fps, nfr, tsec = cpu_baseline(streams[:8])
             cpu = {"value": round(fps, 3), "unit": "frames/s", "cores": 1, "kind": "port",
                    "sample": "%d frames of the same synthetic streams, same extract+match+IMU+pose-opt sequence, oracle (C++ -O3) on 1 host thread, %.1f s"
                              % (nfr, tsec)}

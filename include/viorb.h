@@ -215,6 +215,14 @@ int viorb_profile_read(char* names_buf, int names_cap, double* total_ms, int* ca
 
 /* Host-buffer drop-ins for single calls (they stage through the device and include the PCIe copies). */
 int viorb_descriptor_distance(const uint8_t* a, const uint8_t* b);       /* ORBmatcher::DescriptorDistance */
+/* ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono = true) with host arrays: builds the
+ * current frame's grid and runs the search on the device. bounds4 = mnMinX mnMaxX mnMinY mnMaxY, pose12 =
+ * Rcw(9) tcw(3) of CurrentFrame.mTcw, intr4 = fx fy cx cy, scale_factors[nlevels]; last_flags as above.
+ * cur_match[ncur] and *nmatches receive the assignment and the function's return value. */
+int viorb_search_by_projection_frame(const viorb_keypoint* cur_kps, const uint8_t* cur_desc, int ncur, const float bounds4[4],
+                                     const float pose12[12], const float intr4[4], const float* scale_factors, int nlevels,
+                                     const viorb_keypoint* last_kps, int nlast, const uint8_t* last_flags, const float* last_Pw,
+                                     const uint8_t* last_desc, float th, int check_orientation, int32_t* cur_match, int* nmatches);
 int viorb_preintegrate(const double* imu, int n_imu, const double bg[3], const double ba[3], double t_last,
                        double t_cur, double* preint142);
 int viorb_pose_opt_vi(int variant, int compute_marg, const double cur_ns[22], const double last_ns[22],

@@ -238,3 +238,20 @@ def test_batched_pose_opt_and_observation_builder(torch_cuda, oracle, streams):
         np.testing.assert_allclose(out[b].cpu().numpy(), o["ns"], atol=1e-7)
         # the optimised pose is close to the ground truth of the synthetic stream
         assert np.linalg.norm(out[b].cpu().numpy()[:3] - s["s"]["ns_true"][1][:3]) < 0.02
+
+
+def test_host_dropin_search_by_projection(torch_cuda, oracle, streams):
+    s = streams[1]
+    Rcw, tcw = cam_pose_from_navstate(s["s"]["ns_true"][1], s["s"]["cam"])
+    pose = np.concatenate([Rcw.ravel(), tcw]).astype(np.float32)
+    m = viorb_amd.ORBmatcher(0.9, True)
+    for th in (15.0, 30.0):
+        nm, match = m.SearchByProjection(s["k1"], s["d1"], BOUNDS, pose, s["s"]["cam"][:4], s["tables"]["scale"], s["k0"], s["flags"],
+                                         s["Pw"], s["d0"], th)
+        onm, om = oracle.search_by_projection_frame(s["k1"], s["d1"], BOUNDS, pose, s["s"]["cam"][:4], s["tables"]["scale"], s["flags"],
+                                                    s["Pw"], s["d0"], s["k0"]["octave"], s["k0"]["angle"], th)
+        assert nm == onm
+        np.testing.assert_array_equal(match, om)
+    nm, match = m.SearchByProjection(s["k1"][:0], s["d1"][:0], BOUNDS, pose, s["s"]["cam"][:4], s["tables"]["scale"], s["k0"], s["flags"],
+                                     s["Pw"], s["d0"], 15.0)
+    assert nm == 0 and len(match) == 0

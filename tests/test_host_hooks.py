@@ -193,3 +193,16 @@ def test_descriptor_distance_host(oracle):
     for _ in range(100):
         a, b = rng.integers(0, 256, 32, dtype=np.uint8), rng.integers(0, 256, 32, dtype=np.uint8)
         assert viorb_amd.descriptor_distance(a, b) == oracle.descriptor_distance(a, b)
+
+
+def test_cpp_shim_header_compiles_links_and_runs(tmp_path):
+    """viorb_amd/shim/ORBextractor.h (the drop-in for the reference's include/ORBextractor.h) compiles against
+    include/viorb.h with stand-in cv:: types, links libviorb_hip.so and behaves like the reference on an empty image."""
+    import subprocess
+    exe = str(tmp_path / "shim_test")
+    lib_dir = os.path.join(ROOT, "viorb_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "viorb_amd", "shim"),
+                           "-I", os.path.join(ROOT, "tests", "cpp"), os.path.join(ROOT, "tests", "cpp", "shim_extractor_test.cpp"),
+                           "-L", lib_dir, "-lviorb_hip", "-Wl,-rpath," + lib_dir, "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and out.stdout.startswith("OK"), out.stdout + out.stderr

@@ -64,6 +64,7 @@ SIGNATURES = {
     "viorb_profile_reset": (i32, []),
     "viorb_profile_read": (i32, [C.c_char_p, i32, vp, vp, i32, PP(i32)]),
     "viorb_descriptor_distance": (i32, [vp, vp]),
+    "viorb_search_by_projection_frame": (i32, [vp, vp, i32, vp, vp, vp, vp, i32, vp, i32, vp, vp, vp, f32, i32, vp, PP(i32)]),
     "viorb_preintegrate": (i32, [vp, i32, vp, vp, C.c_double, C.c_double, vp]),
     "viorb_pose_opt_vi": (i32, [i32, i32] + [vp] * 8 + [i32, vp, i32] + [vp] * 6),
     "viorb_debug_pvr_edge": (None, [vp] * 7),

@@ -1055,6 +1055,49 @@ viorb_frontend_config default_cfg() {
 
 extern "C" {
 
+int viorb_search_by_projection_frame(const viorb_keypoint* cur_kps, const uint8_t* cur_desc, int ncur, const float bounds4[4],
+                                     const float pose12[12], const float intr4[4], const float* scale_factors, int nlevels,
+                                     const viorb_keypoint* last_kps, int nlast, const uint8_t* last_flags, const float* last_Pw,
+                                     const uint8_t* last_desc, float th, int check_orientation, int32_t* cur_match, int* nmatches) {
+    VIORB_REQUIRE(bounds4 && pose12 && intr4 && scale_factors && nmatches && ncur >= 0 && nlast >= 0, "null array");
+    VIORB_REQUIRE(nlevels >= 1 && nlevels <= 16, "nlevels must be 1..16");
+    *nmatches = 0;
+    for (int i = 0; i < ncur; i++) cur_match[i] = -1;
+    if (ncur == 0 || nlast == 0) return VIORB_OK;
+    VIORB_REQUIRE(cur_kps && cur_desc && last_kps && last_flags && last_Pw && last_desc && cur_match, "null array");
+    viorb_frontend_config c = default_cfg();
+    c.min_x = bounds4[0]; c.max_x = bounds4[1]; c.min_y = bounds4[2]; c.max_y = bounds4[3];
+    c.fx = intr4[0]; c.fy = intr4[1]; c.cx = intr4[2]; c.cy = intr4[3];
+    c.nlevels = nlevels; c.check_orientation = check_orientation;
+    for (int i = 0; i < 16; i++) c.scale_factors[i] = scale_factors[i < nlevels ? i : nlevels - 1];
+    const int cap = std::max(ncur, nlast);
+    viorb_frontend* h = nullptr;
+    FE_TRY(viorb_frontend_create(&c, 1, cap, 0, &h));
+    struct Guard { viorb_frontend* h; ~Guard() { viorb_frontend_destroy(h); } } g{h};
+    DevBuf B; viorb_keypoint *d_ck, *d_lk; uint8_t *d_cd, *d_ld, *d_lf; float *d_lp, *d_pose; int *d_cc, *d_lc, *d_cs, *d_ci, *d_m, *d_nm, *d_st;
+    FE_TRY(B.up(&d_ck, (const viorb_keypoint*)nullptr, (size_t)cap)); FE_TRY(B.up(&d_lk, (const viorb_keypoint*)nullptr, (size_t)cap));
+    FE_TRY(B.up(&d_cd, (const uint8_t*)nullptr, (size_t)cap * 32)); FE_TRY(B.up(&d_ld, (const uint8_t*)nullptr, (size_t)cap * 32));
+    FE_TRY(B.up(&d_lf, (const uint8_t*)nullptr, (size_t)cap)); FE_TRY(B.up(&d_lp, (const float*)nullptr, (size_t)cap * 3));
+    FE_TRY(B.up(&d_pose, pose12, 12)); FE_TRY(B.up(&d_cc, &ncur, 1)); FE_TRY(B.up(&d_lc, &nlast, 1));
+    FE_TRY(B.up(&d_cs, (const int*)nullptr, GRID_CELLS + 1)); FE_TRY(B.up(&d_ci, (const int*)nullptr, (size_t)cap));
+    FE_TRY(B.up(&d_m, (const int*)nullptr, (size_t)cap)); FE_TRY(B.up(&d_nm, (const int*)nullptr, 1)); FE_TRY(B.up(&d_st, (const int*)nullptr, 1));
+    VIORB_HIP_TRY(hipMemcpy(d_ck, cur_kps, sizeof(viorb_keypoint) * ncur, hipMemcpyHostToDevice));
+    VIORB_HIP_TRY(hipMemcpy(d_cd, cur_desc, (size_t)32 * ncur, hipMemcpyHostToDevice));
+    VIORB_HIP_TRY(hipMemcpy(d_lk, last_kps, sizeof(viorb_keypoint) * nlast, hipMemcpyHostToDevice));
+    VIORB_HIP_TRY(hipMemcpy(d_ld, last_desc, (size_t)32 * nlast, hipMemcpyHostToDevice));
+    VIORB_HIP_TRY(hipMemcpy(d_lf, last_flags, (size_t)nlast, hipMemcpyHostToDevice));
+    VIORB_HIP_TRY(hipMemcpy(d_lp, last_Pw, sizeof(float) * 3 * nlast, hipMemcpyHostToDevice));
+    FE_TRY(viorb_frontend_grid_device(h, d_ck, d_cc, 1, d_cs, d_ci, nullptr));
+    FE_TRY(viorb_frontend_search_projection_device(h, d_ck, d_cd, d_cc, d_cs, d_ci, d_pose, d_lk, d_lc, d_lf, d_lp, d_ld, th, 1, d_m, d_nm, d_st, nullptr));
+    VIORB_HIP_TRY(hipDeviceSynchronize());
+    int st = 0;
+    VIORB_HIP_TRY(hipMemcpy(cur_match, d_m, sizeof(int) * ncur, hipMemcpyDeviceToHost));
+    VIORB_HIP_TRY(hipMemcpy(nmatches, d_nm, sizeof(int), hipMemcpyDeviceToHost));
+    VIORB_HIP_TRY(hipMemcpy(&st, d_st, sizeof(int), hipMemcpyDeviceToHost));
+    if (st != VIORB_OK) { set_error("more than %d grid candidates for one point", (int)CAND_CAP); return st; }
+    return VIORB_OK;
+}
+
 int viorb_preintegrate(const double* imu, int n_imu, const double bg[3], const double ba[3], double t_last, double t_cur, double* preint142) {
     VIORB_REQUIRE(imu && bg && ba && preint142 && n_imu >= 1, "null array / n_imu < 1");
     viorb_frontend_config c = default_cfg();

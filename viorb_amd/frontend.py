@@ -15,6 +15,33 @@ def descriptor_distance(a, b):
     return lib().viorb_descriptor_distance(ptr(np.ascontiguousarray(a, np.uint8)), ptr(np.ascontiguousarray(b, np.uint8)))
 
 
+class ORBmatcher:
+    """Mirror of ORB_SLAM2::ORBmatcher for the frame-side searches (reference include/ORBmatcher.h:37-102)."""
+    TH_LOW, TH_HIGH, HISTO_LENGTH = 50, 100, 30
+
+    def __init__(self, nnratio=0.6, checkOri=True):
+        self.mfNNratio, self.mbCheckOrientation = float(nnratio), bool(checkOri)
+
+    DescriptorDistance = staticmethod(descriptor_distance)
+
+    def SearchByProjection(self, cur_kps, cur_desc, bounds, pose12, intr4, scale_factors, last_kps, last_flags, last_Pw,
+                           last_mp_desc, th, bMono=True):
+        """SearchByProjection(CurrentFrame, LastFrame, th, bMono) on SoA host arrays.
+        Returns (nmatches, cur_match[Ncur]) with cur_match[i2] = last-frame index or -1."""
+        assert bMono, "stereo gating (mvuRight) is not part of this drop-in yet"
+        f32 = lambda a: np.ascontiguousarray(a, np.float32)
+        ck = np.ascontiguousarray(cur_kps, capi.KP_DTYPE); lk = np.ascontiguousarray(last_kps, capi.KP_DTYPE)
+        match = np.full(max(len(ck), 1), -1, np.int32)
+        nm = C.c_int()
+        sf = f32(scale_factors)
+        check(lib().viorb_search_by_projection_frame(ptr(ck), ptr(np.ascontiguousarray(cur_desc, np.uint8)), len(ck), ptr(f32(bounds)),
+                                                     ptr(f32(pose12)), ptr(f32(intr4)), ptr(sf), len(sf), ptr(lk), len(lk),
+                                                     ptr(np.ascontiguousarray(last_flags, np.uint8)), ptr(f32(last_Pw)),
+                                                     ptr(np.ascontiguousarray(last_mp_desc, np.uint8)), float(th),
+                                                     int(self.mbCheckOrientation), ptr(match), C.byref(nm)))
+        return nm.value, match[:len(ck)]
+
+
 def preintegrate(imu, bg, ba, t_last, t_cur):
     """IMU pre-integration between two frames (Frame::ComputeIMUPreIntSinceLastFrame). Returns preint[142]."""
     imu = np.ascontiguousarray(imu, np.float64).reshape(-1, 7)

@@ -1,0 +1,119 @@
+// viorb_amd/shim/viorb_tracking_shim.h — reference-side glue between VIORB's own classes and the C ABI of
+// include/viorb.h for the two per-frame calls Tracking makes after extraction:
+//   ORBmatcher::SearchByProjection(Frame&, const Frame&, th, bMono)            reference src/ORBmatcher.cc:1328-1471
+//   Optimizer::PoseOptimization(Frame*, KeyFrame*|Frame*, preint, gw, marg)    reference src/Optimizer.cc:323-1112
+// Function templates over the reference's Frame / KeyFrame / MapPoint / NavState / IMUPreintegrator: this
+// header includes none of the reference's headers — it is compiled inside the reference tree, after them
+// (INTEGRATION.md shows the three-line replacements of the reference functions that call into it). It only
+// flattens the pointer-rich objects into the SoA arrays the C ABI takes and writes results back where the
+// reference keeps them (mvpMapPoints, mvbOutlier, NavState, mMargCovInv, mNavStatePrior).
+#ifndef VIORB_TRACKING_SHIM_H
+#define VIORB_TRACKING_SHIM_H
+
+#include <vector>
+#include <cstring>
+#include <type_traits>
+#include "viorb.h"
+
+namespace viorb_shim {
+
+// ---- NavState / IMUPreintegrator <-> flat doubles (layouts documented in include/viorb.h) ---------------------
+template <class NavStateT> inline void pack_navstate(const NavStateT& ns, double* o) {
+    for (int i = 0; i < 3; i++) { o[i] = ns.Get_P()[i]; o[3 + i] = ns.Get_V()[i]; }
+    o[6] = ns.Get_R().unit_quaternion().x(); o[7] = ns.Get_R().unit_quaternion().y();
+    o[8] = ns.Get_R().unit_quaternion().z(); o[9] = ns.Get_R().unit_quaternion().w();
+    for (int i = 0; i < 3; i++) {
+        o[10 + i] = ns.Get_BiasGyr()[i]; o[13 + i] = ns.Get_BiasAcc()[i];
+        o[16 + i] = ns.Get_dBias_Gyr()[i]; o[19 + i] = ns.Get_dBias_Acc()[i];
+    }
+}
+template <class NavStateT, class Vec3, class Quat, class SO3T> inline void unpack_navstate(const double* o, NavStateT& ns) {
+    ns.Set_Pos(Vec3(o[0], o[1], o[2])); ns.Set_Vel(Vec3(o[3], o[4], o[5]));
+    ns.Set_Rot(SO3T(Quat(o[9], o[6], o[7], o[8])));                              // Eigen::Quaterniond(w, x, y, z)
+    ns.Set_BiasGyr(Vec3(o[10], o[11], o[12])); ns.Set_BiasAcc(Vec3(o[13], o[14], o[15]));
+    ns.Set_DeltaBiasGyr(Vec3(o[16], o[17], o[18])); ns.Set_DeltaBiasAcc(Vec3(o[19], o[20], o[21]));
+}
+template <class Preint> inline void pack_preint(const Preint& M, double* o) {
+    for (int i = 0; i < 3; i++) { o[i] = M.getDeltaP()[i]; o[3 + i] = M.getDeltaV()[i]; }
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) {
+        o[6 + 3 * r + c] = M.getDeltaR()(r, c); o[15 + 3 * r + c] = M.getJPBiasg()(r, c); o[24 + 3 * r + c] = M.getJPBiasa()(r, c);
+        o[33 + 3 * r + c] = M.getJVBiasg()(r, c); o[42 + 3 * r + c] = M.getJVBiasa()(r, c); o[51 + 3 * r + c] = M.getJRBiasg()(r, c);
+    }
+    for (int r = 0; r < 9; r++) for (int c = 0; c < 9; c++) o[60 + 9 * r + c] = M.getCovPVPhi()(r, c);
+    o[141] = M.getDeltaTime();
+}
+// cam16 = fx fy cx cy Rbc(9, row-major) Pbc(3) from a frame and ConfigParam::GetEigTbc()
+template <class FrameT, class Mat4> inline void pack_camera(const FrameT& F, const Mat4& Tbc, double* cam16) {
+    cam16[0] = F.fx; cam16[1] = F.fy; cam16[2] = F.cx; cam16[3] = F.cy;
+    for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) cam16[4 + 3 * r + c] = Tbc(r, c); cam16[13 + r] = Tbc(r, 3); }
+}
+
+// One mono reprojection observation per map-point match, in keypoint order (src/Optimizer.cc:493-547).
+template <class FrameT> inline void gather_observations(const FrameT& F, std::vector<double>& obs, std::vector<int>& index) {
+    obs.clear(); index.clear();
+    for (int i = 0; i < F.N; i++) {
+        if (!F.mvpMapPoints[i] || !(F.mvuRight[i] < 0)) continue;
+        const cv::Mat Pw = F.mvpMapPoints[i]->GetWorldPos();
+        const cv::KeyPoint& kp = F.mvKeysUn[i];
+        const double o[6] = {Pw.at<float>(0), Pw.at<float>(1), Pw.at<float>(2), kp.pt.x, kp.pt.y, F.mvInvLevelSigma2[kp.octave]};
+        obs.insert(obs.end(), o, o + 6);
+        index.push_back(i);
+    }
+}
+
+// Body of Optimizer::PoseOptimization(Frame* pFrame, Frame* pLastFrame, imupreint, gw, bComputeMarg)
+// (src/Optimizer.cc:323-787). Vec3/Quat/SO3T/Mat12 = Eigen::Vector3d, Eigen::Quaterniond, Sophus::SO3,
+// Eigen::Matrix<double,12,12>. Returns nInitialCorrespondences - nBad like the reference.
+template <class Vec3, class Quat, class SO3T, class FrameT, class Preint, class Mat4>
+inline int pose_optimization_frame(FrameT* pFrame, FrameT* pLast, const Preint& imupreint, const double gw[3], const Mat4& Tbc,
+                                   const cv::Mat& MatTbc, bool bComputeMarg) {
+    double cur[22], last[22], prior[22], pre[142], cam[16], out[22], outl[22], info[4], marg[144], mci[144];
+    pack_navstate(pFrame->GetNavState(), cur); pack_navstate(pLast->GetNavState(), last); pack_navstate(pLast->mNavStatePrior, prior);
+    pack_preint(imupreint, pre); pack_camera(*pFrame, Tbc, cam);
+    for (int r = 0; r < 12; r++) for (int c = 0; c < 12; c++) mci[12 * r + c] = pLast->mMargCovInv(r, c);
+    std::vector<double> oc, ol; std::vector<int> ic, il;
+    gather_observations(*pFrame, oc, ic); gather_observations(*pLast, ol, il);
+    std::vector<unsigned char> fc(ic.size() + 1), fl(il.size() + 1);
+    if (viorb_pose_opt_vi(1, bComputeMarg, cur, last, prior, mci, pre, gw, cam, oc.empty() ? 0 : &oc[0], (int)ic.size(),
+                          ol.empty() ? 0 : &ol[0], (int)il.size(), out, outl, &fc[0], &fl[0], marg, info) != VIORB_OK) return 0;
+    if (ic.size() < 3) return 0;                                              // reference returns before touching the frame
+    for (size_t k = 0; k < ic.size(); k++) pFrame->mvbOutlier[ic[k]] = fc[k] != 0;
+    for (size_t k = 0; k < il.size(); k++) pLast->mvbOutlier[il[k]] = fl[k] != 0;
+    typename std::remove_reference<decltype(pFrame->mNavStatePrior)>::type ns;
+    unpack_navstate<decltype(ns), Vec3, Quat, SO3T>(out, ns);
+    pFrame->SetNavState(ns);
+    pFrame->UpdatePoseFromNS(MatTbc);
+    if (bComputeMarg) {
+        for (int r = 0; r < 12; r++) for (int c = 0; c < 12; c++) pFrame->mMargCovInv(r, c) = marg[12 * r + c];
+        pFrame->mNavStatePrior = ns;
+    }
+    return (int)info[0];
+}
+
+// Body of Optimizer::PoseOptimization(Frame* pFrame, KeyFrame* pLastKF, ...) (src/Optimizer.cc:789-1112).
+template <class Vec3, class Quat, class SO3T, class FrameT, class KeyFrameT, class Preint, class Mat4>
+inline int pose_optimization_keyframe(FrameT* pFrame, KeyFrameT* pLastKF, const Preint& imupreint, const double gw[3], const Mat4& Tbc,
+                                      const cv::Mat& MatTbc, bool bComputeMarg) {
+    double cur[22], last[22], pre[142], cam[16], out[22], info[4], marg[144];
+    pack_navstate(pFrame->GetNavState(), cur); pack_navstate(pLastKF->GetNavState(), last);
+    pack_preint(imupreint, pre); pack_camera(*pFrame, Tbc, cam);
+    std::vector<double> oc; std::vector<int> ic;
+    gather_observations(*pFrame, oc, ic);
+    std::vector<unsigned char> fc(ic.size() + 1);
+    if (viorb_pose_opt_vi(0, bComputeMarg, cur, last, 0, 0, pre, gw, cam, oc.empty() ? 0 : &oc[0], (int)ic.size(), 0, 0, out, 0,
+                          &fc[0], 0, marg, info) != VIORB_OK) return 0;
+    if (ic.size() < 3) return 0;
+    for (size_t k = 0; k < ic.size(); k++) pFrame->mvbOutlier[ic[k]] = fc[k] != 0;
+    typename std::remove_reference<decltype(pFrame->mNavStatePrior)>::type ns;
+    unpack_navstate<decltype(ns), Vec3, Quat, SO3T>(out, ns);
+    pFrame->SetNavState(ns);
+    pFrame->UpdatePoseFromNS(MatTbc);
+    if (bComputeMarg) {
+        for (int r = 0; r < 12; r++) for (int c = 0; c < 12; c++) pFrame->mMargCovInv(r, c) = marg[12 * r + c];
+        pFrame->mNavStatePrior = ns;
+    }
+    return (int)info[0];
+}
+
+} // namespace viorb_shim
+#endif
