@@ -178,6 +178,20 @@ int viorb_frontend_search_projection_device(viorb_frontend* h, const viorb_keypo
                                             float th, int batch, int32_t* cur_match, int32_t* nmatches, int32_t* status,
                                             void* stream);
 
+/* Tracking::SearchLocalPoints (reference src/Tracking.cc:1904-1958): Frame::isInFrustum(pMP, 0.5) for every local map
+ * point that is valid and not yet matched in this frame, then ORBmatcher::SearchByProjection(F, vpMapPoints, th)
+ * (src/ORBmatcher.cc:45-129, ORBmatcher(nnratio)). pts_f[b][pcap][8] = Pw3 normal3 mfMinDistance mfMaxDistance,
+ * pts_flags bit0 !isBad, bit1 mnLastFrameSeen == frame id (skip), bit2 Observations() > 0; pts_desc[b][pcap][32];
+ * cur_owner_obs[b][cap] != 0 where the keypoint already holds a map point with observations. Outputs:
+ * match[b][cap] = local point given to the keypoint by this call or -1, nmatches[b], and (optional)
+ * frustum[b][pcap][5] = mbTrackInView mTrackProjX mTrackProjY mTrackViewCos mnTrackScaleLevel. */
+int viorb_frontend_search_local_points_device(viorb_frontend* h, const viorb_keypoint* cur_kps, const uint8_t* cur_desc,
+                                              const int32_t* cur_count, const int32_t* cell_start, const int32_t* cell_idx,
+                                              const float* pose12, const float* pts_f, const uint8_t* pts_flags,
+                                              const uint8_t* pts_desc, const int32_t* pts_count, int pcap, float th,
+                                              float nnratio, const uint8_t* cur_owner_obs, int batch, int32_t* match,
+                                              int32_t* nmatches, float* frustum, int32_t* status, void* stream);
+
 /* Edge construction of PoseOptimization: one observation per matched keypoint, in keypoint order.
  * match[b][i] >= 0 selects point match_Pw[b][match[b][i]]. obs_index[b][k] = keypoint of obs k. */
 int viorb_frontend_build_observations_device(viorb_frontend* h, const viorb_keypoint* kps, const int32_t* count,

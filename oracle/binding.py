@@ -316,6 +316,7 @@ def _match():
         L.ora_frame_grid.argtypes = [vp, i, f, f, f, f, vp, vp]
         L.ora_features_in_area.argtypes = [vp, i, f, f, f, f, f, f, f, i, i, vp, i]
         L.ora_search_by_projection_frame.argtypes = [vp, vp, i, vp, vp, vp, vp, i, vp, vp, vp, vp, vp, f, i, vp]
+        L.ora_search_local_points.argtypes = [vp, vp, i, vp, vp, vp, vp, i, f, i, vp, vp, vp, f, f, vp, vp, vp]
         _match_ready = True
     return L
 
@@ -354,3 +355,21 @@ def search_by_projection_frame(cur_kps, cur_desc, bounds, pose12, intr4, scale_f
         _p(np.ascontiguousarray(last_mp_desc, np.uint8)), _p(np.ascontiguousarray(last_octave, np.int32)), _p(f32(last_angle)),
         float(th), int(check_ori), _p(m))
     return nm, m[:n]
+
+
+def search_local_points(cur_kps, cur_desc, bounds, pose12, intr4, scale_factors, log_scale_factor, pts_f, pts_flags, pts_desc,
+                        th, nnratio, cur_owner_obs):
+    """Tracking::SearchLocalPoints (isInFrustum per point) + ORBmatcher::SearchByProjection(F, vpMapPoints, th).
+    pts_f [n,8] = Pw3 normal3 minDist maxDist. Returns (nmatches, match[Ncur], frustum[n,5])."""
+    cur_kps = np.ascontiguousarray(cur_kps, KP_DTYPE)
+    n = len(cur_kps)
+    f32 = lambda a: np.ascontiguousarray(a, np.float32)
+    pts_f = f32(pts_f).reshape(-1, 8)
+    m = np.full(max(n, 1), -1, np.int32)
+    fr = np.zeros((max(len(pts_f), 1), 5), np.float32)
+    sf = f32(scale_factors)
+    nm = _match().ora_search_local_points(_p(cur_kps), _p(np.ascontiguousarray(cur_desc, np.uint8)), n, _p(f32(bounds)), _p(f32(pose12)),
+                                          _p(f32(intr4)), _p(sf), len(sf), float(log_scale_factor), len(pts_f), _p(pts_f),
+                                          _p(np.ascontiguousarray(pts_flags, np.uint8)), _p(np.ascontiguousarray(pts_desc, np.uint8)),
+                                          float(th), float(nnratio), _p(np.ascontiguousarray(cur_owner_obs, np.uint8)), _p(m), _p(fr))
+    return nm, m[:n], fr[:len(pts_f)]

@@ -259,3 +259,30 @@ int ora_search_by_projection_frame(const KeyPoint* cur_kps, const uint8_t* cur_d
     return n;
 }
 } // extern "C"
+
+extern "C" {
+// pts_f[n][8] = Pw3 normal3 minDist maxDist; pts_flags[n] bit0 valid, bit1 skip, bit2 has observations.
+// frustum_out[n][5] = in_view projx projy viewcos level (may be NULL).
+int ora_search_local_points(const KeyPoint* cur_kps, const uint8_t* cur_desc, int ncur, const float* bounds4, const float* pose12,
+                            const float* intr4, const float* scale_factors, int nlevels, float log_scale_factor, int npts,
+                            const float* pts_f, const uint8_t* pts_flags, const uint8_t* pts_desc, float th, float nnratio,
+                            const uint8_t* cur_owner_obs, int* match, float* frustum_out) {
+    FrameGrid g; g.build(cur_kps, cur_desc, ncur, bounds4[0], bounds4[1], bounds4[2], bounds4[3]);
+    PoseF T; for (int i = 0; i < 9; i++) T.Rcw[i] = pose12[i]; for (int i = 0; i < 3; i++) T.tcw[i] = pose12[9 + i];
+    T.fx = intr4[0]; T.fy = intr4[1]; T.cx = intr4[2]; T.cy = intr4[3];
+    std::vector<LocalPoint> pts(npts);
+    for (int i = 0; i < npts; i++) {
+        pts[i].valid = pts_flags[i] & 1; pts[i].skip = (pts_flags[i] >> 1) & 1; pts[i].has_observations = (pts_flags[i] >> 2) & 1;
+        for (int k = 0; k < 3; k++) { pts[i].Pw[k] = pts_f[8 * i + k]; pts[i].normal[k] = pts_f[8 * i + 3 + k]; }
+        pts[i].min_dist = pts_f[8 * i + 6]; pts[i].max_dist = pts_f[8 * i + 7]; pts[i].desc = pts_desc + (size_t)32 * i;
+    }
+    std::vector<int> m; std::vector<FrustumResult> fr;
+    int n = search_local_points(g, T, scale_factors, nlevels, log_scale_factor, pts, th, nnratio, cur_owner_obs, m, &fr);
+    for (int i = 0; i < ncur; i++) match[i] = m[i];
+    if (frustum_out) for (int i = 0; i < npts; i++) {
+        frustum_out[5 * i] = fr[i].in_view; frustum_out[5 * i + 1] = fr[i].proj_x; frustum_out[5 * i + 2] = fr[i].proj_y;
+        frustum_out[5 * i + 3] = fr[i].view_cos; frustum_out[5 * i + 4] = (float)fr[i].level;
+    }
+    return n;
+}
+} // extern "C"

@@ -131,4 +131,77 @@ int search_by_projection_frame(const FrameGrid& cur, const PoseF& T, const float
     return nmatches;
 }
 
+void camera_centre(const PoseF& T, float* Ow) {
+    // mOw = -mRcw.t()*mtcw : gemm with alpha = -1 on the 3-term float sums of the transposed rows
+    for (int r = 0; r < 3; r++) {
+        const float t = T.Rcw[r] * T.tcw[0] + T.Rcw[3 + r] * T.tcw[1] + T.Rcw[6 + r] * T.tcw[2];
+        Ow[r] = -t;
+    }
+}
+
+// Frame.cc:449-505
+FrustumResult is_in_frustum(const PoseF& T, const float* Ow, float min_x, float max_x, float min_y, float max_y,
+                            float log_scale_factor, int nlevels, const LocalPoint& p, float viewingCosLimit) {
+    FrustumResult R{0, 0, 0, 0, 0};
+    float Pc[3]; transform_point(T, p.Pw, Pc);
+    const float PcX = Pc[0], PcY = Pc[1], PcZ = Pc[2];
+    if (PcZ < 0.0f) return R;
+    const float invz = 1.0f / PcZ;
+    const float u = T.fx * PcX * invz + T.cx;
+    const float v = T.fy * PcY * invz + T.cy;
+    if (u < min_x || u > max_x) return R;
+    if (v < min_y || v > max_y) return R;
+    const float maxDistance = 1.2f * p.max_dist, minDistance = 0.8f * p.min_dist;
+    const float PO[3] = {p.Pw[0] - Ow[0], p.Pw[1] - Ow[1], p.Pw[2] - Ow[2]};
+    // cv::norm(NORM_L2) on CV_32F accumulates in double; Mat::dot accumulates in double
+    const float dist = (float)std::sqrt((double)PO[0] * PO[0] + (double)PO[1] * PO[1] + (double)PO[2] * PO[2]);
+    if (dist < minDistance || dist > maxDistance) return R;
+    double dotp = 0; for (int i = 0; i < 3; i++) dotp += (double)PO[i] * p.normal[i];
+    const float viewCos = (float)(dotp / dist);
+    if (viewCos < viewingCosLimit) return R;
+    // MapPoint::PredictScale: the reference's log(ratio) is libm logf (not correctly rounded in glibc); here the
+    // double log rounded once to float, like cos/sin in the descriptor (DESIGN.md deviations). Only feeds ceil().
+    const float ratio = p.max_dist / dist;
+    int nScale = (int)std::ceil((float)std::log((double)ratio) / log_scale_factor);
+    if (nScale < 0) nScale = 0; else if (nScale >= nlevels) nScale = nlevels - 1;
+    R.in_view = 1; R.proj_x = u; R.proj_y = v; R.level = nScale; R.view_cos = viewCos;
+    return R;
+}
+
+// Tracking.cc:1922-1937 + ORBmatcher.cc:45-129
+int search_local_points(const FrameGrid& cur, const PoseF& T, const float* sf, int nlevels, float log_scale_factor,
+                        const std::vector<LocalPoint>& pts, float th, float nnratio, const uint8_t* cur_owner_obs,
+                        std::vector<int>& match, std::vector<FrustumResult>* frustum) {
+    float Ow[3]; camera_centre(T, Ow);
+    int nmatches = 0;
+    const bool bFactor = th != 1.0f;
+    match.assign(cur.N, -1);
+    std::vector<uint8_t> owner_obs(cur_owner_obs, cur_owner_obs + cur.N);
+    if (frustum) frustum->assign(pts.size(), FrustumResult{0, 0, 0, 0, 0});
+    for (size_t i = 0; i < pts.size(); i++) {
+        const LocalPoint& p = pts[i];
+        if (p.skip || !p.valid) continue;                         // mnLastFrameSeen == id / isBad(): isInFrustum is not called
+        const FrustumResult fr = is_in_frustum(T, Ow, cur.minX, cur.maxX, cur.minY, cur.maxY, log_scale_factor, nlevels, p, 0.5f);
+        if (frustum) (*frustum)[i] = fr;
+        if (!fr.in_view) continue;
+        float r = fr.view_cos > 0.998 ? 2.5f : 4.0f;              // RadiusByViewingCos
+        if (bFactor) r *= th;
+        const std::vector<int> cand = cur.features_in_area(fr.proj_x, fr.proj_y, r * sf[fr.level], fr.level - 1, fr.level);
+        if (cand.empty()) continue;
+        int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+        for (int idx : cand) {
+            if (owner_obs[idx]) continue;
+            const int dist = descriptor_distance(p.desc, cur.desc + (size_t)32 * idx);
+            if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestLevel2 = bestLevel; bestLevel = cur.kps[idx].octave; bestIdx = idx; }
+            else if (dist < bestDist2) { bestLevel2 = cur.kps[idx].octave; bestDist2 = dist; }
+        }
+        if (bestDist <= TH_HIGH) {
+            if (bestLevel == bestLevel2 && bestDist > nnratio * bestDist2) continue;
+            match[bestIdx] = (int)i; owner_obs[bestIdx] = p.has_observations;
+            nmatches++;
+        }
+    }
+    return nmatches;
+}
+
 } // namespace ora

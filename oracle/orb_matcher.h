@@ -45,6 +45,31 @@ int search_by_projection_frame(const FrameGrid& cur, const PoseF& Tcur, const fl
                                const std::vector<LastFramePoint>& last, float th, bool check_orientation,
                                std::vector<int>& cur_match);
 
+// One local map point as Tracking::SearchLocalPoints sees it (reference src/Tracking.cc:1904-1958).
+struct LocalPoint {
+    uint8_t valid;            // !isBad()
+    uint8_t skip;             // mnLastFrameSeen == CurrentFrame.mnId (already matched in this frame)
+    uint8_t has_observations; // Observations() > 0 (ownership rule of the search)
+    float Pw[3], normal[3];   // GetWorldPos(), GetNormal()
+    float min_dist, max_dist; // mfMinDistance, mfMaxDistance (the 0.8 / 1.2 invariance factors are applied inside)
+    const uint8_t* desc;      // GetDescriptor()
+};
+struct FrustumResult { uint8_t in_view; float proj_x, proj_y, view_cos; int level; };
+// Frame::isInFrustum(pMP, viewingCosLimit) + MapPoint::PredictScale, reference src/Frame.cc:449-505,
+// src/MapPoint.cc:408-424. Ow = -Rcw^T tcw (mOw), log_scale_factor = log(scaleFactor) as float.
+FrustumResult is_in_frustum(const PoseF& T, const float* Ow, float min_x, float max_x, float min_y, float max_y,
+                            float log_scale_factor, int nlevels, const LocalPoint& p, float viewing_cos_limit);
+// mOw of Frame::UpdatePoseMatrices (src/Frame.cc:441-447) in cv::gemm float order.
+void camera_centre(const PoseF& T, float* Ow);
+
+// Tracking::SearchLocalPoints' isInFrustum loop + ORBmatcher::SearchByProjection(Frame&, vector<MapPoint*>&, th),
+// reference src/ORBmatcher.cc:45-129. cur_owner_obs[i2] = 1 when current keypoint i2 already holds a map
+// point with observations (it can then never be taken). match[i2] = index of the local point assigned
+// here, or -1. frustum (optional) receives the per-point isInFrustum fields.
+int search_local_points(const FrameGrid& cur, const PoseF& T, const float* scale_factors, int nlevels, float log_scale_factor,
+                        const std::vector<LocalPoint>& pts, float th, float nnratio, const uint8_t* cur_owner_obs,
+                        std::vector<int>& match, std::vector<FrustumResult>* frustum);
+
 // reference src/ORBmatcher.cc:1602-1643
 void compute_three_maxima(const std::vector<int>* histo, int L, int& ind1, int& ind2, int& ind3);
 

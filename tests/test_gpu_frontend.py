@@ -255,3 +255,54 @@ def test_host_dropin_search_by_projection(torch_cuda, oracle, streams):
     nm, match = m.SearchByProjection(s["k1"][:0], s["d1"][:0], BOUNDS, pose, s["s"]["cam"][:4], s["tables"]["scale"], s["k0"], s["flags"],
                                      s["Pw"], s["d0"], 15.0)
     assert nm == 0 and len(match) == 0
+
+
+@pytest.mark.parametrize("th,nnratio", [(1.0, 0.8), (5.0, 0.8)])
+def test_search_local_points_matches_oracle(torch_cuda, oracle, th, nnratio):
+    """a12: isInFrustum + SearchByProjection(Frame, local map points), two streams in one launch."""
+    torch = torch_cuda
+    from viorb_amd.synth import make_vi_stream, make_local_map, plane_points_f32
+    ex = oracle.Extractor()
+    sf = ex.tables()["scale"]
+    scenes = []
+    for seed in (4, 6):
+        s = make_vi_stream(seed, 3)
+        feats = [ex(f) for f in s["frames"]]
+        pts, descs = [], []
+        for j in (0, 1):
+            k, d = feats[j]
+            Rcw, tcw = cam_pose_from_navstate(s["ns_true"][j], s["cam"])
+            Pw = plane_points_f32(np.stack([k["x"], k["y"]], 1), np.concatenate([Rcw.ravel(), tcw]), s["cam"])
+            pts.append(make_local_map(k, Pw, s["ns_true"][j], s["cam"], sf)); descs.append(d)
+        rng = np.random.default_rng(seed)
+        pts_f, pts_desc = np.concatenate(pts), np.concatenate(descs)
+        flags = np.full(len(pts_f), 1 | 4, np.uint8)
+        flags[rng.random(len(flags)) < 0.05] &= ~np.uint8(1); flags[rng.random(len(flags)) < 0.3] |= 2; flags[rng.random(len(flags)) < 0.1] &= ~np.uint8(4)
+        k2, d2 = feats[2]
+        owner = (rng.random(len(k2)) < 0.3).astype(np.uint8)
+        Rcw, tcw = cam_pose_from_navstate(s["ns_true"][2], s["cam"])
+        scenes.append(dict(s=s, k2=k2, d2=d2, pose=np.concatenate([Rcw.ravel(), tcw]).astype(np.float32), pts_f=pts_f, pts_desc=pts_desc,
+                           flags=flags, owner=owner))
+    B, cap, pcap = len(scenes), 1016, 2100
+    st0 = dict(s=scenes[0]["s"], tables=ex.tables())
+    fe = make_frontend(st0, B, cap)
+    ck = pad(torch, [c["k2"] for c in scenes], cap, viorb_amd.KP_DTYPE); cd = pad(torch, [c["d2"] for c in scenes], cap, np.uint8, (32,))
+    cc = torch.tensor([len(c["k2"]) for c in scenes], dtype=torch.int32, device="cuda")
+    cs = torch.zeros((B, 3073), dtype=torch.int32, device="cuda"); ci = torch.zeros((B, cap), dtype=torch.int32, device="cuda")
+    fe.grid(ck.data_ptr(), cc.data_ptr(), B, cs, ci)
+    pf = pad(torch, [c["pts_f"] for c in scenes], pcap, np.float32, (8,)); pfl = pad(torch, [c["flags"] for c in scenes], pcap, np.uint8)
+    pd = pad(torch, [c["pts_desc"] for c in scenes], pcap, np.uint8, (32,))
+    pc = torch.tensor([len(c["pts_f"]) for c in scenes], dtype=torch.int32, device="cuda")
+    own = pad(torch, [c["owner"] for c in scenes], cap, np.uint8)
+    pose = torch.from_numpy(np.stack([c["pose"] for c in scenes])).cuda()
+    match = torch.full((B, cap), -7, dtype=torch.int32, device="cuda"); nm = torch.zeros(B, dtype=torch.int32, device="cuda")
+    fr = torch.zeros((B, pcap, 5), dtype=torch.float32, device="cuda"); status = torch.zeros(B, dtype=torch.int32, device="cuda")
+    fe.search_local_points(ck.data_ptr(), cd.data_ptr(), cc.data_ptr(), cs, ci, pose, pf, pfl, pd, pc, th, nnratio, own, B, match, nm, fr, status)
+    torch.cuda.synchronize()
+    assert (status.cpu().numpy() == 0).all()
+    for b, c in enumerate(scenes):
+        onm, om, ofr = oracle.search_local_points(c["k2"], c["d2"], BOUNDS, c["pose"], c["s"]["cam"][:4], sf, np.float32(np.log(np.float64(np.float32(1.2)))),
+                                                  c["pts_f"], c["flags"], c["pts_desc"], th, nnratio, c["owner"])
+        np.testing.assert_array_equal(fr[b, :len(ofr)].cpu().numpy(), ofr)
+        assert nm[b].item() == onm and onm > 100
+        np.testing.assert_array_equal(match[b, :len(om)].cpu().numpy(), om)

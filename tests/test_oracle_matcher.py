@@ -145,3 +145,95 @@ def test_search_edge_cases(oracle, pair):
     assert nm == 0
     nm, m = oracle.search_by_projection_frame(k1[:0], d1[:0], BOUNDS, pose, intr, sf, flags, Pw, mpd, loct, lang, 15)
     assert nm == 0 and len(m) == 0
+
+
+# ---- a12: isInFrustum + SearchByProjection(Frame, local map points) ------------------------------------------
+@pytest.fixture(scope="module")
+def local_scene(oracle):
+    from viorb_amd.synth import make_local_map, plane_points_f32
+    s = make_vi_stream(4, 3)
+    ex = oracle.Extractor()
+    feats = [ex(f) for f in s["frames"]]
+    sf = ex.tables()["scale"]
+    pts, descs = [], []
+    for j in (0, 1):                                   # local map = points seen from two earlier frames
+        k, d = feats[j]
+        Rcw, tcw = cam_pose_from_navstate(s["ns_true"][j], s["cam"])
+        Pw = plane_points_f32(np.stack([k["x"], k["y"]], 1), np.concatenate([Rcw.ravel(), tcw]), s["cam"])
+        pts.append(make_local_map(k, Pw, s["ns_true"][j], s["cam"], sf)); descs.append(d)
+    pts_f, pts_desc = np.concatenate(pts), np.concatenate(descs)
+    rng = np.random.default_rng(5)
+    flags = np.full(len(pts_f), 1 | 4, np.uint8)
+    flags[rng.random(len(flags)) < 0.05] &= ~np.uint8(1)        # bad points
+    flags[rng.random(len(flags)) < 0.3] |= 2                    # already matched in this frame
+    flags[rng.random(len(flags)) < 0.1] &= ~np.uint8(4)         # no observations
+    k2, d2 = feats[2]
+    owner = (rng.random(len(k2)) < 0.3).astype(np.uint8)        # keypoints already holding a map point with observations
+    Rcw, tcw = cam_pose_from_navstate(s["ns_true"][2], s["cam"])
+    pose = np.concatenate([Rcw.ravel(), tcw]).astype(np.float32)
+    return dict(s=s, sf=sf, k2=k2, d2=d2, pose=pose, pts_f=pts_f, pts_desc=pts_desc, flags=flags, owner=owner)
+
+
+def literal_local_search(oracle, L, th, nnratio):
+    f = np.float32
+    k2, d2, pose, sf = L["k2"], L["d2"], L["pose"], L["sf"]
+    intr = L["s"]["cam"][:4].astype(np.float32)
+    R, t = pose[:9].reshape(3, 3), pose[9:]
+    Ow = np.array([-f(f(f(R[0, r] * t[0]) + f(R[1, r] * t[1])) + f(R[2, r] * t[2])) for r in range(3)], np.float32)
+    logsf = f(np.log(np.float64(f(1.2))))
+    match = np.full(len(k2), -1, np.int32); owner = L["owner"].copy(); nm = 0
+    fr = np.zeros((len(L["pts_f"]), 5), np.float32)
+    for i, (p, fl) in enumerate(zip(L["pts_f"], L["flags"])):
+        if (fl & 2) or not (fl & 1):
+            continue
+        Pw, nrm, mind, maxd = p[:3], p[3:6], p[6], p[7]
+        pc = [f(f(f(f(R[r, 0] * Pw[0]) + f(R[r, 1] * Pw[1])) + f(R[r, 2] * Pw[2])) + t[r]) for r in range(3)]
+        if pc[2] < 0:
+            continue
+        invz = f(f(1.0) / pc[2])
+        u = f(f(f(intr[0] * pc[0]) * invz) + intr[2]); v = f(f(f(intr[1] * pc[1]) * invz) + intr[3])
+        if u < 0 or u > 752 or v < 0 or v > 480:
+            continue
+        PO = (Pw - Ow).astype(np.float32)
+        dist = f(np.sqrt(np.float64(PO[0]) ** 2 + np.float64(PO[1]) ** 2 + np.float64(PO[2]) ** 2))
+        if dist < f(f(0.8) * mind) or dist > f(f(1.2) * maxd):
+            continue
+        vc = f((np.float64(PO[0]) * nrm[0] + np.float64(PO[1]) * nrm[1] + np.float64(PO[2]) * nrm[2]) / np.float64(dist))
+        if vc < f(0.5):
+            continue
+        lvl = int(np.ceil(f(f(np.log(np.float64(f(maxd / dist)))) / logsf)))
+        lvl = min(max(lvl, 0), 7)
+        fr[i] = (1, u, v, vc, lvl)
+        r = f(2.5) if vc > 0.998 else f(4.0)
+        if th != 1.0:
+            r = f(r * f(th))
+        cand = oracle.features_in_area(k2, BOUNDS, u, v, f(r * sf[lvl]), lvl - 1, lvl)
+        b1 = b2 = 256; l1 = l2 = -1; bi = -1
+        for idx in cand:
+            if owner[idx]:
+                continue
+            dd = oracle.descriptor_distance(L["pts_desc"][i], d2[idx])
+            if dd < b1:
+                b2, b1, l2, l1, bi = b1, dd, l1, int(k2["octave"][idx]), idx
+            elif dd < b2:
+                l2, b2 = int(k2["octave"][idx]), dd
+        if b1 <= 100:
+            if l1 == l2 and b1 > f(nnratio) * b2:
+                continue
+            match[bi] = i; owner[bi] = 1 if (fl & 4) else 0; nm += 1
+    return nm, match, fr
+
+
+@pytest.mark.parametrize("th,nnratio", [(1.0, 0.8), (5.0, 0.8), (3.0, 0.6)])
+def test_search_local_points_equals_literal_restatement(oracle, local_scene, th, nnratio):
+    L = local_scene
+    nm, m, fr = oracle.search_local_points(L["k2"], L["d2"], BOUNDS, L["pose"], L["s"]["cam"][:4], L["sf"], np.float32(np.log(np.float64(np.float32(1.2)))),
+                                           L["pts_f"], L["flags"], L["pts_desc"], th, nnratio, L["owner"])
+    wn, wm, wfr = literal_local_search(oracle, L, th, nnratio)
+    np.testing.assert_array_equal(fr, wfr)
+    assert nm == wn and nm > 100
+    np.testing.assert_array_equal(m, wm)
+    assert not (L["owner"].astype(bool) & (m >= 0)).any()          # owned keypoints are never re-assigned
+    # frustum geometry against float64: projections agree, predicted level within the pyramid
+    inv = fr[:, 0] > 0
+    assert inv.sum() > 500 and ((fr[inv, 4] >= 0) & (fr[inv, 4] <= 7)).all() and (fr[inv, 3] >= 0.5).all()

@@ -273,6 +273,179 @@ __global__ __launch_bounds__(256) void k_search_projection(SearchArgs A) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Tracking::SearchLocalPoints: Frame::isInFrustum for every local map point (reference src/Frame.cc:449-505,
+// MapPoint::PredictScale src/MapPoint.cc:408-424) followed by ORBmatcher::SearchByProjection(F, vpMapPoints, th)
+// (reference src/ORBmatcher.cc:45-129): best / second-best Hamming among unowned grid candidates of levels
+// [lvl-1, lvl], same-level ratio test, greedy ownership in point order (same fixed-point scheme as above).
+// pts_f[i] = Pw3 normal3 minDist maxDist; pts_flags bit0 valid, bit1 skip (already matched in this frame),
+// bit2 has observations. cur_owner_obs[c] != 0: keypoint c already holds a map point with observations.
+// ---------------------------------------------------------------------------------------------
+#define LOCAL_SLOT 4
+struct LocalSearchArgs {
+    const viorb_keypoint* cur_kps; const uint8_t* cur_desc; const int* cur_count;
+    const int* cell_start; const int* cell_idx; const float* pose12;
+    const float* pts_f; const uint8_t* pts_flags; const uint8_t* pts_desc; const int* pts_count;
+    const uint8_t* cur_owner_obs;
+    int* match; int* nmatches; int* status; float* frustum;
+    uint32_t* cand; int* cand_n;
+    int cap, pcap;
+    float minX, maxX, minY, maxY, wInv, hInv, fx, fy, cx, cy, th, nnratio, log_sf;
+    float scale[16];
+    int nlevels;
+};
+__host__ __device__ inline size_t local_search_lds_bytes(int cap, int pcap) {
+    return (size_t)pcap * (LOCAL_SLOT * 4 + 4 + 4) + (size_t)cap * (4 + 8 + 2 + 1 + 1) + (size_t)(GRID_CELLS + 2) * 2 + 64;
+}
+
+__global__ __launch_bounds__(256) void k_search_local_points(LocalSearchArgs A) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+    const int b = blockIdx.x, cap = A.cap, pcap = A.pcap, t = threadIdx.x, lane = t & 63;
+    const int ncur = min(A.cur_count[b], cap), npts = min(A.pts_count[b], pcap);
+    uint32_t* slot = reinterpret_cast<uint32_t*>(s_raw);                       // [pcap][LOCAL_SLOT]
+    int* choice = reinterpret_cast<int*>(slot + (size_t)pcap * LOCAL_SLOT);     // [pcap]
+    int* nchoice = choice + pcap;                                                // [pcap]
+    int* taken = nchoice + pcap;                                                 // [cap]
+    float2* cxy = reinterpret_cast<float2*>(taken + cap);                        // [cap]
+    uint16_t* cs = reinterpret_cast<uint16_t*>(cxy + cap);                       // [GRID_CELLS + 2]
+    uint16_t* ci = cs + GRID_CELLS + 2;                                          // [cap]
+    uint8_t* coct = reinterpret_cast<uint8_t*>(ci + cap);                        // [cap]
+    uint8_t* cown = coct + cap;                                                  // [cap]
+    __shared__ int s_changed, s_nm, s_overflow;
+    const float* P = A.pose12 + (size_t)b * 12;
+    const viorb_keypoint* ck = A.cur_kps + (size_t)b * cap;
+    const uint8_t* pf = A.pts_flags + (size_t)b * pcap;
+    uint32_t* cand = A.cand + (size_t)b * pcap * CAND_CAP;
+    int* cand_n = A.cand_n + (size_t)b * pcap;
+    {
+        const int* gcs = A.cell_start + (size_t)b * (GRID_CELLS + 1);
+        const int* gci = A.cell_idx + (size_t)b * cap;
+        for (int i = t; i <= GRID_CELLS; i += blockDim.x) cs[i] = (uint16_t)gcs[i];
+        for (int i = t; i < ncur; i += blockDim.x) {
+            ci[i] = (uint16_t)gci[i];
+            const viorb_keypoint k = ck[i];
+            cxy[i] = make_float2(k.x, k.y); coct[i] = (uint8_t)k.octave;
+            cown[i] = A.cur_owner_obs[(size_t)b * cap + i] ? 1 : 0;
+        }
+    }
+    if (t == 0) { s_overflow = 0; s_nm = 0; }
+    __syncthreads();
+    // mOw = -Rcw^T tcw
+    float Ow[3];
+#pragma unroll
+    for (int r = 0; r < 3; r++) { const float tt = P[r] * P[9] + P[3 + r] * P[10] + P[6 + r] * P[11]; Ow[r] = -tt; }
+    const bool bFactor = A.th != 1.0f;
+    // ---- phase A: frustum + candidates
+    for (int i = t; i < npts; i += blockDim.x) {
+        int nc = 0;
+        const int fl = pf[i];
+        float fr_in = 0, fr_u = 0, fr_v = 0, fr_cos = 0, fr_lvl = 0;
+        if ((fl & 1) && !(fl & 2)) {
+            const float* X = A.pts_f + ((size_t)b * pcap + i) * 8;
+            float pc[3];
+#pragma unroll
+            for (int r = 0; r < 3; r++) { const float tt = P[3 * r] * X[0] + P[3 * r + 1] * X[1] + P[3 * r + 2] * X[2]; pc[r] = tt + P[9 + r]; }
+            bool ok = !(pc[2] < 0.0f);
+            const float invz = 1.0f / pc[2];
+            const float u = A.fx * pc[0] * invz + A.cx, v = A.fy * pc[1] * invz + A.cy;
+            ok = ok && !(u < A.minX || u > A.maxX) && !(v < A.minY || v > A.maxY);
+            const float maxD = 1.2f * X[7], minD = 0.8f * X[6];
+            const float PO0 = X[0] - Ow[0], PO1 = X[1] - Ow[1], PO2 = X[2] - Ow[2];
+            const float dist = (float)sqrt((double)PO0 * PO0 + (double)PO1 * PO1 + (double)PO2 * PO2);
+            ok = ok && !(dist < minD || dist > maxD);
+            const float viewCos = (float)(((double)PO0 * X[3] + (double)PO1 * X[4] + (double)PO2 * X[5]) / (double)dist);
+            ok = ok && !(viewCos < 0.5f);
+            if (ok) {
+                const float ratio = X[7] / dist;
+                int lvl = (int)ceilf(viorb_logf(ratio) / A.log_sf);
+                lvl = lvl < 0 ? 0 : (lvl >= A.nlevels ? A.nlevels - 1 : lvl);
+                fr_in = 1; fr_u = u; fr_v = v; fr_cos = viewCos; fr_lvl = (float)lvl;
+                float rr = viewCos > 0.998 ? 2.5f : 4.0f;
+                if (bFactor) rr *= A.th;
+                const float radius = rr * A.scale[lvl];
+                const int minL = lvl - 1, maxL = lvl;
+                const int x0 = max(0, (int)floorf((u - A.minX - radius) * A.wInv));
+                const int x1 = min((int)GRID_COLS - 1, (int)ceilf((u - A.minX + radius) * A.wInv));
+                const int y0 = max(0, (int)floorf((v - A.minY - radius) * A.hInv));
+                const int y1 = min((int)GRID_ROWS - 1, (int)ceilf((v - A.minY + radius) * A.hInv));
+                if (x0 < GRID_COLS && x1 >= 0 && y0 < GRID_ROWS && y1 >= 0) {
+                    const uint4* dl = reinterpret_cast<const uint4*>(A.pts_desc + ((size_t)b * pcap + i) * 32);
+                    const uint4 da = dl[0], db = dl[1];
+                    const bool check_levels = (minL > 0) || (maxL >= 0);
+                    for (int ix = x0; ix <= x1; ix++) {
+                        const int pbeg = cs[ix * GRID_ROWS + y0], pend = cs[ix * GRID_ROWS + y1 + 1];
+                        for (int p = pbeg; p < pend; p++) {
+                            const int i2 = ci[p];
+                            const int o2 = coct[i2];
+                            if (check_levels) { if (o2 < minL) continue; if (maxL >= 0 && o2 > maxL) continue; }
+                            const float2 q = cxy[i2];
+                            if (!(fabsf(q.x - u) < radius && fabsf(q.y - v) < radius)) continue;
+                            if (cown[i2]) continue;                 // held by a point with observations: never available
+                            const uint4* dc = reinterpret_cast<const uint4*>(A.cur_desc + ((size_t)b * cap + i2) * 32);
+                            const uint4 ea = dc[0], eb = dc[1];
+                            const int dist2 = __popc(da.x ^ ea.x) + __popc(da.y ^ ea.y) + __popc(da.z ^ ea.z) + __popc(da.w ^ ea.w) +
+                                              __popc(db.x ^ eb.x) + __popc(db.y ^ eb.y) + __popc(db.z ^ eb.z) + __popc(db.w ^ eb.w);
+                            const uint32_t e = ((uint32_t)dist2 << 16) | (uint32_t)i2;
+                            if (nc < LOCAL_SLOT) slot[(size_t)i * LOCAL_SLOT + nc] = e;
+                            else if (nc < CAND_CAP) cand[(size_t)i * CAND_CAP + nc] = e;
+                            nc++;
+                        }
+                    }
+                }
+            }
+        }
+        if (A.frustum) { float* f = A.frustum + ((size_t)b * pcap + i) * 5; f[0] = fr_in; f[1] = fr_u; f[2] = fr_v; f[3] = fr_cos; f[4] = fr_lvl; }
+        if (nc > CAND_CAP) { nc = CAND_CAP; s_overflow = 1; }
+        cand_n[i] = nc;
+        choice[i] = -1;
+    }
+    __syncthreads();
+    // ---- phase B: fixed-point sweeps over the greedy ownership
+    for (int sweep = 0; sweep <= npts; sweep++) {
+        for (int c = t; c < ncur; c += blockDim.x) taken[c] = 0x7fffffff;
+        if (t == 0) s_changed = 0;
+        __syncthreads();
+        for (int i = t; i < npts; i += blockDim.x)
+            if (choice[i] >= 0 && (pf[i] & 4)) atomicMin(&taken[choice[i]], i);
+        __syncthreads();
+        bool changed = false;
+        for (int i = t; i < npts; i += blockDim.x) {
+            const int nc = cand_n[i];
+            int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+            for (int k = 0; k < nc; k++) {
+                const uint32_t e = k < LOCAL_SLOT ? slot[(size_t)i * LOCAL_SLOT + k] : cand[(size_t)i * CAND_CAP + k];
+                const int i2 = (int)(e & 0xffff), dist = (int)(e >> 16);
+                if (taken[i2] < i) continue;
+                if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestLevel2 = bestLevel; bestLevel = coct[i2]; bestIdx = i2; }
+                else if (dist < bestDist2) { bestLevel2 = coct[i2]; bestDist2 = dist; }
+            }
+            int nw = -1;
+            if (bestDist <= TH_HIGH && !(bestLevel == bestLevel2 && (float)bestDist > A.nnratio * (float)bestDist2)) nw = bestIdx;
+            changed = changed || (nw != choice[i]);
+            nchoice[i] = nw;
+        }
+        if (__any(changed) && lane == 0) s_changed = 1;
+        __syncthreads();
+        for (int i = t; i < npts; i += blockDim.x) choice[i] = nchoice[i];
+        __syncthreads();
+        if (!s_changed) break;
+    }
+    // ---- output: last assigner of every keypoint
+    for (int c = t; c < ncur; c += blockDim.x) taken[c] = -1;
+    __syncthreads();
+    {
+        int my_n = 0;
+        for (int i = t; i < npts; i += blockDim.x) if (choice[i] >= 0) { atomicMax(&taken[choice[i]], i); my_n++; }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) my_n += __shfl_xor(my_n, d);
+        if (lane == 0) atomicAdd(&s_nm, my_n);
+    }
+    __syncthreads();
+    int* out = A.match + (size_t)b * cap;
+    for (int c = t; c < cap; c += blockDim.x) out[c] = c < ncur ? taken[c] : -1;
+    if (t == 0) { A.nmatches[b] = s_nm; if (s_overflow) A.status[b] = VIORB_ERR_CAPACITY; }
+}
+
+// ---------------------------------------------------------------------------------------------
 // IMU: pre-integrate the samples between two frames, predict the NavState, derive the float pose.
 // One workgroup (128 threads) per stream; the 9x9 covariance product is spread over 81 lanes, the
 // 3x3 state is carried redundantly by every lane.
@@ -877,6 +1050,7 @@ struct viorb_frontend {
     int max_batch = 0, cap = 0, device = 0, sort_n = 0;
     float wInv = 0, hInv = 0;
     uint32_t* d_cand = nullptr; int* d_cand_n = nullptr;
+    uint32_t* d_lcand = nullptr; int* d_lcand_n = nullptr; int lcand_pcap = 0;
     double *d_cam = nullptr, *d_gw = nullptr; float* d_inv_sigma2 = nullptr;
 };
 
@@ -919,6 +1093,8 @@ int viorb_frontend_destroy(viorb_frontend* h) {
     (void)hipSetDevice(h->device);
     if (h->d_cand) (void)hipFree(h->d_cand);
     if (h->d_cand_n) (void)hipFree(h->d_cand_n);
+    if (h->d_lcand) (void)hipFree(h->d_lcand);
+    if (h->d_lcand_n) (void)hipFree(h->d_lcand_n);
     if (h->d_cam) (void)hipFree(h->d_cam);
     if (h->d_gw) (void)hipFree(h->d_gw);
     if (h->d_inv_sigma2) (void)hipFree(h->d_inv_sigma2);
@@ -973,6 +1149,44 @@ int viorb_frontend_search_projection_device(viorb_frontend* h, const viorb_keypo
     VIORB_HIP_TRY(hipMemsetAsync(status, 0, sizeof(int32_t) * batch, (hipStream_t)stream));
     ProfScope ps("k_search_projection", (hipStream_t)stream);
     hipLaunchKernelGGL(k_search_projection, dim3(batch), dim3(256), search_lds_bytes(h->cap), (hipStream_t)stream, A);
+    VIORB_HIP_TRY(hipGetLastError());
+    return VIORB_OK;
+}
+
+int viorb_frontend_search_local_points_device(viorb_frontend* h, const viorb_keypoint* cur_kps, const uint8_t* cur_desc, const int32_t* cur_count,
+                                              const int32_t* cell_start, const int32_t* cell_idx, const float* pose12, const float* pts_f,
+                                              const uint8_t* pts_flags, const uint8_t* pts_desc, const int32_t* pts_count, int pcap, float th,
+                                              float nnratio, const uint8_t* cur_owner_obs, int batch, int32_t* match, int32_t* nmatches,
+                                              float* frustum, int32_t* status, void* stream) {
+    FE_CHECK_BATCH(h, batch);
+    VIORB_REQUIRE(cur_kps && cur_desc && cur_count && cell_start && cell_idx && pose12 && pts_f && pts_flags && pts_desc && pts_count &&
+                  cur_owner_obs && match && nmatches && status, "null array");
+    VIORB_REQUIRE(pcap >= 1 && pcap <= 65535, "1 <= pcap <= 65535");
+    const size_t lds = local_search_lds_bytes(h->cap, pcap);
+    if (lds > 160 * 1024) { set_error("%d local points x %d keypoints need %zu B of LDS", pcap, h->cap, lds); return VIORB_ERR_UNSUPPORTED; }
+    if (h->lcand_pcap < pcap) {
+        if (h->d_lcand) (void)hipFree(h->d_lcand);
+        if (h->d_lcand_n) (void)hipFree(h->d_lcand_n);
+        h->d_lcand = nullptr; h->d_lcand_n = nullptr; h->lcand_pcap = 0;
+        VIORB_HIP_TRY(hipMalloc(&h->d_lcand, (size_t)h->max_batch * pcap * CAND_CAP * sizeof(uint32_t)));
+        VIORB_HIP_TRY(hipMalloc(&h->d_lcand_n, (size_t)h->max_batch * pcap * sizeof(int)));
+        h->lcand_pcap = pcap;
+        if (lds > 64 * 1024)
+            VIORB_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_search_local_points), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
+    LocalSearchArgs A;
+    A.cur_kps = cur_kps; A.cur_desc = cur_desc; A.cur_count = cur_count; A.cell_start = cell_start; A.cell_idx = cell_idx; A.pose12 = pose12;
+    A.pts_f = pts_f; A.pts_flags = pts_flags; A.pts_desc = pts_desc; A.pts_count = pts_count; A.cur_owner_obs = cur_owner_obs;
+    A.match = match; A.nmatches = nmatches; A.status = status; A.frustum = frustum; A.cand = h->d_lcand; A.cand_n = h->d_lcand_n;
+    A.cap = h->cap; A.pcap = pcap;
+    A.minX = h->cfg.min_x; A.maxX = h->cfg.max_x; A.minY = h->cfg.min_y; A.maxY = h->cfg.max_y; A.wInv = h->wInv; A.hInv = h->hInv;
+    A.fx = h->cfg.fx; A.fy = h->cfg.fy; A.cx = h->cfg.cx; A.cy = h->cfg.cy; A.th = th; A.nnratio = nnratio;
+    A.log_sf = (float)log((double)h->cfg.scale_factors[h->cfg.nlevels > 1 ? 1 : 0]);   // Frame::mfLogScaleFactor = log(mfScaleFactor), rounded once
+    for (int i = 0; i < 16; i++) A.scale[i] = h->cfg.scale_factors[i];
+    A.nlevels = h->cfg.nlevels;
+    VIORB_HIP_TRY(hipMemsetAsync(status, 0, sizeof(int32_t) * batch, (hipStream_t)stream));
+    ProfScope ps("k_search_local_points", (hipStream_t)stream);
+    hipLaunchKernelGGL(k_search_local_points, dim3(batch), dim3(256), lds, (hipStream_t)stream, A);
     VIORB_HIP_TRY(hipGetLastError());
     return VIORB_OK;
 }

@@ -87,6 +87,10 @@ VIORB_HD void sincos_f32(float r, float* s_out, float* c_out) {
     *c_out = (float)c;
 }
 
+// logf for MapPoint::PredictScale (reference src/MapPoint.cc:408-424: log(ratio)/mfLogScaleFactor, then ceil).
+// Evaluated in double and rounded once so host and device agree; the result only feeds a ceil().
+VIORB_HD float viorb_logf(float x) { return (float)log((double)x); }
+
 // 256-bit Hamming distance, reference src/ORBmatcher.cc:1648-1664 (SWAR popcount there).
 VIORB_HD int hamming256(const uint32_t* a, const uint32_t* b) {
     int d = 0;

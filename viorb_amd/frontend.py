@@ -121,6 +121,14 @@ class Frontend:
             p(last_count), ptr(last_flags), ptr(last_Pw), p(last_desc), float(th), batch, ptr(cur_match), ptr(nmatches), ptr(status),
             self._st(stream)))
 
+    def search_local_points(self, cur_kps_ptr, cur_desc_ptr, cur_count_ptr, cell_start, cell_idx, pose12, pts_f, pts_flags, pts_desc,
+                            pts_count, th, nnratio, cur_owner_obs, batch, match, nmatches, frustum, status, stream=None):
+        p = lambda a: a if isinstance(a, C.c_void_p) else (C.c_void_p(a) if isinstance(a, int) else ptr(a))
+        check(self.L.viorb_frontend_search_local_points_device(
+            self.h, p(cur_kps_ptr), p(cur_desc_ptr), p(cur_count_ptr), ptr(cell_start), ptr(cell_idx), ptr(pose12), ptr(pts_f),
+            ptr(pts_flags), ptr(pts_desc), ptr(pts_count), pts_f.shape[1], float(th), float(nnratio), ptr(cur_owner_obs), batch,
+            ptr(match), ptr(nmatches), ptr(frustum) if frustum is not None else None, ptr(status), self._st(stream)))
+
     def build_observations(self, kps_ptr, count_ptr, match, match_Pw, batch, obs, obs_index, n_obs, stream=None):
         p = lambda a: a if isinstance(a, C.c_void_p) else (C.c_void_p(a) if isinstance(a, int) else ptr(a))
         check(self.L.viorb_frontend_build_observations_device(self.h, p(kps_ptr), p(count_ptr), ptr(match), ptr(match_Pw), batch,

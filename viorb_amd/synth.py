@@ -322,3 +322,18 @@ def plane_points_f32(kps_xy, pose12_true, cam):
     oz = -(T[2] * T[9] + T[5] * T[10] + T[8] * T[11])
     s = (PLANE_Z0 - oz) / rz
     return np.stack([ox + s * rx, oy + s * ry, oz + s * rz], 1).astype(np.float32)
+
+
+def make_local_map(kps, Pw, ns_ref, cam, scale_factors):
+    """Local map points from the keypoints of a reference key frame (MapPoint::UpdateNormalAndDepth, reference
+    src/MapPoint.cc:339-378): normal = unit viewing ray, mfMaxDistance = dist * scale[octave],
+    mfMinDistance = mfMaxDistance / scale[nLevels-1]. Returns pts_f [n,8] float32 = Pw3 normal3 minDist maxDist."""
+    Rcw, tcw = cam_pose_from_navstate(ns_ref, cam)
+    Ow = -Rcw.T @ tcw
+    PO = Pw.astype(np.float64) - Ow
+    dist = np.linalg.norm(PO, axis=1)
+    normal = PO / dist[:, None]
+    sf = np.asarray(scale_factors, np.float64)
+    maxd = dist * sf[kps["octave"]]
+    mind = maxd / sf[-1]
+    return np.concatenate([Pw.astype(np.float64), normal, mind[:, None], maxd[:, None]], 1).astype(np.float32)
