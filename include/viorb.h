@@ -211,6 +211,14 @@ int viorb_frontend_pose_opt_device(viorb_frontend* h, int variant, int compute_m
                                    double* out_last_ns, uint8_t* outlier_cur, uint8_t* outlier_last, double* marg_out,
                                    double* info, void* stream);
 
+/* Optimizer::PoseOptimization(Frame*) — vision-only 6-DoF solve (reference src/Optimizer.cc:3749-3978) for a batch.
+ * pose12[b] = Rcw(9) tcw(3) of pFrame->mTcw (float), obs7[b][cap][7] = Xw3 u v uRight invSigma2 in keypoint order
+ * (uRight < 0: monocular edge, else stereo edge with baseline*fx = bf). Intrinsics are the handle's fx fy cx cy.
+ * Outputs: out_pose12[b] (SetPose), outlier[b][cap] (mvbOutlier per observation), info[b][4] = {return value, final
+ * robust chi2, LM iterations, 0}. Fewer than 3 observations: pose unchanged, return value 0. */
+int viorb_frontend_pose_opt_se3_device(viorb_frontend* h, const float* pose12, const double* obs7, const int32_t* n_obs,
+                                       double bf, int batch, float* out_pose12, uint8_t* outlier, double* info, void* stream);
+
 /* Workload support for bench.py / tests (no reference counterpart): map points of the synthetic plane
  * world (viorb_amd/synth.py) for all keypoints of a frame; pose12 = Rcw(9) tcw(3) in double per stream.
  * Writes Pw[b][cap][3] and flags[b][cap] = 1|4 (map point with observations), 0 beyond count[b]. */
@@ -244,6 +252,10 @@ int viorb_pose_opt_vi(int variant, int compute_marg, const double cur_ns[22], co
                       const double gw[3], const double cam[16], const double* obs_cur, int n_cur, const double* obs_last,
                       int n_last, double out_ns[22], double out_last_ns[22], uint8_t* outlier_cur, uint8_t* outlier_last,
                       double* marg_out144, double info[4]);
+
+/* Host-buffer form of the vision-only solve; intr5 = fx fy cx cy bf (float, as Frame stores them). */
+int viorb_pose_opt_se3(const float pose12[12], const float intr5[5], const double* obs7, int n, float out_pose12[12],
+                       uint8_t* outlier, double info[4]);
 
 /* Host-only test hooks (no GPU needed; used by the CPU test-suite to compare product host code with
  * the oracle): the flat-array formulation of DistributeOctTree that the device kernel mirrors

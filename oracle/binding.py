@@ -182,6 +182,7 @@ def _vio():
         L.ora_edge_pvr.argtypes = [vp] * 9
         L.ora_edge_proj.argtypes = [vp] * 5
         L.ora_edge_prior.argtypes = [vp] * 6
+        L.ora_pose_opt_se3.argtypes = [vp, vp, vp, i, vp, vp, vp]
         L.ora_pose_opt_vi_kf.argtypes = [vp, vp, vp, vp, vp, vp, i, i, vp, vp, vp, vp, vp, i]
         L.ora_pose_opt_vi_frame.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i, vp, i, i, vp, vp, vp, vp, vp, vp, vp, i]
         _vio_ready = True
@@ -373,3 +374,12 @@ def search_local_points(cur_kps, cur_desc, bounds, pose12, intr4, scale_factors,
                                           _p(np.ascontiguousarray(pts_flags, np.uint8)), _p(np.ascontiguousarray(pts_desc, np.uint8)),
                                           float(th), float(nnratio), _p(np.ascontiguousarray(cur_owner_obs, np.uint8)), _p(m), _p(fr))
     return nm, m[:n], fr[:len(pts_f)]
+
+
+def pose_opt_se3(pose12, intr5, obs7):
+    """Optimizer::PoseOptimization(Frame*) (vision only). obs7 [n,7] = Xw3 u v ur invSigma2 (ur < 0 = mono edge),
+    intr5 = fx fy cx cy bf. Returns dict(pose12 float32, outlier, n_inliers, final_chi2, lm_iterations)."""
+    obs7 = _f64(obs7).reshape(-1, 7)
+    out, fl, info = np.zeros(12, np.float32), np.zeros(max(len(obs7), 1), np.uint8), np.zeros(3)
+    _vio().ora_pose_opt_se3(_p(np.ascontiguousarray(pose12, np.float32)), _p(_f64(intr5, 5)), _p(obs7), len(obs7), _p(out), _p(fl), _p(info))
+    return dict(pose12=out, outlier=fl[:len(obs7)], n_inliers=int(info[0]), final_chi2=float(info[1]), lm_iterations=int(info[2]))

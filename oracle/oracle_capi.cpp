@@ -286,3 +286,15 @@ int ora_search_local_points(const KeyPoint* cur_kps, const uint8_t* cur_desc, in
     return n;
 }
 } // extern "C"
+
+extern "C" {
+// obs7[n][7] = Xw3 u v ur invSigma2 (ur < 0: mono); intr5 = fx fy cx cy bf; info3 = inliers, chi2, LM iterations.
+void ora_pose_opt_se3(const float* pose12, const double* intr5, const double* obs7, int n, float* out_pose12, uint8_t* outlier, double* info3) {
+    std::vector<Se3Obs> o(n);
+    for (int i = 0; i < n; i++) { o[i].Xw = v3(obs7 + 7 * i); o[i].u = obs7[7 * i + 3]; o[i].v = obs7[7 * i + 4]; o[i].ur = obs7[7 * i + 5]; o[i].inv_sigma2 = obs7[7 * i + 6]; }
+    Se3Result R = pose_opt_se3(pose12, intr5[0], intr5[1], intr5[2], intr5[3], intr5[4], o);
+    for (int i = 0; i < 12; i++) out_pose12[i] = R.pose12[i];
+    for (int i = 0; i < n; i++) outlier[i] = R.outlier[i];
+    info3[0] = R.n_inliers; info3[1] = R.final_chi2; info3[2] = R.lm_iterations;
+}
+} // extern "C"

@@ -407,4 +407,126 @@ PoseOptResult pose_opt_vi_frame(const NavState& cur, const NavState& last, const
     return R;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Vision-only PoseOptimization(Frame*) — one VertexSE3Expmap, mono (2-D) and stereo (3-D) only-pose edges
+// ------------------------------------------------------------------------------------------------
+namespace {
+struct SE3Q {                                  // g2o::SE3Quat
+    Quat r; V3 t;
+    void normalize_rotation() { if (r.w < 0) { r.x = -r.x; r.y = -r.y; r.z = -r.z; r.w = -r.w; } r = normalized(r); }
+    V3 map(V3 p) const { return rotate(r, p) + t; }
+};
+static SE3Q se3_mul(const SE3Q& a, const SE3Q& b) { SE3Q o = a; o.t = o.t + rotate(a.r, b.t); o.r = a.r * b.r; o.normalize_rotation(); return o; }
+// SE3Quat::exp, se3quat.h:223-257 (update = [omega, upsilon])
+static SE3Q se3_exp(const double* u) {
+    const V3 omega{u[0], u[1], u[2]}, ups{u[3], u[4], u[5]};
+    const double theta = norm(omega);
+    const M3 Om = hat(omega);
+    M3 R, Vm;
+    if (theta < 0.00001) { R = M3::identity() + Om + Om * Om; Vm = R; }
+    else {
+        const M3 Om2 = Om * Om;
+        R = M3::identity() + Om * (std::sin(theta) / theta) + Om2 * ((1 - std::cos(theta)) / (theta * theta));
+        Vm = M3::identity() + Om * ((1 - std::cos(theta)) / (theta * theta)) + Om2 * ((theta - std::sin(theta)) / std::pow(theta, 3));
+    }
+    SE3Q o; o.r = quat_from_matrix(R); o.t = Vm * ups; o.normalize_rotation(); return o;
+}
+struct Se3Edge { Se3Obs o; bool stereo; int level = 0; double delta; double err[3]; double J[3][6]; int dim; };
+} // namespace
+
+Se3Result pose_opt_se3(const float* pose12, double fx, double fy, double cx, double cy, double bf, const std::vector<Se3Obs>& obs) {
+    Se3Result R; for (int i = 0; i < 12; i++) R.pose12[i] = pose12[i];
+    R.outlier.assign(obs.size(), 0);
+    auto from_pose = [&]() {                     // Converter::toSE3Quat(pFrame->mTcw)
+        M3 Rm; for (int i = 0; i < 9; i++) Rm.m[i] = (double)pose12[i];
+        SE3Q s; s.r = quat_from_matrix(Rm); s.t = V3{(double)pose12[9], (double)pose12[10], (double)pose12[11]}; s.normalize_rotation(); return s;
+    };
+    std::vector<Se3Edge> E(obs.size());
+    for (size_t i = 0; i < obs.size(); i++) {
+        E[i].o = obs[i]; E[i].stereo = !(obs[i].ur < 0); E[i].dim = E[i].stereo ? 3 : 2;
+        E[i].delta = E[i].stereo ? fsqrt(7.815) : fsqrt(5.991);
+    }
+    const int nInitial = (int)obs.size();
+    if (nInitial < 3) { R.n_inliers = 0; return R; }
+    SE3Q est = from_pose();
+    auto compute_error = [&](Se3Edge& e) {
+        const V3 p = est.map(e.o.Xw);
+        if (!e.stereo) { e.err[0] = e.o.u - (p.x / p.z * fx + cx); e.err[1] = e.o.v - (p.y / p.z * fy + cy); e.err[2] = 0; }
+        else {
+            const float invz = 1.0f / (float)p.z;                      // the reference computes this reciprocal in float
+            const double r0 = p.x * invz * fx + cx, r1 = p.y * invz * fy + cy, r2 = r0 - bf * invz;
+            e.err[0] = e.o.u - r0; e.err[1] = e.o.v - r1; e.err[2] = e.o.ur - r2;
+        }
+    };
+    auto chi2 = [&](const Se3Edge& e) { double s = 0; for (int k = 0; k < e.dim; k++) s += e.err[k] * e.o.inv_sigma2 * e.err[k]; return s; };
+    auto linearize = [&](Se3Edge& e) {
+        const V3 p = est.map(e.o.Xw);
+        const double x = p.x, y = p.y, invz = 1.0 / p.z, invz_2 = invz * invz;
+        double (*J)[6] = e.J;
+        J[0][0] = x * y * invz_2 * fx; J[0][1] = -(1 + (x * x * invz_2)) * fx; J[0][2] = y * invz * fx; J[0][3] = -invz * fx; J[0][4] = 0; J[0][5] = x * invz_2 * fx;
+        J[1][0] = (1 + y * y * invz_2) * fy; J[1][1] = -x * y * invz_2 * fy; J[1][2] = -x * invz * fy; J[1][3] = 0; J[1][4] = -invz * fy; J[1][5] = y * invz_2 * fy;
+        if (e.stereo) { J[2][0] = J[0][0] - bf * y * invz_2; J[2][1] = J[0][1] + bf * x * invz_2; J[2][2] = J[0][2]; J[2][3] = J[0][3]; J[2][4] = 0; J[2][5] = J[0][5] - bf * invz_2; }
+    };
+    auto active_chi = [&]() { double c = 0; for (auto& e : E) if (e.level == 0) { if (e.delta > 0) { double r[3]; huber(chi2(e), e.delta, r); c += r[0]; } else c += chi2(e); } return c; };
+    const float chi2Mono = 5.991f, chi2Stereo = 7.815f;
+    int nBad = 0; double lambda = 0, ni = 2; int its_total = 0; double last_chi = 0;
+    for (int round = 0; round < 4; round++) {
+        est = from_pose();
+        int nBadLM = 0;
+        for (int it = 0; it < 10; it++) {
+            for (auto& e : E) if (e.level == 0) compute_error(e);
+            double currentChi = active_chi(); const double iniChi = currentChi;
+            Mat H(6, 6); std::vector<double> b(6, 0.0), x;
+            for (auto& e : E) {
+                if (e.level != 0) continue;
+                linearize(e);
+                double w = 1.0; if (e.delta > 0) { double r[3]; huber(chi2(e), e.delta, r); w = r[1]; }
+                for (int c = 0; c < 6; c++) {
+                    double s = 0; for (int k = 0; k < e.dim; k++) s += e.J[k][c] * e.o.inv_sigma2 * e.err[k];
+                    b[c] -= w * s;
+                    for (int d = 0; d < 6; d++) { double q = 0; for (int k = 0; k < e.dim; k++) q += e.J[k][c] * e.o.inv_sigma2 * e.J[k][d]; H(c, d) += w * q; }
+                }
+            }
+            if (it == 0) { double mx = 0; for (int i = 0; i < 6; i++) mx = std::max(std::fabs(H(i, i)), mx); lambda = 1e-5 * mx; ni = 2; nBadLM = 0; }
+            double rho = 0; int qmax = 0;
+            do {
+                const SE3Q backup = est;
+                Mat Hl = H; for (int i = 0; i < 6; i++) Hl(i, i) += lambda;
+                const bool ok2 = cholesky_solve(Hl, b, x);
+                if (!ok2) x.assign(6, 0.0);
+                est = se3_mul(se3_exp(x.data()), est);                 // VertexSE3Expmap::oplusImpl
+                for (auto& e : E) if (e.level == 0) compute_error(e);
+                double tempChi = active_chi();
+                if (!ok2) tempChi = std::numeric_limits<double>::max();
+                double scale = 0; for (int j = 0; j < 6; j++) scale += x[j] * (lambda * x[j] + b[j]);
+                scale += 1e-3;
+                rho = (currentChi - tempChi) / scale;
+                if (rho > 0 && std::isfinite(tempChi)) {
+                    double alpha = 1. - std::pow((2 * rho - 1), 3); alpha = std::min(alpha, 2. / 3.);
+                    lambda *= std::max(1. / 3., alpha); ni = 2; currentChi = tempChi;
+                } else { lambda *= ni; ni *= 2; est = backup; }
+                qmax++;
+            } while (rho < 0 && qmax < 10);
+            its_total++; last_chi = currentChi;
+            if (qmax == 10 || rho == 0) break;
+            if ((iniChi - currentChi) * 1e3 < iniChi) nBadLM++; else nBadLM = 0;
+            if (nBadLM >= 3) break;
+        }
+        nBad = 0;
+        for (size_t i = 0; i < E.size(); i++) {
+            Se3Edge& e = E[i];
+            if (R.outlier[i]) compute_error(e);
+            const float c2 = (float)chi2(e);
+            if (c2 > (e.stereo ? chi2Stereo : chi2Mono)) { R.outlier[i] = 1; e.level = 1; nBad++; } else { R.outlier[i] = 0; e.level = 0; }
+            if (round == 2) e.delta = 0;
+        }
+        if (E.size() < 10) break;
+    }
+    const M3 Rm = to_matrix(est.r);
+    for (int i = 0; i < 9; i++) R.pose12[i] = (float)Rm.m[i];
+    R.pose12[9] = (float)est.t.x; R.pose12[10] = (float)est.t.y; R.pose12[11] = (float)est.t.z;
+    R.n_inliers = nInitial - nBad; R.final_chi2 = last_chi; R.lm_iterations = its_total;
+    return R;
+}
+
 } // namespace ora

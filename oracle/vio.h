@@ -78,6 +78,17 @@ PoseOptResult pose_opt_vi_frame(const NavState& cur, const NavState& last, const
                                 const std::vector<Observation>& obs_cur, const std::vector<Observation>& obs_last,
                                 bool compute_marg);
 
+// ---- vision-only pose optimisation, Optimizer::PoseOptimization(Frame*), reference src/Optimizer.cc:3749-3978,
+// edges Thirdparty/g2o/g2o/types/types_six_dof_expmap.cpp:266-364, SE3Quat::exp se3quat.h:223-257.
+struct Se3Obs { V3 Xw; double u, v, ur; double inv_sigma2; };     // ur < 0: monocular edge, else stereo edge
+struct Se3Result {
+    float pose12[12];                   // Converter::toCvMat(SE3Quat): Rcw row-major + tcw, float
+    std::vector<uint8_t> outlier;
+    int n_inliers = 0; double final_chi2 = 0; int lm_iterations = 0;
+};
+Se3Result pose_opt_se3(const float* pose12, double fx, double fy, double cx, double cy, double bf,
+                       const std::vector<Se3Obs>& obs);
+
 // Residual / Jacobian blocks of the individual edges, exposed for the definitional tests.
 void edge_pvr_error(const NavState& i, const NavState& j, const NavState& bias_i, const Preint& M, V3 gw, double* e9);
 void edge_pvr_jacobians(const NavState& i, const NavState& j, const NavState& bias_i, const Preint& M, V3 gw,

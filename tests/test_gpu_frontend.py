@@ -306,3 +306,22 @@ def test_search_local_points_matches_oracle(torch_cuda, oracle, th, nnratio):
         np.testing.assert_array_equal(fr[b, :len(ofr)].cpu().numpy(), ofr)
         assert nm[b].item() == onm and onm > 100
         np.testing.assert_array_equal(match[b, :len(om)].cpu().numpy(), om)
+
+
+@pytest.mark.parametrize("stereo_frac", [0.0, 0.6, 1.0])
+def test_pose_optimisation_se3_matches_oracle(torch_cuda, oracle, stereo_frac):
+    """a21: vision-only PoseOptimization(Frame*) with mono and stereo edges."""
+    from viorb_amd.synth import make_se3_problem
+    for seed in (0, 1, 2):
+        p = make_se3_problem(seed, n_points=300 + 150 * seed, stereo_frac=stereo_frac)
+        intr5 = p["intr5"].astype(np.float32)
+        o = oracle.pose_opt_se3(p["pose0"], intr5.astype(np.float64), p["obs7"])
+        g = viorb_amd.PoseOptimizationSE3(p["pose0"], intr5, p["obs7"])
+        assert g["n_inliers"] == o["n_inliers"] and g["lm_iterations"] == o["lm_iterations"]
+        np.testing.assert_array_equal(g["outlier"], o["outlier"])
+        assert abs(g["final_chi2"] - o["final_chi2"]) <= 1e-5 * o["final_chi2"]
+        np.testing.assert_allclose(g["pose12"], o["pose12"], rtol=0, atol=2e-6)
+    p = make_se3_problem(5)
+    g = viorb_amd.PoseOptimizationSE3(p["pose0"], p["intr5"].astype(np.float32), p["obs7"][:2])
+    assert g["n_inliers"] == 0
+    np.testing.assert_array_equal(g["pose12"], p["pose0"])

@@ -1038,6 +1038,172 @@ __global__ __launch_bounds__(256) void k_pose_opt_vi(PoseOptArgs A) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Vision-only pose optimisation, Optimizer::PoseOptimization(Frame*) (reference src/Optimizer.cc:3749-3978):
+// one 6-DoF SE3 vertex (left-multiplicative update), mono and stereo only-pose edges, the same 4 x optimize(10)
+// outlier scheme and g2o LM as the VI solve. One workgroup per problem.
+// ---------------------------------------------------------------------------------------------
+struct Se3Args {
+    const float* pose12; const double* obs7; const int* n_obs; int cap;
+    double fx, fy, cx, cy, bf;
+    float* out_pose12; uint8_t* outlier; double* info;
+};
+struct Se3Shared { double H[36], Lm[36], b[6], x[6]; double red[4][28]; double est[7], bak[7]; double sc[8]; int flag[4]; };
+
+__global__ __launch_bounds__(256) void k_pose_opt_se3(Se3Args A) {
+    __shared__ Se3Shared S;
+    const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6, cap = A.cap;
+    const int n = min(A.n_obs[b], cap);
+    const double* ob = A.obs7 + (size_t)b * cap * 7;
+    uint8_t* ol = A.outlier + (size_t)b * cap;
+    const float* p0 = A.pose12 + (size_t)b * 12;
+    const double d_mono = (double)(float)sqrt(5.991), d_stereo = (double)(float)sqrt(7.815);
+    for (int i = t; i < n; i += blockDim.x) ol[i] = 0;
+    if (t == 0) S.flag[1] = 0;
+    __syncthreads();
+    if (n < 3) {
+        if (t == 0) { for (int k = 0; k < 12; k++) A.out_pose12[(size_t)b * 12 + k] = p0[k]; double* inf = A.info + (size_t)b * 4; inf[0] = inf[1] = inf[2] = inf[3] = 0; }
+        return;
+    }
+    auto ld_est = [&]() { se3q s; s.r = mkq(S.est[0], S.est[1], S.est[2], S.est[3]); s.t = mk3(S.est[4], S.est[5], S.est[6]); return s; };
+    int kernel_on = 1, nbad = 0;
+    auto evaluate = [&](bool lin) -> double {
+        const se3q s = ld_est();
+        double a[28];
+#pragma unroll
+        for (int k = 0; k < 28; k++) a[k] = 0;
+        for (int i = t; i < n; i += blockDim.x) {
+            if (ol[i]) continue;
+            const double* o = ob + 7 * i;
+            double e[3], J[18];
+            const int dim = se3_edge(s, ld3(o), o[3], o[4], o[5], A.fx, A.fy, A.cx, A.cy, A.bf, lin, e, J);
+            const double is2 = o[6];
+            const double chi = is2 * (e[0] * e[0] + e[1] * e[1] + e[2] * e[2]);
+            double r0 = chi, r1 = 1;
+            if (kernel_on) huber(chi, dim == 3 ? d_stereo : d_mono, &r0, &r1);
+            a[27] += r0;
+            if (lin) {
+                const double w = r1 * is2;
+                int k = 0;
+#pragma unroll
+                for (int r = 0; r < 6; r++)
+#pragma unroll
+                    for (int c = r; c < 6; c++) a[k++] += w * (J[r] * J[c] + J[6 + r] * J[6 + c] + J[12 + r] * J[12 + c]);
+#pragma unroll
+                for (int r = 0; r < 6; r++) a[21 + r] -= w * (J[r] * e[0] + J[6 + r] * e[1] + J[12 + r] * e[2]);
+            }
+        }
+        if (lin) {
+            double v[32];
+#pragma unroll
+            for (int k = 0; k < 28; k++) v[k] = a[k];
+#pragma unroll
+            for (int k = 28; k < 32; k++) v[k] = 0;
+#pragma unroll
+            for (int half = 16, bit = 32; half >= 1; half >>= 1, bit >>= 1) {
+                const bool up = (lane & bit) != 0;
+#pragma unroll
+                for (int i = 0; i < half; i++) { const double keep = up ? v[half + i] : v[i]; const double send = up ? v[i] : v[half + i]; v[i] = keep + __shfl_xor(send, bit); }
+            }
+            const double tot = v[0] + __shfl_xor(v[0], 1);
+            const int idx = ((lane >> 5) & 1) * 16 + ((lane >> 4) & 1) * 8 + ((lane >> 3) & 1) * 4 + ((lane >> 2) & 1) * 2 + ((lane >> 1) & 1);
+            if ((lane & 1) == 0 && idx < 28) S.red[wave][idx] = tot;
+        } else {
+            double vv = a[27];
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) vv += __shfl_xor(vv, d);
+            if (lane == 0) S.red[wave][27] = vv;
+        }
+        __syncthreads();
+        if (lin && t < 27) {
+            const double v = S.red[0][t] + S.red[1][t] + S.red[2][t] + S.red[3][t];
+            if (t < 21) {
+                int kk = 0, rr = 0, cc = 0;
+                for (int r = 0; r < 6; r++) for (int c = r; c < 6; c++) { if (kk == t) { rr = r; cc = c; } kk++; }
+                S.H[rr * 6 + cc] = v; S.H[cc * 6 + rr] = v;
+            } else S.b[t - 21] = v;
+        }
+        if (t == 32) S.sc[0] = S.red[0][27] + S.red[1][27] + S.red[2][27] + S.red[3][27];
+        __syncthreads();
+        return S.sc[0];
+    };
+    for (int round = 0; round < 4; round++) {
+        if (t == 0) {        // Converter::toSE3Quat(pFrame->mTcw)
+            const m33 R = mkm(p0[0], p0[1], p0[2], p0[3], p0[4], p0[5], p0[6], p0[7], p0[8]);
+            const quat q = se3_norm_rot(mat2q(R));
+            S.est[0] = q.x; S.est[1] = q.y; S.est[2] = q.z; S.est[3] = q.w; S.est[4] = p0[9]; S.est[5] = p0[10]; S.est[6] = p0[11];
+        }
+        __syncthreads();
+        double lambda = 0, ni = 2; int nBadLM = 0;
+        for (int it = 0; it < 10; it++) {
+            double currentChi = evaluate(true);
+            const double iniChi = currentChi;
+            if (it == 0) { double mx = 0; for (int i = 0; i < 6; i++) mx = fmax(fabs(S.H[i * 7]), mx); lambda = 1e-5 * mx; ni = 2; nBadLM = 0; }
+            double rho = 0; int qmax = 0;
+            do {
+                if (t < 7) S.bak[t] = S.est[t];
+                if (wave == 0) {
+                    const bool ok = wave_solve_reg<6>(S.H, S.b, lambda, S.Lm, S.x, lane);
+                    if (!ok && lane < 6) S.x[lane] = 0;
+                    if (lane == 0) S.flag[0] = ok ? 1 : 0;
+                }
+                __syncthreads();
+                const int ok2 = S.flag[0];
+                if (t == 0) {
+                    const se3q nw = se3_mul(se3_exp(S.x), ld_est());
+                    S.est[0] = nw.r.x; S.est[1] = nw.r.y; S.est[2] = nw.r.z; S.est[3] = nw.r.w; S.est[4] = nw.t.x; S.est[5] = nw.t.y; S.est[6] = nw.t.z;
+                }
+                __syncthreads();
+                double tempChi = evaluate(false);
+                if (!ok2) tempChi = 1.7976931348623157e308;
+                double scale = 0; for (int j = 0; j < 6; j++) scale += S.x[j] * (lambda * S.x[j] + S.b[j]);
+                scale += 1e-3;
+                rho = (currentChi - tempChi) / scale;
+                if (rho > 0 && isfinite(tempChi)) { double alpha = 1. - pow(2 * rho - 1, 3); alpha = fmin(alpha, 2. / 3.); lambda *= fmax(1. / 3., alpha); ni = 2; currentChi = tempChi; }
+                else { lambda *= ni; ni *= 2; if (t < 7) S.est[t] = S.bak[t]; }
+                __syncthreads();
+                qmax++;
+            } while (rho < 0 && qmax < 10);
+            if (t == 0) { S.flag[1]++; S.sc[7] = currentChi; }
+            if (qmax == 10 || rho == 0) break;
+            if ((iniChi - currentChi) * 1e3 < iniChi) nBadLM++; else nBadLM = 0;
+            if (nBadLM >= 3) break;
+        }
+        __syncthreads();
+        {
+            const se3q s = ld_est();
+            int bad_local = 0;
+            for (int i = t; i < n; i += blockDim.x) {
+                const double* o = ob + 7 * i;
+                double e[3];
+                const int dim = se3_edge(s, ld3(o), o[3], o[4], o[5], A.fx, A.fy, A.cx, A.cy, A.bf, false, e, nullptr);
+                const float chi2 = (float)(o[6] * (e[0] * e[0] + e[1] * e[1] + e[2] * e[2]));
+                const int bad = chi2 > (dim == 3 ? 7.815f : 5.991f);
+                ol[i] = (uint8_t)bad; bad_local += bad;
+            }
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) bad_local += __shfl_xor(bad_local, d);
+            if (t == 0) S.flag[2] = 0;
+            __syncthreads();
+            if (lane == 0) atomicAdd(&S.flag[2], bad_local);
+            __syncthreads();
+            nbad = S.flag[2];
+        }
+        if (round == 2) kernel_on = 0;
+        __syncthreads();
+        if (n < 10) break;
+    }
+    if (t == 0) {            // Converter::toCvMat(SE3Quat)
+        const se3q s = ld_est();
+        const m33 R = qmat(s.r);
+        float* o = A.out_pose12 + (size_t)b * 12;
+        o[0] = (float)R.a00; o[1] = (float)R.a01; o[2] = (float)R.a02; o[3] = (float)R.a10; o[4] = (float)R.a11; o[5] = (float)R.a12;
+        o[6] = (float)R.a20; o[7] = (float)R.a21; o[8] = (float)R.a22; o[9] = (float)s.t.x; o[10] = (float)s.t.y; o[11] = (float)s.t.z;
+        double* inf = A.info + (size_t)b * 4;
+        inf[0] = n - nbad; inf[1] = S.sc[7]; inf[2] = S.flag[1]; inf[3] = 0;
+    }
+}
+
 } // namespace viorb
 
 // ---------------------------------------------------------------------------------------------
@@ -1236,6 +1402,20 @@ int viorb_synth_plane_points_device(viorb_frontend* h, const viorb_keypoint* kps
     return VIORB_OK;
 }
 
+int viorb_frontend_pose_opt_se3_device(viorb_frontend* h, const float* pose12, const double* obs7, const int32_t* n_obs, double bf, int batch,
+                                       float* out_pose12, uint8_t* outlier, double* info, void* stream) {
+    FE_CHECK_BATCH(h, batch);
+    VIORB_REQUIRE(pose12 && obs7 && n_obs && out_pose12 && outlier && info, "null array");
+    Se3Args A;
+    A.pose12 = pose12; A.obs7 = obs7; A.n_obs = n_obs; A.cap = h->cap;
+    A.fx = (double)h->cfg.fx; A.fy = (double)h->cfg.fy; A.cx = (double)h->cfg.cx; A.cy = (double)h->cfg.cy; A.bf = bf;   // e->fx = pFrame->fx (float -> double)
+    A.out_pose12 = out_pose12; A.outlier = outlier; A.info = info;
+    ProfScope ps("k_pose_opt_se3", (hipStream_t)stream);
+    hipLaunchKernelGGL(k_pose_opt_se3, dim3(batch), dim3(256), 0, (hipStream_t)stream, A);
+    VIORB_HIP_TRY(hipGetLastError());
+    return VIORB_OK;
+}
+
 // ---- host-buffer drop-ins ------------------------------------------------------------------------
 int viorb_descriptor_distance(const uint8_t* a, const uint8_t* b) {
     uint32_t x[8], y[8];
@@ -1360,6 +1540,26 @@ int viorb_pose_opt_vi(int variant, int compute_marg, const double cur_ns[22], co
     if (n_cur) VIORB_HIP_TRY(hipMemcpy(outlier_cur, d_fc, n_cur, hipMemcpyDeviceToHost));
     if (n_last && outlier_last && variant) VIORB_HIP_TRY(hipMemcpy(outlier_last, d_fl, n_last, hipMemcpyDeviceToHost));
     if (compute_marg && marg_out144) VIORB_HIP_TRY(hipMemcpy(marg_out144, d_marg, 144 * sizeof(double), hipMemcpyDeviceToHost));
+    VIORB_HIP_TRY(hipMemcpy(info, d_info, 4 * sizeof(double), hipMemcpyDeviceToHost));
+    return VIORB_OK;
+}
+
+int viorb_pose_opt_se3(const float pose12[12], const float intr5[5], const double* obs7, int n, float out_pose12[12], uint8_t* outlier,
+                       double info[4]) {
+    VIORB_REQUIRE(pose12 && intr5 && out_pose12 && info && n >= 0 && (n == 0 || (obs7 && outlier)), "null array");
+    viorb_frontend_config c = default_cfg();
+    c.fx = intr5[0]; c.fy = intr5[1]; c.cx = intr5[2]; c.cy = intr5[3];
+    const int cap = std::max(n, 1);
+    viorb_frontend* h = nullptr;
+    FE_TRY(viorb_frontend_create(&c, 1, cap, 0, &h));
+    struct Guard { viorb_frontend* h; ~Guard() { viorb_frontend_destroy(h); } } g{h};
+    DevBuf B; float *d_p, *d_o; double *d_obs, *d_info; int* d_n; uint8_t* d_f;
+    FE_TRY(B.up(&d_p, pose12, 12)); FE_TRY(B.up(&d_o, (const float*)nullptr, 12)); FE_TRY(B.up(&d_obs, obs7, (size_t)n * 7));
+    FE_TRY(B.up(&d_info, (const double*)nullptr, 4)); FE_TRY(B.up(&d_n, &n, 1)); FE_TRY(B.up(&d_f, (const uint8_t*)nullptr, (size_t)cap));
+    FE_TRY(viorb_frontend_pose_opt_se3_device(h, d_p, d_obs, d_n, (double)intr5[4], 1, d_o, d_f, d_info, nullptr));
+    VIORB_HIP_TRY(hipDeviceSynchronize());
+    VIORB_HIP_TRY(hipMemcpy(out_pose12, d_o, 12 * sizeof(float), hipMemcpyDeviceToHost));
+    if (n) VIORB_HIP_TRY(hipMemcpy(outlier, d_f, n, hipMemcpyDeviceToHost));
     VIORB_HIP_TRY(hipMemcpy(info, d_info, 4 * sizeof(double), hipMemcpyDeviceToHost));
     return VIORB_OK;
 }

@@ -210,6 +210,47 @@ VIO_HD void proj_edge(const cam_t& k, const m33& RwbT, d3 Pwb, d3 Pw, double u, 
     JR[3] = -(j11 * HR.a10 + j12 * HR.a20); JR[4] = -(j11 * HR.a11 + j12 * HR.a21); JR[5] = -(j11 * HR.a12 + j12 * HR.a22);
 }
 
+// ---- g2o::SE3Quat for the vision-only pose solve (Thirdparty/g2o/g2o/types/se3quat.h) ---------------------
+struct se3q { quat r; d3 t; };
+VIO_HD quat se3_norm_rot(quat r) { if (r.w < 0) r = mkq(-r.x, -r.y, -r.z, -r.w); return qnorm(r); }
+VIO_HD d3 se3_map(const se3q& s, d3 p) { return qrot(s.r, p) + s.t; }
+VIO_HD se3q se3_mul(const se3q& a, const se3q& b) { se3q o; o.t = a.t + qrot(a.r, b.t); o.r = se3_norm_rot(qmul(a.r, b.r)); return o; }
+// SE3Quat::exp(update = [omega, upsilon]), se3quat.h:223-257
+VIO_HD se3q se3_exp(const double* u) {
+    const d3 om = mk3(u[0], u[1], u[2]), ups = mk3(u[3], u[4], u[5]);
+    const double th = norm3(om);
+    const m33 Om = hat3(om), Om2 = mul(Om, Om);
+    m33 R, V;
+    if (th < 0.00001) { R = add(add(eye3(), Om), Om2); V = R; }
+    else {
+        const double a = sin(th) / th, b = (1 - cos(th)) / (th * th), c = (th - sin(th)) / (th * th * th);
+        R = add(add(eye3(), scl(Om, a)), scl(Om2, b));
+        V = add(add(eye3(), scl(Om, b)), scl(Om2, c));
+    }
+    se3q o; o.r = se3_norm_rot(mat2q(R)); o.t = mulv(V, ups); return o;
+}
+// EdgeSE3ProjectXYZOnlyPose / EdgeStereoSE3ProjectXYZOnlyPose (types_six_dof_expmap.cpp:266-364): error (dim 2 or 3)
+// and the 6-column Jacobian rows; the stereo projection uses a FLOAT reciprocal depth, as the reference does.
+VIO_HD int se3_edge(const se3q& s, d3 Xw, double u, double v, double ur, double fx, double fy, double cx, double cy, double bf,
+                    bool jac, double* e, double* J /* 3 x 6 */) {
+    const d3 p = se3_map(s, Xw);
+    const bool stereo = !(ur < 0);
+    if (!stereo) { e[0] = u - (p.x / p.z * fx + cx); e[1] = v - (p.y / p.z * fy + cy); e[2] = 0; }
+    else {
+        const float invzf = 1.0f / (float)p.z;
+        const double r0 = p.x * invzf * fx + cx, r1 = p.y * invzf * fy + cy, r2 = r0 - bf * invzf;
+        e[0] = u - r0; e[1] = v - r1; e[2] = ur - r2;
+    }
+    if (jac) {
+        const double x = p.x, y = p.y, invz = 1.0 / p.z, invz_2 = invz * invz;
+        J[0] = x * y * invz_2 * fx; J[1] = -(1 + (x * x * invz_2)) * fx; J[2] = y * invz * fx; J[3] = -invz * fx; J[4] = 0; J[5] = x * invz_2 * fx;
+        J[6] = (1 + y * y * invz_2) * fy; J[7] = -x * y * invz_2 * fy; J[8] = -x * invz * fy; J[9] = 0; J[10] = -invz * fy; J[11] = y * invz_2 * fy;
+        if (stereo) { J[12] = J[0] - bf * y * invz_2; J[13] = J[1] + bf * x * invz_2; J[14] = J[2]; J[15] = J[3]; J[16] = 0; J[17] = J[5] - bf * invz_2; }
+        else { for (int k = 12; k < 18; k++) J[k] = 0; }
+    }
+    return stereo ? 3 : 2;
+}
+
 // RobustKernelHuber::robustify (rho, rho')
 VIO_HD void huber(double e, double delta, double* rho0, double* rho1) {
     const double dsqr = delta * delta;

@@ -70,6 +70,16 @@ def PoseOptimization(cur_ns, last_ns, preint, gw, cam, obs_cur, obs_last=None, p
                 n_inliers=int(info[0]), final_chi2=float(info[1]), lm_iterations=int(info[2]))
 
 
+def PoseOptimizationSE3(pose12, intr5, obs7):
+    """Optimizer::PoseOptimization(Frame*) (vision only, reference src/Optimizer.cc:3749-3978) with host buffers.
+    obs7 [n,7] = Xw3 u v uRight invSigma2 (uRight < 0 = mono), intr5 = fx fy cx cy bf."""
+    obs7 = np.ascontiguousarray(obs7, np.float64).reshape(-1, 7)
+    out, fl, info = np.zeros(12, np.float32), np.zeros(max(len(obs7), 1), np.uint8), np.zeros(4)
+    check(lib().viorb_pose_opt_se3(ptr(np.ascontiguousarray(pose12, np.float32)), ptr(np.ascontiguousarray(intr5, np.float32)), ptr(obs7),
+                                   len(obs7), ptr(out), ptr(fl), ptr(info)))
+    return dict(pose12=out, outlier=fl[:len(obs7)], n_inliers=int(info[0]), final_chi2=float(info[1]), lm_iterations=int(info[2]))
+
+
 class Frontend:
     """Batched device-resident front-end: every method only enqueues kernels on the given torch stream."""
 
@@ -133,6 +143,10 @@ class Frontend:
         p = lambda a: a if isinstance(a, C.c_void_p) else (C.c_void_p(a) if isinstance(a, int) else ptr(a))
         check(self.L.viorb_frontend_build_observations_device(self.h, p(kps_ptr), p(count_ptr), ptr(match), ptr(match_Pw), batch,
                                                               ptr(obs), ptr(obs_index), ptr(n_obs), self._st(stream)))
+
+    def pose_opt_se3(self, pose12, obs7, n_obs, bf, batch, out_pose12, outlier, info, stream=None):
+        check(self.L.viorb_frontend_pose_opt_se3_device(self.h, ptr(pose12), ptr(obs7), ptr(n_obs), float(bf), batch, ptr(out_pose12),
+                                                        ptr(outlier), ptr(info), self._st(stream)))
 
     def pose_opt(self, variant, compute_marg, cur_ns, last_ns, prior_ns, marg_cov_inv, preint, obs_cur, n_cur, obs_last, n_last,
                  batch, out_ns, out_last_ns, outlier_cur, outlier_last, marg_out, info, stream=None):

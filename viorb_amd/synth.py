@@ -337,3 +337,30 @@ def make_local_map(kps, Pw, ns_ref, cam, scale_factors):
     maxd = dist * sf[kps["octave"]]
     mind = maxd / sf[-1]
     return np.concatenate([Pw.astype(np.float64), normal, mind[:, None], maxd[:, None]], 1).astype(np.float32)
+
+
+def make_se3_problem(seed, n_points=300, stereo_frac=0.0, outlier_frac=0.05, bf=386.1448, w=752, h=480):
+    """A vision-only pose problem (Optimizer::PoseOptimization(Frame*)): points in front of a camera with pose
+    (Rcw, tcw), float32 observations, an initial pose a few cm / tenths of a degree off. obs7 = Xw3 u v ur invSigma2."""
+    rng = np.random.Generator(np.random.PCG64(seed + 5150))
+    fx, fy, cx, cy = EUROC_K["fx"], EUROC_K["fy"], EUROC_K["cx"], EUROC_K["cy"]
+    Rcw = _rotvec_to_R(rng.normal(0, 0.3, 3)); tcw = rng.normal(0, 0.5, 3)
+    uv = np.stack([rng.uniform(20, w - 20, n_points), rng.uniform(20, h - 20, n_points)], 1)
+    z = rng.uniform(2, 10, n_points)
+    Pc = np.stack([(uv[:, 0] - cx) / fx * z, (uv[:, 1] - cy) / fy * z, z], 1)
+    Xw = (Rcw.T @ (Pc - tcw).T).T
+    octave = rng.integers(0, 8, n_points)
+    sig = 1.2 ** octave
+    inv_s2 = (1.0 / (np.float32(1.2) ** octave).astype(np.float32) ** 2).astype(np.float64)
+    o = uv + rng.normal(0, 1, uv.shape) * sig[:, None]
+    ur = o[:, 0] - bf / z + rng.normal(0, 1, n_points) * sig
+    bad = rng.random(n_points) < outlier_frac
+    o[bad] += rng.choice([-1, 1], (bad.sum(), 2)) * rng.uniform(15, 25, (bad.sum(), 2))
+    is_stereo = rng.random(n_points) < stereo_frac
+    ur = np.where(is_stereo, ur, -1.0)
+    obs7 = np.concatenate([np.float32(Xw).astype(np.float64), np.float32(o).astype(np.float64), np.float32(ur).astype(np.float64)[:, None],
+                           inv_s2[:, None]], 1)
+    R0 = _rotvec_to_R(rng.normal(0, 0.004, 3)) @ Rcw
+    t0 = tcw + rng.normal(0, 0.03, 3)
+    pose0 = np.concatenate([R0.ravel(), t0]).astype(np.float32)
+    return dict(pose0=pose0, pose_true=np.concatenate([Rcw.ravel(), tcw]), obs7=obs7, intr5=np.array([fx, fy, cx, cy, bf]), outlier_true=bad)
