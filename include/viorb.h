@@ -117,6 +117,17 @@ int viorb_extractor_level_device(const viorb_extractor* h, int b, int level, int
 int viorb_extractor_level_download(viorb_extractor* h, int b, int level, int blurred, uint8_t* dst,
                                    int* width, int* height);
 
+/* Frame::ComputeStereoMatches (reference src/Frame.cc:646-820) on the features and pyramids two extractor handles hold
+ * after extraction (the reference runs two ORBextractor instances, src/Frame.cc:258-261): image left_index + p of L is
+ * matched against image right_index + p of R (L and R may be the same batched handle). bf = Camera.bf, fx = Camera.fx.
+ * Outputs per left keypoint: d_uright[p][cap], d_depth[p][cap] (-1 where unmatched, cap = viorb_extractor_max_keypoints)
+ * and d_nmatched[p]. */
+int viorb_stereo_match_device(const viorb_extractor* L, int left_index, const viorb_extractor* R, int right_index, int pairs,
+                              float bf, float fx, float* d_uright, float* d_depth, int32_t* d_nmatched, void* stream);
+/* Host-buffer form for the literal two-instance use: image 0 of both handles; uright/depth hold min(cap, max_keypoints). */
+int viorb_stereo_match(viorb_extractor* L, viorb_extractor* R, float bf, float fx, float* uright, float* depth, int cap,
+                       int* nmatched);
+
 /* Stage introspection for parity tests: FAST candidates of one level before the quadtree
  * (ComputeKeyPointsOctTree's vToDistributeKeys, src/ORBextractor.cc:765-830), in the reference's
  * push order, as (x, y, response) int32 triples relative to the (16,16) border origin.

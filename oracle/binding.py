@@ -383,3 +383,16 @@ def pose_opt_se3(pose12, intr5, obs7):
     out, fl, info = np.zeros(12, np.float32), np.zeros(max(len(obs7), 1), np.uint8), np.zeros(3)
     _vio().ora_pose_opt_se3(_p(np.ascontiguousarray(pose12, np.float32)), _p(_f64(intr5, 5)), _p(obs7), len(obs7), _p(out), _p(fl), _p(info))
     return dict(pose12=out, outlier=fl[:len(obs7)], n_inliers=int(info[0]), final_chi2=float(info[1]), lm_iterations=int(info[2]))
+
+
+def stereo_match(ex_left, ex_right, kl, dl, kr, dr, bf, fx):
+    """Frame::ComputeStereoMatches on the pyramids the two oracle Extractor objects hold after their last call.
+    Returns (uRight[N], depth[N], best_sad[N]) with -1 where unmatched."""
+    L = lib()
+    L.ora_stereo_match.argtypes = [C.c_void_p] * 3 + [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
+    kl = np.ascontiguousarray(kl, KP_DTYPE); kr = np.ascontiguousarray(kr, KP_DTYPE)
+    n = len(kl)
+    u, d, sad = np.zeros(max(n, 1), np.float32), np.zeros(max(n, 1), np.float32), np.zeros(max(n, 1), np.int32)
+    L.ora_stereo_match(ex_left.h, ex_right.h, _p(kl), _p(np.ascontiguousarray(dl, np.uint8)), n, _p(kr), _p(np.ascontiguousarray(dr, np.uint8)), len(kr),
+                       float(bf), float(fx), _p(u), _p(d), _p(sad))
+    return u[:n], d[:n], sad[:n]

@@ -298,3 +298,18 @@ void ora_pose_opt_se3(const float* pose12, const double* intr5, const double* ob
     info3[0] = R.n_inliers; info3[1] = R.final_chi2; info3[2] = R.lm_iterations;
 }
 } // extern "C"
+
+#include "orb_stereo.h"
+extern "C" {
+// Stereo matching on the features / pyramids two oracle extractors hold after extract() (left, right).
+int ora_stereo_match(void* hl, void* hr, const KeyPoint* kl, const uint8_t* dl, int nl, const KeyPoint* kr, const uint8_t* dr, int nr,
+                     float bf, float fx, float* uRight, float* depth, int* best_sad) {
+    OrbExtractor* L = (OrbExtractor*)hl; OrbExtractor* Rr = (OrbExtractor*)hr;
+    std::vector<KeyPoint> KL(kl, kl + nl), KR(kr, kr + nr);
+    std::vector<uint8_t> DL(dl, dl + (size_t)32 * nl), DR(dr, dr + (size_t)32 * nr);
+    StereoResult S = compute_stereo_matches(KL, DL, KR, DR, L->pyramid, Rr->pyramid, L->mvScaleFactor, L->mvInvScaleFactor, bf, fx);
+    int m = 0;
+    for (int i = 0; i < nl; i++) { uRight[i] = S.uRight[i]; depth[i] = S.depth[i]; best_sad[i] = S.best_sad[i]; if (S.uRight[i] >= 0) m++; }
+    return m;
+}
+} // extern "C"

@@ -50,6 +50,8 @@ SIGNATURES = {
     "viorb_extractor_download": (i32, [vp, i32, vp, vp, i32, PP(i32)]),
     "viorb_extractor_level_device": (i32, [vp, i32, i32, i32, PP(vp), PP(i32), PP(i32), PP(i32)]),
     "viorb_extractor_level_download": (i32, [vp, i32, i32, i32, vp, PP(i32), PP(i32)]),
+    "viorb_stereo_match_device": (i32, [vp, i32, vp, i32, i32, f32, f32, vp, vp, vp, vp]),
+    "viorb_stereo_match": (i32, [vp, vp, f32, f32, vp, vp, i32, PP(i32)]),
     "viorb_extractor_debug_level_points": (i32, [vp, i32, i32, i32, vp, i32, PP(i32)]),
     "viorb_frontend_create": (i32, [PP(FrontendConfig), i32, i32, i32, PP(vp)]),
     "viorb_frontend_destroy": (i32, [vp]),

@@ -751,6 +751,166 @@ __global__ __launch_bounds__(256) void k_orient_describe(const uint8_t* __restri
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Frame::ComputeStereoMatches (reference src/Frame.cc:646-820), one workgroup per rectified stereo pair.
+//   1. right keypoints sorted by y (bitonic, u64 keys in LDS) so that the reference's row table
+//      vRowIndices[(int)vL] becomes a y-window scan; the best candidate is the minimum of
+//      (Hamming << 16 | iR), i.e. the first minimum in the reference's iR push order;
+//   2. 11x11 SAD over 11 shifts on the un-blurred pyramid level of the left keypoint (integer arithmetic: the
+//      centre-subtracted float patches of the reference hold small integers), parabola fit, disparity -> depth;
+//   3. median-based rejection: sort (SAD << 16 | iL), drop SAD >= 1.5 * 1.4 * median.
+// ---------------------------------------------------------------------------------------------
+struct StereoArgs {
+    const viorb_keypoint *kl, *kr; const uint8_t *dl, *dr; const int *nl, *nr;
+    const uint8_t *planesL, *planesR; size_t frame_bytes; const LevelDev* lv;
+    int cap, sort_n, nlevels; float bf, fx;
+    float scale[16], inv_scale[16];
+    float* uright; float* depth; int* nmatched;
+};
+__host__ __device__ inline size_t stereo_lds_bytes(int cap, int sort_n) { return (size_t)sort_n * (8 + 4 + 4 + 4) + (size_t)cap * 4 + 64; }
+
+__global__ __launch_bounds__(256) void k_stereo_match(StereoArgs A) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_st[];
+    const int p = blockIdx.x, t = threadIdx.x, cap = A.cap, sn = A.sort_n;
+    unsigned long long* keys = reinterpret_cast<unsigned long long*>(s_st);            // [sn] (ybits << 32 | iR)
+    float* ry = reinterpret_cast<float*>(keys + sn);                                    // [sn] y of the sorted right keypoints
+    int* rid = reinterpret_cast<int*>(ry + sn);                                         // [sn] their indices
+    uint32_t* skeys = reinterpret_cast<uint32_t*>(rid + sn);                            // [sn] (sad << 16 | iL)
+    int* sad = reinterpret_cast<int*>(skeys + sn);                                      // [cap]
+    __shared__ int s_cnt, s_removed;
+    const int N = min(A.nl[p], cap), Nr = min(A.nr[p], cap);
+    const viorb_keypoint* kl = A.kl + (size_t)p * cap; const viorb_keypoint* kr = A.kr + (size_t)p * cap;
+    const uint8_t* dl = A.dl + (size_t)p * cap * 32; const uint8_t* dr = A.dr + (size_t)p * cap * 32;
+    float* uR = A.uright + (size_t)p * cap; float* dep = A.depth + (size_t)p * cap;
+    for (int i = t; i < sn; i += blockDim.x)
+        keys[i] = i < Nr ? (((unsigned long long)__float_as_uint(kr[i].y) << 32) | (unsigned)i) : ~0ull;    // y > 0: float bits order like the values
+    if (t == 0) { s_cnt = 0; s_removed = 0; }
+    __syncthreads();
+    for (int k = 2; k <= sn; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int q = t; q < (sn >> 1); q += blockDim.x) {
+                const int lo = ((q & ~(j - 1)) << 1) | (q & (j - 1)), hi = lo | j;
+                const bool up = (lo & k) == 0;
+                const unsigned long long x = keys[lo], y = keys[hi];
+                if ((x > y) == up) { keys[lo] = y; keys[hi] = x; }
+            }
+            __syncthreads();
+        }
+    for (int i = t; i < sn; i += blockDim.x) { ry[i] = i < Nr ? __uint_as_float((unsigned)(keys[i] >> 32)) : 3.0e38f; rid[i] = (int)(keys[i] & 0xffffffffu); }
+    __syncthreads();
+    const float mb = A.bf / A.fx, minD = 0.f, maxD = A.bf / mb;
+    const float rmax = 2.0f * A.scale[A.nlevels - 1];
+    const int nRows = A.lv[0].h;
+    const int thOrbDist = (100 + 50) / 2;
+    for (int iL = t; iL < cap; iL += blockDim.x) {
+        float out_u = -1.f, out_d = -1.f; int out_sad = -1;
+        if (iL < N) {
+            const viorb_keypoint kpL = kl[iL];
+            const int levelL = kpL.octave; const float vL = kpL.y, uL = kpL.x;
+            const int rowi = (int)vL;
+            const float minU = uL - maxD, maxU = uL - minD;
+            if (rowi >= 0 && rowi < nRows && !(maxU < 0)) {
+                const float ylo = (float)rowi - rmax - 1.0f, yhi = (float)rowi + rmax + 1.0f;
+                int lo = 0, hi = Nr;
+                while (lo < hi) { const int mid = (lo + hi) >> 1; if (ry[mid] < ylo) lo = mid + 1; else hi = mid; }
+                const uint4* pl = reinterpret_cast<const uint4*>(dl + (size_t)iL * 32);
+                const uint4 da = pl[0], db = pl[1];
+                uint32_t best = 0xffffffffu;
+                for (int k = lo; k < Nr && ry[k] <= yhi; k++) {
+                    const int iR = rid[k];
+                    const viorb_keypoint kpR = kr[iR];
+                    const float r = 2.0f * A.scale[kpR.octave];
+                    const int maxr = (int)ceilf(kpR.y + r), minr = (int)floorf(kpR.y - r);
+                    if (rowi < minr || rowi > maxr) continue;
+                    if (kpR.octave < levelL - 1 || kpR.octave > levelL + 1) continue;
+                    if (!(kpR.x >= minU && kpR.x <= maxU)) continue;
+                    const uint4* pr = reinterpret_cast<const uint4*>(dr + (size_t)iR * 32);
+                    const uint4 ea = pr[0], eb = pr[1];
+                    const int dist = __popc(da.x ^ ea.x) + __popc(da.y ^ ea.y) + __popc(da.z ^ ea.z) + __popc(da.w ^ ea.w) +
+                                     __popc(db.x ^ eb.x) + __popc(db.y ^ eb.y) + __popc(db.z ^ eb.z) + __popc(db.w ^ eb.w);
+                    if (dist < 100) best = min(best, ((uint32_t)dist << 16) | (uint32_t)iR);
+                }
+                if (best != 0xffffffffu && (int)(best >> 16) < thOrbDist) {
+                    const int bestIdxR = (int)(best & 0xffff);
+                    const float uR0 = kr[bestIdxR].x;
+                    const float sfac = A.inv_scale[levelL];
+                    const int cu = (int)roundf(kpL.x * sfac), cv = (int)roundf(kpL.y * sfac), cr = (int)roundf(uR0 * sfac);
+                    const LevelDev Lv = A.lv[levelL];
+                    const int w = 5, L = 5;
+                    const float iniu = (float)cr + L - w, endu = (float)cr + L + w + 1;
+                    const bool inside = !(iniu < 0 || endu >= Lv.w) && cv - w >= 0 && cv + w < Lv.h && cu - w >= 0 && cu + w < Lv.w &&
+                                        cr - L - w >= 0 && cr + L + w < Lv.w;
+                    if (inside) {
+                        const uint8_t* IL = A.planesL + (size_t)p * A.frame_bytes + Lv.plane_off;
+                        const uint8_t* IR = A.planesR + (size_t)p * A.frame_bytes + Lv.plane_off;
+                        const int cL = IL[(size_t)cv * Lv.stride + cu];
+                        int cRv[11], acc[11];
+#pragma unroll
+                        for (int sft = 0; sft < 11; sft++) { cRv[sft] = IR[(size_t)cv * Lv.stride + cr + sft - L]; acc[sft] = 0; }
+                        for (int dy = -w; dy <= w; dy++) {
+                            const uint8_t* rl = IL + (size_t)(cv + dy) * Lv.stride + cu - w;
+                            const uint8_t* rr = IR + (size_t)(cv + dy) * Lv.stride + cr - L - w;
+                            int lrow[11], rrow[21];
+#pragma unroll
+                            for (int x = 0; x < 11; x++) lrow[x] = (int)rl[x] - cL;
+#pragma unroll
+                            for (int x = 0; x < 21; x++) rrow[x] = rr[x];
+#pragma unroll
+                            for (int sft = 0; sft < 11; sft++)
+#pragma unroll
+                                for (int x = 0; x < 11; x++) acc[sft] += abs(lrow[x] - (rrow[sft + x] - cRv[sft]));
+                        }
+                        int bestSad = 0x7fffffff, bestinc = 0;
+#pragma unroll
+                        for (int sft = 0; sft < 11; sft++) if (acc[sft] < bestSad) { bestSad = acc[sft]; bestinc = sft - L; }
+                        if (!(bestinc == -L || bestinc == L)) {
+                            float d1 = 0, d2 = 0, d3 = 0;
+#pragma unroll
+                            for (int sft = 1; sft < 10; sft++) if (sft - L == bestinc) { d1 = (float)acc[sft - 1]; d2 = (float)acc[sft]; d3 = (float)acc[sft + 1]; }
+                            const float deltaR = (d1 - d3) / (2.0f * (d1 + d3 - 2.0f * d2));
+                            if (!(deltaR < -1 || deltaR > 1)) {
+                                float bestuR = A.scale[levelL] * ((float)cr + (float)bestinc + deltaR);
+                                float disparity = uL - bestuR;
+                                if (disparity >= minD && disparity < maxD) {
+                                    if (disparity <= 0) { disparity = 0.01f; bestuR = uL - 0.01f; }
+                                    out_d = A.bf / disparity; out_u = bestuR; out_sad = bestSad;
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        uR[iL] = out_u; dep[iL] = out_d; sad[iL] = out_sad;
+    }
+    __syncthreads();
+    // ---- median rejection (SAD <= 121 * 510 fits 16 bits)
+    for (int i = t; i < sn; i += blockDim.x) skeys[i] = (i < cap && sad[i] >= 0) ? (((uint32_t)sad[i] << 16) | (uint32_t)i) : 0xffffffffu;
+    for (int i = t; i < cap; i += blockDim.x) if (sad[i] >= 0) atomicAdd(&s_cnt, 1);
+    __syncthreads();
+    for (int k = 2; k <= sn; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int q = t; q < (sn >> 1); q += blockDim.x) {
+                const int lo = ((q & ~(j - 1)) << 1) | (q & (j - 1)), hi = lo | j;
+                const bool up = (lo & k) == 0;
+                const uint32_t x = skeys[lo], y = skeys[hi];
+                if ((x > y) == up) { skeys[lo] = y; skeys[hi] = x; }
+            }
+            __syncthreads();
+        }
+    const int cnt = s_cnt;
+    if (cnt > 0) {
+        const float median = (float)(skeys[cnt / 2] >> 16);
+        const float thDist = 1.5f * 1.4f * median;
+        for (int i = t; i < cnt; i += blockDim.x) {
+            const uint32_t e = skeys[i];
+            if (!((float)(e >> 16) < thDist)) { const int iL = (int)(e & 0xffff); uR[iL] = -1.f; dep[iL] = -1.f; atomicAdd(&s_removed, 1); }
+        }
+    }
+    __syncthreads();
+    if (t == 0) A.nmatched[p] = cnt - s_removed;
+}
+
 } // namespace viorb
 
 // ---------------------------------------------------------------------------------------------
@@ -1220,6 +1380,55 @@ int viorb_extractor_level_download(viorb_extractor* h, int b, int level, int blu
     if (width) *width = w;
     if (height) *height = hh;
     return VIORB_OK;
+}
+
+int viorb_stereo_match_device(const viorb_extractor* L, int left_index, const viorb_extractor* R, int right_index, int pairs, float bf, float fx,
+                              float* d_uright, float* d_depth, int32_t* d_nmatched, void* stream) {
+    VIORB_REQUIRE(L && R && L->d_kps && R->d_kps && d_uright && d_depth && d_nmatched, "extract both images first");
+    VIORB_REQUIRE(pairs >= 1 && left_index >= 0 && right_index >= 0 && left_index + pairs <= L->max_batch && right_index + pairs <= R->max_batch,
+                  "image indices out of range");
+    VIORB_REQUIRE(L->img_w == R->img_w && L->img_h == R->img_h && L->out_cap == R->out_cap && L->p.nlevels == R->p.nlevels && L->device == R->device,
+                  "left and right extractors must have the same geometry and parameters");
+    VIORB_HIP_TRY(hipSetDevice(L->device));
+    StereoArgs A;
+    const int cap = L->out_cap;
+    A.kl = L->d_kps + (size_t)left_index * cap; A.kr = R->d_kps + (size_t)right_index * cap;
+    A.dl = L->d_desc + (size_t)left_index * cap * 32; A.dr = R->d_desc + (size_t)right_index * cap * 32;
+    A.nl = L->d_count + left_index; A.nr = R->d_count + right_index;
+    A.planesL = L->d_planes + (size_t)left_index * L->frame_bytes; A.planesR = R->d_planes + (size_t)right_index * R->frame_bytes;
+    A.frame_bytes = L->frame_bytes; A.lv = L->d_lv; A.cap = cap; A.nlevels = L->p.nlevels; A.bf = bf; A.fx = fx;
+    int sn = 64; while (sn < cap) sn <<= 1;
+    A.sort_n = sn;
+    for (int i = 0; i < 16; i++) { A.scale[i] = L->scale[i < L->p.nlevels ? i : L->p.nlevels - 1]; A.inv_scale[i] = L->inv_scale[i < L->p.nlevels ? i : L->p.nlevels - 1]; }
+    A.uright = d_uright; A.depth = d_depth; A.nmatched = d_nmatched;
+    const size_t lds = stereo_lds_bytes(cap, sn);
+    if (lds > 160 * 1024) { set_error("stereo matcher needs %zu B of LDS", lds); return VIORB_ERR_UNSUPPORTED; }
+    if (lds > 64 * 1024) VIORB_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_stereo_match), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    ProfScope ps("k_stereo_match", (hipStream_t)stream);
+    hipLaunchKernelGGL(k_stereo_match, dim3(pairs), dim3(256), lds, (hipStream_t)stream, A);
+    VIORB_HIP_TRY(hipGetLastError());
+    return VIORB_OK;
+}
+
+int viorb_stereo_match(viorb_extractor* L, viorb_extractor* R, float bf, float fx, float* uright, float* depth, int cap, int* nmatched) {
+    VIORB_REQUIRE(L && R && uright && depth && nmatched, "null argument");
+    VIORB_REQUIRE(L->d_kps && R->d_kps, "extract both images first");
+    VIORB_HIP_TRY(hipSetDevice(L->device));
+    VIORB_HIP_TRY(hipStreamSynchronize(L->last_stream));
+    VIORB_HIP_TRY(hipStreamSynchronize(R->last_stream));
+    float *d_u = nullptr, *d_d = nullptr; int* d_n = nullptr;
+    const int oc = L->out_cap;
+    VIORB_HIP_TRY(hipMalloc(&d_u, sizeof(float) * oc)); VIORB_HIP_TRY(hipMalloc(&d_d, sizeof(float) * oc)); VIORB_HIP_TRY(hipMalloc(&d_n, sizeof(int)));
+    int rc = viorb_stereo_match_device(L, 0, R, 0, 1, bf, fx, d_u, d_d, d_n, nullptr);
+    if (rc == VIORB_OK && hipDeviceSynchronize() != hipSuccess) { set_error("stereo kernel failed"); rc = VIORB_ERR_HIP; }
+    if (rc == VIORB_OK) {
+        const int m = std::min(cap, oc);
+        (void)hipMemcpy(uright, d_u, sizeof(float) * m, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(depth, d_d, sizeof(float) * m, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(nmatched, d_n, sizeof(int), hipMemcpyDeviceToHost);
+    }
+    (void)hipFree(d_u); (void)hipFree(d_d); (void)hipFree(d_n);
+    return rc;
 }
 
 int viorb_extractor_debug_level_points(viorb_extractor* h, int b, int level, int which, int32_t* xyr, int cap, int* n) {

@@ -110,6 +110,14 @@ class ORBextractor:
         return buf[:min(n.value, len(buf))].copy()
 
 
+def ComputeStereoMatches(ex_left, ex_right, bf, fx):
+    """Frame::ComputeStereoMatches on image 0 of two extractors (host buffers). Returns (mvuRight, mvDepth, nmatched)."""
+    u, d = np.zeros(ex_left.cap, np.float32), np.zeros(ex_left.cap, np.float32)
+    n = C.c_int()
+    check(lib().viorb_stereo_match(ex_left.h, ex_right.h, float(bf), float(fx), ptr(u), ptr(d), ex_left.cap, C.byref(n)))
+    return u, d, n.value
+
+
 def octree_host(keys_xyr, width, height, N):
     """Host test hook: the product's flat-array DistributeOctTree on (x, y, response) int triples."""
     k = np.asarray(keys_xyr, np.int64).reshape(-1, 3)

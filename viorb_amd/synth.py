@@ -364,3 +364,19 @@ def make_se3_problem(seed, n_points=300, stereo_frac=0.0, outlier_frac=0.05, bf=
     t0 = tcw + rng.normal(0, 0.03, 3)
     pose0 = np.concatenate([R0.ravel(), t0]).astype(np.float32)
     return dict(pose0=pose0, pose_true=np.concatenate([Rcw.ravel(), tcw]), obs7=obs7, intr5=np.array([fx, fy, cx, cy, bf]), outlier_true=bad)
+
+
+KITTI_K = dict(fx=718.856, fy=718.856, cx=607.1928, cy=185.2157, bf=386.1448)    # reference Examples/Stereo/KITTI00-02.yaml
+
+
+def make_stereo_pair(seed, w=1241, h=376, fx=718.856, bf=386.1448, zmin=4.0, zmax=40.0):
+    """Rectified stereo pair with a smooth known depth field: right(x, y) = left(x + d(x, y), y), d = bf / Z.
+    Returns (left, right, disparity_of_right_pixels [h, w])."""
+    rng = np.random.Generator(np.random.PCG64(seed + 777))
+    left = make_image(seed, w, h)
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+    z = zmin + (zmax - zmin) * (0.5 + 0.5 * np.sin(xx / w * 2.1 + rng.uniform(0, 3)) * np.cos(yy / h * 1.3 + rng.uniform(0, 3)))
+    d = bf / z
+    right = ndimage.map_coordinates(left.astype(np.float32), [yy, xx + d], order=1, mode="reflect")
+    right += np.random.Generator(np.random.PCG64(seed + 778)).normal(0, 1.0, right.shape)
+    return left, np.clip(np.rint(right), 0, 255).astype(np.uint8), d
