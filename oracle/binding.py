@@ -396,3 +396,18 @@ def stereo_match(ex_left, ex_right, kl, dl, kr, dr, bf, fx):
     L.ora_stereo_match(ex_left.h, ex_right.h, _p(kl), _p(np.ascontiguousarray(dl, np.uint8)), n, _p(kr), _p(np.ascontiguousarray(dr, np.uint8)), len(kr),
                        float(bf), float(fx), _p(u), _p(d), _p(sad))
     return u[:n], d[:n], sad[:n]
+
+
+def local_ba(kfs, n_local, prev_kf, preint, points, edge_idx, edge_obs, gw, cam, stop=None):
+    """Optimizer::LocalBundleAdjustmentNavState on the oracle. kfs [NK,22] local first; preint [W,142]; points [NP,3];
+    edge_idx [NE,2] int32 (point, kf) grouped by point; edge_obs [NE,3] = u v invSigma2."""
+    L = lib()
+    L.ora_local_ba.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 7
+    kfs = _f64(kfs).reshape(-1, 22); preint = _f64(preint).reshape(-1, 142); points = _f64(points).reshape(-1, 3)
+    ei = np.ascontiguousarray(edge_idx, np.int32).reshape(-1, 2); eo = _f64(edge_obs).reshape(-1, 3)
+    ko, po = np.zeros((n_local, 22)), np.zeros_like(points)
+    er, info = np.zeros(max(len(ei), 1), np.uint8), np.zeros(6)
+    st = np.ascontiguousarray(stop, np.int32) if stop is not None else None
+    L.ora_local_ba(_p(kfs), len(kfs), n_local, prev_kf, _p(preint), _p(points), len(points), _p(ei), _p(eo), len(ei), _p(_f64(gw, 3)),
+                   _p(_f64(cam, 16)), _p(st) if st is not None else None, _p(ko), _p(po), _p(er), _p(info))
+    return dict(kfs=ko, points=po, erase=er[:len(ei)], chi2_first=info[0], chi2_final=info[1], its_first=int(info[2]), its_second=int(info[3]))

@@ -313,3 +313,25 @@ int ora_stereo_match(void* hl, void* hr, const KeyPoint* kl, const uint8_t* dl, 
     return m;
 }
 } // extern "C"
+
+#include "local_ba.h"
+extern "C" {
+// Local BA on flat arrays: kfs[NK][22] (local first), preint[W][142], points[NP][3], edge_idx[NE][2] = (point, kf),
+// edge_obs[NE][3] = u v invSigma2 (edges grouped by point). info6 = chi2_first chi2_final its_first its_second 0 0.
+void ora_local_ba(const double* kfs, int nk, int n_local, int prev_kf, const double* preint, const double* points, int np_,
+                  const int* edge_idx, const double* edge_obs, int ne, const double* gw, const double* cam16, const int* stop,
+                  double* kfs_out, double* points_out, uint8_t* erase, double* info6) {
+    BaProblem P;
+    P.kfs.resize(nk); for (int i = 0; i < nk; i++) P.kfs[i] = ns_in(kfs + 22 * i);
+    P.n_local = n_local; P.prev_kf = prev_kf;
+    P.preint.resize(n_local); for (int i = 0; i < n_local; i++) P.preint[i] = pre_in(preint + 142 * i);
+    P.points.resize(np_); for (int i = 0; i < np_; i++) P.points[i] = v3(points + 3 * i);
+    P.edges.resize(ne); for (int k = 0; k < ne; k++) { P.edges[k].point = edge_idx[2 * k]; P.edges[k].kf = edge_idx[2 * k + 1]; P.edges[k].u = edge_obs[3 * k]; P.edges[k].v = edge_obs[3 * k + 1]; P.edges[k].inv_sigma2 = edge_obs[3 * k + 2]; }
+    P.gw = v3(gw); P.cam = cam_in(cam16);
+    BaResult R = local_ba_navstate(P, (const volatile int*)stop);
+    for (int i = 0; i < n_local; i++) ns_out(kfs_out + 22 * i, R.kfs[i]);
+    for (int i = 0; i < np_; i++) put3(points_out + 3 * i, R.points[i]);
+    for (int k = 0; k < ne; k++) erase[k] = R.erase[k];
+    info6[0] = R.chi2_after_first; info6[1] = R.chi2_final; info6[2] = R.its_first; info6[3] = R.its_second; info6[4] = 0; info6[5] = 0;
+}
+} // extern "C"

@@ -1,0 +1,99 @@
+"""Pins the oracle's LocalBundleAdjustmentNavState restatement (oracle/local_ba.cpp): the result must be the optimum of
+the final objective as re-derived independently with scipy (dense, no Schur trick), recover the synthetic truth, flag
+the planted outliers, and honour the stop flag."""
+import numpy as np
+import pytest
+from scipy.optimize import least_squares
+from scipy.spatial.transform import Rotation
+from viorb_amd.synth import make_local_ba_problem
+
+
+def preints(oracle, p):
+    out = []
+    for i, (imu, t0, t1) in enumerate(p["imu"]):
+        j = i - 1 if i > 0 else p["prev_kf"]
+        out.append(oracle.preintegrate(imu, p["kfs"][j][10:13], p["kfs"][j][13:16], t0, t1))
+    return np.stack(out)
+
+
+def test_local_ba_recovers_truth_and_flags_outliers(oracle):
+    p = make_local_ba_problem(1, W=10, n_points=600)
+    pre = preints(oracle, p)
+    r = oracle.local_ba(p["kfs"], p["n_local"], p["prev_kf"], pre, p["points"], p["edge_idx"], p["edge_obs"], p["gw"], p["cam"])
+    W = p["n_local"]
+    e0 = np.linalg.norm(p["kfs"][:W, :3] - p["kfs_true"][:W, :3], axis=1).mean()
+    e1 = np.linalg.norm(r["kfs"][:, :3] - p["kfs_true"][:W, :3], axis=1).mean()
+    assert e1 < 0.2 * e0 and e1 < 0.01
+    # (point depth is only weakly observable at these baselines and 2-px noise, so point accuracy is not asserted; the
+    #  lateral error, which the images do constrain, must be small)
+    lateral = np.linalg.norm((r["points"] - p["points_true"])[:, :2], axis=1)
+    assert np.median(lateral) < 0.1
+    assert 1 <= r["its_first"] <= 5 and 1 <= r["its_second"] <= 10 and r["chi2_final"] < r["chi2_first"]
+    assert 0.03 * len(r["erase"]) < r["erase"].sum() < 0.2 * len(r["erase"])            # ~5 % planted outliers (+ their neighbours)
+    # the fixed key frames never move and are not returned
+    assert r["kfs"].shape == (W, 22)
+
+
+def test_local_ba_final_cost_is_the_optimum(oracle):
+    """Second optimisation = plain least squares over the level-0 edges (no kernel on mono edges) + Huber IMU / bias factors:
+    re-optimise that objective densely with scipy from the oracle's solution and compare costs."""
+    p = make_local_ba_problem(2, W=4, n_points=80, n_fixed_extra=2)
+    pre = preints(oracle, p)
+    r = oracle.local_ba(p["kfs"], p["n_local"], p["prev_kf"], pre, p["points"], p["edge_idx"], p["edge_obs"], p["gw"], p["cam"])
+    W, cam = p["n_local"], p["cam"]
+    fx, fy, cx, cy = cam[:4]; Rbc, Pbc = cam[4:13].reshape(3, 3), cam[13:16]
+    keep = r["erase"] == 0                      # level-0 set of the second optimisation == edges not erased (for this seed)
+    ei, eo = p["edge_idx"][keep], p["edge_obs"][keep]
+    kf_all = p["kfs"].copy(); kf_all[:W] = r["kfs"]
+    infos = [np.linalg.inv(pre[i][60:141].reshape(9, 9)) for i in range(W)]
+    Ls = [np.linalg.cholesky(I) for I in infos]
+
+    def hub(chi2, d):
+        return np.sqrt(chi2) if chi2 <= d * d else np.sqrt(2 * np.sqrt(chi2) * d - d * d)
+
+    def unpack(x):
+        ks = kf_all.copy()
+        for i in range(W):
+            u = x[12 * i:12 * i + 12]
+            Rm = Rotation.from_quat(kf_all[i, 6:10]).as_matrix()
+            ks[i, :3] = kf_all[i, :3] + Rm @ u[:3]; ks[i, 3:6] = kf_all[i, 3:6] + u[3:6]
+            q = (Rotation.from_quat(kf_all[i, 6:10]) * Rotation.from_rotvec(u[6:9])).as_quat(); ks[i, 6:10] = q
+            ks[i, 19:22] = kf_all[i, 19:22] + u[9:12]
+        return ks, r["points"] + x[12 * W:].reshape(-1, 3)
+
+    def resid(x):
+        ks, pts = unpack(x)
+        out = []
+        Rs = [Rotation.from_quat(k[6:10]).as_matrix() for k in ks]
+        for (pi, ki), (u, v, w) in zip(ei, eo):
+            Pc = Rbc.T @ (Rs[ki].T @ (pts[pi] - ks[ki, :3])) - Rbc.T @ Pbc
+            out += [(u - (fx * Pc[0] / Pc[2] + cx)) * np.sqrt(w), (v - (fy * Pc[1] / Pc[2] + cy)) * np.sqrt(w)]
+        for i in range(W):
+            j = i - 1 if i > 0 else p["prev_kf"]
+            M = pre[i]; dT = M[141]
+            Ri = Rs[j]; g = p["gw"]
+            rP = Ri.T @ (ks[i, :3] - ks[j, :3] - ks[j, 3:6] * dT - 0.5 * g * dT * dT) - (M[:3] + M[24:33].reshape(3, 3) @ ks[j, 19:22])
+            rV = Ri.T @ (ks[i, 3:6] - ks[j, 3:6] - g * dT) - (M[3:6] + M[42:51].reshape(3, 3) @ ks[j, 19:22])
+            rR = Rotation.from_matrix(M[6:15].reshape(3, 3).T @ Ri.T @ Rs[i]).as_rotvec()
+            e9 = np.concatenate([rP, rV, rR]); chi = e9 @ infos[i] @ e9
+            wv = Ls[i].T @ e9
+            out += list(wv / (np.linalg.norm(wv) + 1e-300) * hub(chi, np.float32(np.sqrt(21.666))))
+            eb = (ks[i, 13:16] + ks[i, 19:22]) - (ks[j, 13:16] + ks[j, 19:22])
+            chib = eb @ eb / (5e-3 ** 2) / dT
+            out += list(eb / (np.linalg.norm(eb) + 1e-300) * hub(chib, np.float32(np.sqrt(16.812))))
+        return np.array(out)
+    x0 = np.zeros(12 * W + 3 * len(r["points"]))
+    c0 = float((resid(x0) ** 2).sum())
+    assert abs(c0 - r["chi2_final"]) <= 1e-6 * r["chi2_final"]                 # the oracle's reported chi2 is this objective
+    sol = least_squares(resid, x0, method="trf", xtol=1e-15, ftol=1e-15, gtol=1e-15, max_nfev=60)
+    c1 = float((sol.fun ** 2).sum())
+    assert c1 <= c0 * (1 + 1e-9) and (c0 - c1) / c0 < 5e-3                     # LM stop rule: < 0.1 % gain three times in a row
+
+
+def test_local_ba_stop_flag(oracle):
+    p = make_local_ba_problem(3, W=5, n_points=120)
+    pre = preints(oracle, p)
+    r = oracle.local_ba(p["kfs"], p["n_local"], p["prev_kf"], pre, p["points"], p["edge_idx"], p["edge_obs"], p["gw"], p["cam"], stop=[1])
+    np.testing.assert_array_equal(r["kfs"], p["kfs"][:5])                       # aborted before the first iteration
+    np.testing.assert_array_equal(r["points"], p["points"])
+    assert r["its_first"] == 0 and r["its_second"] == 0

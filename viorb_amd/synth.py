@@ -380,3 +380,75 @@ def make_stereo_pair(seed, w=1241, h=376, fx=718.856, bf=386.1448, zmin=4.0, zma
     right = ndimage.map_coordinates(left.astype(np.float32), [yy, xx + d], order=1, mode="reflect")
     right += np.random.Generator(np.random.PCG64(seed + 778)).normal(0, 1.0, right.shape)
     return left, np.clip(np.rint(right), 0, 255).astype(np.uint8), d
+
+
+def make_local_ba_problem(seed, W=20, n_points=2000, n_fixed_extra=3, outlier_frac=0.05, pix_sigma=2.0, kf_dt=0.15, imu_dt=0.005,
+                          w=752, h=480):
+    """A LocalBundleAdjustmentNavState problem: W local key frames on a smooth trajectory, the previous
+    key frame and a few older covisible key frames fixed, n_points points each seen by 3..8 key frames, pix_sigma-px
+    Gaussian noise, outlier_frac gross outliers at ~20 px. Returns flat arrays (layouts of include/viorb.h) + truth."""
+    rng = np.random.Generator(np.random.PCG64(seed + 20202))
+    cam = euroc_cam()
+    fx, fy, cx, cy = cam[:4]; Rbc, Pbc = cam[4:13].reshape(3, 3), cam[13:16]
+    nkf = W + 1 + n_fixed_extra                      # chronological: extras, prev, local window
+    n_imu = int(round(kf_dt / imu_dt))
+    R = Rbc.T.copy(); Pw = -R @ Pbc; V = rng.normal(0, 0.4, 3) * np.array([1, 1, 0.3])
+    bg, ba = rng.normal(0, 0.002, 3), rng.normal(0, 0.02, 3)
+    states, preints_imu, t = [], [None], 10.0
+    from scipy.spatial.transform import Rotation
+    for k in range(nkf):
+        states.append(navstate(Pw, V, R, bg, ba))
+        if k == nkf - 1:
+            break
+        omega = rng.normal(0, 0.15, 3); a_w = rng.normal(0, 0.6, 3) * np.array([1, 1, 0.3]) - 0.5 * V
+        imu = np.zeros((n_imu, 7))
+        for j in range(n_imu):
+            tj = t + imu_dt * (j + 0.3)
+            Rt = R @ _rotvec_to_R(omega * (tj - t))
+            imu[j, :3] = omega + bg + rng.normal(0, 1e-3, 3); imu[j, 3:6] = Rt.T @ (a_w - GRAVITY_CAM_WORLD) + ba + rng.normal(0, 1e-2, 3); imu[j, 6] = tj
+        preints_imu.append((imu, t, t + kf_dt))
+        Pw = Pw + V * kf_dt + 0.5 * a_w * kf_dt ** 2; V = V + a_w * kf_dt; R = R @ _rotvec_to_R(omega * kf_dt); t += kf_dt
+    states = np.stack(states)
+    # order for the solver: local window first (chronological), then prev, then extras
+    chrono_local = list(range(n_fixed_extra + 1, nkf)); prev_c = n_fixed_extra; extra_c = list(range(n_fixed_extra))
+    order = chrono_local + [prev_c] + extra_c
+    kfs_true = states[order]
+    prev_kf = W
+    # points: seen from a random local key frame at depth 2..10 m, then observed by every key frame that sees them
+    pts, edges_i, edges_o = [], [], []
+    poses = [cam_pose_from_navstate(s, cam) for s in kfs_true]
+    sf = np.float32(1.2) ** np.arange(8)
+    while len(pts) < n_points:
+        k0 = int(rng.integers(0, W))
+        u0, v0, z = rng.uniform(30, w - 30), rng.uniform(30, h - 30), rng.uniform(2, 10)
+        Rcw, tcw = poses[k0]
+        X = Rcw.T @ (np.array([(u0 - cx) / fx * z, (v0 - cy) / fy * z, z]) - tcw)
+        vis = []
+        for k, (Rk, tk) in enumerate(poses):
+            Pc = Rk @ X + tk
+            if Pc[2] < 0.5: continue
+            uu, vv = fx * Pc[0] / Pc[2] + cx, fy * Pc[1] / Pc[2] + cy
+            if 20 < uu < w - 20 and 20 < vv < h - 20: vis.append((k, uu, vv))
+        if len(vis) < 3: continue
+        nobs = int(min(len(vis), rng.integers(3, 9)))
+        sel = sorted(rng.choice(len(vis), nobs, replace=False))
+        pid = len(pts); pts.append(X)
+        for si in sel:
+            k, uu, vv = vis[si]
+            octv = int(rng.integers(0, 8)); sg = pix_sigma * float(sf[octv]) / 2.0
+            ou, ov = uu + rng.normal(0, sg), vv + rng.normal(0, sg)
+            if rng.random() < outlier_frac: ou += rng.choice([-1, 1]) * rng.uniform(15, 25); ov += rng.choice([-1, 1]) * rng.uniform(15, 25)
+            edges_i.append((pid, k)); edges_o.append((np.float32(ou), np.float32(ov), 1.0 / float(np.float32(sf[octv]) ** 2)))
+    pts = np.array(pts)
+    # IMU pre-integrations of the local key frames (predecessor = prev for the first one), with the predecessor's bias
+    from . import synth as _self  # noqa: F401
+    imu_list = [preints_imu[c] for c in chrono_local]          # interval ending at chrono index c
+    # initial estimates
+    kfs0 = kfs_true.copy()
+    for i in range(W):
+        kfs0[i, :3] += rng.normal(0, 0.02, 3); kfs0[i, 3:6] += rng.normal(0, 0.05, 3)
+        q = Rotation.from_quat(kfs0[i, 6:10]) * Rotation.from_rotvec(rng.normal(0, 0.005, 3))
+        qq = q.as_quat(); kfs0[i, 6:10] = qq if qq[3] >= 0 else -qq
+    pts0 = pts + rng.normal(0, 0.05, pts.shape)
+    return dict(kfs=kfs0, kfs_true=kfs_true, n_local=W, prev_kf=prev_kf, imu=imu_list, points=np.float32(pts0).astype(np.float64), points_true=pts,
+                edge_idx=np.array(edges_i, np.int32), edge_obs=np.array(edges_o, np.float64), gw=GRAVITY_CAM_WORLD.copy(), cam=cam)
