@@ -268,6 +268,24 @@ int viorb_pose_opt_vi(int variant, int compute_marg, const double cur_ns[22], co
 int viorb_pose_opt_se3(const float pose12[12], const float intr5[5], const double* obs7, int n, float out_pose12[12],
                        uint8_t* outlier, double info[4]);
 
+/* Optimizer::LocalBundleAdjustmentNavState (reference src/Optimizer.cc:1690-2241): the local-mapping window solve.
+ * Vertices: n_local free key frames (PVR 9 + accelerometer-bias 3, src/IMU/g2otypes.h:16-75), fixed key frames
+ * [n_local, nk), np marginalised points (Thirdparty/g2o/g2o/types/types_sba.h VertexSBAPointXYZ). Factors: one
+ * EdgeNavStatePVR + EdgeNavStateBias per local key frame i between its predecessor (i-1, or prev_kf for i == 0;
+ * prev_kf == -1: none) and i (src/Optimizer.cc:1872-1930), one EdgeNavStatePVRPointXYZ per observation
+ * (src/IMU/g2otypes.h:129-203). Solver: g2o Levenberg with the Schur complement of the point block
+ * (Thirdparty/g2o/g2o/core/block_solver.hpp:367-486), optimize(5), chi2 > 5.991 / depth <= 0 edges to level 1 and the
+ * mono kernel dropped, optimize(10) (src/Optimizer.cc:2027-2063); erase[k] = 1 for observations the caller must remove
+ * (:2105-2118). kfs [nk][22] (local window first, chronological), preint [n_local][142] of the interval ending at local
+ * key frame i, points [np][3], edge_idx [ne][2] = (point, key frame) sorted by point, edge_obs [ne][3] = u v invSigma2.
+ * stop: the reference's pbStopFlag (polled between LM trials; may be NULL). Outputs: kfs_out [n_local][22],
+ * points_out [np][3], erase [ne], info = chi2 after optimize(5), final chi2, iterations of both runs, 0, 0.
+ * Host buffers in and out (the caller is the LocalMapping thread); all arithmetic runs on the GPU in FP64. */
+int viorb_local_ba_navstate(const double* kfs, int nk, int n_local, int prev_kf, const double* preint,
+                            const double* points, int np, const int32_t* edge_idx, const double* edge_obs, int ne,
+                            const double gw[3], const double cam[16], const volatile int* stop, double* kfs_out,
+                            double* points_out, uint8_t* erase, double info[6]);
+
 /* Host-only test hooks (no GPU needed; used by the CPU test-suite to compare product host code with
  * the oracle): the flat-array formulation of DistributeOctTree that the device kernel mirrors
  * (keys packed x | y<<12 | score<<24, border-relative), and the scalar math shared with the kernels. */

@@ -1,0 +1,64 @@
+"""GPU parity of Optimizer::LocalBundleAdjustmentNavState (viorb_local_ba_navstate, csrc/local_ba.hip) against the oracle
+(oracle/local_ba.cpp): same LM trajectory (iteration counts), chi2 within 1e-5 relative, identical erase flags, key-frame
+states and points to solver precision; stop flag honoured; argument checks."""
+import numpy as np
+import pytest
+from viorb_amd.synth import make_local_ba_problem
+
+pytestmark = pytest.mark.gpu
+
+
+def _preints(oracle, p):
+    out = []
+    for i, (imu, t0, t1) in enumerate(p["imu"]):
+        j = i - 1 if i > 0 else p["prev_kf"]
+        out.append(oracle.preintegrate(imu, p["kfs"][j][10:13], p["kfs"][j][13:16], t0, t1))
+    return np.stack(out)
+
+
+def _args(p, pre):
+    return (p["kfs"], p["n_local"], p["prev_kf"], pre, p["points"], p["edge_idx"], p["edge_obs"], p["gw"], p["cam"])
+
+
+@pytest.mark.parametrize("seed,W,npts,extra", [(1, 10, 600, 3), (2, 4, 80, 2), (3, 20, 2000, 3), (4, 1, 60, 2)])
+def test_local_ba_matches_oracle(oracle, seed, W, npts, extra):
+    from viorb_amd import LocalBundleAdjustmentNavState
+    p = make_local_ba_problem(seed, W=W, n_points=npts, n_fixed_extra=extra)
+    pre = _preints(oracle, p)
+    ref = oracle.local_ba(*_args(p, pre))
+    got = LocalBundleAdjustmentNavState(*_args(p, pre))
+    assert (got["its_first"], got["its_second"]) == (ref["its_first"], ref["its_second"])
+    assert abs(got["chi2_first"] - ref["chi2_first"]) <= 1e-5 * ref["chi2_first"]        # north_star tolerance
+    assert abs(got["chi2_final"] - ref["chi2_final"]) <= 1e-5 * ref["chi2_final"]
+    assert np.array_equal(got["erase"], ref["erase"])
+    np.testing.assert_allclose(got["kfs"], ref["kfs"], rtol=0, atol=1e-7)
+    np.testing.assert_allclose(got["points"], ref["points"], rtol=0, atol=1e-6)
+
+
+def test_local_ba_without_prev_keyframe(oracle):
+    """prev_kf = -1: the first local key frame has no IMU / bias factor (map start)."""
+    from viorb_amd import LocalBundleAdjustmentNavState
+    p = make_local_ba_problem(5, W=6, n_points=300, n_fixed_extra=2)
+    pre = _preints(oracle, p)
+    a = list(_args(p, pre)); a[2] = -1
+    ref = oracle.local_ba(*a)
+    got = LocalBundleAdjustmentNavState(*a)
+    assert (got["its_first"], got["its_second"]) == (ref["its_first"], ref["its_second"])
+    assert abs(got["chi2_final"] - ref["chi2_final"]) <= 1e-5 * ref["chi2_final"]
+    assert np.array_equal(got["erase"], ref["erase"])
+    np.testing.assert_allclose(got["kfs"], ref["kfs"], rtol=0, atol=1e-7)
+
+
+def test_local_ba_stop_flag_and_argument_checks(oracle):
+    from viorb_amd import LocalBundleAdjustmentNavState, ViorbError
+    p = make_local_ba_problem(6, W=5, n_points=200)
+    pre = _preints(oracle, p)
+    stop = np.ones(1, np.int32)
+    got = LocalBundleAdjustmentNavState(*_args(p, pre), stop=stop)           # pbStopFlag already set: nothing moves (:2023-2026)
+    assert np.array_equal(got["kfs"], p["kfs"][:p["n_local"]]) and np.array_equal(got["points"], p["points"])
+    assert got["erase"].sum() == 0 and got["its_first"] == 0
+    bad = p["edge_idx"].copy(); bad[0, 1] = 99
+    with pytest.raises(ViorbError):
+        LocalBundleAdjustmentNavState(p["kfs"], p["n_local"], p["prev_kf"], pre, p["points"], bad, p["edge_obs"], p["gw"], p["cam"])
+    with pytest.raises(ViorbError):                                           # edges must be sorted by point
+        LocalBundleAdjustmentNavState(p["kfs"], p["n_local"], p["prev_kf"], pre, p["points"], p["edge_idx"][::-1], p["edge_obs"][::-1], p["gw"], p["cam"])

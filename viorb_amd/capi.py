@@ -63,6 +63,7 @@ SIGNATURES = {
     "viorb_frontend_pose_opt_device": (i32, [vp, i32, i32] + [vp] * 9 + [i32] + [vp] * 7),
     "viorb_frontend_pose_opt_se3_device": (i32, [vp, vp, vp, vp, C.c_double, i32, vp, vp, vp, vp]),
     "viorb_pose_opt_se3": (i32, [vp, vp, vp, i32, vp, vp, vp]),
+    "viorb_local_ba_navstate": (i32, [vp, i32, i32, i32, vp, vp, i32, vp, vp, i32] + [vp] * 7),
     "viorb_synth_plane_points_device": (i32, [vp, vp, vp, vp, C.c_double, i32, vp, vp, vp]),
     "viorb_memcpy_dtod_async": (i32, [vp, vp, sz, vp]),
     "viorb_profile_enable": (i32, [i32]),

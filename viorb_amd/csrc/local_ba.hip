@@ -1,0 +1,507 @@
+// viorb_amd/csrc/local_ba.hip — Optimizer::LocalBundleAdjustmentNavState (reference src/Optimizer.cc:1690-2241) on the GPU.
+//
+// Graph: W local key frames with free PVR(9)+Bias(3) vertices, fixed key frames, marginalised 3-D points, one IMU factor
+// (src/IMU/g2otypes.cpp:8-229, information = cov^-1, not inflated: Optimizer.cc:1901-1902) and one bias factor per local
+// key frame, one EdgeNavStatePVRPointXYZ (src/IMU/g2otypes.h:129-203, g2otypes.cpp:299-354) per observation.
+// Solver: g2o's Levenberg-Marquardt (optimization_algorithm_levenberg.cpp:61-189) with the Schur complement of the point
+// block (block_solver.hpp:367-486), 5 + 10 iterations with the chi2 / depth gate in between.
+//
+// Kernels (all FP64): k_ba_errors (per edge residuals + robust chi2), k_ba_lin_points (one thread per point: Jacobians,
+// weights, Hll, bl), k_ba_hpp (one workgroup per local key frame: its 6x6 (P,Phi) block), k_ba_imu (one workgroup per IMU
+// factor), k_ba_schur (one thread per point: (Hll + lambda I)^-1 and the -W D^-1 W^T scatter with FP64 atomics),
+// k_ba_chol_solve (dense Cholesky of the <= 240x240 reduced system by one 1024-thread workgroup), k_ba_backsub,
+// k_ba_update. The LM control flow (accept / reject, lambda schedule, stop rule, stop flag) runs on the host and reads
+// three scalars back per trial. The Schur products use FP64 atomics, not MFMA yet.
+#include <hip/hip_runtime.h>
+#include <vector>
+#include <algorithm>
+#include <cmath>
+#include <limits>
+#include "viorb_common.h"
+#include "vio_core.h"
+
+namespace viorb {
+
+struct BaDev {
+    int W, NK, NP, NE, np, prev_kf;
+    double *kf, *kf_bak;            // [NK][22]
+    double *pt, *pt_bak;            // [NP][3]
+    const int *e_pt, *e_kf;         // [NE]
+    const double *e_obs;            // [NE][3] u v invSigma2
+    uint8_t* level;                 // [NE]
+    double *err, *Jp, *Jk, *wgt;    // [NE][2], [NE][6], [NE][12], [NE]
+    const int *pt_start;            // [NP+1]
+    const int *kf_start, *kf_list;  // CSR of the edges of each local key frame
+    double *Hll, *bl, *Dinv;        // [NP][9], [NP][3], [NP][9]
+    double *Hpp, *bp, *S, *bs, *xp, *xl;
+    const double *preint, *info_pvr; // [W][142], [W][81]
+    double *e_pvr, *e_b;            // [W][9], [W][3]
+    double *scal;                   // [8]: 0 chi2, 1 scale, 2 ok, 3 max diag
+    double cam[16], gw[3];
+    double acc_bias_rw2;
+};
+
+__device__ __forceinline__ void ba_edge_geom(const BaDev& D, int k, const double* kfv, const double* ptv, d3& Pc, m33& RwbT, d3& Paux, cam_t& K) {
+    K = ld_cam(D.cam);
+    const pvr s = ld_pvr(kfv + (size_t)D.e_kf[k] * 22);
+    RwbT = tr(qmat(s.q));
+    Paux = mulv(K.Rcb, mulv(RwbT, ld3(ptv + (size_t)D.e_pt[k] * 3) - s.P));
+    Pc = Paux - K.RcbPbc;
+}
+__device__ __forceinline__ int ba_pred(const BaDev& D, int i) { return i == 0 ? D.prev_kf : i - 1; }
+
+// residuals of the active edges + robust chi2 (mono kernel optional) + IMU / bias factors
+__global__ void k_ba_errors(BaDev D, int mono_kernel) {
+    __shared__ double s_red[8];
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    double c = 0;
+    const double d_mono = (double)(float)sqrt(5.991);
+    if (k < D.NE && D.level[k] == 0) {
+        d3 Pc, Paux; m33 RT; cam_t K;
+        ba_edge_geom(D, k, D.kf, D.pt, Pc, RT, Paux, K);
+        const double e0 = D.e_obs[3 * k] - (Pc.x / Pc.z * K.fx + K.cx), e1 = D.e_obs[3 * k + 1] - (Pc.y / Pc.z * K.fy + K.cy);
+        D.err[2 * k] = e0; D.err[2 * k + 1] = e1;
+        const double chi = D.e_obs[3 * k + 2] * (e0 * e0 + e1 * e1);
+        double r0 = chi, r1;
+        if (mono_kernel) huber(chi, d_mono, &r0, &r1);
+        c = r0;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < D.W) {               // W <= blockDim.x
+        const int i = threadIdx.x, j = ba_pred(D, i);
+        if (j >= 0) {
+            const double* ki = D.kf + (size_t)i * 22; const double* kj = D.kf + (size_t)j * 22;
+            double e[9];
+            pvr_edge(ld_pvr(kj), ld_pvr(ki), ld3(kj + 16), ld3(kj + 19), D.preint + (size_t)i * 142, ld3(D.gw), e, nullptr);
+            double chi = 0;
+            for (int a = 0; a < 9; a++) { double t = 0; for (int b = 0; b < 9; b++) t += D.info_pvr[i * 81 + a * 9 + b] * e[b]; chi += e[a] * t; D.e_pvr[i * 9 + a] = e[a]; }
+            double r0, r1; huber(chi, (double)(float)sqrt(21.666), &r0, &r1); c += r0;
+            const d3 eb = (ld3(ki + 13) + ld3(ki + 19)) - (ld3(kj + 13) + ld3(kj + 19));
+            st3(D.e_b + i * 3, eb);
+            huber(dot3(eb, eb) / D.acc_bias_rw2 / D.preint[(size_t)i * 142 + 141], (double)(float)sqrt(16.812), &r0, &r1); c += r0;
+        }
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) c += __shfl_xor(c, d);
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) { double t = 0; for (int w = 0; w < (int)(blockDim.x >> 6); w++) t += s_red[w]; atomicAdd(&D.scal[0], t); }
+}
+
+// one thread per point: Jacobians + weights of its active edges (stored per edge), Hll and bl of the point
+__global__ void k_ba_lin_points(BaDev D, int mono_kernel) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= D.NP) return;
+    double H[6] = {0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};
+    const double d_mono = (double)(float)sqrt(5.991);
+    for (int k = D.pt_start[p]; k < D.pt_start[p + 1]; k++) {
+        if (D.level[k] != 0) continue;
+        d3 Pc, Paux; m33 RT; cam_t K;
+        ba_edge_geom(D, k, D.kf, D.pt, Pc, RT, Paux, K);
+        const double x = Pc.x, y = Pc.y, z = Pc.z;
+        const double j00 = K.fx / z, j02 = -x / z * K.fx / z, j11 = K.fy / z, j12 = -y / z * K.fy / z;
+        const m33 RR = mul(K.Rcb, RT), HR = mul(hat3(Paux), K.Rcb);
+        double Jp[6], Jk[12];
+        // point block: -Jpi * Rcb * Rwb^T ; key-frame block: Jpi * Rcb | -Jpi * hat(Paux) * Rcb
+        Jp[0] = -(j00 * RR.a00 + j02 * RR.a20); Jp[1] = -(j00 * RR.a01 + j02 * RR.a21); Jp[2] = -(j00 * RR.a02 + j02 * RR.a22);
+        Jp[3] = -(j11 * RR.a10 + j12 * RR.a20); Jp[4] = -(j11 * RR.a11 + j12 * RR.a21); Jp[5] = -(j11 * RR.a12 + j12 * RR.a22);
+        Jk[0] = j00 * K.Rcb.a00 + j02 * K.Rcb.a20; Jk[1] = j00 * K.Rcb.a01 + j02 * K.Rcb.a21; Jk[2] = j00 * K.Rcb.a02 + j02 * K.Rcb.a22;
+        Jk[3] = -(j00 * HR.a00 + j02 * HR.a20); Jk[4] = -(j00 * HR.a01 + j02 * HR.a21); Jk[5] = -(j00 * HR.a02 + j02 * HR.a22);
+        Jk[6] = j11 * K.Rcb.a10 + j12 * K.Rcb.a20; Jk[7] = j11 * K.Rcb.a11 + j12 * K.Rcb.a21; Jk[8] = j11 * K.Rcb.a12 + j12 * K.Rcb.a22;
+        Jk[9] = -(j11 * HR.a10 + j12 * HR.a20); Jk[10] = -(j11 * HR.a11 + j12 * HR.a21); Jk[11] = -(j11 * HR.a12 + j12 * HR.a22);
+        const double e0 = D.err[2 * k], e1 = D.err[2 * k + 1], is2 = D.e_obs[3 * k + 2];
+        double r0, r1 = 1;
+        if (mono_kernel) huber(is2 * (e0 * e0 + e1 * e1), d_mono, &r0, &r1);
+        const double w = r1 * is2;
+        D.wgt[k] = w;
+        for (int a = 0; a < 6; a++) D.Jp[6 * k + a] = Jp[a];
+        for (int a = 0; a < 12; a++) D.Jk[12 * k + a] = Jk[a];
+        H[0] += w * (Jp[0] * Jp[0] + Jp[3] * Jp[3]); H[1] += w * (Jp[0] * Jp[1] + Jp[3] * Jp[4]); H[2] += w * (Jp[0] * Jp[2] + Jp[3] * Jp[5]);
+        H[3] += w * (Jp[1] * Jp[1] + Jp[4] * Jp[4]); H[4] += w * (Jp[1] * Jp[2] + Jp[4] * Jp[5]); H[5] += w * (Jp[2] * Jp[2] + Jp[5] * Jp[5]);
+        for (int a = 0; a < 3; a++) b[a] -= w * (Jp[a] * e0 + Jp[3 + a] * e1);
+    }
+    double* Ho = D.Hll + (size_t)p * 9;
+    Ho[0] = H[0]; Ho[1] = H[1]; Ho[2] = H[2]; Ho[3] = H[1]; Ho[4] = H[3]; Ho[5] = H[4]; Ho[6] = H[2]; Ho[7] = H[4]; Ho[8] = H[5];
+    for (int a = 0; a < 3; a++) D.bl[(size_t)p * 3 + a] = b[a];
+}
+
+// one workgroup per local key frame: sum of Jk^T w Jk / Jk^T w e over its active edges -> (P, Phi) block of Hpp, bp
+__global__ __launch_bounds__(256) void k_ba_hpp(BaDev D) {
+    __shared__ double s_red[4][27];
+    const int i = blockIdx.x, t = threadIdx.x;
+    double a[27];
+#pragma unroll
+    for (int k = 0; k < 27; k++) a[k] = 0;
+    for (int q = D.kf_start[i] + t; q < D.kf_start[i + 1]; q += blockDim.x) {
+        const int k = D.kf_list[q];
+        if (D.level[k] != 0) continue;
+        const double* J = D.Jk + (size_t)12 * k; const double w = D.wgt[k], e0 = D.err[2 * k], e1 = D.err[2 * k + 1];
+        int c = 0;
+#pragma unroll
+        for (int r = 0; r < 6; r++)
+#pragma unroll
+            for (int cc = r; cc < 6; cc++) a[c++] += w * (J[r] * J[cc] + J[6 + r] * J[6 + cc]);
+#pragma unroll
+        for (int r = 0; r < 6; r++) a[21 + r] -= w * (J[r] * e0 + J[6 + r] * e1);
+    }
+#pragma unroll
+    for (int k = 0; k < 27; k++) {
+        double v = a[k];
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d);
+        if ((t & 63) == 0) s_red[t >> 6][k] = v;
+    }
+    __syncthreads();
+    if (t < 27) {
+        const double v = s_red[0][t] + s_red[1][t] + s_red[2][t] + s_red[3][t];
+        const int base = 12 * i, loc[6] = {0, 1, 2, 6, 7, 8}, n = D.np;
+        if (t < 21) {
+            int kk = 0, rr = 0, cc = 0;
+            for (int r = 0; r < 6; r++) for (int c = r; c < 6; c++) { if (kk == t) { rr = r; cc = c; } kk++; }
+            atomicAdd(&D.Hpp[(size_t)(base + loc[rr]) * n + base + loc[cc]], v);
+            if (rr != cc) atomicAdd(&D.Hpp[(size_t)(base + loc[cc]) * n + base + loc[rr]], v);
+        } else atomicAdd(&D.bp[base + loc[t - 21]], v);
+    }
+}
+
+// one workgroup per local key frame i: IMU factor (pred(i) -> i) and bias factor
+__global__ __launch_bounds__(256) void k_ba_imu(BaDev D) {
+    __shared__ double J[9 * 21], OJ[9 * 21], e[9];
+    __shared__ int map[21];
+    __shared__ double s_w;
+    const int i = blockIdx.x, t = threadIdx.x, j = ba_pred(D, i), n = D.np;
+    if (j < 0) return;
+    const double* ki = D.kf + (size_t)i * 22; const double* kj = D.kf + (size_t)j * 22;
+    if (t == 0) {
+        pvr_edge(ld_pvr(kj), ld_pvr(ki), ld3(kj + 16), ld3(kj + 19), D.preint + (size_t)i * 142, ld3(D.gw), e, J);
+        double chi = 0;
+        for (int a = 0; a < 9; a++) { double s = 0; for (int b = 0; b < 9; b++) s += D.info_pvr[i * 81 + a * 9 + b] * e[b]; chi += e[a] * s; }
+        double r0, r1; huber(chi, (double)(float)sqrt(21.666), &r0, &r1); s_w = r1;
+        for (int c = 0; c < 9; c++) { map[c] = j < D.W ? 12 * j + c : -1; map[9 + c] = 12 * i + c; }
+        for (int c = 0; c < 3; c++) map[18 + c] = j < D.W ? 12 * j + 9 + c : -1;
+        // bias factor
+        const d3 eb = (ld3(ki + 13) + ld3(ki + 19)) - (ld3(kj + 13) + ld3(kj + 19));
+        const double binfo = 1.0 / D.acc_bias_rw2 / D.preint[(size_t)i * 142 + 141];
+        huber(binfo * dot3(eb, eb), (double)(float)sqrt(16.812), &r0, &r1);
+        const double wb = r1 * binfo, ev[3] = {eb.x, eb.y, eb.z};
+        for (int c = 0; c < 3; c++) {
+            const int ic = 12 * i + 9 + c, jc = j < D.W ? 12 * j + 9 + c : -1;
+            atomicAdd(&D.Hpp[(size_t)ic * n + ic], wb); atomicAdd(&D.bp[ic], -wb * ev[c]);
+            if (jc >= 0) { atomicAdd(&D.Hpp[(size_t)jc * n + jc], wb); atomicAdd(&D.Hpp[(size_t)ic * n + jc], -wb); atomicAdd(&D.Hpp[(size_t)jc * n + ic], -wb); atomicAdd(&D.bp[jc], wb * ev[c]); }
+        }
+    }
+    __syncthreads();
+    for (int q = t; q < 189; q += blockDim.x) { const int r = q / 21, c = q % 21; double s = 0; for (int k = 0; k < 9; k++) s += D.info_pvr[i * 81 + r * 9 + k] * J[k * 21 + c]; OJ[q] = s; }
+    __syncthreads();
+    const double w = s_w;
+    for (int q = t; q < 441 + 21; q += blockDim.x) {
+        if (q < 441) { const int r = q / 21, c = q % 21; if (map[r] >= 0 && map[c] >= 0) { double s = 0; for (int k = 0; k < 9; k++) s += J[k * 21 + r] * OJ[k * 21 + c]; atomicAdd(&D.Hpp[(size_t)map[r] * n + map[c]], w * s); } }
+        else { const int r = q - 441; if (map[r] >= 0) { double s = 0; for (int k = 0; k < 9; k++) s += OJ[k * 21 + r] * e[k]; atomicAdd(&D.bp[map[r]], -w * s); } }
+    }
+}
+
+// S = Hpp + lambda I, bs = bp (element-wise); also the max |diag| for the initial lambda
+__global__ void k_ba_init_reduced(BaDev D, double lambda) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x, n = D.np;
+    if (q < n * n) D.S[q] = D.Hpp[q] + ((q / n == q % n) ? lambda : 0.0);
+    if (q < n) D.bs[q] = D.bp[q];
+}
+__global__ void k_ba_max_diag(BaDev D) {
+    __shared__ double s_red[4];
+    double m = 0;
+    for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < D.np + 3 * D.NP; q += gridDim.x * blockDim.x)
+        m = fmax(m, fabs(q < D.np ? D.Hpp[(size_t)q * D.np + q] : D.Hll[(size_t)((q - D.np) / 3) * 9 + ((q - D.np) % 3) * 4]));
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) m = fmax(m, __shfl_xor(m, d));
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = fmax(fmax(s_red[0], s_red[1]), fmax(s_red[2], s_red[3]));
+        // fmax over non-negative doubles == max over their bit patterns as unsigned integers
+        atomicMax(reinterpret_cast<unsigned long long*>(&D.scal[3]), (unsigned long long)__double_as_longlong(t));
+    }
+}
+
+// one thread per point: Dinv = (Hll + lambda I)^-1 and the Schur scatter S -= W Dinv W^T, bs -= W Dinv bl
+__global__ void k_ba_schur(BaDev D, double lambda) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= D.NP) return;
+    const double* H = D.Hll + (size_t)p * 9;
+    const double a = H[0] + lambda, b = H[1], c = H[2], d = H[4] + lambda, e = H[5], f = H[8] + lambda;
+    const double det = a * (d * f - e * e) - b * (b * f - c * e) + c * (b * e - c * d), id = 1.0 / det;
+    const double i00 = (d * f - e * e) * id, i01 = (c * e - b * f) * id, i02 = (b * e - c * d) * id, i11 = (a * f - c * c) * id, i12 = (b * c - a * e) * id, i22 = (a * d - b * b) * id;
+    double* Di = D.Dinv + (size_t)p * 9;
+    Di[0] = i00; Di[1] = i01; Di[2] = i02; Di[3] = i01; Di[4] = i11; Di[5] = i12; Di[6] = i02; Di[7] = i12; Di[8] = i22;
+    const double b0 = D.bl[3 * p], b1 = D.bl[3 * p + 1], b2 = D.bl[3 * p + 2];
+    const double db0 = i00 * b0 + i01 * b1 + i02 * b2, db1 = i01 * b0 + i11 * b1 + i12 * b2, db2 = i02 * b0 + i12 * b1 + i22 * b2;
+    const int loc[6] = {0, 1, 2, 6, 7, 8}, n = D.np, k0 = D.pt_start[p], k1 = D.pt_start[p + 1];
+    for (int ea = k0; ea < k1; ea++) {
+        if (D.level[ea] != 0 || D.e_kf[ea] >= D.W) continue;
+        const double* Ja = D.Jk + (size_t)12 * ea; const double* Pa = D.Jp + (size_t)6 * ea; const double wa = D.wgt[ea];
+        double Wa[18], BD[18];
+        for (int r = 0; r < 6; r++) for (int q = 0; q < 3; q++) Wa[r * 3 + q] = wa * (Ja[r] * Pa[q] + Ja[6 + r] * Pa[3 + q]);
+        for (int r = 0; r < 6; r++) {
+            BD[r * 3] = Wa[r * 3] * i00 + Wa[r * 3 + 1] * i01 + Wa[r * 3 + 2] * i02;
+            BD[r * 3 + 1] = Wa[r * 3] * i01 + Wa[r * 3 + 1] * i11 + Wa[r * 3 + 2] * i12;
+            BD[r * 3 + 2] = Wa[r * 3] * i02 + Wa[r * 3 + 1] * i12 + Wa[r * 3 + 2] * i22;
+        }
+        const int ba = 12 * D.e_kf[ea];
+        for (int r = 0; r < 6; r++) atomicAdd(&D.bs[ba + loc[r]], -(Wa[r * 3] * db0 + Wa[r * 3 + 1] * db1 + Wa[r * 3 + 2] * db2));
+        for (int eb = k0; eb < k1; eb++) {
+            if (D.level[eb] != 0 || D.e_kf[eb] >= D.W) continue;
+            const double* Jb = D.Jk + (size_t)12 * eb; const double* Pb = D.Jp + (size_t)6 * eb; const double wb = D.wgt[eb];
+            const int bb = 12 * D.e_kf[eb];
+            for (int cc = 0; cc < 6; cc++) {
+                const double w0 = wb * (Jb[cc] * Pb[0] + Jb[6 + cc] * Pb[3]), w1 = wb * (Jb[cc] * Pb[1] + Jb[6 + cc] * Pb[4]), w2 = wb * (Jb[cc] * Pb[2] + Jb[6 + cc] * Pb[5]);
+                for (int r = 0; r < 6; r++) atomicAdd(&D.S[(size_t)(ba + loc[r]) * n + bb + loc[cc]], -(BD[r * 3] * w0 + BD[r * 3 + 1] * w1 + BD[r * 3 + 2] * w2));
+            }
+        }
+    }
+}
+
+// dense Cholesky solve S xp = bs by ONE 1024-thread workgroup (n <= 240); scal[2] = 1 on success
+__global__ __launch_bounds__(1024) void k_ba_chol_solve(BaDev D) {
+    __shared__ double s_col[256], s_y[256];
+    __shared__ int s_ok;
+    const int n = D.np, t = threadIdx.x;
+    double* A = D.S;
+    if (t == 0) s_ok = 1;
+    __syncthreads();
+    for (int j = 0; j < n; j++) {
+        if (t == 0) { const double d = A[(size_t)j * n + j]; if (!(d > 0) || !isfinite(d)) s_ok = 0; s_col[j] = sqrt(d > 0 ? d : 1.0); }
+        __syncthreads();
+        const double dj = s_col[j];
+        for (int i = j + t; i < n; i += blockDim.x) { const double v = (i == j) ? dj : A[(size_t)i * n + j] / dj; A[(size_t)i * n + j] = v; if (i > j) s_col[i] = v; }
+        __syncthreads();
+        const int m = n - j - 1;
+        for (int q = t; q < m * m; q += blockDim.x) {
+            const int r = j + 1 + q / m, c = j + 1 + q % m;
+            if (c <= r) A[(size_t)r * n + c] -= s_col[r] * s_col[c];
+        }
+        __syncthreads();
+    }
+    // forward / backward substitution, one unknown per step, updates spread over the threads
+    for (int i = t; i < n; i += blockDim.x) s_y[i] = D.bs[i];
+    __syncthreads();
+    for (int j = 0; j < n; j++) {
+        if (t == 0) s_y[j] /= A[(size_t)j * n + j];
+        __syncthreads();
+        const double yj = s_y[j];
+        for (int i = j + 1 + t; i < n; i += blockDim.x) s_y[i] -= A[(size_t)i * n + j] * yj;
+        __syncthreads();
+    }
+    for (int j = n - 1; j >= 0; j--) {
+        if (t == 0) s_y[j] /= A[(size_t)j * n + j];
+        __syncthreads();
+        const double xj = s_y[j];
+        for (int i = t; i < j; i += blockDim.x) s_y[i] -= A[(size_t)j * n + i] * xj;
+        __syncthreads();
+    }
+    for (int i = t; i < n; i += blockDim.x) D.xp[i] = s_ok ? s_y[i] : 0.0;
+    if (t == 0) D.scal[2] = s_ok ? 1.0 : 0.0;
+}
+
+// xl = Dinv (bl - W^T xp) per point, and the LM scale term sum x (lambda x + b)
+__global__ void k_ba_backsub(BaDev D, double lambda) {
+    __shared__ double s_red[4];
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    double sc = 0;
+    if (p < D.NP) {
+        double c0 = D.bl[3 * p], c1 = D.bl[3 * p + 1], c2 = D.bl[3 * p + 2];
+        const int loc[6] = {0, 1, 2, 6, 7, 8};
+        for (int k = D.pt_start[p]; k < D.pt_start[p + 1]; k++) {
+            if (D.level[k] != 0 || D.e_kf[k] >= D.W) continue;
+            const double* J = D.Jk + (size_t)12 * k; const double* Pp = D.Jp + (size_t)6 * k; const double w = D.wgt[k];
+            const int ba = 12 * D.e_kf[k];
+            for (int r = 0; r < 6; r++) { const double x = D.xp[ba + loc[r]]; c0 -= w * (J[r] * Pp[0] + J[6 + r] * Pp[3]) * x; c1 -= w * (J[r] * Pp[1] + J[6 + r] * Pp[4]) * x; c2 -= w * (J[r] * Pp[2] + J[6 + r] * Pp[5]) * x; }
+        }
+        const double* Di = D.Dinv + (size_t)p * 9;
+        const double x0 = Di[0] * c0 + Di[1] * c1 + Di[2] * c2, x1 = Di[3] * c0 + Di[4] * c1 + Di[5] * c2, x2 = Di[6] * c0 + Di[7] * c1 + Di[8] * c2;
+        D.xl[3 * p] = x0; D.xl[3 * p + 1] = x1; D.xl[3 * p + 2] = x2;
+        sc = x0 * (lambda * x0 + D.bl[3 * p]) + x1 * (lambda * x1 + D.bl[3 * p + 1]) + x2 * (lambda * x2 + D.bl[3 * p + 2]);
+    }
+    if (blockIdx.x == 0) for (int q = threadIdx.x; q < D.np; q += blockDim.x) sc += D.xp[q] * (lambda * D.xp[q] + D.bp[q]);
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) sc += __shfl_xor(sc, d);
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = sc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(&D.scal[1], s_red[0] + s_red[1] + s_red[2] + s_red[3]);
+}
+
+__global__ void k_ba_update(BaDev D) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < D.W) {
+        double* k = D.kf + (size_t)q * 22;
+        const pvr s = inc_small_pvr(ld_pvr(k), D.xp + 12 * q);
+        st_pvr(k, s);
+        for (int c = 0; c < 3; c++) k[19 + c] += D.xp[12 * q + 9 + c];
+    }
+    if (q < D.NP) for (int c = 0; c < 3; c++) D.pt[3 * q + c] += D.xl[3 * q + c];
+}
+
+// chi2 / depth gate on every edge (stale error on excluded edges, fresh depth), Optimizer.cc:2037-2051 and :2105-2118
+__global__ void k_ba_gate(BaDev D, uint8_t* out, int set_level) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= D.NE) return;
+    d3 Pc, Paux; m33 RT; cam_t K;
+    ba_edge_geom(D, k, D.kf, D.pt, Pc, RT, Paux, K);
+    const double chi = D.e_obs[3 * k + 2] * (D.err[2 * k] * D.err[2 * k] + D.err[2 * k + 1] * D.err[2 * k + 1]);
+    const int bad = (chi > 5.991 || !(Pc.z > 0.0)) ? 1 : 0;
+    if (set_level) { if (bad) D.level[k] = 1; } else out[k] = (uint8_t)bad;
+}
+
+} // namespace viorb
+
+using namespace viorb;
+
+namespace {
+struct BaBuf {
+    std::vector<void*> ptrs;
+    ~BaBuf() { for (void* p : ptrs) (void)hipFree(p); }
+    template <class T> bool alloc(T** d, size_t n, const T* src = nullptr) {
+        if (hipMalloc((void**)d, std::max<size_t>(n, 1) * sizeof(T)) != hipSuccess) return false;
+        ptrs.push_back(*d);
+        if (src && n) return hipMemcpy(*d, src, n * sizeof(T), hipMemcpyHostToDevice) == hipSuccess;
+        return hipMemset(*d, 0, std::max<size_t>(n, 1) * sizeof(T)) == hipSuccess;
+    }
+};
+bool host_inverse9(const double* a_in, double* inv) {
+    double a[81]; for (int i = 0; i < 81; i++) { a[i] = a_in[i]; inv[i] = (i / 9 == i % 9) ? 1.0 : 0.0; }
+    for (int col = 0; col < 9; col++) {
+        int p = col; double best = std::fabs(a[col * 9 + col]);
+        for (int i = col + 1; i < 9; i++) if (std::fabs(a[i * 9 + col]) > best) { best = std::fabs(a[i * 9 + col]); p = i; }
+        if (best == 0) return false;
+        if (p != col) for (int j = 0; j < 9; j++) { std::swap(a[p * 9 + j], a[col * 9 + j]); std::swap(inv[p * 9 + j], inv[col * 9 + j]); }
+        const double iv = 1.0 / a[col * 9 + col];
+        for (int j = 0; j < 9; j++) { a[col * 9 + j] *= iv; inv[col * 9 + j] *= iv; }
+        for (int i = 0; i < 9; i++) if (i != col) { const double f = a[i * 9 + col]; if (f == 0) continue; for (int j = 0; j < 9; j++) { a[i * 9 + j] -= f * a[col * 9 + j]; inv[i * 9 + j] -= f * inv[col * 9 + j]; } }
+    }
+    return true;
+}
+} // namespace
+
+extern "C" int viorb_local_ba_navstate(const double* kfs, int nk, int n_local, int prev_kf, const double* preint, const double* points, int npts,
+                                       const int32_t* edge_idx, const double* edge_obs, int ne, const double gw[3], const double cam[16],
+                                       const volatile int* stop, double* kfs_out, double* points_out, uint8_t* erase, double info[6]) {
+    VIORB_REQUIRE(kfs && preint && points && edge_idx && edge_obs && gw && cam && kfs_out && points_out && erase && info, "null array");
+    VIORB_REQUIRE(n_local >= 1 && n_local <= 20 && nk >= n_local && npts >= 1 && ne >= 1, "1 <= n_local <= 20 key frames, at least one point and edge");
+    VIORB_REQUIRE(prev_kf == -1 || (prev_kf >= n_local && prev_kf < nk), "prev_kf must index a fixed key frame or be -1");
+    if (viorb_device_count() < 1) { set_error("no HIP device: libviorb_hip has no CPU fallback"); return VIORB_ERR_NO_DEVICE; }
+    for (int i = 0; i < 6; i++) info[i] = 0;
+    for (int i = 0; i < n_local * 22; i++) kfs_out[i] = kfs[i];
+    for (int i = 0; i < npts * 3; i++) points_out[i] = points[i];
+    for (int k = 0; k < ne; k++) erase[k] = 0;
+    auto terminate = [&]() { return stop && *stop; };
+    if (terminate()) return VIORB_OK;
+    // ---- host-side graph bookkeeping
+    std::vector<int> e_pt(ne), e_kf(ne), pt_start(npts + 1, 0);
+    for (int k = 0; k < ne; k++) {
+        e_pt[k] = edge_idx[2 * k]; e_kf[k] = edge_idx[2 * k + 1];
+        VIORB_REQUIRE(e_pt[k] >= 0 && e_pt[k] < npts && e_kf[k] >= 0 && e_kf[k] < nk, "edge index out of range");
+        VIORB_REQUIRE(k == 0 || e_pt[k] >= e_pt[k - 1], "edges must be grouped by point (ascending point index)");
+        pt_start[e_pt[k] + 1]++;
+    }
+    for (int p = 0; p < npts; p++) pt_start[p + 1] += pt_start[p];
+    std::vector<int> kf_start(n_local + 1, 0), kf_list;
+    for (int k = 0; k < ne; k++) if (e_kf[k] < n_local) kf_start[e_kf[k] + 1]++;
+    for (int i = 0; i < n_local; i++) kf_start[i + 1] += kf_start[i];
+    kf_list.resize(kf_start[n_local]);
+    { std::vector<int> pos(kf_start.begin(), kf_start.end() - 1); for (int k = 0; k < ne; k++) if (e_kf[k] < n_local) kf_list[pos[e_kf[k]]++] = k; }
+    std::vector<double> info_pvr((size_t)n_local * 81);
+    for (int i = 0; i < n_local; i++) if (!host_inverse9(preint + (size_t)i * 142 + 60, &info_pvr[(size_t)i * 81])) { set_error("singular IMU covariance"); return VIORB_ERR_INVALID_ARG; }
+
+    VIORB_HIP_TRY(hipSetDevice(0));
+    BaBuf B; BaDev D;
+    D.W = n_local; D.NK = nk; D.NP = npts; D.NE = ne; D.np = 12 * n_local; D.prev_kf = prev_kf; D.acc_bias_rw2 = 5e-3 * 5e-3;
+    for (int i = 0; i < 16; i++) D.cam[i] = cam[i];
+    for (int i = 0; i < 3; i++) D.gw[i] = gw[i];
+    int *d_ept, *d_ekf, *d_pts, *d_kfs, *d_kfl; double *d_obs, *d_pre, *d_info; uint8_t* d_erase;
+    const size_t n2 = (size_t)D.np * D.np;
+    bool ok = B.alloc(&D.kf, (size_t)nk * 22, kfs) && B.alloc(&D.kf_bak, (size_t)nk * 22) && B.alloc(&D.pt, (size_t)npts * 3, points) && B.alloc(&D.pt_bak, (size_t)npts * 3) &&
+              B.alloc(&d_ept, ne, e_pt.data()) && B.alloc(&d_ekf, ne, e_kf.data()) && B.alloc(&d_obs, (size_t)ne * 3, edge_obs) && B.alloc(&D.level, ne) &&
+              B.alloc(&D.err, (size_t)ne * 2) && B.alloc(&D.Jp, (size_t)ne * 6) && B.alloc(&D.Jk, (size_t)ne * 12) && B.alloc(&D.wgt, ne) &&
+              B.alloc(&d_pts, npts + 1, pt_start.data()) && B.alloc(&d_kfs, n_local + 1, kf_start.data()) && B.alloc(&d_kfl, kf_list.size(), kf_list.data()) &&
+              B.alloc(&D.Hll, (size_t)npts * 9) && B.alloc(&D.bl, (size_t)npts * 3) && B.alloc(&D.Dinv, (size_t)npts * 9) &&
+              B.alloc(&D.Hpp, n2) && B.alloc(&D.bp, D.np) && B.alloc(&D.S, n2) && B.alloc(&D.bs, D.np) && B.alloc(&D.xp, D.np) && B.alloc(&D.xl, (size_t)npts * 3) &&
+              B.alloc(&d_pre, (size_t)n_local * 142, preint) && B.alloc(&d_info, info_pvr.size(), info_pvr.data()) &&
+              B.alloc(&D.e_pvr, (size_t)n_local * 9) && B.alloc(&D.e_b, (size_t)n_local * 3) && B.alloc(&D.scal, 8) && B.alloc(&d_erase, ne);
+    if (!ok) { set_error("device allocation / upload failed"); return VIORB_ERR_HIP; }
+    D.e_pt = d_ept; D.e_kf = d_ekf; D.e_obs = d_obs; D.pt_start = d_pts; D.kf_start = d_kfs; D.kf_list = d_kfl; D.preint = d_pre; D.info_pvr = d_info;
+    hipStream_t st = nullptr;
+    const int TB = 256, gE = (ne + TB - 1) / TB, gP = (npts + TB - 1) / TB;
+    int mono_kernel = 1;
+    double h_scal[8];
+    auto eval_chi2 = [&](double* chi) -> int {
+        VIORB_HIP_TRY(hipMemsetAsync(D.scal, 0, sizeof(double), st));
+        hipLaunchKernelGGL(k_ba_errors, dim3(gE), dim3(TB), 0, st, D, mono_kernel);
+        VIORB_HIP_TRY(hipMemcpy(chi, D.scal, sizeof(double), hipMemcpyDeviceToHost));
+        return VIORB_OK;
+    };
+    auto build_system = [&]() -> int {
+        VIORB_HIP_TRY(hipMemsetAsync(D.Hpp, 0, n2 * sizeof(double), st));
+        VIORB_HIP_TRY(hipMemsetAsync(D.bp, 0, D.np * sizeof(double), st));
+        hipLaunchKernelGGL(k_ba_lin_points, dim3(gP), dim3(TB), 0, st, D, mono_kernel);
+        hipLaunchKernelGGL(k_ba_hpp, dim3(n_local), dim3(256), 0, st, D);
+        hipLaunchKernelGGL(k_ba_imu, dim3(n_local), dim3(256), 0, st, D);
+        return VIORB_OK;
+    };
+    double lambda = 0, ni = 2;
+    int rc = VIORB_OK;
+    auto optimize = [&](int iterations, int& its_done, double& chi_out) -> int {
+        double currentChi = 0; int nBad = 0;
+        for (int it = 0; it < iterations && !terminate(); it++) {
+            if ((rc = eval_chi2(&currentChi)) != VIORB_OK) return rc;
+            const double iniChi = currentChi;
+            if ((rc = build_system()) != VIORB_OK) return rc;
+            if (it == 0) {
+                VIORB_HIP_TRY(hipMemsetAsync(D.scal + 3, 0, sizeof(double), st));
+                hipLaunchKernelGGL(k_ba_max_diag, dim3(32), dim3(256), 0, st, D);
+                VIORB_HIP_TRY(hipMemcpy(h_scal, D.scal, 8 * sizeof(double), hipMemcpyDeviceToHost));
+                lambda = 1e-5 * h_scal[3]; ni = 2; nBad = 0;
+            }
+            double rho = 0; int qmax = 0;
+            do {
+                VIORB_HIP_TRY(hipMemcpyAsync(D.kf_bak, D.kf, (size_t)nk * 22 * sizeof(double), hipMemcpyDeviceToDevice, st));
+                VIORB_HIP_TRY(hipMemcpyAsync(D.pt_bak, D.pt, (size_t)npts * 3 * sizeof(double), hipMemcpyDeviceToDevice, st));
+                hipLaunchKernelGGL(k_ba_init_reduced, dim3((unsigned)((n2 + TB - 1) / TB)), dim3(TB), 0, st, D, lambda);
+                hipLaunchKernelGGL(k_ba_schur, dim3(gP), dim3(TB), 0, st, D, lambda);
+                hipLaunchKernelGGL(k_ba_chol_solve, dim3(1), dim3(1024), 0, st, D);
+                VIORB_HIP_TRY(hipMemsetAsync(D.scal + 1, 0, sizeof(double), st));
+                hipLaunchKernelGGL(k_ba_backsub, dim3(gP), dim3(TB), 0, st, D, lambda);
+                hipLaunchKernelGGL(k_ba_update, dim3(std::max(gP, 1)), dim3(TB), 0, st, D);
+                double tempChi = 0;
+                if ((rc = eval_chi2(&tempChi)) != VIORB_OK) return rc;
+                VIORB_HIP_TRY(hipMemcpy(h_scal, D.scal, 8 * sizeof(double), hipMemcpyDeviceToHost));
+                const bool ok2 = h_scal[2] > 0.5;
+                if (!ok2) tempChi = std::numeric_limits<double>::max();
+                const double scale = (ok2 ? h_scal[1] : 0.0) + 1e-3;
+                rho = (currentChi - tempChi) / scale;
+                if (rho > 0 && std::isfinite(tempChi)) { double alpha = 1. - std::pow((2 * rho - 1), 3); alpha = std::min(alpha, 2. / 3.); lambda *= std::max(1. / 3., alpha); ni = 2; currentChi = tempChi; }
+                else {
+                    lambda *= ni; ni *= 2;
+                    VIORB_HIP_TRY(hipMemcpyAsync(D.kf, D.kf_bak, (size_t)nk * 22 * sizeof(double), hipMemcpyDeviceToDevice, st));
+                    VIORB_HIP_TRY(hipMemcpyAsync(D.pt, D.pt_bak, (size_t)npts * 3 * sizeof(double), hipMemcpyDeviceToDevice, st));
+                }
+                qmax++;
+            } while (rho < 0 && qmax < 10 && !terminate());
+            its_done++; chi_out = currentChi;
+            if (qmax == 10 || rho == 0) break;
+            if ((iniChi - currentChi) * 1e3 < iniChi) nBad++; else nBad = 0;
+            if (nBad >= 3) break;
+        }
+        return VIORB_OK;
+    };
+    int its1 = 0, its2 = 0; double chi1 = 0, chi2v = 0;
+    if ((rc = optimize(5, its1, chi1)) != VIORB_OK) return rc;
+    if (!terminate()) {
+        hipLaunchKernelGGL(k_ba_gate, dim3(gE), dim3(TB), 0, st, D, d_erase, 1);
+        mono_kernel = 0;
+        if ((rc = optimize(10, its2, chi2v)) != VIORB_OK) return rc;
+    }
+    hipLaunchKernelGGL(k_ba_gate, dim3(gE), dim3(TB), 0, st, D, d_erase, 0);
+    VIORB_HIP_TRY(hipDeviceSynchronize());
+    VIORB_HIP_TRY(hipMemcpy(kfs_out, D.kf, (size_t)n_local * 22 * sizeof(double), hipMemcpyDeviceToHost));
+    VIORB_HIP_TRY(hipMemcpy(points_out, D.pt, (size_t)npts * 3 * sizeof(double), hipMemcpyDeviceToHost));
+    VIORB_HIP_TRY(hipMemcpy(erase, d_erase, ne, hipMemcpyDeviceToHost));
+    info[0] = chi1; info[1] = chi2v; info[2] = its1; info[3] = its2;
+    return VIORB_OK;
+}

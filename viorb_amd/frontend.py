@@ -80,6 +80,21 @@ def PoseOptimizationSE3(pose12, intr5, obs7):
     return dict(pose12=out, outlier=fl[:len(obs7)], n_inliers=int(info[0]), final_chi2=float(info[1]), lm_iterations=int(info[2]))
 
 
+def LocalBundleAdjustmentNavState(kfs, n_local, prev_kf, preint, points, edge_idx, edge_obs, gw, cam, stop=None):
+    """Optimizer::LocalBundleAdjustmentNavState (reference src/Optimizer.cc:1690-2241) with host buffers, solved on the GPU.
+    kfs [NK,22] local window first; preint [W,142]; points [NP,3]; edge_idx [NE,2] int32 (point, kf) sorted by point;
+    edge_obs [NE,3] = u v invSigma2; stop = optional int32 array of one element (pbStopFlag)."""
+    kfs = np.ascontiguousarray(kfs, np.float64).reshape(-1, 22); preint = np.ascontiguousarray(preint, np.float64).reshape(-1, 142)
+    points = np.ascontiguousarray(points, np.float64).reshape(-1, 3)
+    ei = np.ascontiguousarray(edge_idx, np.int32).reshape(-1, 2); eo = np.ascontiguousarray(edge_obs, np.float64).reshape(-1, 3)
+    ko, po = np.zeros((n_local, 22)), np.zeros_like(points)
+    er, info = np.zeros(max(len(ei), 1), np.uint8), np.zeros(6)
+    check(lib().viorb_local_ba_navstate(ptr(kfs), len(kfs), n_local, prev_kf, ptr(preint), ptr(points), len(points), ptr(ei), ptr(eo), len(ei),
+                                        ptr(np.ascontiguousarray(gw, np.float64)), ptr(np.ascontiguousarray(cam, np.float64)),
+                                        ptr(stop) if stop is not None else None, ptr(ko), ptr(po), ptr(er), ptr(info)))
+    return dict(kfs=ko, points=po, erase=er[:len(ei)], chi2_first=info[0], chi2_final=info[1], its_first=int(info[2]), its_second=int(info[3]))
+
+
 class Frontend:
     """Batched device-resident front-end: every method only enqueues kernels on the given torch stream."""
 
