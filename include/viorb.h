@@ -286,6 +286,42 @@ int viorb_local_ba_navstate(const double* kfs, int nk, int n_local, int prev_kf,
                             const double gw[3], const double cam[16], const volatile int* stop, double* kfs_out,
                             double* points_out, uint8_t* erase, double info[6]);
 
+/* ---- Bag of words: DBoW2 vocabulary-tree descent and ORBmatcher::SearchByBoW -------------------------------------
+ * viorb_vocabulary replaces ORBVocabulary (= DBoW2::TemplatedVocabulary<FORB::TDescriptor, FORB>, reference
+ * include/ORBVocabulary.h:30-31) for the one call the trackers make, transform(features, BowVector, FeatureVector, 4)
+ * (src/Frame.cc:575-582, src/KeyFrame.cc ComputeBoW). Flat tree: node 0 is the root; the children of node n are
+ * child_ids[child_start[n] .. child_start[n+1]) in file order (the order TemplatedVocabulary::m_nodes[n].children holds,
+ * Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1351-1508 loadFromTextFile); a node without children is a word with
+ * word_id >= 0 and its TF-IDF weight; desc[n][32] is the node descriptor. The arrays are copied to the device. */
+typedef struct viorb_vocabulary viorb_vocabulary;   /* opaque */
+int viorb_vocabulary_create(int n_nodes, int L, const int32_t* child_start, const int32_t* child_ids, const uint8_t* desc,
+                            const int32_t* word_id, const double* weight, viorb_vocabulary** out);
+int viorb_vocabulary_destroy(viorb_vocabulary* v);
+
+/* TemplatedVocabulary::transform(feature, word_id, weight, nid, levelsup) (TemplatedVocabulary.h:1231-1272) for every
+ * descriptor: word[i], weight[i] of the leaf reached and node[i] = the ancestor at level L - levelsup (0 = root when
+ * L - levelsup <= 0). The caller builds BowVector (sum of weights per word over features with weight > 0, L1-normalised,
+ * BowVector.cpp:36-85) and FeatureVector (features with weight > 0 grouped by node, FeatureVector.cpp:31-45) from them;
+ * viorb_amd/shim and viorb_amd/frontend.py show how. Device form: desc[(b*cap+i)*32], count[b], outputs [b*cap+i]. */
+int viorb_bow_transform_device(const viorb_vocabulary* v, const uint8_t* desc, const int32_t* count, int cap, int batch,
+                               int levelsup, int32_t* word, double* weight, int32_t* node, void* stream);
+int viorb_bow_transform(const viorb_vocabulary* v, const uint8_t* desc, int n, int levelsup, int32_t* word,
+                        double* weight, int32_t* node);
+
+/* ORBmatcher::SearchByBoW(KeyFrame* pKF, Frame& F, vector<MapPoint*>& vpMapPointMatches) (src/ORBmatcher.cc:159-288).
+ * kf_node / f_node: the FeatureVector node of each feature (-1: feature absent from the FeatureVector, i.e. a stopped
+ * word); kf_has_point[i] = pKF's map point i exists and !isBad(); angles are read from the keypoints (mvKeysUn / mvKeys
+ * carry the same angle). match[iF] = key-frame feature index whose map point the frame feature receives, or -1;
+ * nnratio = mfNNratio (0.7 in Tracking.cc:1500). Device form: all arrays [b*cap + i], counts per pair. */
+int viorb_search_by_bow_device(const viorb_keypoint* kf_kps, const uint8_t* kf_desc, const int32_t* kf_node,
+                               const uint8_t* kf_has_point, const int32_t* kf_count, const viorb_keypoint* f_kps,
+                               const uint8_t* f_desc, const int32_t* f_node, const int32_t* f_count, int cap, int batch,
+                               float nnratio, int check_orientation, int32_t* match, int32_t* nmatches, void* stream);
+int viorb_search_by_bow(const viorb_keypoint* kf_kps, const uint8_t* kf_desc, const int32_t* kf_node,
+                        const uint8_t* kf_has_point, int nkf, const viorb_keypoint* f_kps, const uint8_t* f_desc,
+                        const int32_t* f_node, int nf, float nnratio, int check_orientation, int32_t* match,
+                        int* nmatches);
+
 /* Host-only test hooks (no GPU needed; used by the CPU test-suite to compare product host code with
  * the oracle): the flat-array formulation of DistributeOctTree that the device kernel mirrors
  * (keys packed x | y<<12 | score<<24, border-relative), and the scalar math shared with the kernels. */

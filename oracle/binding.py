@@ -411,3 +411,28 @@ def local_ba(kfs, n_local, prev_kf, preint, points, edge_idx, edge_obs, gw, cam,
     L.ora_local_ba(_p(kfs), len(kfs), n_local, prev_kf, _p(preint), _p(points), len(points), _p(ei), _p(eo), len(ei), _p(_f64(gw, 3)),
                    _p(_f64(cam, 16)), _p(st) if st is not None else None, _p(ko), _p(po), _p(er), _p(info))
     return dict(kfs=ko, points=po, erase=er[:len(ei)], chi2_first=info[0], chi2_final=info[1], its_first=int(info[2]), its_second=int(info[3]))
+
+
+def bow_transform(voc, desc, levelsup=4):
+    """DBoW2 TemplatedVocabulary::transform (TF_IDF, L1) over a flat vocabulary dict (viorb_amd.synth.make_vocabulary).
+    Returns dict(word, weight, node per feature; bow_ids, bow_vals = the L1-normalised BowVector)."""
+    L = lib()
+    L.ora_bow_transform.argtypes = [C.c_int, C.c_int] + [C.c_void_p] * 6 + [C.c_int, C.c_int] + [C.c_void_p] * 5
+    desc = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32); n = len(desc)
+    word, weight, node = np.zeros(max(n, 1), np.int32), np.zeros(max(n, 1)), np.zeros(max(n, 1), np.int32)
+    bi, bv = np.zeros(max(n, 1), np.int32), np.zeros(max(n, 1))
+    k = L.ora_bow_transform(len(voc["word_id"]), int(voc["L"]), _p(voc["child_start"]), _p(voc["child_ids"]), _p(voc["desc"]), _p(voc["word_id"]),
+                            _p(voc["weight"]), _p(desc), n, levelsup, _p(word), _p(weight), _p(node), _p(bi), _p(bv))
+    return dict(word=word[:n], weight=weight[:n], node=node[:n], bow_ids=bi[:k], bow_vals=bv[:k])
+
+
+def search_by_bow(kf_desc, kf_angle, kf_node, kf_has_point, f_desc, f_angle, f_node, nnratio=0.7, check_orientation=True):
+    """ORBmatcher::SearchByBoW(KeyFrame*, Frame&, ...). Returns (nmatches, match[nF]) with match = key-frame feature index or -1."""
+    L = lib()
+    L.ora_search_by_bow.argtypes = [C.c_void_p] * 4 + [C.c_int] + [C.c_void_p] * 3 + [C.c_int, C.c_float, C.c_int, C.c_void_p]
+    kd = np.ascontiguousarray(kf_desc, np.uint8).reshape(-1, 32); fd = np.ascontiguousarray(f_desc, np.uint8).reshape(-1, 32)
+    m = np.full(max(len(fd), 1), -1, np.int32)
+    n = L.ora_search_by_bow(_p(kd), _p(np.ascontiguousarray(kf_angle, np.float32)), _p(np.ascontiguousarray(kf_node, np.int32)),
+                            _p(np.ascontiguousarray(kf_has_point, np.uint8)), len(kd), _p(fd), _p(np.ascontiguousarray(f_angle, np.float32)),
+                            _p(np.ascontiguousarray(f_node, np.int32)), len(fd), float(nnratio), int(check_orientation), _p(m))
+    return n, m[:len(fd)]

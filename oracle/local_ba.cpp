@@ -39,7 +39,7 @@ static void edge_lin(const NavState& ns, const Camera& cam, V3 Pw, Lin& L) {
 } // namespace
 
 BaResult local_ba_navstate(const BaProblem& P, const volatile int* stop) {
-    const int W = P.n_local, NK = (int)P.kfs.size(), NP = (int)P.points.size(), NE = (int)P.edges.size();
+    const int W = P.n_local, NP = (int)P.points.size(), NE = (int)P.edges.size();
     const int np = 12 * W;                                   // pose unknowns: [PVR(9) | bias(3)] per local KF
     BaResult R; R.kfs.assign(P.kfs.begin(), P.kfs.begin() + W); R.points = P.points; R.erase.assign(NE, 0);
     auto terminate = [&]() { return stop && *stop; };

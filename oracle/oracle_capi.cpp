@@ -335,3 +335,28 @@ void ora_local_ba(const double* kfs, int nk, int n_local, int prev_kf, const dou
     info6[0] = R.chi2_after_first; info6[1] = R.chi2_final; info6[2] = R.its_first; info6[3] = R.its_second; info6[4] = 0; info6[5] = 0;
 }
 } // extern "C"
+
+#include "bow.h"
+extern "C" {
+// DBoW2 transform over a flat vocabulary; word/weight/node per feature, plus the L1-normalised BowVector (sorted by word id).
+int ora_bow_transform(int n_nodes, int L, const int32_t* child_start, const int32_t* child_ids, const uint8_t* vdesc, const int32_t* word_id,
+                      const double* vweight, const uint8_t* desc, int n, int levelsup, int* word, double* weight, int* node,
+                      int* bow_ids, double* bow_vals) {
+    ora::Vocabulary V; V.n_nodes = n_nodes; V.L = L; V.child_start = child_start; V.child_ids = child_ids; V.desc = vdesc; V.word_id = word_id; V.weight = vweight;
+    std::map<int, double> bow; std::map<int, std::vector<unsigned>> fv;
+    ora::bow_transform(V, desc, n, levelsup, bow, fv, word, weight, node);
+    int k = 0; for (auto& kv : bow) { bow_ids[k] = kv.first; bow_vals[k] = kv.second; k++; }
+    return k;
+}
+// SearchByBoW with per-feature node ids (node < 0: feature absent from the FeatureVector)
+int ora_search_by_bow(const uint8_t* kf_desc, const float* kf_angle, const int* kf_node, const uint8_t* kf_has_point, int nK,
+                      const uint8_t* f_desc, const float* f_angle, const int* f_node, int nF, float nnratio, int check_ori, int* match) {
+    std::map<int, std::vector<unsigned>> a, b;
+    for (int i = 0; i < nK; i++) if (kf_node[i] >= 0) a[kf_node[i]].push_back((unsigned)i);
+    for (int i = 0; i < nF; i++) if (f_node[i] >= 0) b[f_node[i]].push_back((unsigned)i);
+    std::vector<int> m;
+    const int n = ora::search_by_bow(a, kf_desc, kf_angle, kf_has_point, b, f_desc, f_angle, nF, nnratio, check_ori != 0, m);
+    for (int i = 0; i < nF; i++) match[i] = m[i];
+    return n;
+}
+} // extern "C"

@@ -95,6 +95,58 @@ def LocalBundleAdjustmentNavState(kfs, n_local, prev_kf, preint, points, edge_id
     return dict(kfs=ko, points=po, erase=er[:len(ei)], chi2_first=info[0], chi2_final=info[1], its_first=int(info[2]), its_second=int(info[3]))
 
 
+class ORBVocabulary:
+    """The part of ORBVocabulary (DBoW2::TemplatedVocabulary<FORB>, reference include/ORBVocabulary.h:30-31) the trackers use:
+    transform(features, BowVector, FeatureVector, levelsup). `voc` = flat tree arrays (layout of viorb_vocabulary_create)."""
+
+    def __init__(self, voc):
+        self.L = int(voc["L"]); self.n_nodes = len(voc["word_id"])
+        h = C.c_void_p()
+        a = lambda k, dt: np.ascontiguousarray(voc[k], dt)
+        check(lib().viorb_vocabulary_create(self.n_nodes, self.L, ptr(a("child_start", np.int32)), ptr(a("child_ids", np.int32)), ptr(a("desc", np.uint8)),
+                                            ptr(a("word_id", np.int32)), ptr(a("weight", np.float64)), C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().viorb_vocabulary_destroy(self.h); self.h = None
+
+    __del__ = close
+
+    def transform_features(self, desc, levelsup=4):
+        """word, weight, node per descriptor (TemplatedVocabulary.h:1231-1272)."""
+        desc = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32); n = len(desc)
+        word, weight, node = np.zeros(max(n, 1), np.int32), np.zeros(max(n, 1)), np.zeros(max(n, 1), np.int32)
+        check(lib().viorb_bow_transform(self.h, ptr(desc), n, levelsup, ptr(word), ptr(weight), ptr(node)))
+        return word[:n], weight[:n], node[:n]
+
+    def transform(self, desc, levelsup=4):
+        """Frame::ComputeBoW: (BowVector as sorted (ids, values) with L1 normalisation, per-feature node ids with -1 for stopped
+        words — the flat form of FeatureVector). TemplatedVocabulary.h:1140-1208, BowVector.cpp:36-85."""
+        word, weight, node = self.transform_features(desc, levelsup)
+        bow = {}
+        for w, wt in zip(word.tolist(), weight.tolist()):          # addWeight in feature order
+            if wt > 0:
+                bow[w] = bow.get(w, 0.0) + wt
+        ids = sorted(bow)
+        norm = 0.0
+        for k in ids:
+            norm += abs(bow[k])
+        vals = np.array([bow[k] / norm if norm > 0 else bow[k] for k in ids])
+        return np.array(ids, np.int32), vals, np.where(weight > 0, node, -1).astype(np.int32)
+
+
+def SearchByBoW(kf_kps, kf_desc, kf_node, kf_has_point, f_kps, f_desc, f_node, nnratio=0.7, check_orientation=True):
+    """ORBmatcher::SearchByBoW(KeyFrame*, Frame&, vpMapPointMatches) (reference src/ORBmatcher.cc:159-288), host buffers.
+    Returns (nmatches, match[nF]) with match = key-frame feature index or -1."""
+    kk = np.ascontiguousarray(kf_kps, capi.KP_DTYPE); fk = np.ascontiguousarray(f_kps, capi.KP_DTYPE)
+    m = np.full(max(len(fk), 1), -1, np.int32); n = C.c_int(0)
+    check(lib().viorb_search_by_bow(ptr(kk), ptr(np.ascontiguousarray(kf_desc, np.uint8)), ptr(np.ascontiguousarray(kf_node, np.int32)),
+                                    ptr(np.ascontiguousarray(kf_has_point, np.uint8)), len(kk), ptr(fk), ptr(np.ascontiguousarray(f_desc, np.uint8)),
+                                    ptr(np.ascontiguousarray(f_node, np.int32)), len(fk), float(nnratio), int(check_orientation), ptr(m), C.byref(n)))
+    return n.value, m[:len(fk)]
+
+
 class Frontend:
     """Batched device-resident front-end: every method only enqueues kernels on the given torch stream."""
 

@@ -452,3 +452,59 @@ def make_local_ba_problem(seed, W=20, n_points=2000, n_fixed_extra=3, outlier_fr
     pts0 = pts + rng.normal(0, 0.05, pts.shape)
     return dict(kfs=kfs0, kfs_true=kfs_true, n_local=W, prev_kf=prev_kf, imu=imu_list, points=np.float32(pts0).astype(np.float64), points_true=pts,
                 edge_idx=np.array(edges_i, np.int32), edge_obs=np.array(edges_o, np.float64), gw=GRAVITY_CAM_WORLD.copy(), cam=cam)
+
+
+def make_vocabulary(seed, k=10, L=6, flip_bits=(96, 64, 40, 24, 14, 8, 5, 3)):
+    """A synthetic DBoW2-shaped ORB vocabulary (the reference's ORBvoc.txt is not distributable with the repo): a complete
+    k-ary tree of depth L over 256-bit descriptors, each child = its parent with flip_bits[level] random bits flipped
+    (root children are uniform random), node ids in breadth-first order shuffled within a level so that child ids are not
+    contiguous (as in a k-means-built file), leaves numbered as words in id order with TF-IDF-like weights in (0, 8] and
+    about 0.2 % stopped words (weight 0). Flat layout = include/viorb.h `viorb_vocabulary`."""
+    rng = np.random.Generator(np.random.PCG64(seed + 777))
+    n_level = [k ** l for l in range(L + 1)]
+    n_nodes = sum(n_level)
+    base = np.cumsum([0] + n_level)
+    desc = np.zeros((n_nodes, 32), np.uint8)
+    ids = [np.arange(base[l], base[l + 1]) for l in range(L + 1)]
+    for l in range(1, L + 1):
+        ids[l] = base[l] + rng.permutation(n_level[l])          # node id of the j-th node (in parent-major order) of level l
+    child_start = np.zeros(n_nodes + 1, np.int64)
+    child_ids = np.zeros(n_nodes - 1, np.int32)
+    counts = np.zeros(n_nodes, np.int64)
+    for l in range(L):
+        counts[ids[l]] = k
+    child_start[1:] = np.cumsum(counts)
+    for l in range(L):
+        par = ids[l]                                            # parents in order j
+        ch = ids[l + 1].reshape(n_level[l], k)                  # children of parent j
+        pos = child_start[par][:, None] + np.arange(k)[None, :]
+        child_ids[pos.ravel()] = ch.ravel()
+        if l == 0:
+            d = rng.integers(0, 256, (k, 32), dtype=np.uint8)
+        else:
+            pd = np.repeat(desc[par], k, axis=0)
+            nflip = flip_bits[min(l, len(flip_bits) - 1)]
+            bits = rng.integers(0, 256, (len(pd), nflip))
+            mask = np.zeros((len(pd), 32), np.uint8)
+            np.bitwise_xor.at(mask, (np.arange(len(pd))[:, None].repeat(nflip, 1).ravel(), (bits >> 3).ravel()), (1 << (bits & 7)).astype(np.uint8).ravel())
+            d = pd ^ mask
+        desc[ch.ravel()] = d
+    word_id = np.full(n_nodes, -1, np.int32)
+    leaves = np.sort(ids[L])
+    word_id[leaves] = np.arange(len(leaves), dtype=np.int32)
+    weight = np.zeros(n_nodes)
+    wl = rng.uniform(0.05, 8.0, len(leaves)); wl[rng.random(len(leaves)) < 0.002] = 0.0
+    weight[leaves] = wl
+    return dict(k=k, L=L, child_start=child_start.astype(np.int32), child_ids=child_ids, desc=desc, word_id=word_id, weight=weight)
+
+
+def descriptors_near_words(seed, voc, n, noise_bits=6):
+    """n descriptors, each a random vocabulary leaf with noise_bits random bits flipped (so the tree descent is non-trivial
+    but features of one scene cluster in a few nodes)."""
+    rng = np.random.Generator(np.random.PCG64(seed + 4242))
+    leaves = np.nonzero(voc["word_id"] >= 0)[0]
+    d = voc["desc"][rng.choice(leaves, n)].copy()
+    for _ in range(noise_bits):
+        b = rng.integers(0, 256, n)
+        d[np.arange(n), b >> 3] ^= (1 << (b & 7)).astype(np.uint8)
+    return d
