@@ -74,6 +74,9 @@ public:
     std::vector<float> inline GetScaleSigmaSquares(){ return mvLevelSigma2; }
     std::vector<float> inline GetInverseScaleSigmaSquares(){ return mvInvLevelSigma2; }
 
+    // not in the reference: the device handle, for Frame::ComputeStereoMatches -> viorb_stereo_match
+    viorb_extractor* handle() { return mHandle; }
+
     std::vector<cv::Mat> mvImagePyramid;          // un-padded levels (the reference's 19-px border is never read)
 
 protected:
