@@ -328,6 +328,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t* __restrict__ p
 // ---------------------------------------------------------------------------------------------
 // single-wavefront workgroups: a workgroup barrier is one s_barrier and also orders LDS traffic
 #define WAVE_SYNC() __syncthreads()
+#define OCT_NCAP_SMALL 2048
 struct OctLds {
     uint32_t* keys; uint16_t* perm0; uint16_t* perm1; OctNode* nd; uint32_t* sortb;
 };
@@ -438,7 +439,7 @@ __global__ __launch_bounds__(64) void k_octree(const LevelDev* __restrict__ lv, 
                                                int slot_cap, const int* __restrict__ cell_cnt, int ncells_total,
                                                uint32_t* __restrict__ lvl_kp, int kp_pitch, int* __restrict__ lvl_cnt,
                                                int* __restrict__ lvl_ncand, int nlevels, int* __restrict__ status,
-                                               int ncap, int nodecap, int sortcap) {
+                                               int ncap, int nodecap, int sortcap, int n_above, int n_upto) {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_oct[];
     OctLds S;
     S.keys = s_oct;
@@ -449,6 +450,16 @@ __global__ __launch_bounds__(64) void k_octree(const LevelDev* __restrict__ lv, 
     const int lane = threadIdx.x, level = blockIdx.x, b = blockIdx.y;
     const LevelDev L = lv[level];
     const int N = L.quota;
+    // ---- 0. this launch only takes the (image, level) pairs with n_above < candidates <= n_upto: the common case runs
+    //         with a small LDS footprint (4 workgroups per CU), a second launch with the full capacity takes the rest
+    {
+        const int* cc = cell_cnt + (size_t)b * ncells_total + L.cell_base;
+        int tot = 0;
+        for (int ci = lane; ci < L.ncells; ci += 64) tot += cc[ci];
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) tot += __shfl_xor(tot, d);
+        if (tot <= n_above || tot > n_upto) return;
+    }
     // ---- 1. gather candidates in the reference's push order (cell-major, row-major inside a cell)
     int n = 0;
     bool overflow = false;
@@ -1164,11 +1175,22 @@ static int launch_all(viorb_extractor* h, const uint8_t* d_images, int batch, in
                            h->fast_tile_pitch, h->fast_tile_rows, h->fast_score_bytes, h->fast_list_cap);
     }
     {
-        const size_t lds = (size_t)h->oct_ncap * 8 + (size_t)h->oct_nodecap * sizeof(OctNode) + (size_t)h->oct_sortcap * 4;
-        ProfScope ps("k_octree", st);
-        hipLaunchKernelGGL(k_octree, dim3(nl, batch), dim3(64), lds, st, h->d_lv, h->d_slots, h->slot_cap, h->d_cell_cnt, ncells,
-                           h->d_lvl_kp, h->kp_pitch, h->d_lvl_cnt, h->d_lvl_ncand, nl, h->d_status, h->oct_ncap, h->oct_nodecap,
-                           h->oct_sortcap);
+        // common case first: <= OCT_NCAP_SMALL candidates per level fit a ~35 KB footprint (4 single-wave workgroups per CU);
+        // the second launch covers the rest with the full capacity (its workgroups return at once when they have no work)
+        const size_t fixed = (size_t)h->oct_nodecap * sizeof(OctNode) + (size_t)h->oct_sortcap * 4;
+        const int small = std::min(h->oct_ncap, (int)OCT_NCAP_SMALL);
+        {
+            ProfScope ps("k_octree", st);
+            hipLaunchKernelGGL(k_octree, dim3(nl, batch), dim3(64), (size_t)small * 8 + fixed, st, h->d_lv, h->d_slots, h->slot_cap, h->d_cell_cnt,
+                               ncells, h->d_lvl_kp, h->kp_pitch, h->d_lvl_cnt, h->d_lvl_ncand, nl, h->d_status, small, h->oct_nodecap,
+                               h->oct_sortcap, -1, small);
+        }
+        if (small < h->oct_ncap) {
+            ProfScope ps("k_octree_large", st);
+            hipLaunchKernelGGL(k_octree, dim3(nl, batch), dim3(64), (size_t)h->oct_ncap * 8 + fixed, st, h->d_lv, h->d_slots, h->slot_cap,
+                               h->d_cell_cnt, ncells, h->d_lvl_kp, h->kp_pitch, h->d_lvl_cnt, h->d_lvl_ncand, nl, h->d_status, h->oct_ncap,
+                               h->oct_nodecap, h->oct_sortcap, small, 0x7fffffff);
+        }
     }
     {
         ProfScope ps("k_blur", st);
