@@ -685,8 +685,10 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t* __restrict__ planes
 // One wavefront per keypoint: IC_Angle (reference :77-104) on the un-blurred level, then the
 // steered 256-bit BRIEF (reference :107-147) on the blurred level, then the cv::KeyPoint record
 // (reference :837-847, :1095-1101).
-__constant__ uint32_t c_pattern[256];                  // x0 | y0<<8 | x1<<16 | y1<<24 (int8 each)
+__constant__ __attribute__((aligned(16))) uint32_t c_pattern[256];   // x0 | y0<<8 | x1<<16 | y1<<24 (int8 each)
 __constant__ int c_umax[16];
+__constant__ uint32_t c_orient_mask[256];              // [row 0..31][dword 0..7]: 0xff per byte inside the circle (row 31: 0)
+typedef uint32_t u32_unaligned __attribute__((aligned(1)));
 __global__ __launch_bounds__(256) void k_orient_describe(const uint8_t* __restrict__ planes,
                                                          const uint8_t* __restrict__ blur, size_t frame_bytes,
                                                          const LevelDev* __restrict__ lv, int nlevels,
@@ -710,21 +712,29 @@ __global__ __launch_bounds__(256) void k_orient_describe(const uint8_t* __restri
     const LevelDev L = lv[level];
     const uint32_t key = lvl_kp[(size_t)b * kp_pitch + L.kp_off + local];
     const int cx = (int)(key & 0xfff), cy = (int)((key >> 12) & 0xfff), score = (int)(key >> 24);
-    // ---- orientation: integer moments over the circular patch, two rows per iteration
+    // ---- orientation: integer moments over the circular patch. Lane = (row r8, dword j) of an 8-row x 32-byte slab, four
+    // slabs cover the 31 rows; the circle is a constant byte-mask table, so the four (unaligned) dword loads are
+    // independent and branch-free; sum I and sum (u+15) I come from two v_dot4_u32_u8 per dword.
     const uint8_t* img = planes + (size_t)b * frame_bytes + L.plane_off + (size_t)cy * L.stride + cx;
     int m10 = 0, m01 = 0;
-    const int u = (lane & 31) - HALF_PATCH;
-#pragma unroll 4
-    for (int it = 0; it < 16; it++) {
-        const int v = -HALF_PATCH + 2 * it + (lane >> 5);
-        const int av = v < 0 ? -v : v;
-        if (av <= HALF_PATCH && (lane & 31) < PATCH) {
-            const int au = u < 0 ? -u : u;
-            if (au <= c_umax[av]) {
-                const int val = img[v * L.stride + u];
-                m10 += u * val;
-                m01 += v * val;
-            }
+    {
+        const int j = lane & 7, r8 = lane >> 3;
+        const uint32_t wu = 0x03020100u + 0x04040404u * (uint32_t)j;       // u + 15 of the four bytes
+        const uint8_t* col = img - HALF_PATCH + 4 * j;
+        uint32_t px[4]; int vv[4];
+#pragma unroll
+        for (int it = 0; it < 4; it++) {
+            const int row = min(it * 8 + r8, PATCH - 1);                   // slab 3 has 7 rows; the 8th is masked off
+            vv[it] = row - HALF_PATCH;
+            px[it] = *reinterpret_cast<const u32_unaligned*>(col + vv[it] * L.stride);
+        }
+#pragma unroll
+        for (int it = 0; it < 4; it++) {
+            const uint32_t q = px[it] & c_orient_mask[it * 64 + lane];
+            const int s1 = (int)__builtin_amdgcn_udot4(q, 0x01010101u, 0u, false);
+            const int su = (int)__builtin_amdgcn_udot4(q, wu, 0u, false);
+            m10 += su - HALF_PATCH * s1;
+            m01 += vv[it] * s1;
         }
     }
 #pragma unroll
@@ -737,9 +747,11 @@ __global__ __launch_bounds__(256) void k_orient_describe(const uint8_t* __restri
     const float a = cs, bb = sn;
     const uint8_t* bim = blur + (size_t)b * frame_bytes + L.plane_off + (size_t)cy * L.stride + cx;
     uint32_t nib = 0;
+    const uint4 pq = reinterpret_cast<const uint4*>(c_pattern)[lane];
+    const uint32_t pqa[4] = {pq.x, pq.y, pq.z, pq.w};
 #pragma unroll
     for (int t = 0; t < 4; t++) {
-        const uint32_t q = c_pattern[lane * 4 + t];
+        const uint32_t q = pqa[t];
         const float x0 = (float)(int8_t)(q & 0xff), y0 = (float)(int8_t)((q >> 8) & 0xff);
         const float x1 = (float)(int8_t)((q >> 16) & 0xff), y1 = (float)(int8_t)(q >> 24);
         const int r0 = round_half_even(x0 * bb + y0 * a), c0 = round_half_even(x0 * a - y0 * bb);
@@ -1143,6 +1155,17 @@ static int configure(viorb_extractor* h, int w, int hgt) {
         VIORB_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_gauss), g, sizeof(g)));
         VIORB_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_pattern), pat, sizeof(pat)));
         VIORB_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_umax), h->umax, sizeof(int) * 16));
+        uint32_t om[256];
+        for (int row = 0; row < 32; row++)
+            for (int j = 0; j < 8; j++) {
+                uint32_t m = 0;
+                for (int k2 = 0; k2 < 4; k2++) {
+                    const int u = -HALF_PATCH + 4 * j + k2, v = row - HALF_PATCH;
+                    if (row < PATCH && u <= HALF_PATCH && std::abs(u) <= h->umax[std::abs(v)]) m |= 0xffu << (8 * k2);
+                }
+                om[row * 8 + j] = m;
+            }
+        VIORB_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_orient_mask), om, sizeof(om)));
         h->tables_uploaded = true;
     }
     h->img_w = w; h->img_h = hgt;
