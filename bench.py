@@ -85,6 +85,8 @@ def main():
     ap.add_argument("--groups", type=int, default=1, help="split the streams of a GPU into this many independently enqueued groups "
                     "(each with its own HIP streams) so that latency-bound kernels of one group overlap chip-filling kernels of another")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true", help="skip the per-kernel HIP events (roofline becomes null); dev aid "
+                    "to measure what the events themselves cost")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -144,7 +146,7 @@ def main():
         run_step(k); k += 1
     torch.cuda.synchronize()
     L = viorb_amd.lib()
-    L.viorb_profile_reset(); L.viorb_profile_enable(1)
+    L.viorb_profile_reset(); L.viorb_profile_enable(0 if args.no_kernel_events else 1)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()

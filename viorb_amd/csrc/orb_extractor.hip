@@ -233,10 +233,15 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t* __restrict__ p
     const int x0a = c.x0 & ~3, xoff = c.x0 - x0a;
     const int ndw = ((c.x0 + c.cw - 1 - x0a) >> 2) + 1;
     const int pitch_dw = tile_pitch >> 2;
-    for (int i = lane; i < c.ch * pitch_dw; i += 64) {
-        const int r = i / pitch_dw, q = i - r * pitch_dw;
-        if (q < ndw)
-            s_mem[i] = *reinterpret_cast<const uint32_t*>(img + (size_t)(c.y0 + r) * L.stride + x0a + 4 * q);
+    {
+        const int st_r = 64 / pitch_dw, st_q = 64 - st_r * pitch_dw;      // one division per wave instead of one per dword
+        int r = lane / pitch_dw, q = lane - r * pitch_dw;
+        const uint8_t* src = img + (size_t)c.y0 * L.stride + x0a;
+        for (int i = lane; i < c.ch * pitch_dw; i += 64) {
+            if (q < ndw) s_mem[i] = *reinterpret_cast<const uint32_t*>(src + r * L.stride + 4 * q);
+            r += st_r; q += st_q;
+            if (q >= pitch_dw) { q -= pitch_dw; r++; }
+        }
     }
     const int dw = c.cw - 6, dh = c.ch - 6;          // interior (detection) region
     const int sp = dw + 2;                            // score map pitch, 1-px zero frame
@@ -250,23 +255,31 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t* __restrict__ p
         // ---- pass 1
         int nsurv = 0;
         {
+            // four 64-pixel chunks per trip: their LDS reads are independent, so one trip pays one LDS round-trip
             const int step_r = 64 / dw, step_q = 64 - step_r * dw;
             int r = lane / dw, q = lane - r * dw;
-            for (int base = 0; base < npx; base += 64) {
-                bool pass = false;
-                if (base + lane < npx) {
-                    const uint8_t* p = tile + (r + 3) * tile_pitch + xoff + q + 3;
-                    const int v = p[0];
-                    const int d0 = v - p[3 * tile_pitch], d4 = v - p[3], d8 = v - p[-3 * tile_pitch], d12 = v - p[-3];
-                    const int lo = min(min(max(d0, d4), max(d4, d8)), min(max(d8, d12), max(d12, d0)));   // some adjacent pair both < -t
-                    const int hi = max(max(min(d0, d4), min(d4, d8)), max(min(d8, d12), min(d12, d0)));   // some adjacent pair both >  t
-                    pass = (hi > min_th) || (lo < -min_th);
+            for (int base = 0; base < npx; base += 256) {
+                bool pass[4]; uint16_t rq[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    pass[u] = false; rq[u] = (uint16_t)((r << 8) | q);
+                    if (base + 64 * u + lane < npx) {
+                        const uint8_t* p = tile + (r + 3) * tile_pitch + xoff + q + 3;
+                        const int v = p[0];
+                        const int d0 = v - p[3 * tile_pitch], d4 = v - p[3], d8 = v - p[-3 * tile_pitch], d12 = v - p[-3];
+                        const int lo = min(min(max(d0, d4), max(d4, d8)), min(max(d8, d12), max(d12, d0)));   // some adjacent pair both < -t
+                        const int hi = max(max(min(d0, d4), min(d4, d8)), max(min(d8, d12), min(d12, d0)));   // some adjacent pair both >  t
+                        pass[u] = (hi > min_th) || (lo < -min_th);
+                    }
+                    r += step_r; q += step_q;
+                    if (q >= dw) { q -= dw; r++; }
                 }
-                const unsigned long long m = __ballot(pass);
-                if (pass) surv[nsurv + __popcll(m & lt)] = (uint16_t)((r << 8) | q);
-                nsurv += __popcll(m);
-                r += step_r; q += step_q;
-                if (q >= dw) { q -= dw; r++; }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const unsigned long long m = __ballot(pass[u]);
+                    if (pass[u]) surv[nsurv + __popcll(m & lt)] = rq[u];
+                    nsurv += __popcll(m);
+                }
             }
         }
         __syncthreads();
@@ -1216,6 +1229,7 @@ static int launch_all(viorb_extractor* h, const uint8_t* d_images, int batch, in
         }
     }
     {
+        // (running the blur on a second stream beside FAST + quadtree was measured: no gain, the kernels contend for the same CUs)
         ProfScope ps("k_blur", st);
         hipLaunchKernelGGL(k_blur, dim3((unsigned)h->blur_tiles.size(), batch), dim3(256), 0, st, h->d_planes, h->d_blur, h->frame_bytes,
                            h->d_lv, h->d_blur_tiles);
