@@ -255,31 +255,46 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t* __restrict__ p
         // ---- pass 1
         int nsurv = 0;
         {
-            // four 64-pixel chunks per trip: their LDS reads are independent, so one trip pays one LDS round-trip
-            const int step_r = 64 / dw, step_q = 64 - step_r * dw;
-            int r = lane / dw, q = lane - r * dw;
-            for (int base = 0; base < npx; base += 256) {
-                bool pass[4]; uint16_t rq[4];
+            // A lane takes one aligned dword = 4 horizontally adjacent pixels of a row (lanes run over (row, dword) in row-major
+            // order, so lane order x byte order is cv::FAST's keypoint order): five dword LDS reads (centre, left, right, three rows
+            // up, three rows down) instead of twenty byte reads, and the address / stepping / compaction overhead is paid once per
+            // four pixels. The kernel is VALU-issue bound (integer min/max are 4-cycle ops), so instructions per pixel is the lever.
+            const int g0 = (xoff + 3) >> 2;                                  // tile dword holding the first interior pixel
+            const int G = ((xoff + 3 + dw - 1) >> 2) - g0 + 1;               // dwords per interior row
+            const int step_r = 64 / G, step_g = 64 - step_r * G;
+            int r = lane / G, g = lane - r * G;
+            const int ntrip = (dh * G + 63) >> 6;
+            for (int trip = 0; trip < ntrip; trip++) {
+                const int rc = min(r, dh - 1);                                // lanes past the last row read a valid address and are masked
+                const uint32_t* pc = reinterpret_cast<const uint32_t*>(tile + (rc + 3) * tile_pitch) + g0 + g;
+                const uint32_t C = pc[0], Lf = pc[-1], Rt = pc[1];
+                const uint32_t U = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(pc) - 3 * tile_pitch);
+                const uint32_t D = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(pc) + 3 * tile_pitch);
+                const uint32_t W = __builtin_amdgcn_alignbyte(C, Lf, 1);     // pixels 3 to the left of C's four
+                const uint32_t E = __builtin_amdgcn_alignbyte(Rt, C, 3);     // pixels 3 to the right
+                const int q0 = 4 * (g0 + g) - (xoff + 3);                    // interior column of byte 0 (may be < 0 in the first dword)
+                uint32_t bits = 0;
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    pass[u] = false; rq[u] = (uint16_t)((r << 8) | q);
-                    if (base + 64 * u + lane < npx) {
-                        const uint8_t* p = tile + (r + 3) * tile_pitch + xoff + q + 3;
-                        const int v = p[0];
-                        const int d0 = v - p[3 * tile_pitch], d4 = v - p[3], d8 = v - p[-3 * tile_pitch], d12 = v - p[-3];
-                        const int lo = min(min(max(d0, d4), max(d4, d8)), min(max(d8, d12), max(d12, d0)));   // some adjacent pair both < -t
-                        const int hi = max(max(min(d0, d4), min(d4, d8)), max(min(d8, d12), min(d12, d0)));   // some adjacent pair both >  t
-                        pass[u] = (hi > min_th) || (lo < -min_th);
-                    }
-                    r += step_r; q += step_q;
-                    if (q >= dw) { q -= dw; r++; }
+                for (int k = 0; k < 4; k++) {
+                    const int v = (int)((C >> (8 * k)) & 0xff);
+                    const int d0 = v - (int)((D >> (8 * k)) & 0xff), d4 = v - (int)((E >> (8 * k)) & 0xff);
+                    const int d8 = v - (int)((U >> (8 * k)) & 0xff), d12 = v - (int)((W >> (8 * k)) & 0xff);
+                    const int lo = min(min(max(d0, d4), max(d4, d8)), min(max(d8, d12), max(d12, d0)));   // some adjacent pair both < -t
+                    const int hi = max(max(min(d0, d4), min(d4, d8)), max(min(d8, d12), min(d12, d0)));   // some adjacent pair both >  t
+                    const uint32_t ok = (uint32_t)((hi > min_th) | (lo < -min_th)) & (uint32_t)((unsigned)(q0 + k) < (unsigned)dw);
+                    bits |= ok << k;
                 }
+                if (r >= dh) bits = 0;
+                // ordered compaction: position = survivors in lower lanes + survivors in lower bytes of this lane
+                const unsigned long long m0 = __ballot(bits & 1), m1 = __ballot(bits & 2), m2 = __ballot(bits & 4), m3 = __ballot(bits & 8);
+                int pos = nsurv + __popcll(m0 & lt) + __popcll(m1 & lt) + __popcll(m2 & lt) + __popcll(m3 & lt);
+                const uint32_t rq0 = ((uint32_t)r << 8) + (uint32_t)q0;
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const unsigned long long m = __ballot(pass[u]);
-                    if (pass[u]) surv[nsurv + __popcll(m & lt)] = rq[u];
-                    nsurv += __popcll(m);
-                }
+                for (int k = 0; k < 4; k++)
+                    if (bits & (1u << k)) { surv[pos] = (uint16_t)(rq0 + k); pos++; }
+                nsurv += __popcll(m0) + __popcll(m1) + __popcll(m2) + __popcll(m3);
+                r += step_r; g += step_g;
+                if (g >= G) { g -= G; r++; }
             }
         }
         __syncthreads();
@@ -310,17 +325,13 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t* __restrict__ p
                     r = rq >> 8; q = rq & 0xff;
                     const uint8_t* z = sc + (r + 1) * sp + q + 1;
                     s = z[0];
-                    if (s >= th) {
-                        keep = true;
+                    // all eight neighbours are read before any is tested: one LDS round trip instead of a short-circuit chain of eight
+                    int nb[8];
+                    nb[0] = z[-sp - 1]; nb[1] = z[-sp]; nb[2] = z[-sp + 1]; nb[3] = z[-1]; nb[4] = z[1]; nb[5] = z[sp - 1]; nb[6] = z[sp]; nb[7] = z[sp + 1];
+                    int mx = 0;                                       // neighbours below th do not count (they are not corners at th)
 #pragma unroll
-                        for (int dy = -1; dy <= 1; dy++)
-#pragma unroll
-                            for (int dx = -1; dx <= 1; dx++) {
-                                if (dx == 0 && dy == 0) continue;
-                                const int nb = z[dy * sp + dx];
-                                keep = keep && (s > (nb >= th ? nb : 0));
-                            }
-                    }
+                    for (int k = 0; k < 8; k++) mx = max(mx, nb[k] >= th ? nb[k] : 0);
+                    keep = (s >= th) & (s > mx);
                 }
                 const unsigned long long m = __ballot(keep);
                 if (keep) {
