@@ -471,7 +471,10 @@ __global__ __launch_bounds__(64) void k_octree(const LevelDev* __restrict__ lv, 
     S.perm1 = S.perm0 + ncap;
     S.nd = reinterpret_cast<OctNode*>(S.perm1 + ncap);
     S.sortb = reinterpret_cast<uint32_t*>(S.nd + nodecap);
-    const int lane = threadIdx.x, level = blockIdx.x, b = blockIdx.y;
+    // grid = (image, level): with the level in x and 8 levels, the round-robin deal of workgroups to the 8 XCDs would send every
+    // level-0 quadtree (the longest) to XCD 0 and every level-7 one to XCD 7; image-major order spreads each level over all XCDs
+    // and starts the long ones first
+    const int lane = threadIdx.x, level = blockIdx.y, b = blockIdx.x;
     const LevelDev L = lv[level];
     const int N = L.quota;
     // ---- 0. this launch only takes the (image, level) pairs with n_above < candidates <= n_upto: the common case runs
@@ -1228,13 +1231,13 @@ static int launch_all(viorb_extractor* h, const uint8_t* d_images, int batch, in
         const int small = std::min(h->oct_ncap, (int)OCT_NCAP_SMALL);
         {
             ProfScope ps("k_octree", st);
-            hipLaunchKernelGGL(k_octree, dim3(nl, batch), dim3(64), (size_t)small * 8 + fixed, st, h->d_lv, h->d_slots, h->slot_cap, h->d_cell_cnt,
+            hipLaunchKernelGGL(k_octree, dim3(batch, nl), dim3(64), (size_t)small * 8 + fixed, st, h->d_lv, h->d_slots, h->slot_cap, h->d_cell_cnt,
                                ncells, h->d_lvl_kp, h->kp_pitch, h->d_lvl_cnt, h->d_lvl_ncand, nl, h->d_status, small, h->oct_nodecap,
                                h->oct_sortcap, -1, small);
         }
         if (small < h->oct_ncap) {
             ProfScope ps("k_octree_large", st);
-            hipLaunchKernelGGL(k_octree, dim3(nl, batch), dim3(64), (size_t)h->oct_ncap * 8 + fixed, st, h->d_lv, h->d_slots, h->slot_cap,
+            hipLaunchKernelGGL(k_octree, dim3(batch, nl), dim3(64), (size_t)h->oct_ncap * 8 + fixed, st, h->d_lv, h->d_slots, h->slot_cap,
                                h->d_cell_cnt, ncells, h->d_lvl_kp, h->kp_pitch, h->d_lvl_cnt, h->d_lvl_ncand, nl, h->d_status, h->oct_ncap,
                                h->oct_nodecap, h->oct_sortcap, small, 0x7fffffff);
         }
