@@ -23,7 +23,7 @@
 namespace viorb {
 
 struct BaDev {
-    int W, NK, NP, NE, np, prev_kf;
+    int W, NK, NP, NE, np, ld, prev_kf;
     double *kf, *kf_bak;            // [NK][22]
     double *pt, *pt_bak;            // [NP][3]
     const int *e_pt, *e_kf;         // [NE]
@@ -32,7 +32,7 @@ struct BaDev {
     double *err, *Jp, *Jk, *wgt;    // [NE][2], [NE][6], [NE][12], [NE]
     const int *pt_start;            // [NP+1]
     const int *kf_start, *kf_list;  // CSR of the edges of each local key frame
-    double *Hll, *bl, *Dinv;        // [NP][9], [NP][3], [NP][9]
+    double *Hll, *bl, *Dinv, *db;   // [NP][9], [NP][3], [NP][9], [NP][3] = Dinv bl
     double *Hpp, *bp, *S, *bs, *xp, *xl;
     const double *preint, *info_pvr; // [W][142], [W][81]
     double *e_pvr, *e_b;            // [W][9], [W][3]
@@ -199,11 +199,14 @@ __global__ __launch_bounds__(256) void k_ba_imu(BaDev D) {
     }
 }
 
-// S = Hpp + lambda I, bs = bp (element-wise); also the max |diag| for the initial lambda
+// S = Hpp + lambda I, bs = bp, written with the padded leading dimension ld (a multiple of 16: identity on the padding)
 __global__ void k_ba_init_reduced(BaDev D, double lambda) {
-    const int q = blockIdx.x * blockDim.x + threadIdx.x, n = D.np;
-    if (q < n * n) D.S[q] = D.Hpp[q] + ((q / n == q % n) ? lambda : 0.0);
-    if (q < n) D.bs[q] = D.bp[q];
+    const int q = blockIdx.x * blockDim.x + threadIdx.x, n = D.np, ld = D.ld;
+    if (q < ld * ld) {
+        const int i = q / ld, j = q - i * ld;
+        D.S[q] = (i < n && j < n) ? D.Hpp[(size_t)i * n + j] + (i == j ? lambda : 0.0) : (i == j ? 1.0 : 0.0);
+    }
+    if (q < ld) D.bs[q] = q < n ? D.bp[q] : 0.0;
 }
 __global__ void k_ba_max_diag(BaDev D) {
     __shared__ double s_red[4];
@@ -221,8 +224,8 @@ __global__ void k_ba_max_diag(BaDev D) {
     }
 }
 
-// one thread per point: Dinv = (Hll + lambda I)^-1 and the Schur scatter S -= W Dinv W^T, bs -= W Dinv bl
-__global__ void k_ba_schur(BaDev D, double lambda) {
+// one thread per point: Dinv = (Hll + lambda I)^-1 and Dinv * bl
+__global__ void k_ba_dinv(BaDev D, double lambda) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= D.NP) return;
     const double* H = D.Hll + (size_t)p * 9;
@@ -232,68 +235,162 @@ __global__ void k_ba_schur(BaDev D, double lambda) {
     double* Di = D.Dinv + (size_t)p * 9;
     Di[0] = i00; Di[1] = i01; Di[2] = i02; Di[3] = i01; Di[4] = i11; Di[5] = i12; Di[6] = i02; Di[7] = i12; Di[8] = i22;
     const double b0 = D.bl[3 * p], b1 = D.bl[3 * p + 1], b2 = D.bl[3 * p + 2];
-    const double db0 = i00 * b0 + i01 * b1 + i02 * b2, db1 = i01 * b0 + i11 * b1 + i12 * b2, db2 = i02 * b0 + i12 * b1 + i22 * b2;
-    const int loc[6] = {0, 1, 2, 6, 7, 8}, n = D.np, k0 = D.pt_start[p], k1 = D.pt_start[p + 1];
-    for (int ea = k0; ea < k1; ea++) {
-        if (D.level[ea] != 0 || D.e_kf[ea] >= D.W) continue;
-        const double* Ja = D.Jk + (size_t)12 * ea; const double* Pa = D.Jp + (size_t)6 * ea; const double wa = D.wgt[ea];
-        double Wa[18], BD[18];
-        for (int r = 0; r < 6; r++) for (int q = 0; q < 3; q++) Wa[r * 3 + q] = wa * (Ja[r] * Pa[q] + Ja[6 + r] * Pa[3 + q]);
-        for (int r = 0; r < 6; r++) {
-            BD[r * 3] = Wa[r * 3] * i00 + Wa[r * 3 + 1] * i01 + Wa[r * 3 + 2] * i02;
-            BD[r * 3 + 1] = Wa[r * 3] * i01 + Wa[r * 3 + 1] * i11 + Wa[r * 3 + 2] * i12;
-            BD[r * 3 + 2] = Wa[r * 3] * i02 + Wa[r * 3 + 1] * i12 + Wa[r * 3 + 2] * i22;
-        }
-        const int ba = 12 * D.e_kf[ea];
-        for (int r = 0; r < 6; r++) atomicAdd(&D.bs[ba + loc[r]], -(Wa[r * 3] * db0 + Wa[r * 3 + 1] * db1 + Wa[r * 3 + 2] * db2));
-        for (int eb = k0; eb < k1; eb++) {
-            if (D.level[eb] != 0 || D.e_kf[eb] >= D.W) continue;
-            const double* Jb = D.Jk + (size_t)12 * eb; const double* Pb = D.Jp + (size_t)6 * eb; const double wb = D.wgt[eb];
-            const int bb = 12 * D.e_kf[eb];
-            for (int cc = 0; cc < 6; cc++) {
-                const double w0 = wb * (Jb[cc] * Pb[0] + Jb[6 + cc] * Pb[3]), w1 = wb * (Jb[cc] * Pb[1] + Jb[6 + cc] * Pb[4]), w2 = wb * (Jb[cc] * Pb[2] + Jb[6 + cc] * Pb[5]);
-                for (int r = 0; r < 6; r++) atomicAdd(&D.S[(size_t)(ba + loc[r]) * n + bb + loc[cc]], -(BD[r * 3] * w0 + BD[r * 3 + 1] * w1 + BD[r * 3 + 2] * w2));
+    D.db[3 * p] = i00 * b0 + i01 * b1 + i02 * b2; D.db[3 * p + 1] = i01 * b0 + i11 * b1 + i12 * b2; D.db[3 * p + 2] = i02 * b0 + i12 * b1 + i22 * b2;
+}
+// Schur complement of the point block (block_solver.hpp:381-432): one thread per observation a of a local key frame; with its point's
+// other observations b it scatters -W_a Dinv W_b^T into S (lower block triangle only: the Cholesky never reads above the diagonal)
+// and -W_a Dinv bl into bs, with FP64 atomics (the 12W x 12W matrix lives in L2).
+__global__ void k_ba_schur(BaDev D) {
+    const int ea = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ea >= D.NE || D.level[ea] != 0 || D.e_kf[ea] >= D.W) return;
+    const int p = D.e_pt[ea], ka = D.e_kf[ea], ld = D.ld;
+    const double* Di = D.Dinv + (size_t)p * 9;
+    const double* Ja = D.Jk + (size_t)12 * ea; const double* Pa = D.Jp + (size_t)6 * ea; const double wa = D.wgt[ea];
+    double BD[18];
+#pragma unroll
+    for (int r = 0; r < 6; r++) {
+        const double w0 = wa * (Ja[r] * Pa[0] + Ja[6 + r] * Pa[3]), w1 = wa * (Ja[r] * Pa[1] + Ja[6 + r] * Pa[4]), w2 = wa * (Ja[r] * Pa[2] + Ja[6 + r] * Pa[5]);
+        BD[r * 3] = w0 * Di[0] + w1 * Di[1] + w2 * Di[2]; BD[r * 3 + 1] = w0 * Di[3] + w1 * Di[4] + w2 * Di[5]; BD[r * 3 + 2] = w0 * Di[6] + w1 * Di[7] + w2 * Di[8];
+        const int row = 12 * ka + (r < 3 ? r : r + 3);
+        atomicAdd(&D.bs[row], -(w0 * D.db[3 * p] + w1 * D.db[3 * p + 1] + w2 * D.db[3 * p + 2]));
+    }
+    for (int eb = D.pt_start[p]; eb < D.pt_start[p + 1]; eb++) {
+        const int kb = D.e_kf[eb];
+        if (D.level[eb] != 0 || kb > ka) continue;                       // kb > ka: the transposed block, written by the other observation
+        const double* Jb = D.Jk + (size_t)12 * eb; const double* Pb = D.Jp + (size_t)6 * eb; const double wb = D.wgt[eb];
+#pragma unroll
+        for (int cc = 0; cc < 6; cc++) {
+            const double w0 = wb * (Jb[cc] * Pb[0] + Jb[6 + cc] * Pb[3]), w1 = wb * (Jb[cc] * Pb[1] + Jb[6 + cc] * Pb[4]), w2 = wb * (Jb[cc] * Pb[2] + Jb[6 + cc] * Pb[5]);
+            const int col = 12 * kb + (cc < 3 ? cc : cc + 3);
+#pragma unroll
+            for (int r = 0; r < 6; r++) {
+                const int row = 12 * ka + (r < 3 ? r : r + 3);
+                if (row >= col) atomicAdd(&D.S[(size_t)row * ld + col], -(BD[r * 3] * w0 + BD[r * 3 + 1] * w1 + BD[r * 3 + 2] * w2));
             }
         }
     }
 }
 
-// dense Cholesky solve S xp = bs by ONE 1024-thread workgroup (n <= 240); scal[2] = 1 on success
+// Dense Cholesky solve S xp = bs of the reduced system by ONE 1024-thread workgroup, blocked by 16 (n <= 240, padded to ld):
+// per block column: (1) one wave factors the 16x16 diagonal block in LDS, (2) a thread per row solves the panel below it against
+// that block, (3) the 16 waves apply the rank-16 update to the trailing lower triangle, one 16x16 tile at a time, with
+// v_mfma_f64_16x16x4_f64 (operands A[i][k]: lane 16k+i, B[k][j]: lane 16k+j; result row = lane/16 + 4*reg, col = lane%16 — probed
+// on gfx950, tools/ubench/mfma_f64_layout.hip). The matrix stays in L2; the panel is staged in LDS. scal[2] = 1 on success;
+// a pivot that is not positive and finite fails the solve like the reference's LLT (linear_solver_eigen.h / Eigen info()).
+typedef double v4d __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(1024) void k_ba_chol_solve(BaDev D) {
-    __shared__ double s_col[256], s_y[256];
+    __shared__ double s_L[16][17], s_P[240][17], s_y[256];
     __shared__ int s_ok;
-    const int n = D.np, t = threadIdx.x;
+    const int n = D.np, ld = D.ld, nb = ld >> 4, t = threadIdx.x, lane = t & 63, wv = t >> 6;
     double* A = D.S;
     if (t == 0) s_ok = 1;
-    __syncthreads();
-    for (int j = 0; j < n; j++) {
-        if (t == 0) { const double d = A[(size_t)j * n + j]; if (!(d > 0) || !isfinite(d)) s_ok = 0; s_col[j] = sqrt(d > 0 ? d : 1.0); }
+    for (int kb = 0; kb < nb; kb++) {
+        const int k0 = kb << 4;
+        if (wv == 0) {                                           // (1) diagonal block
+            for (int q = lane; q < 256; q += 64) s_L[q >> 4][q & 15] = A[(size_t)(k0 + (q >> 4)) * ld + k0 + (q & 15)];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            for (int j = 0; j < 16; j++) {
+                const double d = s_L[j][j];
+                const bool good = (d > 0) && isfinite(d);
+                if (!good && lane == 0) s_ok = 0;
+                const double dj = sqrt(good ? d : 1.0);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                if (lane >= j && lane < 16) s_L[lane][j] = (lane == j) ? dj : s_L[lane][j] / dj;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int q = lane + 64 * u, r = q >> 4, c = q & 15;
+                    if (c > j && c <= r) s_L[r][c] -= s_L[r][j] * s_L[c][j];
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
+            for (int q = lane; q < 256; q += 64) if ((q & 15) <= (q >> 4)) A[(size_t)(k0 + (q >> 4)) * ld + k0 + (q & 15)] = s_L[q >> 4][q & 15];
+        }
         __syncthreads();
-        const double dj = s_col[j];
-        for (int i = j + t; i < n; i += blockDim.x) { const double v = (i == j) ? dj : A[(size_t)i * n + j] / dj; A[(size_t)i * n + j] = v; if (i > j) s_col[i] = v; }
+        const int below = ld - k0 - 16;                          // rows under the diagonal block
+        if (t < below) {                                         // (2) panel: row r of L21 = A21 L11^-T
+            const int r = k0 + 16 + t;
+            double x[16];
+#pragma unroll
+            for (int c = 0; c < 16; c++) x[c] = A[(size_t)r * ld + k0 + c];
+#pragma unroll
+            for (int c = 0; c < 16; c++) {
+                double v = x[c];
+#pragma unroll
+                for (int u = 0; u < c; u++) v -= x[u] * s_L[c][u];
+                x[c] = v / s_L[c][c];
+            }
+#pragma unroll
+            for (int c = 0; c < 16; c++) { A[(size_t)r * ld + k0 + c] = x[c]; s_P[t][c] = x[c]; }
+        }
         __syncthreads();
-        const int m = n - j - 1;
-        for (int q = t; q < m * m; q += blockDim.x) {
-            const int r = j + 1 + q / m, c = j + 1 + q % m;
-            if (c <= r) A[(size_t)r * n + c] -= s_col[r] * s_col[c];
+        const int m = below >> 4, ntiles = m * (m + 1) / 2;     // (3) trailing update, lower block triangle
+        for (int tile = wv; tile < ntiles; tile += 16) {
+            int I = 0, rem = tile;
+            while (rem > I) { rem -= I + 1; I++; }               // tile -> (I, J), J <= I
+            const int J = rem;
+            v4d acc = {0, 0, 0, 0};
+#pragma unroll
+            for (int kc = 0; kc < 4; kc++)
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(s_P[I * 16 + (lane & 15)][4 * kc + (lane >> 4)], s_P[J * 16 + (lane & 15)][4 * kc + (lane >> 4)], acc, 0, 0, 0);
+            double* T = A + (size_t)(k0 + 16 + I * 16) * ld + k0 + 16 + J * 16;
+#pragma unroll
+            for (int r = 0; r < 4; r++) T[(size_t)((lane >> 4) + 4 * r) * ld + (lane & 15)] -= acc[r];
         }
         __syncthreads();
     }
-    // forward / backward substitution, one unknown per step, updates spread over the threads
-    for (int i = t; i < n; i += blockDim.x) s_y[i] = D.bs[i];
+    // forward substitution L y = bs, then backward L^T x = y, 16 unknowns at a time
+    for (int i = t; i < ld; i += blockDim.x) s_y[i] = D.bs[i];
     __syncthreads();
-    for (int j = 0; j < n; j++) {
-        if (t == 0) s_y[j] /= A[(size_t)j * n + j];
+    for (int kb = 0; kb < nb; kb++) {
+        const int k0 = kb << 4;
+        if (t < 256) s_L[t >> 4][t & 15] = A[(size_t)(k0 + (t >> 4)) * ld + k0 + (t & 15)];
         __syncthreads();
-        const double yj = s_y[j];
-        for (int i = j + 1 + t; i < n; i += blockDim.x) s_y[i] -= A[(size_t)i * n + j] * yj;
+        if (t == 0) {
+            double y[16];
+#pragma unroll
+            for (int c = 0; c < 16; c++) {
+                double v = s_y[k0 + c];
+#pragma unroll
+                for (int u = 0; u < c; u++) v -= s_L[c][u] * y[u];
+                y[c] = v / s_L[c][c];
+            }
+#pragma unroll
+            for (int c = 0; c < 16; c++) s_y[k0 + c] = y[c];
+        }
+        __syncthreads();
+        if (t < ld - k0 - 16) {
+            const int r = k0 + 16 + t;
+            double v = s_y[r];
+#pragma unroll
+            for (int c = 0; c < 16; c++) v -= A[(size_t)r * ld + k0 + c] * s_y[k0 + c];
+            s_y[r] = v;
+        }
         __syncthreads();
     }
-    for (int j = n - 1; j >= 0; j--) {
-        if (t == 0) s_y[j] /= A[(size_t)j * n + j];
+    for (int kb = nb - 1; kb >= 0; kb--) {
+        const int k0 = kb << 4;
+        if (t < 256) s_L[t >> 4][t & 15] = A[(size_t)(k0 + (t >> 4)) * ld + k0 + (t & 15)];
         __syncthreads();
-        const double xj = s_y[j];
-        for (int i = t; i < j; i += blockDim.x) s_y[i] -= A[(size_t)j * n + i] * xj;
+        if (t == 0) {
+            double x[16];
+#pragma unroll
+            for (int c = 15; c >= 0; c--) {
+                double v = s_y[k0 + c];
+#pragma unroll
+                for (int u = c + 1; u < 16; u++) v -= s_L[u][c] * x[u];
+                x[c] = v / s_L[c][c];
+            }
+#pragma unroll
+            for (int c = 0; c < 16; c++) s_y[k0 + c] = x[c];
+        }
+        __syncthreads();
+        if (t < k0) {
+            double v = s_y[t];
+#pragma unroll
+            for (int c = 0; c < 16; c++) v -= A[(size_t)(k0 + c) * ld + t] * s_y[k0 + c];
+            s_y[t] = v;
+        }
         __syncthreads();
     }
     for (int i = t; i < n; i += blockDim.x) D.xp[i] = s_ok ? s_y[i] : 0.0;
@@ -415,13 +512,14 @@ extern "C" int viorb_local_ba_navstate(const double* kfs, int nk, int n_local, i
     for (int i = 0; i < 16; i++) D.cam[i] = cam[i];
     for (int i = 0; i < 3; i++) D.gw[i] = gw[i];
     int *d_ept, *d_ekf, *d_pts, *d_kfs, *d_kfl; double *d_obs, *d_pre, *d_info; uint8_t* d_erase;
-    const size_t n2 = (size_t)D.np * D.np;
+    D.ld = (D.np + 15) & ~15;
+    const size_t n2 = (size_t)D.np * D.np, nl2 = (size_t)D.ld * D.ld;
     bool ok = B.alloc(&D.kf, (size_t)nk * 22, kfs) && B.alloc(&D.kf_bak, (size_t)nk * 22) && B.alloc(&D.pt, (size_t)npts * 3, points) && B.alloc(&D.pt_bak, (size_t)npts * 3) &&
               B.alloc(&d_ept, ne, e_pt.data()) && B.alloc(&d_ekf, ne, e_kf.data()) && B.alloc(&d_obs, (size_t)ne * 3, edge_obs) && B.alloc(&D.level, ne) &&
               B.alloc(&D.err, (size_t)ne * 2) && B.alloc(&D.Jp, (size_t)ne * 6) && B.alloc(&D.Jk, (size_t)ne * 12) && B.alloc(&D.wgt, ne) &&
               B.alloc(&d_pts, npts + 1, pt_start.data()) && B.alloc(&d_kfs, n_local + 1, kf_start.data()) && B.alloc(&d_kfl, kf_list.size(), kf_list.data()) &&
               B.alloc(&D.Hll, (size_t)npts * 9) && B.alloc(&D.bl, (size_t)npts * 3) && B.alloc(&D.Dinv, (size_t)npts * 9) &&
-              B.alloc(&D.Hpp, n2) && B.alloc(&D.bp, D.np) && B.alloc(&D.S, n2) && B.alloc(&D.bs, D.np) && B.alloc(&D.xp, D.np) && B.alloc(&D.xl, (size_t)npts * 3) &&
+              B.alloc(&D.Hpp, n2) && B.alloc(&D.bp, D.np) && B.alloc(&D.S, nl2) && B.alloc(&D.bs, D.ld) && B.alloc(&D.xp, D.ld) && B.alloc(&D.db, (size_t)npts * 3) && B.alloc(&D.xl, (size_t)npts * 3) &&
               B.alloc(&d_pre, (size_t)n_local * 142, preint) && B.alloc(&d_info, info_pvr.size(), info_pvr.data()) &&
               B.alloc(&D.e_pvr, (size_t)n_local * 9) && B.alloc(&D.e_b, (size_t)n_local * 3) && B.alloc(&D.scal, 8) && B.alloc(&d_erase, ne);
     if (!ok) { set_error("device allocation / upload failed"); return VIORB_ERR_HIP; }
@@ -462,8 +560,9 @@ extern "C" int viorb_local_ba_navstate(const double* kfs, int nk, int n_local, i
             do {
                 VIORB_HIP_TRY(hipMemcpyAsync(D.kf_bak, D.kf, (size_t)nk * 22 * sizeof(double), hipMemcpyDeviceToDevice, st));
                 VIORB_HIP_TRY(hipMemcpyAsync(D.pt_bak, D.pt, (size_t)npts * 3 * sizeof(double), hipMemcpyDeviceToDevice, st));
-                hipLaunchKernelGGL(k_ba_init_reduced, dim3((unsigned)((n2 + TB - 1) / TB)), dim3(TB), 0, st, D, lambda);
-                hipLaunchKernelGGL(k_ba_schur, dim3(gP), dim3(TB), 0, st, D, lambda);
+                hipLaunchKernelGGL(k_ba_init_reduced, dim3((unsigned)((nl2 + TB - 1) / TB)), dim3(TB), 0, st, D, lambda);
+                hipLaunchKernelGGL(k_ba_dinv, dim3(gP), dim3(TB), 0, st, D, lambda);
+                hipLaunchKernelGGL(k_ba_schur, dim3(gE), dim3(TB), 0, st, D);
                 hipLaunchKernelGGL(k_ba_chol_solve, dim3(1), dim3(1024), 0, st, D);
                 VIORB_HIP_TRY(hipMemsetAsync(D.scal + 1, 0, sizeof(double), st));
                 hipLaunchKernelGGL(k_ba_backsub, dim3(gP), dim3(TB), 0, st, D, lambda);
