@@ -17,6 +17,7 @@
 #include <algorithm>
 #include <cmath>
 #include <limits>
+#include <mutex>
 #include "viorb_common.h"
 #include "vio_core.h"
 
@@ -237,38 +238,48 @@ __global__ void k_ba_dinv(BaDev D, double lambda) {
     const double b0 = D.bl[3 * p], b1 = D.bl[3 * p + 1], b2 = D.bl[3 * p + 2];
     D.db[3 * p] = i00 * b0 + i01 * b1 + i02 * b2; D.db[3 * p + 1] = i01 * b0 + i11 * b1 + i12 * b2; D.db[3 * p + 2] = i02 * b0 + i12 * b1 + i22 * b2;
 }
-// Schur complement of the point block (block_solver.hpp:381-432): one thread per observation a of a local key frame; with its point's
-// other observations b it scatters -W_a Dinv W_b^T into S (lower block triangle only: the Cholesky never reads above the diagonal)
-// and -W_a Dinv bl into bs, with FP64 atomics (the 12W x 12W matrix lives in L2).
-__global__ void k_ba_schur(BaDev D) {
-    const int ea = blockIdx.x * blockDim.x + threadIdx.x;
-    if (ea >= D.NE || D.level[ea] != 0 || D.e_kf[ea] >= D.W) return;
-    const int p = D.e_pt[ea], ka = D.e_kf[ea], ld = D.ld;
-    const double* Di = D.Dinv + (size_t)p * 9;
-    const double* Ja = D.Jk + (size_t)12 * ea; const double* Pa = D.Jp + (size_t)6 * ea; const double wa = D.wgt[ea];
-    double BD[18];
+// Schur complement of the point block (block_solver.hpp:381-432): one workgroup per local key frame a accumulates the block row
+// [a][0..a] of -sum_p W_pa Dinv_p W_pb^T (6 x 12(a+1) values; the Cholesky never reads above the diagonal) and -W_pa Dinv_p bl_p in
+// LDS with ds_add_f64, walking a's observations and, for each, the other observations of that point; the row is then added to S
+// and bs without global atomics (rows of key frame a belong to this workgroup alone).
+__global__ __launch_bounds__(256) void k_ba_schur(BaDev D) {
+    __shared__ double s_row[6][240], s_b[6];
+    const int ka = blockIdx.x, t = threadIdx.x, ld = D.ld, ncol = 12 * (ka + 1);
+    for (int q = t; q < 6 * 240; q += blockDim.x) (&s_row[0][0])[q] = 0.0;
+    if (t < 6) s_b[t] = 0.0;
+    __syncthreads();
+    for (int q = D.kf_start[ka] + t; q < D.kf_start[ka + 1]; q += blockDim.x) {
+        const int ea = D.kf_list[q];
+        if (D.level[ea] != 0) continue;
+        const int p = D.e_pt[ea];
+        const double* Di = D.Dinv + (size_t)p * 9;
+        const double* Ja = D.Jk + (size_t)12 * ea; const double* Pa = D.Jp + (size_t)6 * ea; const double wa = D.wgt[ea];
+        double BD[18];
 #pragma unroll
-    for (int r = 0; r < 6; r++) {
-        const double w0 = wa * (Ja[r] * Pa[0] + Ja[6 + r] * Pa[3]), w1 = wa * (Ja[r] * Pa[1] + Ja[6 + r] * Pa[4]), w2 = wa * (Ja[r] * Pa[2] + Ja[6 + r] * Pa[5]);
-        BD[r * 3] = w0 * Di[0] + w1 * Di[1] + w2 * Di[2]; BD[r * 3 + 1] = w0 * Di[3] + w1 * Di[4] + w2 * Di[5]; BD[r * 3 + 2] = w0 * Di[6] + w1 * Di[7] + w2 * Di[8];
-        const int row = 12 * ka + (r < 3 ? r : r + 3);
-        atomicAdd(&D.bs[row], -(w0 * D.db[3 * p] + w1 * D.db[3 * p + 1] + w2 * D.db[3 * p + 2]));
-    }
-    for (int eb = D.pt_start[p]; eb < D.pt_start[p + 1]; eb++) {
-        const int kb = D.e_kf[eb];
-        if (D.level[eb] != 0 || kb > ka) continue;                       // kb > ka: the transposed block, written by the other observation
-        const double* Jb = D.Jk + (size_t)12 * eb; const double* Pb = D.Jp + (size_t)6 * eb; const double wb = D.wgt[eb];
+        for (int r = 0; r < 6; r++) {
+            const double w0 = wa * (Ja[r] * Pa[0] + Ja[6 + r] * Pa[3]), w1 = wa * (Ja[r] * Pa[1] + Ja[6 + r] * Pa[4]), w2 = wa * (Ja[r] * Pa[2] + Ja[6 + r] * Pa[5]);
+            BD[r * 3] = w0 * Di[0] + w1 * Di[1] + w2 * Di[2]; BD[r * 3 + 1] = w0 * Di[3] + w1 * Di[4] + w2 * Di[5]; BD[r * 3 + 2] = w0 * Di[6] + w1 * Di[7] + w2 * Di[8];
+            atomicAdd(&s_b[r], -(w0 * D.db[3 * p] + w1 * D.db[3 * p + 1] + w2 * D.db[3 * p + 2]));
+        }
+        for (int eb = D.pt_start[p]; eb < D.pt_start[p + 1]; eb++) {
+            const int kb = D.e_kf[eb];
+            if (D.level[eb] != 0 || kb > ka) continue;                   // kb > ka: the transposed block, accumulated by key frame kb's workgroup
+            const double* Jb = D.Jk + (size_t)12 * eb; const double* Pb = D.Jp + (size_t)6 * eb; const double wb = D.wgt[eb];
 #pragma unroll
-        for (int cc = 0; cc < 6; cc++) {
-            const double w0 = wb * (Jb[cc] * Pb[0] + Jb[6 + cc] * Pb[3]), w1 = wb * (Jb[cc] * Pb[1] + Jb[6 + cc] * Pb[4]), w2 = wb * (Jb[cc] * Pb[2] + Jb[6 + cc] * Pb[5]);
-            const int col = 12 * kb + (cc < 3 ? cc : cc + 3);
+            for (int cc = 0; cc < 6; cc++) {
+                const double w0 = wb * (Jb[cc] * Pb[0] + Jb[6 + cc] * Pb[3]), w1 = wb * (Jb[cc] * Pb[1] + Jb[6 + cc] * Pb[4]), w2 = wb * (Jb[cc] * Pb[2] + Jb[6 + cc] * Pb[5]);
+                const int col = 12 * kb + (cc < 3 ? cc : cc + 3);
 #pragma unroll
-            for (int r = 0; r < 6; r++) {
-                const int row = 12 * ka + (r < 3 ? r : r + 3);
-                if (row >= col) atomicAdd(&D.S[(size_t)row * ld + col], -(BD[r * 3] * w0 + BD[r * 3 + 1] * w1 + BD[r * 3 + 2] * w2));
+                for (int r = 0; r < 6; r++) atomicAdd(&s_row[r][col], -(BD[r * 3] * w0 + BD[r * 3 + 1] * w1 + BD[r * 3 + 2] * w2));
             }
         }
     }
+    __syncthreads();
+    for (int q = t; q < 6 * ncol; q += blockDim.x) {
+        const int r = q / ncol, c = q - r * ncol, row = 12 * ka + (r < 3 ? r : r + 3);
+        if (c <= row) D.S[(size_t)row * ld + c] += s_row[r][c];
+    }
+    if (t < 6) D.bs[12 * ka + (t < 3 ? t : t + 3)] += s_b[t];
 }
 
 // Dense Cholesky solve S xp = bs of the reduced system by ONE 1024-thread workgroup, blocked by 16 (n <= 240, padded to ld):
@@ -451,14 +462,48 @@ __global__ void k_ba_gate(BaDev D, uint8_t* out, int set_level) {
 using namespace viorb;
 
 namespace {
+// A solve borrows a context (a HIP stream + a device arena) from a small pool, so that concurrent callers (the LocalMapping threads
+// of several SLAM instances) run on different streams and no call pays hipMalloc / hipFree, which synchronise the whole device.
+struct BaCtx { hipStream_t st = nullptr; void* arena = nullptr; size_t bytes = 0; };
+std::mutex g_ctx_mu;
+std::vector<BaCtx*> g_ctx_free;
+struct BaCtxLease {
+    BaCtx* c = nullptr;
+    BaCtxLease() {
+        std::lock_guard<std::mutex> lk(g_ctx_mu);
+        if (!g_ctx_free.empty()) { c = g_ctx_free.back(); g_ctx_free.pop_back(); }
+    }
+    ~BaCtxLease() { if (c) { std::lock_guard<std::mutex> lk(g_ctx_mu); g_ctx_free.push_back(c); } }
+    bool ready() {
+        if (!c) { c = new BaCtx(); if (hipStreamCreateWithFlags(&c->st, hipStreamNonBlocking) != hipSuccess) { delete c; c = nullptr; return false; } }
+        return true;
+    }
+};
+// alloc() lays the arrays out in a host mirror (inputs copied, work arrays zero); commit() uploads the mirror into the context's
+// arena in one copy and patches the recorded pointers.
 struct BaBuf {
-    std::vector<void*> ptrs;
-    ~BaBuf() { for (void* p : ptrs) (void)hipFree(p); }
+    struct Item { void** slot; size_t off; };
+    std::vector<Item> items;
+    std::vector<uint8_t> mirror;
     template <class T> bool alloc(T** d, size_t n, const T* src = nullptr) {
-        if (hipMalloc((void**)d, std::max<size_t>(n, 1) * sizeof(T)) != hipSuccess) return false;
-        ptrs.push_back(*d);
-        if (src && n) return hipMemcpy(*d, src, n * sizeof(T), hipMemcpyHostToDevice) == hipSuccess;
-        return hipMemset(*d, 0, std::max<size_t>(n, 1) * sizeof(T)) == hipSuccess;
+        const size_t off = (mirror.size() + 255) & ~(size_t)255, bytes = std::max<size_t>(n, 1) * sizeof(T);
+        mirror.resize(off + bytes, 0);
+        if (src && n) memcpy(mirror.data() + off, src, n * sizeof(T));
+        items.push_back({reinterpret_cast<void**>(d), off});
+        *d = nullptr;
+        return true;
+    }
+    bool commit(BaCtx* c) {
+        if (c->bytes < mirror.size()) {
+            if (c->arena) (void)hipFree(c->arena);
+            c->arena = nullptr; c->bytes = 0;
+            const size_t want = mirror.size() + mirror.size() / 4;
+            if (hipMalloc(&c->arena, want) != hipSuccess) { c->arena = nullptr; return false; }
+            c->bytes = want;
+        }
+        if (hipMemcpyAsync(c->arena, mirror.data(), mirror.size(), hipMemcpyHostToDevice, c->st) != hipSuccess || hipStreamSynchronize(c->st) != hipSuccess) return false;
+        for (const Item& it : items) *it.slot = static_cast<uint8_t*>(c->arena) + it.off;
+        return true;
     }
 };
 bool host_inverse9(const double* a_in, double* inv) {
@@ -507,6 +552,9 @@ extern "C" int viorb_local_ba_navstate(const double* kfs, int nk, int n_local, i
     for (int i = 0; i < n_local; i++) if (!host_inverse9(preint + (size_t)i * 142 + 60, &info_pvr[(size_t)i * 81])) { set_error("singular IMU covariance"); return VIORB_ERR_INVALID_ARG; }
 
     VIORB_HIP_TRY(hipSetDevice(0));
+    BaCtxLease lease;
+    if (!lease.ready()) { set_error("could not create a HIP stream"); return VIORB_ERR_HIP; }
+    hipStream_t st = lease.c->st;
     BaBuf B; BaDev D;
     D.W = n_local; D.NK = nk; D.NP = npts; D.NE = ne; D.np = 12 * n_local; D.prev_kf = prev_kf; D.acc_bias_rw2 = 5e-3 * 5e-3;
     for (int i = 0; i < 16; i++) D.cam[i] = cam[i];
@@ -521,17 +569,17 @@ extern "C" int viorb_local_ba_navstate(const double* kfs, int nk, int n_local, i
               B.alloc(&D.Hll, (size_t)npts * 9) && B.alloc(&D.bl, (size_t)npts * 3) && B.alloc(&D.Dinv, (size_t)npts * 9) &&
               B.alloc(&D.Hpp, n2) && B.alloc(&D.bp, D.np) && B.alloc(&D.S, nl2) && B.alloc(&D.bs, D.ld) && B.alloc(&D.xp, D.ld) && B.alloc(&D.db, (size_t)npts * 3) && B.alloc(&D.xl, (size_t)npts * 3) &&
               B.alloc(&d_pre, (size_t)n_local * 142, preint) && B.alloc(&d_info, info_pvr.size(), info_pvr.data()) &&
-              B.alloc(&D.e_pvr, (size_t)n_local * 9) && B.alloc(&D.e_b, (size_t)n_local * 3) && B.alloc(&D.scal, 8) && B.alloc(&d_erase, ne);
+              B.alloc(&D.e_pvr, (size_t)n_local * 9) && B.alloc(&D.e_b, (size_t)n_local * 3) && B.alloc(&D.scal, 8) && B.alloc(&d_erase, ne) && B.commit(lease.c);
     if (!ok) { set_error("device allocation / upload failed"); return VIORB_ERR_HIP; }
     D.e_pt = d_ept; D.e_kf = d_ekf; D.e_obs = d_obs; D.pt_start = d_pts; D.kf_start = d_kfs; D.kf_list = d_kfl; D.preint = d_pre; D.info_pvr = d_info;
-    hipStream_t st = nullptr;
     const int TB = 256, gE = (ne + TB - 1) / TB, gP = (npts + TB - 1) / TB;
     int mono_kernel = 1;
     double h_scal[8];
     auto eval_chi2 = [&](double* chi) -> int {
         VIORB_HIP_TRY(hipMemsetAsync(D.scal, 0, sizeof(double), st));
         hipLaunchKernelGGL(k_ba_errors, dim3(gE), dim3(TB), 0, st, D, mono_kernel);
-        VIORB_HIP_TRY(hipMemcpy(chi, D.scal, sizeof(double), hipMemcpyDeviceToHost));
+        VIORB_HIP_TRY(hipMemcpyAsync(chi, D.scal, sizeof(double), hipMemcpyDeviceToHost, st));
+        VIORB_HIP_TRY(hipStreamSynchronize(st));
         return VIORB_OK;
     };
     auto build_system = [&]() -> int {
@@ -553,7 +601,8 @@ extern "C" int viorb_local_ba_navstate(const double* kfs, int nk, int n_local, i
             if (it == 0) {
                 VIORB_HIP_TRY(hipMemsetAsync(D.scal + 3, 0, sizeof(double), st));
                 hipLaunchKernelGGL(k_ba_max_diag, dim3(32), dim3(256), 0, st, D);
-                VIORB_HIP_TRY(hipMemcpy(h_scal, D.scal, 8 * sizeof(double), hipMemcpyDeviceToHost));
+                VIORB_HIP_TRY(hipMemcpyAsync(h_scal, D.scal, 8 * sizeof(double), hipMemcpyDeviceToHost, st));
+                VIORB_HIP_TRY(hipStreamSynchronize(st));
                 lambda = 1e-5 * h_scal[3]; ni = 2; nBad = 0;
             }
             double rho = 0; int qmax = 0;
@@ -562,14 +611,15 @@ extern "C" int viorb_local_ba_navstate(const double* kfs, int nk, int n_local, i
                 VIORB_HIP_TRY(hipMemcpyAsync(D.pt_bak, D.pt, (size_t)npts * 3 * sizeof(double), hipMemcpyDeviceToDevice, st));
                 hipLaunchKernelGGL(k_ba_init_reduced, dim3((unsigned)((nl2 + TB - 1) / TB)), dim3(TB), 0, st, D, lambda);
                 hipLaunchKernelGGL(k_ba_dinv, dim3(gP), dim3(TB), 0, st, D, lambda);
-                hipLaunchKernelGGL(k_ba_schur, dim3(gE), dim3(TB), 0, st, D);
+                hipLaunchKernelGGL(k_ba_schur, dim3(n_local), dim3(256), 0, st, D);
                 hipLaunchKernelGGL(k_ba_chol_solve, dim3(1), dim3(1024), 0, st, D);
                 VIORB_HIP_TRY(hipMemsetAsync(D.scal + 1, 0, sizeof(double), st));
                 hipLaunchKernelGGL(k_ba_backsub, dim3(gP), dim3(TB), 0, st, D, lambda);
                 hipLaunchKernelGGL(k_ba_update, dim3(std::max(gP, 1)), dim3(TB), 0, st, D);
                 double tempChi = 0;
                 if ((rc = eval_chi2(&tempChi)) != VIORB_OK) return rc;
-                VIORB_HIP_TRY(hipMemcpy(h_scal, D.scal, 8 * sizeof(double), hipMemcpyDeviceToHost));
+                VIORB_HIP_TRY(hipMemcpyAsync(h_scal, D.scal, 8 * sizeof(double), hipMemcpyDeviceToHost, st));
+                VIORB_HIP_TRY(hipStreamSynchronize(st));
                 const bool ok2 = h_scal[2] > 0.5;
                 if (!ok2) tempChi = std::numeric_limits<double>::max();
                 const double scale = (ok2 ? h_scal[1] : 0.0) + 1e-3;
@@ -597,10 +647,10 @@ extern "C" int viorb_local_ba_navstate(const double* kfs, int nk, int n_local, i
         if ((rc = optimize(10, its2, chi2v)) != VIORB_OK) return rc;
     }
     hipLaunchKernelGGL(k_ba_gate, dim3(gE), dim3(TB), 0, st, D, d_erase, 0);
-    VIORB_HIP_TRY(hipDeviceSynchronize());
-    VIORB_HIP_TRY(hipMemcpy(kfs_out, D.kf, (size_t)n_local * 22 * sizeof(double), hipMemcpyDeviceToHost));
-    VIORB_HIP_TRY(hipMemcpy(points_out, D.pt, (size_t)npts * 3 * sizeof(double), hipMemcpyDeviceToHost));
-    VIORB_HIP_TRY(hipMemcpy(erase, d_erase, ne, hipMemcpyDeviceToHost));
+    VIORB_HIP_TRY(hipMemcpyAsync(kfs_out, D.kf, (size_t)n_local * 22 * sizeof(double), hipMemcpyDeviceToHost, st));
+    VIORB_HIP_TRY(hipMemcpyAsync(points_out, D.pt, (size_t)npts * 3 * sizeof(double), hipMemcpyDeviceToHost, st));
+    VIORB_HIP_TRY(hipMemcpyAsync(erase, d_erase, ne, hipMemcpyDeviceToHost, st));
+    VIORB_HIP_TRY(hipStreamSynchronize(st));
     info[0] = chi1; info[1] = chi2v; info[2] = its1; info[3] = its2;
     return VIORB_OK;
 }
