@@ -286,15 +286,23 @@ __global__ __launch_bounds__(256) void k_ba_schur(BaDev D) {
 // per block column: (1) one wave factors the 16x16 diagonal block in LDS, (2) a thread per row solves the panel below it against
 // that block, (3) the 16 waves apply the rank-16 update to the trailing lower triangle, one 16x16 tile at a time, with
 // v_mfma_f64_16x16x4_f64 (operands A[i][k]: lane 16k+i, B[k][j]: lane 16k+j; result row = lane/16 + 4*reg, col = lane%16 — probed
-// on gfx950, tools/ubench/mfma_f64_layout.hip). The matrix stays in L2; the panel is staged in LDS. scal[2] = 1 on success;
-// a pivot that is not positive and finite fails the solve like the reference's LLT (linear_solver_eigen.h / Eigen info()).
+// on gfx950, tools/ubench/mfma_f64_layout.hip). The right-hand side rides along as one more row under the matrix (row ld of the
+// ld+16 row buffer), so the forward substitution L y = bs is done by the panel solves and updates themselves; the backward
+// substitution uses the inverted diagonal blocks (one thread per column of each inverse) and is a 16x16 mat-vec + a rank-16 update
+// per block. The matrix stays in L2; the panel is staged in LDS. scal[2] = 1 on success; a pivot that is not positive and finite
+// fails the solve like the reference's LLT (linear_solver_eigen.h / Eigen info()).
 typedef double v4d __attribute__((ext_vector_type(4)));
+#define BA_MAX_TILES_PER_WAVE 9              // ceil(16 * 17 / 2 / 16) trailing tiles per wave at ld = 256 (+ the rhs block row)
 __global__ __launch_bounds__(1024) void k_ba_chol_solve(BaDev D) {
-    __shared__ double s_L[16][17], s_P[240][17], s_y[256];
+    __shared__ double s_L[16][17], s_P[256][17], s_y[256], s_rd[16];
     __shared__ int s_ok;
     const int n = D.np, ld = D.ld, nb = ld >> 4, t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int rows = ld + 16;                                    // + the block row that carries bs^T in its first row
     double* A = D.S;
+    double* inv = A + (size_t)rows * ld;                         // [nb][16][16] inverted diagonal blocks
     if (t == 0) s_ok = 1;
+    for (int q = t; q < 16 * ld; q += blockDim.x) A[(size_t)ld * ld + q] = (q < ld) ? D.bs[q] : 0.0;
+    __syncthreads();
     for (int kb = 0; kb < nb; kb++) {
         const int k0 = kb << 4;
         if (wv == 0) {                                           // (1) diagonal block
@@ -316,9 +324,10 @@ __global__ __launch_bounds__(1024) void k_ba_chol_solve(BaDev D) {
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             }
             for (int q = lane; q < 256; q += 64) if ((q & 15) <= (q >> 4)) A[(size_t)(k0 + (q >> 4)) * ld + k0 + (q & 15)] = s_L[q >> 4][q & 15];
+            if (lane < 16) s_rd[lane] = 1.0 / s_L[lane][lane];          // the panel rows multiply by the reciprocal pivots
         }
         __syncthreads();
-        const int below = ld - k0 - 16;                          // rows under the diagonal block
+        const int below = rows - k0 - 16;                        // rows under the diagonal block (the rhs block row included)
         if (t < below) {                                         // (2) panel: row r of L21 = A21 L11^-T
             const int r = k0 + 16 + t;
             double x[16];
@@ -329,72 +338,64 @@ __global__ __launch_bounds__(1024) void k_ba_chol_solve(BaDev D) {
                 double v = x[c];
 #pragma unroll
                 for (int u = 0; u < c; u++) v -= x[u] * s_L[c][u];
-                x[c] = v / s_L[c][c];
+                x[c] = v * s_rd[c];
             }
 #pragma unroll
             for (int c = 0; c < 16; c++) { A[(size_t)r * ld + k0 + c] = x[c]; s_P[t][c] = x[c]; }
-        }
-        __syncthreads();
-        const int m = below >> 4, ntiles = m * (m + 1) / 2;     // (3) trailing update, lower block triangle
-        for (int tile = wv; tile < ntiles; tile += 16) {
-            int I = 0, rem = tile;
-            while (rem > I) { rem -= I + 1; I++; }               // tile -> (I, J), J <= I
-            const int J = rem;
-            v4d acc = {0, 0, 0, 0};
-#pragma unroll
-            for (int kc = 0; kc < 4; kc++)
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(s_P[I * 16 + (lane & 15)][4 * kc + (lane >> 4)], s_P[J * 16 + (lane & 15)][4 * kc + (lane >> 4)], acc, 0, 0, 0);
-            double* T = A + (size_t)(k0 + 16 + I * 16) * ld + k0 + 16 + J * 16;
-#pragma unroll
-            for (int r = 0; r < 4; r++) T[(size_t)((lane >> 4) + 4 * r) * ld + (lane & 15)] -= acc[r];
-        }
-        __syncthreads();
-    }
-    // forward substitution L y = bs, then backward L^T x = y, 16 unknowns at a time
-    for (int i = t; i < ld; i += blockDim.x) s_y[i] = D.bs[i];
-    __syncthreads();
-    for (int kb = 0; kb < nb; kb++) {
-        const int k0 = kb << 4;
-        if (t < 256) s_L[t >> 4][t & 15] = A[(size_t)(k0 + (t >> 4)) * ld + k0 + (t & 15)];
-        __syncthreads();
-        if (t == 0) {
-            double y[16];
-#pragma unroll
-            for (int c = 0; c < 16; c++) {
-                double v = s_y[k0 + c];
-#pragma unroll
-                for (int u = 0; u < c; u++) v -= s_L[c][u] * y[u];
-                y[c] = v / s_L[c][c];
-            }
-#pragma unroll
-            for (int c = 0; c < 16; c++) s_y[k0 + c] = y[c];
-        }
-        __syncthreads();
-        if (t < ld - k0 - 16) {
-            const int r = k0 + 16 + t;
-            double v = s_y[r];
-#pragma unroll
-            for (int c = 0; c < 16; c++) v -= A[(size_t)r * ld + k0 + c] * s_y[k0 + c];
-            s_y[r] = v;
-        }
-        __syncthreads();
-    }
-    for (int kb = nb - 1; kb >= 0; kb--) {
-        const int k0 = kb << 4;
-        if (t < 256) s_L[t >> 4][t & 15] = A[(size_t)(k0 + (t >> 4)) * ld + k0 + (t & 15)];
-        __syncthreads();
-        if (t == 0) {
+        } else if (t >= 1008) {                                  // 16 idle threads invert the diagonal block: column c of L11^-1
+            const int c = t - 1008;
             double x[16];
 #pragma unroll
-            for (int c = 15; c >= 0; c--) {
-                double v = s_y[k0 + c];
+            for (int i = 0; i < 16; i++) {
+                double v = (i == c) ? 1.0 : 0.0;
 #pragma unroll
-                for (int u = c + 1; u < 16; u++) v -= s_L[u][c] * x[u];
-                x[c] = v / s_L[c][c];
+                for (int u = 0; u < i; u++) v -= s_L[i][u] * x[u];
+                x[i] = v * s_rd[i];
             }
 #pragma unroll
-            for (int c = 0; c < 16; c++) s_y[k0 + c] = x[c];
+            for (int i = 0; i < 16; i++) inv[(size_t)kb * 256 + i * 16 + c] = x[i];
         }
+        __syncthreads();
+        // (3) trailing update, lower block triangle; the last block row (rhs) only against the matrix block columns
+        const int m = below >> 4, mm = m - 1, ntiles = mm * (mm + 1) / 2 + mm;
+        v4d acc[BA_MAX_TILES_PER_WAVE]; double* T[BA_MAX_TILES_PER_WAVE];
+#pragma unroll
+        for (int u = 0; u < BA_MAX_TILES_PER_WAVE; u++) {
+            const int tile = wv + 16 * u;
+            T[u] = nullptr;
+            if (tile < ntiles) {
+                int I, J;
+                if (tile < mm * (mm + 1) / 2) { I = 0; int rem = tile; while (rem > I) { rem -= I + 1; I++; } J = rem; }
+                else { I = mm; J = tile - mm * (mm + 1) / 2; }
+                T[u] = A + (size_t)(k0 + 16 + I * 16) * ld + k0 + 16 + J * 16;
+#pragma unroll
+                for (int r = 0; r < 4; r++) acc[u][r] = T[u][(size_t)((lane >> 4) + 4 * r) * ld + (lane & 15)];
+                const int Io = I * 16 + (lane & 15), Jo = J * 16 + (lane & 15);
+#pragma unroll
+                for (int kc = 0; kc < 4; kc++)
+                    acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(-s_P[Io][4 * kc + (lane >> 4)], s_P[Jo][4 * kc + (lane >> 4)], acc[u], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < BA_MAX_TILES_PER_WAVE; u++)
+            if (T[u]) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) T[u][(size_t)((lane >> 4) + 4 * r) * ld + (lane & 15)] = acc[u][r];
+            }
+        __syncthreads();
+    }
+    // y = L^-1 bs now sits in the rhs row; backward substitution L^T x = y, 16 unknowns at a time
+    for (int i = t; i < ld; i += blockDim.x) s_y[i] = A[(size_t)ld * ld + i];
+    __syncthreads();
+    for (int kb = nb - 1; kb >= 0; kb--) {
+        const int k0 = kb << 4;
+        double xi = 0;
+        if (t < 16) {                                            // x_blk = L11^-T y_blk
+#pragma unroll
+            for (int c = 0; c < 16; c++) xi += inv[(size_t)kb * 256 + c * 16 + t] * s_y[k0 + c];
+        }
+        __syncthreads();
+        if (t < 16) s_y[k0 + t] = xi;
         __syncthreads();
         if (t < k0) {
             double v = s_y[t];
@@ -567,7 +568,7 @@ extern "C" int viorb_local_ba_navstate(const double* kfs, int nk, int n_local, i
               B.alloc(&D.err, (size_t)ne * 2) && B.alloc(&D.Jp, (size_t)ne * 6) && B.alloc(&D.Jk, (size_t)ne * 12) && B.alloc(&D.wgt, ne) &&
               B.alloc(&d_pts, npts + 1, pt_start.data()) && B.alloc(&d_kfs, n_local + 1, kf_start.data()) && B.alloc(&d_kfl, kf_list.size(), kf_list.data()) &&
               B.alloc(&D.Hll, (size_t)npts * 9) && B.alloc(&D.bl, (size_t)npts * 3) && B.alloc(&D.Dinv, (size_t)npts * 9) &&
-              B.alloc(&D.Hpp, n2) && B.alloc(&D.bp, D.np) && B.alloc(&D.S, nl2) && B.alloc(&D.bs, D.ld) && B.alloc(&D.xp, D.ld) && B.alloc(&D.db, (size_t)npts * 3) && B.alloc(&D.xl, (size_t)npts * 3) &&
+              B.alloc(&D.Hpp, n2) && B.alloc(&D.bp, D.np) && B.alloc(&D.S, nl2 + (size_t)16 * D.ld + (size_t)(D.ld / 16) * 256) && B.alloc(&D.bs, D.ld) && B.alloc(&D.xp, D.ld) && B.alloc(&D.db, (size_t)npts * 3) && B.alloc(&D.xl, (size_t)npts * 3) &&
               B.alloc(&d_pre, (size_t)n_local * 142, preint) && B.alloc(&d_info, info_pvr.size(), info_pvr.data()) &&
               B.alloc(&D.e_pvr, (size_t)n_local * 9) && B.alloc(&D.e_b, (size_t)n_local * 3) && B.alloc(&D.scal, 8) && B.alloc(&d_erase, ne) && B.commit(lease.c);
     if (!ok) { set_error("device allocation / upload failed"); return VIORB_ERR_HIP; }
