@@ -230,6 +230,30 @@ int viorb_frontend_pose_opt_device(viorb_frontend* h, int variant, int compute_m
 int viorb_frontend_pose_opt_se3_device(viorb_frontend* h, const float* pose12, const double* obs7, const int32_t* n_obs,
                                        double bf, int batch, float* out_pose12, uint8_t* outlier, double* info, void* stream);
 
+/* ---- Tracking::TrackLocalMapWithIMU glue (reference src/Tracking.cc:228-346, 489-507) ----------------------------------------
+ * viorb_frontend_discard_outliers_device: TrackWithIMU's "Discard outliers" loop (:489-507). outlier[b][k] / obs_index[b][k] /
+ * n_obs[b] are PoseOptimization's outputs for the current frame; match[b][c] (index into the last frame's points) is set to -1
+ * where the edge ended as an outlier. owner_obs[b][c] = 1 when keypoint c still holds a map point with Observations() > 0
+ * (pt_flags bit 2 of that point) — the cur_owner_obs input of viorb_frontend_search_local_points_device; n_map[b] = nmatchesMap.
+ * viorb_frontend_pose_from_navstate_device: Frame::UpdatePoseFromNS (src/Frame.cc:88-105), NavState -> float Tcw (pose12).
+ * viorb_frontend_build_observations2_device: PoseOptimization's edge construction when the frame's map points come from the
+ * last frame (match_a into Pw_a[b][cap][3]) or, where match_a < 0, from the local map (match_b into pts_b[b][stride_b][8],
+ * the pts_f layout of the local-points search), in keypoint order. */
+int viorb_frontend_discard_outliers_device(viorb_frontend* h, int32_t* match, const int32_t* obs_index, const uint8_t* outlier,
+                                           const int32_t* n_obs, const uint8_t* pt_flags, int batch, uint8_t* owner_obs,
+                                           int32_t* n_map, void* stream);
+int viorb_frontend_pose_from_navstate_device(viorb_frontend* h, const double* ns, int batch, float* pose12, void* stream);
+int viorb_frontend_build_observations2_device(viorb_frontend* h, const viorb_keypoint* kps, const int32_t* count,
+                                              const int32_t* match_a, const float* Pw_a, const int32_t* match_b,
+                                              const float* pts_b, int stride_b, int batch, double* obs, int32_t* obs_index,
+                                              int32_t* n_obs, void* stream);
+
+/* Workload support (no reference counterpart): the MapPoint fields Frame::isInFrustum reads (normal, min / max distance,
+ * MapPoint::UpdateNormalAndDepth with one observation) for the points viorb_synth_plane_points_device created from a frame:
+ * pts_f[b][cap][8] = Pw3 normal3 minDist maxDist. */
+int viorb_synth_local_points_device(viorb_frontend* h, const viorb_keypoint* kps, const int32_t* count, const double* pose12,
+                                    const float* Pw, int batch, float* pts_f, void* stream);
+
 /* Workload support for bench.py / tests (no reference counterpart): map points of the synthetic plane
  * world (viorb_amd/synth.py) for all keypoints of a frame; pose12 = Rcw(9) tcw(3) in double per stream.
  * Writes Pw[b][cap][3] and flags[b][cap] = 1|4 (map point with observations), 0 beyond count[b]. */

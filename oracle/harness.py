@@ -1,25 +1,34 @@
 """Oracle-side twin of viorb_amd.tracker.BatchedTracker for ONE stream — TEST INFRASTRUCTURE ONLY (used by
 tests/ and by bench.py's cpu_baseline leg). Same call order as Tracking::TrackWithIMU's steady state
 (reference src/Tracking.cc:412-534): extract -> grid -> pre-integrate/predict -> SearchByProjection(th=15)
--> PoseOptimization(Frame, Frame, marg)."""
+-> PoseOptimization(Frame, Frame, marg), and with track_local_map=True the steady state of TrackLocalMapWithIMU
+(reference src/Tracking.cc:228-346) after it: discard outliers -> SearchLocalPoints -> PoseOptimization(Frame, Frame, marg)."""
 import numpy as np
 from . import binding as ora
 from viorb_amd import synth
 
 
 class OracleTracker:
-    def __init__(self, cam, gw, width=752, height=480, nfeatures=1000, th=15.0, compute_marg=True):
+    LOCAL_FRAMES = 2
+
+    def __init__(self, cam, gw, width=752, height=480, nfeatures=1000, th=15.0, compute_marg=True, track_local_map=False):
         self.ex = ora.Extractor(nfeatures, 1.2, 8, 20, 7)
         self.tab = self.ex.tables()
         self.cam, self.gw, self.th = np.asarray(cam, np.float64), np.asarray(gw, np.float64), float(th)
         self.bounds = (0.0, float(width), 0.0, float(height))
         self.compute_marg = compute_marg
+        self.track_local_map = track_local_map
+        self.local = []                      # newest first: (pts_f, flags, desc) of the frames before the last one
 
     def _adopt(self, kps, desc, pose_true, ns, t):
+        if self.track_local_map and hasattr(self, "last_pts_f"):
+            self.local = [(self.last_pts_f, self.last_flags, self.last_desc)] + self.local[:self.LOCAL_FRAMES - 1]
         self.last_kps, self.last_desc = kps, desc
         self.last_Pw = synth.plane_points_f32(np.stack([kps["x"], kps["y"]], 1), pose_true, self.cam)
         self.last_flags = np.full(len(kps), 1 | 4, np.uint8)
         self.last_ns, self.prior_ns, self.t_last = ns.copy(), ns.copy(), float(t)
+        if self.track_local_map:
+            self.last_pts_f = synth.local_points_f32(kps["octave"], pose_true, self.last_Pw, self.tab["scale"])
 
     def bootstrap(self, image, pose_true, t0, ns0, marg_cov_inv):
         k, d = self.ex(image)
@@ -42,10 +51,37 @@ class OracleTracker:
         lk = self.last_kps
         obs_last = np.concatenate([self.last_Pw.astype(np.float64), np.stack([lk["x"], lk["y"]], 1).astype(np.float64),
                                    inv_s2[lk["octave"]].astype(np.float64)[:, None]], 1).reshape(-1, 6)
+        tlm = self.track_local_map
         r = ora.pose_opt_vi_frame(cur_ns, last, self.prior_ns, self.marg_cov_inv, pre, self.gw, self.cam, obs_cur, obs_last,
-                                  marg=self.compute_marg)
+                                  marg=self.compute_marg and not tlm)
         out = dict(n_kps=len(kps), nmatches=nm, match=match, n_inliers=r["n_inliers"], final_chi2=r["final_chi2"], ns=r["ns"],
                    pred_ns=cur_ns, outlier_cur=r["outlier_cur"], kps=kps, desc=desc)
+        if tlm:
+            # discard outliers (Tracking.cc:489-507), then SearchLocalPoints + the second pose solve (:228-346)
+            match2 = match.copy()
+            match2[sel[r["outlier_cur"][:len(sel)] != 0]] = -1
+            owner = ((match2 >= 0) & ((self.last_flags[np.maximum(match2, 0)] & 4) != 0)).astype(np.uint8)
+            pts_f = np.concatenate([l[0] for l in self.local]) if self.local else np.zeros((0, 8), np.float32)
+            pflags = np.concatenate([l[1] for l in self.local]) if self.local else np.zeros(0, np.uint8)
+            pdesc = np.concatenate([l[2] for l in self.local]) if self.local else np.zeros((0, 32), np.uint8)
+            offs = np.cumsum([0] + [len(l[0]) for l in self.local])
+            pose12_b = ora.pose_from_navstate(r["ns"], self.cam)
+            log_sf = np.float32(np.log(np.float64(self.tab["scale"][1])))
+            if len(pts_f):
+                n_loc, loc_match, _ = ora.search_local_points(kps, desc, self.bounds, pose12_b, self.cam[:4], self.tab["scale"], log_sf, pts_f, pflags,
+                                                              pdesc, 1.0, 0.8, owner)
+            else:
+                n_loc, loc_match = 0, np.full(len(kps), -1, np.int32)
+            use_a = match2 >= 0
+            use_b = (~use_a) & (loc_match >= 0)
+            sel2 = np.nonzero(use_a | use_b)[0]
+            X = np.where(use_a[sel2, None], self.last_Pw[np.maximum(match2[sel2], 0)], pts_f[np.maximum(loc_match[sel2], 0), :3] if len(pts_f) else 0.0)
+            obs_cur2 = np.concatenate([X.astype(np.float64), np.stack([kps["x"][sel2], kps["y"][sel2]], 1).astype(np.float64),
+                                       inv_s2[kps["octave"][sel2]].astype(np.float64)[:, None]], 1).reshape(-1, 6)
+            r2 = ora.pose_opt_vi_frame(r["ns"], last, self.prior_ns, self.marg_cov_inv, pre, self.gw, self.cam, obs_cur2, obs_last, marg=self.compute_marg)
+            out.update(n_map=int(owner.sum()), match_after_discard=match2, n_loc=n_loc, loc_match=loc_match, loc_offsets=offs, n_inliers2=r2["n_inliers"],
+                       final_chi2_2=r2["final_chi2"], ns2=r2["ns"], n_obs2=len(sel2))
+            r = r2
         if self.compute_marg:
             self.marg_cov_inv = r["marg_cov_inv"].copy()
         self._adopt(kps, desc, pose_true, r["ns"], t_cur if t_next_last is None else t_next_last)

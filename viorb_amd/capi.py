@@ -70,6 +70,10 @@ SIGNATURES = {
     "viorb_bow_transform": (i32, [vp, vp, i32, i32, vp, vp, vp]),
     "viorb_search_by_bow_device": (i32, [vp] * 9 + [i32, i32, f32, i32, vp, vp, vp]),
     "viorb_search_by_bow": (i32, [vp, vp, vp, vp, i32, vp, vp, vp, i32, f32, i32, vp, PP(i32)]),
+    "viorb_frontend_discard_outliers_device": (i32, [vp, vp, vp, vp, vp, vp, i32, vp, vp, vp]),
+    "viorb_frontend_pose_from_navstate_device": (i32, [vp, vp, i32, vp, vp]),
+    "viorb_frontend_build_observations2_device": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp]),
+    "viorb_synth_local_points_device": (i32, [vp, vp, vp, vp, vp, i32, vp, vp]),
     "viorb_synth_plane_points_device": (i32, [vp, vp, vp, vp, C.c_double, i32, vp, vp, vp]),
     "viorb_memcpy_dtod_async": (i32, [vp, vp, sz, vp]),
     "viorb_profile_enable": (i32, [i32]),

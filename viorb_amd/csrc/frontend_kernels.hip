@@ -551,6 +551,102 @@ __global__ __launch_bounds__(256) void k_build_observations(const viorb_keypoint
     if (threadIdx.x == 0) n_obs[b] = s_base;
 }
 
+// TrackLocalMap's edge construction: as k_build_observations, with the frame's map points coming from two tables — the last
+// frame's points (match_a, stride cap) for the keypoints matched by SearchByProjection(Frame, Frame) and the local map
+// (match_b, stride stride_b) for those added by SearchLocalPoints. Keypoint order, as the loop over mvpMapPoints builds edges.
+__global__ __launch_bounds__(256) void k_build_observations2(const viorb_keypoint* __restrict__ kps, const int* __restrict__ count,
+                                                             const int* __restrict__ match_a, const float* __restrict__ Pw_a,
+                                                             const int* __restrict__ match_b, const float* __restrict__ pts_b, int stride_b,
+                                                             const float* __restrict__ inv_sigma2, int cap,
+                                                             double* __restrict__ obs, int* __restrict__ obs_index, int* __restrict__ n_obs) {
+    __shared__ int s_base, s_wave[4];
+    const int b = blockIdx.x;
+    const int n = min(count[b], cap);
+    if (threadIdx.x == 0) s_base = 0;
+    __syncthreads();
+    for (int base = 0; base < n; base += blockDim.x) {
+        const int i = base + threadIdx.x;
+        const int ma = i < n ? match_a[(size_t)b * cap + i] : -1;
+        const int mb = (i < n && ma < 0) ? match_b[(size_t)b * cap + i] : -1;
+        const bool has = ma >= 0 || mb >= 0;
+        const unsigned long long bm = __ballot(has);
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        if (lane == 0) s_wave[wv] = __popcll(bm);
+        __syncthreads();
+        int off = s_base;
+        for (int k = 0; k < wv; k++) off += s_wave[k];
+        if (has) {
+            const int pos = off + __popcll(bm & ((1ull << lane) - 1ull));
+            const viorb_keypoint kp = kps[(size_t)b * cap + i];
+            const float* X = ma >= 0 ? Pw_a + ((size_t)b * cap + ma) * 3 : pts_b + ((size_t)b * stride_b + mb) * 8;   // local points: pts_f[8], Pw first
+            double* o = obs + ((size_t)b * cap + pos) * 6;
+            o[0] = X[0]; o[1] = X[1]; o[2] = X[2]; o[3] = kp.x; o[4] = kp.y; o[5] = inv_sigma2[kp.octave];
+            obs_index[(size_t)b * cap + pos] = i;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) s_base += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) n_obs[b] = s_base;
+}
+
+// Tracking::TrackWithIMU's "Discard outliers" loop (reference src/Tracking.cc:489-507): matches whose edge ended as an outlier
+// lose their map point; owner_obs[c] = the keypoint still holds a map point with observations (what SearchLocalPoints'
+// SearchByProjection must not overwrite); n_map = nmatchesMap.
+__global__ __launch_bounds__(256) void k_discard_outliers(int* __restrict__ match, const int* __restrict__ obs_index,
+                                                          const uint8_t* __restrict__ outlier, const int* __restrict__ n_obs,
+                                                          const uint8_t* __restrict__ pt_flags, int cap, uint8_t* __restrict__ owner_obs,
+                                                          int* __restrict__ n_map) {
+    __shared__ int s_n;
+    const int b = blockIdx.x;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    const int n = min(n_obs[b], cap);
+    for (int k = threadIdx.x; k < n; k += blockDim.x)
+        if (outlier[(size_t)b * cap + k]) match[(size_t)b * cap + obs_index[(size_t)b * cap + k]] = -1;
+    __syncthreads();
+    int mine = 0;
+    for (int c = threadIdx.x; c < cap; c += blockDim.x) {
+        const int m = match[(size_t)b * cap + c];
+        const uint8_t own = (m >= 0 && (pt_flags[(size_t)b * cap + m] & 4)) ? 1 : 0;
+        owner_obs[(size_t)b * cap + c] = own;
+        mine += own;
+    }
+    if (mine) atomicAdd(&s_n, mine);
+    __syncthreads();
+    if (threadIdx.x == 0) n_map[b] = s_n;
+}
+
+// Frame::UpdatePoseFromNS (reference src/Frame.cc:88-105) for a batch of NavStates.
+__global__ void k_pose_from_navstate(const double* __restrict__ ns, const double* __restrict__ cam16, int batch, float* __restrict__ pose12) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= batch) return;
+    pose_from_navstate_f32(ld_pvr(ns + (size_t)b * 22), cam16, pose12 + (size_t)b * 12);
+}
+
+// Workload support (not a reference function): the MapPoint fields Frame::isInFrustum reads, for points created from one frame
+// of the synthetic world — MapPoint::UpdateNormalAndDepth with a single observation (reference src/MapPoint.cc:350-392):
+// normal = (Pw - Ow) / |Pw - Ow|, mfMaxDistance = |Pw - Ow| * scaleFactor[octave], mfMinDistance = mfMaxDistance /
+// scaleFactor[nlevels - 1]; evaluated in double from the float point and the double pose, rounded once.
+__global__ void k_synth_local_points(const viorb_keypoint* __restrict__ kps, const int* __restrict__ count, int cap,
+                                     const double* __restrict__ pose12, const float* __restrict__ Pw, const float* __restrict__ scale, int nlevels,
+                                     float* __restrict__ pts_f) {
+    const int b = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cap) return;
+    const size_t o = (size_t)b * cap + i;
+    float* out = pts_f + o * 8;
+    if (i >= count[b]) { for (int k = 0; k < 8; k++) out[k] = 0.f; return; }
+    const double* T = pose12 + (size_t)b * 12;
+    const double ox = -(T[0] * T[9] + T[3] * T[10] + T[6] * T[11]), oy = -(T[1] * T[9] + T[4] * T[10] + T[7] * T[11]),
+                 oz = -(T[2] * T[9] + T[5] * T[10] + T[8] * T[11]);
+    const double px = Pw[3 * o], py = Pw[3 * o + 1], pz = Pw[3 * o + 2];
+    const double dx = px - ox, dy = py - oy, dz = pz - oz, dist = sqrt(dx * dx + dy * dy + dz * dz);
+    const double maxd = dist * (double)scale[kps[o].octave], mind = maxd / (double)scale[nlevels - 1];
+    out[0] = Pw[3 * o]; out[1] = Pw[3 * o + 1]; out[2] = Pw[3 * o + 2];
+    out[3] = (float)(dx / dist); out[4] = (float)(dy / dist); out[5] = (float)(dz / dist);
+    out[6] = (float)mind; out[7] = (float)maxd;
+}
+
 // Workload support (not a reference function): map points for the keypoints of a frame of the
 // synthetic plane world of viorb_amd/synth.py — intersects the pixel ray with the plane z = z0 using
 // the given camera pose (Rcw, tcw) in double, writes float world points and flags = 1|4.
@@ -1217,7 +1313,7 @@ struct viorb_frontend {
     float wInv = 0, hInv = 0;
     uint32_t* d_cand = nullptr; int* d_cand_n = nullptr;
     uint32_t* d_lcand = nullptr; int* d_lcand_n = nullptr; int lcand_pcap = 0;
-    double *d_cam = nullptr, *d_gw = nullptr; float* d_inv_sigma2 = nullptr;
+    double *d_cam = nullptr, *d_gw = nullptr; float* d_inv_sigma2 = nullptr; float* d_scale = nullptr;
 };
 
 extern "C" {
@@ -1264,6 +1360,7 @@ int viorb_frontend_destroy(viorb_frontend* h) {
     if (h->d_cam) (void)hipFree(h->d_cam);
     if (h->d_gw) (void)hipFree(h->d_gw);
     if (h->d_inv_sigma2) (void)hipFree(h->d_inv_sigma2);
+    if (h->d_scale) (void)hipFree(h->d_scale);
     delete h;
     return VIORB_OK;
 }
@@ -1365,6 +1462,53 @@ int viorb_frontend_build_observations_device(viorb_frontend* h, const viorb_keyp
     ProfScope ps("k_build_observations", (hipStream_t)stream);
     hipLaunchKernelGGL(k_build_observations, dim3(batch), dim3(256), 0, (hipStream_t)stream, kps, count, match, match_Pw,
                        h->d_inv_sigma2, h->cap, obs, obs_index, n_obs);
+    VIORB_HIP_TRY(hipGetLastError());
+    return VIORB_OK;
+}
+
+int viorb_frontend_build_observations2_device(viorb_frontend* h, const viorb_keypoint* kps, const int32_t* count, const int32_t* match_a,
+                                              const float* Pw_a, const int32_t* match_b, const float* pts_b, int stride_b, int batch,
+                                              double* obs, int32_t* obs_index, int32_t* n_obs, void* stream) {
+    FE_CHECK_BATCH(h, batch);
+    VIORB_REQUIRE(kps && count && match_a && Pw_a && match_b && pts_b && obs && obs_index && n_obs && stride_b >= 1, "null array");
+    ProfScope ps("k_build_observations", (hipStream_t)stream);
+    hipLaunchKernelGGL(k_build_observations2, dim3(batch), dim3(256), 0, (hipStream_t)stream, kps, count, match_a, Pw_a, match_b, pts_b, stride_b,
+                       h->d_inv_sigma2, h->cap, obs, obs_index, n_obs);
+    VIORB_HIP_TRY(hipGetLastError());
+    return VIORB_OK;
+}
+
+int viorb_frontend_discard_outliers_device(viorb_frontend* h, int32_t* match, const int32_t* obs_index, const uint8_t* outlier,
+                                           const int32_t* n_obs, const uint8_t* pt_flags, int batch, uint8_t* owner_obs, int32_t* n_map,
+                                           void* stream) {
+    FE_CHECK_BATCH(h, batch);
+    VIORB_REQUIRE(match && obs_index && outlier && n_obs && pt_flags && owner_obs && n_map, "null array");
+    ProfScope ps("k_discard_outliers", (hipStream_t)stream);
+    hipLaunchKernelGGL(k_discard_outliers, dim3(batch), dim3(256), 0, (hipStream_t)stream, match, obs_index, outlier, n_obs, pt_flags, h->cap,
+                       owner_obs, n_map);
+    VIORB_HIP_TRY(hipGetLastError());
+    return VIORB_OK;
+}
+
+int viorb_frontend_pose_from_navstate_device(viorb_frontend* h, const double* ns, int batch, float* pose12, void* stream) {
+    FE_CHECK_BATCH(h, batch);
+    VIORB_REQUIRE(ns && pose12, "null array");
+    hipLaunchKernelGGL(k_pose_from_navstate, dim3((batch + 63) / 64), dim3(64), 0, (hipStream_t)stream, ns, h->d_cam, batch, pose12);
+    VIORB_HIP_TRY(hipGetLastError());
+    return VIORB_OK;
+}
+
+int viorb_synth_local_points_device(viorb_frontend* h, const viorb_keypoint* kps, const int32_t* count, const double* pose12, const float* Pw,
+                                    int batch, float* pts_f, void* stream) {
+    FE_CHECK_BATCH(h, batch);
+    VIORB_REQUIRE(kps && count && pose12 && Pw && pts_f, "null array");
+    if (!h->d_scale) {
+        VIORB_HIP_TRY(hipMalloc(&h->d_scale, 16 * sizeof(float)));
+        VIORB_HIP_TRY(hipMemcpy(h->d_scale, h->cfg.scale_factors, 16 * sizeof(float), hipMemcpyHostToDevice));
+    }
+    ProfScope ps("k_synth_plane_points", (hipStream_t)stream);
+    hipLaunchKernelGGL(k_synth_local_points, dim3((h->cap + 255) / 256, batch), dim3(256), 0, (hipStream_t)stream, kps, count, h->cap, pose12, Pw,
+                       h->d_scale, h->cfg.nlevels, pts_f);
     VIORB_HIP_TRY(hipGetLastError());
     return VIORB_OK;
 }

@@ -211,6 +211,24 @@ class Frontend:
         check(self.L.viorb_frontend_build_observations_device(self.h, p(kps_ptr), p(count_ptr), ptr(match), ptr(match_Pw), batch,
                                                               ptr(obs), ptr(obs_index), ptr(n_obs), self._st(stream)))
 
+    def discard_outliers(self, match, obs_index, outlier, n_obs, pt_flags, batch, owner_obs, n_map, stream=None):
+        """TrackWithIMU's "Discard outliers" loop (reference src/Tracking.cc:489-507)."""
+        check(self.L.viorb_frontend_discard_outliers_device(self.h, ptr(match), ptr(obs_index), ptr(outlier), ptr(n_obs), ptr(pt_flags), batch,
+                                                            ptr(owner_obs), ptr(n_map), self._st(stream)))
+
+    def pose_from_navstate(self, ns, batch, pose12, stream=None):
+        """Frame::UpdatePoseFromNS (reference src/Frame.cc:88-105)."""
+        check(self.L.viorb_frontend_pose_from_navstate_device(self.h, ptr(ns), batch, ptr(pose12), self._st(stream)))
+
+    def build_observations2(self, kps_ptr, count_ptr, match_a, Pw_a, match_b, pts_b, batch, obs, obs_index, n_obs, stream=None):
+        p = lambda a: a if isinstance(a, C.c_void_p) else (C.c_void_p(a) if isinstance(a, int) else ptr(a))
+        check(self.L.viorb_frontend_build_observations2_device(self.h, p(kps_ptr), p(count_ptr), ptr(match_a), ptr(Pw_a), ptr(match_b), ptr(pts_b),
+                                                               pts_b.shape[1], batch, ptr(obs), ptr(obs_index), ptr(n_obs), self._st(stream)))
+
+    def synth_local_points(self, kps_ptr, count_ptr, pose12_true, Pw, batch, pts_f, stream=None):
+        p = lambda a: a if isinstance(a, C.c_void_p) else (C.c_void_p(a) if isinstance(a, int) else ptr(a))
+        check(self.L.viorb_synth_local_points_device(self.h, p(kps_ptr), p(count_ptr), ptr(pose12_true), ptr(Pw), batch, ptr(pts_f), self._st(stream)))
+
     def pose_opt_se3(self, pose12, obs7, n_obs, bf, batch, out_pose12, outlier, info, stream=None):
         check(self.L.viorb_frontend_pose_opt_se3_device(self.h, ptr(pose12), ptr(obs7), ptr(n_obs), float(bf), batch, ptr(out_pose12),
                                                         ptr(outlier), ptr(info), self._st(stream)))

@@ -324,6 +324,21 @@ def plane_points_f32(kps_xy, pose12_true, cam):
     return np.stack([ox + s * rx, oy + s * ry, oz + s * rz], 1).astype(np.float32)
 
 
+def local_points_f32(octaves, pose12_true, Pw, scale_factors):
+    """numpy twin of viorb_synth_local_points_device (same FP64 operation order, one rounding to float32):
+    pts_f [n,8] = Pw3 normal3 minDist maxDist of points created from one frame with true pose pose12_true."""
+    T = np.asarray(pose12_true, np.float64)
+    ox = -(T[0] * T[9] + T[3] * T[10] + T[6] * T[11]); oy = -(T[1] * T[9] + T[4] * T[10] + T[7] * T[11])
+    oz = -(T[2] * T[9] + T[5] * T[10] + T[8] * T[11])
+    P = np.asarray(Pw, np.float32).astype(np.float64)
+    dx, dy, dz = P[:, 0] - ox, P[:, 1] - oy, P[:, 2] - oz
+    dist = np.sqrt(dx * dx + dy * dy + dz * dz)
+    sf = np.asarray(scale_factors, np.float32).astype(np.float64)
+    maxd = dist * sf[np.asarray(octaves)]
+    mind = maxd / sf[len(sf) - 1]
+    return np.concatenate([np.asarray(Pw, np.float32), np.stack([dx / dist, dy / dist, dz / dist, mind, maxd], 1).astype(np.float32)], 1)
+
+
 def make_local_map(kps, Pw, ns_ref, cam, scale_factors):
     """Local map points from the keypoints of a reference key frame (MapPoint::UpdateNormalAndDepth, reference
     src/MapPoint.cc:339-378): normal = unit viewing ray, mfMaxDistance = dist * scale[octave],

@@ -3,6 +3,11 @@ Tracking::TrackWithIMU (reference src/Tracking.cc:412-534) for B independent mon
 
     extract -> AssignFeaturesToGrid -> IMU pre-integration + NavState prediction (PredictNavStateByIMU)
             -> SearchByProjection(cur, last, th=15) -> PoseOptimization(cur, last frame, preint, gw, marg)
+    and, with track_local_map=True, the steady state of Tracking::TrackLocalMapWithIMU (reference src/Tracking.cc:228-346) after it:
+            -> discard outliers -> SearchLocalPoints (isInFrustum + SearchByProjection(F, local points, th=1), nnratio 0.8)
+            -> PoseOptimization(cur, last frame, preint, gw, marg=true) on the last-frame and local-map matches together
+    (stage one then runs without the marginal, as the reference does). The local map is the points created for the
+    LOCAL_FRAMES frames before the last one (UpdateLocalMap itself is map management, outside the hot path).
 
 Everything stays in HBM; the only host work per step is enqueueing kernels. Two HIP streams: extraction of
 frame k+1 (bandwidth/ALU-bound, fills the chip) overlaps the matching + pose solve of frame k (latency-bound,
@@ -20,7 +25,10 @@ from . import synth
 
 
 class BatchedTracker:
-    def __init__(self, cam, gw, batch, width=752, height=480, nfeatures=1000, th=15.0, device=0, compute_marg=True, overlap=True):
+    LOCAL_FRAMES = 2
+
+    def __init__(self, cam, gw, batch, width=752, height=480, nfeatures=1000, th=15.0, device=0, compute_marg=True, overlap=True,
+                 track_local_map=False):
         import torch
         self.torch = torch
         self.B, self.w, self.h, self.th = batch, width, height, float(th)
@@ -35,6 +43,7 @@ class BatchedTracker:
         self.ev_ex = [torch.cuda.Event() for _ in range(2)]
         self.ev_tr = [None, None]
         self.k = 0
+        self.k_rolls = 0
         self.fe = Frontend(cam, gw, t["scale"], t["inv_sigma2"], (0.0, float(width), 0.0, float(height)), max_batch=batch,
                            cap=self.cap, device=device)
         self.cam = np.asarray(cam, np.float64)
@@ -74,6 +83,26 @@ class BatchedTracker:
         self.marg_out = z((B, 144), torch.float64)
         self.info = z((B, 4), torch.float64)
         self.iota = torch.arange(cap, dtype=torch.int32, device=self.dev)[None, :].expand(B, cap).contiguous()
+        self.track_local_map = track_local_map
+        if track_local_map:
+            R = self.LOCAL_FRAMES
+            self.last_pts_f = z((B, cap, 8), torch.float32)              # isInFrustum fields of the last frame's points
+            self.loc_pts_f = z((B, R * cap, 8), torch.float32)           # local map: slot r = points created r + 1 frames before the last
+            self.loc_flags = z((B, R * cap), torch.uint8)
+            self.loc_desc = z((B, R * cap, 32), torch.uint8)
+            self.loc_count = torch.full((B,), R * cap, dtype=torch.int32, device=self.dev)
+            self.owner_obs = z((B, cap), torch.uint8)
+            self.n_map = z((B,), torch.int32)
+            self.pose12_b = z((B, 12), torch.float32)
+            self.loc_match = z((B, cap), torch.int32)
+            self.n_loc = z((B,), torch.int32)
+            self.status2 = z((B,), torch.int32)
+            self.obs_cur2 = z((B, cap, 6), torch.float64)
+            self.idx_cur2 = z((B, cap), torch.int32)
+            self.n_cur2 = z((B,), torch.int32)
+            self.out_ns2 = z((B, 22), torch.float64)
+            self.outlier_cur2 = z((B, cap), torch.uint8)
+            self.info2 = z((B, 4), torch.float64)
 
     # -- helpers ------------------------------------------------------------------------------------
     def _cur_ptrs(self):
@@ -87,6 +116,17 @@ class BatchedTracker:
         L = lib()
         st = Frontend._st(stream)
         nb = self.B * cap
+        if self.track_local_map and self.k_rolls > 0:                     # the outgoing last frame's points join the local map
+            B, R = self.B, self.LOCAL_FRAMES
+            for tbl, new, w in ((self.loc_pts_f, self.last_pts_f, 8), (self.loc_desc, self.last_desc, 32)):
+                v = tbl.view(B, R, cap, w)
+                if R > 1:
+                    v[:, 1:] = v[:, :-1].clone()
+                v[:, 0] = new.view(B, cap, w)
+            vf = self.loc_flags.view(B, R, cap)
+            if R > 1:
+                vf[:, 1:] = vf[:, :-1].clone()
+            vf[:, 0] = self.last_flags
         for dst, src, nbytes in ((self.last_kps, kps, nb * KP_DTYPE.itemsize), (self.last_desc, desc, nb * 32), (self.last_count, count, self.B * 4)):
             rc = _hip_memcpy_dtod_async(dst.data_ptr(), src, nbytes, st)
             assert rc == 0
@@ -96,10 +136,14 @@ class BatchedTracker:
         self.prior_ns.copy_(ns_for_last, non_blocking=True)
         self.t_last.copy_(t_cur, non_blocking=True)
         self.last_self.copy_(torch.where(self.last_flags > 0, self.iota, torch.full_like(self.iota, -1)))
+        if self.track_local_map:
+            self.fe.synth_local_points(self.last_kps.data_ptr(), self.last_count.data_ptr(), true_pose12, self.last_Pw, self.B, self.last_pts_f)
+            self.k_rolls += 1
 
     def bootstrap(self, images, true_pose12, t0, ns0, marg_cov_inv):
         """First frame of every stream: extract, adopt as last frame with ground-truth state."""
         self.torch.cuda.synchronize()
+        self.k_rolls = 0
         self.ex = self.exs[0]
         self.ex.extract_batch_device(images)
         self.marg_cov_inv.copy_(marg_cov_inv)
@@ -120,12 +164,26 @@ class BatchedTracker:
         fe.build_observations(kps, count, self.cur_match, self.last_Pw, B, self.obs_cur, self.idx_cur, self.n_cur)
         fe.build_observations(self.last_kps.data_ptr(), self.last_count.data_ptr(), self.last_self, self.last_Pw, B, self.obs_last,
                               self.idx_last, self.n_last)
-        fe.pose_opt(1, self.compute_marg, self.cur_ns, self.last_ns, self.prior_ns, self.marg_cov_inv, self.preint, self.obs_cur, self.n_cur,
-                    self.obs_last, self.n_last, B, self.out_ns, self.out_last_ns, self.outlier_cur, self.outlier_last, self.marg_out,
+        tlm = self.track_local_map
+        fe.pose_opt(1, self.compute_marg and not tlm, self.cur_ns, self.last_ns, self.prior_ns, self.marg_cov_inv, self.preint, self.obs_cur,
+                    self.n_cur, self.obs_last, self.n_last, B, self.out_ns, self.out_last_ns, self.outlier_cur, self.outlier_last, self.marg_out,
                     self.info)
+        final_ns = self.out_ns
+        if tlm:
+            # ---- TrackLocalMapWithIMU (reference src/Tracking.cc:228-346)
+            fe.discard_outliers(self.cur_match, self.idx_cur, self.outlier_cur, self.n_cur, self.last_flags, B, self.owner_obs, self.n_map)
+            fe.pose_from_navstate(self.out_ns, B, self.pose12_b)
+            fe.search_local_points(kps, desc, count, self.cell_start, self.cell_idx, self.pose12_b, self.loc_pts_f, self.loc_flags, self.loc_desc,
+                                   self.loc_count, 1.0, 0.8, self.owner_obs, B, self.loc_match, self.n_loc, None, self.status2)
+            fe.build_observations2(kps, count, self.cur_match, self.last_Pw, self.loc_match, self.loc_pts_f, B, self.obs_cur2, self.idx_cur2,
+                                   self.n_cur2)
+            fe.pose_opt(1, self.compute_marg, self.out_ns, self.last_ns, self.prior_ns, self.marg_cov_inv, self.preint, self.obs_cur2, self.n_cur2,
+                        self.obs_last, self.n_last, B, self.out_ns2, self.out_last_ns, self.outlier_cur2, self.outlier_last, self.marg_out,
+                        self.info2)
+            final_ns = self.out_ns2
         if self.compute_marg and chain_estimate:
             self.marg_cov_inv.copy_(self.marg_out, non_blocking=True)
-        self._roll(true_pose12, t_cur if t_next_last is None else t_next_last, self.out_ns if chain_estimate else true_ns)
+        self._roll(true_pose12, t_cur if t_next_last is None else t_next_last, final_ns if chain_estimate else true_ns)
 
     def step(self, images, imu, t_cur, true_pose12, chain_estimate=True, true_ns=None, t_next_last=None):
         """One tracking step for all streams. images [B,h,w] u8, imu [B,n,7] f64, t_cur [B] f64,
