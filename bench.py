@@ -55,12 +55,12 @@ def generate_streams(seeds):
         return pool.map(_gen_stream, seeds)
 
 
-def cpu_baseline(streams, budget_s=12.0, max_frames=150):
+def cpu_baseline(streams, budget_s=12.0, max_frames=150, track_local_map=True):
     """The oracle (CPU port of the reference path) on one host core, same streams, same per-frame sequence."""
     from oracle.harness import OracleTracker           # checker only; never on the product path
     done, t_total = 0, 0.0
     for s in streams:
-        tr = OracleTracker(s["cam"], s["gw"], W_IMG, H_IMG, NFEAT)
+        tr = OracleTracker(s["cam"], s["gw"], W_IMG, H_IMG, NFEAT, track_local_map=track_local_map)
         tr.bootstrap(s["frames"][0], s["pose_true"][0], s["t"][0], s["ns_true"][0], np.eye(12) * 1e3)
         k = 1
         while t_total < budget_s and done < max_frames:
@@ -84,6 +84,8 @@ def main():
     ap.add_argument("--streams", type=int, default=256, help="independent camera streams per GPU")
     ap.add_argument("--groups", type=int, default=1, help="split the streams of a GPU into this many independently enqueued groups "
                     "(each with its own HIP streams) so that latency-bound kernels of one group overlap chip-filling kernels of another")
+    ap.add_argument("--no-track-local-map", action="store_true", help="stop after TrackWithIMU's pose solve (skip the SearchLocalPoints + "
+                    "second PoseOptimization stage of TrackLocalMapWithIMU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip the per-kernel HIP events (roofline becomes null); dev aid "
                     "to measure what the events themselves cost")
@@ -129,7 +131,8 @@ def main():
     fr_g = [cut(frames, g) for g in range(G)]; imu_g = [cut(imu, g) for g in range(G)]; tf_g = [cut(t_frames, g) for g in range(G)]
     pt_g = [cut(pose_true, g) for g in range(G)]; ns_g = [cut(ns_true, g) for g in range(G)]; tp_g = [t_period[sl[g]].contiguous() for g in range(G)]
     zeros_g = zeros_t[:Sg].contiguous()
-    trs = [BatchedTracker(cam, gw, Sg, W_IMG, H_IMG, NFEAT, th=15.0, device=local_rank, compute_marg=True) for _ in range(G)]
+    TLM = not args.no_track_local_map
+    trs = [BatchedTracker(cam, gw, Sg, W_IMG, H_IMG, NFEAT, th=15.0, device=local_rank, compute_marg=True, track_local_map=TLM) for _ in range(G)]
     for g, tr in enumerate(trs):
         tr.bootstrap(fr_g[g][0], pt_g[g][0], tf_g[g][0], ns_g[g][0], mci0[sl[g]].contiguous())
 
@@ -161,7 +164,8 @@ def main():
     L.viorb_profile_enable(0)
 
     # ---- sanity of the timed work (outside the timed region): every stream tracked its frame ------------
-    info = np.concatenate([tr.info.cpu().numpy() for tr in trs])
+    info = np.concatenate([(tr.info2 if TLM else tr.info).cpu().numpy() for tr in trs])
+    n_loc = np.concatenate([tr.n_loc.cpu().numpy() for tr in trs]) if TLM else np.zeros(1)
     nm = np.concatenate([tr.nmatches.cpu().numpy() for tr in trs])
     status_ok = bool(all((tr.status.cpu().numpy() == 0).all() for tr in trs))
     tracked = int((info[:, 0] >= 20).sum())
@@ -194,17 +198,20 @@ def main():
                     "kernel_ms_per_step": {kname: round(v[0] / args.steps, 4) for kname, v in sorted(prof.items())}}
         cpu = None
         if not args.no_cpu_baseline:
-            fps, nfr, tsec = cpu_baseline(streams[:8])
+            fps, nfr, tsec = cpu_baseline(streams[:8], track_local_map=TLM)
             cpu = {"value": round(fps, 3), "unit": "frames/s", "cores": 1, "kind": "port",
-                   "sample": "%d frames of the same synthetic streams, same extract+match+IMU+pose-opt sequence, oracle (C++ -O3) on 1 host thread, %.1f s"
+                   "sample": "%d frames of the same synthetic streams, same per-frame sequence, oracle (C++ -O3) on 1 host thread, %.1f s"
                              % (nfr, tsec)}
         out = {
             "metric": "frames/sec ORB extract+match+pose-opt, EuRoC 752x480, 1/2/4/8 GPUs",
             "value": round(frames_done / elapsed, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "EuRoC-shaped synthetic mono-inertial streams 752x480, 8 levels, 1000 features: extract + "
-                                   "SearchByProjection(th=15) + IMU pre-integration (10 samples) + PoseOptimization(Frame,Frame,marg) per frame",
+            "config": {"workload": "EuRoC-shaped synthetic mono-inertial streams 752x480, 8 levels, 1000 features, per frame: extract + IMU "
+                                   "pre-integration (10 samples) + SearchByProjection(th=15) + PoseOptimization(Frame,Frame)" +
+                                   (" + SearchLocalPoints(~2000 local points, th=1) + PoseOptimization(Frame,Frame,marg)  [TrackWithIMU + TrackLocalMapWithIMU]"
+                                    if TLM else " with marginal  [TrackWithIMU only]"),
+                       "track_local_map": TLM, "mean_local_matches_last_step": round(float(n_loc.mean()), 1),
                        "streams_per_gpu": S, "stream_groups_per_gpu": G, "frames_per_step": S * world, "solver_dtype": "f64",
                        "tracked_streams_last_step": tracked, "mean_matches_last_step": round(float(nm.mean()), 1),
                        "mean_inliers_last_step": round(float(info[:, 0].mean()), 1), "status_ok": status_ok},
