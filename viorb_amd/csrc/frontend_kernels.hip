@@ -684,7 +684,7 @@ struct PoseOptArgs {
 };
 
 struct PoseOptShared {
-    double H[24 * 24], Lm[24 * 24], b[24], x[24], y[24];
+    double Hb[2][24 * 24], Lm[24 * 24], bb[2][24], x[24], y[24];   // two normal-equation buffers: current system / speculative next
     double J1[9 * 21], OJ1[9 * 21], e1[12];            // IMU factor
     double J2[12 * 12], OJ2[12 * 12], e2[12];          // prior factor
     double q[32];                                       // per-row terms of the quadratic forms
@@ -805,7 +805,7 @@ __global__ __launch_bounds__(256) void k_pose_opt_vi(PoseOptArgs A) {
     for (int i = t; i < nlast; i += blockDim.x) out_l[i] = 0;
     // information of the IMU factor: cov^-1 + diag(1e2,1,1e2) (x) I3, by Gauss-Jordan over all threads
     {
-        double* a = S.Lm; double* inv = S.H;                  // scratch: [9x9 | 9x9]
+        double* a = S.Lm; double* inv = S.Hb[0];              // scratch: [9x9 | 9x9]
         for (int i = t; i < 81; i += blockDim.x) { a[i] = pre[60 + i]; inv[i] = (i / 9 == i % 9) ? 1.0 : 0.0; }
         __syncthreads();
         for (int col = 0; col < 9; col++) {
@@ -854,15 +854,16 @@ __global__ __launch_bounds__(256) void k_pose_opt_vi(PoseOptArgs A) {
     }
     const int n_edges_total = ncur + nlast + (variant ? 3 : 2);
     int kernel_on = 1;           // mono edges keep their Huber kernel until the end of round 3
+    int hb_last = 0;
     int nbad = 0;
 
     // One pass over the active reprojection edges at the current estimate: robust chi2 and, when `lin`,
     // the 6x6 (P, Phi) normal-equation blocks of both frames. Followed by the two dense factors (IMU on
     // wave 0, prior on wave 1) and the bias factor. Leaves H, b (when lin) and the total robust chi2 in S.sc[0].
-    auto evaluate = [&](bool lin) -> double {
+    auto evaluate = [&](bool lin, double* Hm, double* bv) -> double {
         if (lin) {
-            for (int i = t; i < n * n; i += blockDim.x) S.H[i] = 0;
-            for (int i = t; i < n; i += blockDim.x) S.b[i] = 0;
+            for (int i = t; i < n * n; i += blockDim.x) Hm[i] = 0;
+            for (int i = t; i < n; i += blockDim.x) bv[i] = 0;
         }
         // dense factors: residuals (+ Jacobians) by one lane of two different waves
         if (t == 0) {
@@ -942,9 +943,9 @@ __global__ __launch_bounds__(256) void k_pose_opt_vi(PoseOptArgs A) {
                 if (k < 21) {
                     int kk = 0, rr = 0, cc = 0;
                     for (int r = 0; r < 6; r++) for (int c = r; c < 6; c++) { if (kk == k) { rr = r; cc = c; } kk++; }
-                    S.H[(base + loc[rr]) * n + base + loc[cc]] += v;
-                    if (rr != cc) S.H[(base + loc[cc]) * n + base + loc[rr]] += v;
-                } else S.b[base + loc[k - 21]] += v;
+                    Hm[(base + loc[rr]) * n + base + loc[cc]] += v;
+                    if (rr != cc) Hm[(base + loc[cc]) * n + base + loc[rr]] += v;
+                } else bv[base + loc[k - 21]] += v;
             }
         }
         __syncthreads();
@@ -960,8 +961,8 @@ __global__ __launch_bounds__(256) void k_pose_opt_vi(PoseOptArgs A) {
                 const double w = r1 * bias_info; const double ev[3] = {eb.x, eb.y, eb.z};
                 for (int k = 0; k < 3; k++) {
                     const int jc = 9 + k, ic = variant ? 21 + k : -1;
-                    S.H[jc * n + jc] += w; S.b[jc] -= w * ev[k];
-                    if (ic >= 0) { S.H[ic * n + ic] += w; S.H[ic * n + jc] -= w; S.H[jc * n + ic] -= w; S.b[ic] += w * ev[k]; }
+                    Hm[jc * n + jc] += w; bv[jc] -= w * ev[k];
+                    if (ic >= 0) { Hm[ic * n + ic] += w; Hm[ic * n + jc] -= w; Hm[jc * n + ic] -= w; bv[ic] += w * ev[k]; }
                 }
             }
             if (variant) {
@@ -983,18 +984,18 @@ __global__ __launch_bounds__(256) void k_pose_opt_vi(PoseOptArgs A) {
             for (int i = t; i < 441 + 21; i += blockDim.x) {
                 if (i < 441) {
                     const int r = i / 21, c = i % 21;
-                    if (s_map21[r] >= 0 && s_map21[c] >= 0) { double s = 0; for (int k = 0; k < 9; k++) s += S.J1[k * 21 + r] * S.OJ1[k * 21 + c]; S.H[s_map21[r] * n + s_map21[c]] += w1 * s; }
+                    if (s_map21[r] >= 0 && s_map21[c] >= 0) { double s = 0; for (int k = 0; k < 9; k++) s += S.J1[k * 21 + r] * S.OJ1[k * 21 + c]; Hm[s_map21[r] * n + s_map21[c]] += w1 * s; }
                 } else {
                     const int r = i - 441;
-                    if (s_map21[r] >= 0) { double s = 0; for (int k = 0; k < 9; k++) s += S.OJ1[k * 21 + r] * S.e1[k]; S.b[s_map21[r]] -= w1 * s; }
+                    if (s_map21[r] >= 0) { double s = 0; for (int k = 0; k < 9; k++) s += S.OJ1[k * 21 + r] * S.e1[k]; bv[s_map21[r]] -= w1 * s; }
                 }
             }
             __syncthreads();
             if (variant) {
                 const double w2 = S.sc[2];
                 for (int i = t; i < 144 + 12; i += blockDim.x) {
-                    if (i < 144) { const int r = i / 12, c = i % 12; double s = 0; for (int k = 0; k < 12; k++) s += S.J2[k * 12 + r] * S.OJ2[k * 12 + c]; S.H[s_map12[r] * n + s_map12[c]] += w2 * s; }
-                    else { const int r = i - 144; double s = 0; for (int k = 0; k < 12; k++) s += S.OJ2[k * 12 + r] * S.e2[k]; S.b[s_map12[r]] -= w2 * s; }
+                    if (i < 144) { const int r = i / 12, c = i % 12; double s = 0; for (int k = 0; k < 12; k++) s += S.J2[k * 12 + r] * S.OJ2[k * 12 + c]; Hm[s_map12[r] * n + s_map12[c]] += w2 * s; }
+                    else { const int r = i - 144; double s = 0; for (int k = 0; k < 12; k++) s += S.OJ2[k * 12 + r] * S.e2[k]; bv[s_map12[r]] -= w2 * s; }
                 }
             }
         }
@@ -1003,9 +1004,9 @@ __global__ __launch_bounds__(256) void k_pose_opt_vi(PoseOptArgs A) {
     };
 
     // (H + lambda I) x = b on wave 0, matrix rows in registers (wave_solve_reg). S.flag[0] = success.
-    auto solve = [&](double lambda) {
+    auto solve = [&](double lambda, const double* Hm, const double* bv) {
         if (wave == 0) {
-            const bool ok = variant ? wave_solve_reg<24>(S.H, S.b, lambda, S.Lm, S.x, lane) : wave_solve_reg<12>(S.H, S.b, lambda, S.Lm, S.x, lane);
+            const bool ok = variant ? wave_solve_reg<24>(Hm, bv, lambda, S.Lm, S.x, lane) : wave_solve_reg<12>(Hm, bv, lambda, S.Lm, S.x, lane);
             if (!ok && lane < n) S.x[lane] = 0;
             if (lane == 0) S.flag[0] = ok ? 1 : 0;
         }
@@ -1020,18 +1021,26 @@ __global__ __launch_bounds__(256) void k_pose_opt_vi(PoseOptArgs A) {
         }
         __syncthreads();
         // ---- optimize(10): g2o Levenberg
+        // Every trial state is linearised speculatively (errors + Jacobians in one pass into the other H/b buffer): an accepted trial
+        // is exactly the state g2o's next iteration re-evaluates and re-linearises, so that pass is skipped; a rejected trial leaves the
+        // current buffer untouched for the re-solve with a larger lambda. hb_last = buffer of the last buildSystem (what
+        // computeMarginals sees at the end).
         double lambda = 0, ni = 2; int nBadLM = 0;
+        int cur = 0; bool have_lin = false; double chi_lin = 0;
         for (int it = 0; it < 10; it++) {
-            double currentChi = evaluate(true);              // computeActiveErrors + activeRobustChi2 + buildSystem
+            double* Hc = S.Hb[cur]; double* bc = S.bb[cur];
+            double currentChi = have_lin ? chi_lin : evaluate(true, Hc, bc);   // computeActiveErrors + activeRobustChi2 + buildSystem
+            hb_last = cur;
             const double iniChi = currentChi;
             if (it == 0) {
-                double mx = 0; for (int i = 0; i < n; i++) mx = fmax(fabs(S.H[i * n + i]), mx);
+                double mx = 0; for (int i = 0; i < n; i++) mx = fmax(fabs(Hc[i * n + i]), mx);
                 lambda = 1e-5 * mx; ni = 2; nBadLM = 0;
             }
             double rho = 0; int qmax = 0;
+            bool accepted = false;
             do {
                 if (t < 20) S.bak[t / 10][t % 10] = S.est[t / 10][t % 10]; else if (t < 26) S.bakb[(t - 20) / 3][(t - 20) % 3] = S.bias[(t - 20) / 3][(t - 20) % 3];
-                solve(lambda);
+                solve(lambda, Hc, bc);
                 const int ok2 = S.flag[0];
                 if (t == 0) {
                     sh_put(S.est[0], inc_small_pvr(sh_pvr(S.est[0]), S.x));
@@ -1041,12 +1050,13 @@ __global__ __launch_bounds__(256) void k_pose_opt_vi(PoseOptArgs A) {
                     for (int k = 0; k < 3; k++) S.bias[1][k] += S.x[21 + k];
                 }
                 __syncthreads();
-                double tempChi = evaluate(false);
+                double tempChi = evaluate(true, S.Hb[cur ^ 1], S.bb[cur ^ 1]);
                 if (!ok2) tempChi = 1.7976931348623157e308;
-                double scale = 0; for (int j = 0; j < n; j++) scale += S.x[j] * (lambda * S.x[j] + S.b[j]);
+                double scale = 0; for (int j = 0; j < n; j++) scale += S.x[j] * (lambda * S.x[j] + bc[j]);
                 scale += 1e-3;
                 rho = (currentChi - tempChi) / scale;
-                if (rho > 0 && isfinite(tempChi)) {
+                accepted = rho > 0 && isfinite(tempChi);
+                if (accepted) {
                     double alpha = 1. - pow(2 * rho - 1, 3);
                     alpha = fmin(alpha, 2. / 3.);
                     lambda *= fmax(1. / 3., alpha); ni = 2; currentChi = tempChi;
@@ -1057,6 +1067,8 @@ __global__ __launch_bounds__(256) void k_pose_opt_vi(PoseOptArgs A) {
                 __syncthreads();
                 qmax++;
             } while (rho < 0 && qmax < 10);
+            if (accepted) { cur ^= 1; have_lin = true; chi_lin = currentChi; }      // the speculative buffer is the next iteration's system
+            else have_lin = true, chi_lin = currentChi;                               // state restored: the current system is still its linearisation
             if (t == 0) { S.flag[1]++; S.sc[7] = currentChi; }
             if (qmax == 10 || rho == 0) break;
             if ((iniChi - currentChi) * 1e3 < iniChi) nBadLM++; else nBadLM = 0;
@@ -1115,7 +1127,7 @@ __global__ __launch_bounds__(256) void k_pose_opt_vi(PoseOptArgs A) {
         if (variant) {
             for (int i = t; i < 576; i += blockDim.x) {
                 const int r = i / 24, c = i % 24;
-                S.Lm[i] = S.H[((r + 12) % 24) * 24 + (c + 12) % 24];              // [last | cur] ordering
+                S.Lm[i] = S.Hb[hb_last][((r + 12) % 24) * 24 + (c + 12) % 24];     // [last | cur] ordering
             }
             __syncthreads();
             if (wave == 0) wave_cholesky(S.Lm, 24, 12, lane);
@@ -1128,7 +1140,7 @@ __global__ __launch_bounds__(256) void k_pose_opt_vi(PoseOptArgs A) {
             // H = diag(H_pp (9x9), H_bb (3x3)) exactly (no factor couples cur PVR and cur bias when the KF is fixed)
             for (int i = t; i < 144; i += blockDim.x) {
                 const int r = i / 12, c = i % 12;
-                mo[i] = ((r < 9) == (c < 9)) ? S.H[r * 12 + c] : 0.0;
+                mo[i] = ((r < 9) == (c < 9)) ? S.Hb[hb_last][r * 12 + c] : 0.0;
             }
         }
     }
