@@ -853,6 +853,7 @@ __global__ __launch_bounds__(256) void k_pose_opt_vi(PoseOptArgs A) {
         return;
     }
     const int n_edges_total = ncur + nlast + (variant ? 3 : 2);
+    const int edge_nslot = t < 128 ? 1 : 2, edge_slot0 = t < 128 ? t : 128 + 2 * (t - 128);
     int kernel_on = 1;           // mono edges keep their Huber kernel until the end of round 3
     int hb_last = 0;
     int nbad = 0;
@@ -880,7 +881,10 @@ __global__ __launch_bounds__(256) void k_pose_opt_vi(PoseOptArgs A) {
             double a[28];
 #pragma unroll
             for (int k = 0; k < 28; k++) a[k] = 0;
-            for (int i = t; i < ne; i += blockDim.x) {
+            // waves 0 and 1 reach this loop late (their first lanes have just evaluated the IMU / prior factors: ~13 k cycles by
+            // s_memtime, about 70 % of a wave's even share of the edges), so waves 2 and 3 take two edge slots per thread and
+            // waves 0 and 1 one: 384 slots per trip
+            for (int i = edge_slot0; i < ne; i += ((i - edge_slot0) % 384 + 1 < edge_nslot) ? 1 : 385 - edge_nslot) {
                 if (ol[i]) continue;
                 double e[2], JP[6], JR[6];
                 proj_edge(K, RT, s.P, ld3(ob + 6 * i), ob[6 * i + 3], ob[6 * i + 4], lin, e, JP, JR);
