@@ -862,10 +862,6 @@ __global__ __launch_bounds__(256) void k_pose_opt_vi(PoseOptArgs A) {
     // the 6x6 (P, Phi) normal-equation blocks of both frames. Followed by the two dense factors (IMU on
     // wave 0, prior on wave 1) and the bias factor. Leaves H, b (when lin) and the total robust chi2 in S.sc[0].
     auto evaluate = [&](bool lin, double* Hm, double* bv) -> double {
-        if (lin) {
-            for (int i = t; i < n * n; i += blockDim.x) Hm[i] = 0;
-            for (int i = t; i < n; i += blockDim.x) bv[i] = 0;
-        }
         // dense factors: residuals (+ Jacobians) by one lane of two different waves
         if (t == 0) {
             const pvr sc = sh_pvr(S.est[0]), sl = sh_pvr(S.est[1]);
@@ -935,72 +931,74 @@ __global__ __launch_bounds__(256) void k_pose_opt_vi(PoseOptArgs A) {
             }
         }
         __syncthreads();
-        // quadratic forms of the dense factors: q[r] = e_r * (Omega e)_r ; proj partials -> H, b
-        if (t < 9) { double s = 0; for (int c = 0; c < 9; c++) s += S.info_pvr[t * 9 + c] * S.e1[c]; S.q[t] = S.e1[t] * s; }
-        else if (t >= 64 && t < 76 && variant) { const int r = t - 64; double s = 0; for (int c = 0; c < 12; c++) s += S.info_prior[r * 12 + c] * S.e2[c]; S.q[12 + r] = S.e2[r] * s; }
-        else if (lin && t >= 128 && t < 128 + 54) {
-            const int side = (t - 128) / 27, k = (t - 128) % 27;
-            if (side == 0 || variant) {
-                const double v = S.red[0][side][k] + S.red[1][side][k] + S.red[2][side][k] + S.red[3][side][k];
-                const int base = side ? 12 : 0;
-                const int loc[6] = {0, 1, 2, 6, 7, 8};
-                if (k < 21) {
-                    int kk = 0, rr = 0, cc = 0;
-                    for (int r = 0; r < 6; r++) for (int c = r; c < 6; c++) { if (kk == k) { rr = r; cc = c; } kk++; }
-                    Hm[(base + loc[rr]) * n + base + loc[cc]] += v;
-                    if (rr != cc) Hm[(base + loc[cc]) * n + base + loc[rr]] += v;
-                } else bv[base + loc[k - 21]] += v;
+        // ---- assembly. Step 1 (parallel): quadratic forms q[r] = e_r (Omega e)_r of the dense factors, Omega*J of both, and the
+        // bias random-walk factor's weight; step 2: every thread derives the two Huber weights itself and builds complete H / b
+        // entries from all their sources (reprojection partials, IMU factor, prior factor, bias factor) — one pass, no zeroing.
+        if (t < 9) { double sq = 0; for (int c = 0; c < 9; c++) sq += S.info_pvr[t * 9 + c] * S.e1[c]; S.q[t] = S.e1[t] * sq; }
+        else if (t >= 64 && t < 76 && variant) { const int r = t - 64; double sq = 0; for (int c = 0; c < 12; c++) sq += S.info_prior[r * 12 + c] * S.e2[c]; S.q[12 + r] = S.e2[r] * sq; }
+        else if (t == 128) {
+            const d3 eb = (ld3(S.base_ba[0]) + ld3(S.bias[0])) - (ld3(S.base_ba[1]) + ld3(S.bias[1]));
+            double r0, r1; huber(bias_info * dot3(eb, eb), d_bias, &r0, &r1);
+            S.sc[3] = r1 * bias_info; S.sc[4] = eb.x; S.sc[5] = eb.y; S.sc[6] = eb.z; S.sc[8] = r0;
+        }
+        if (lin) {
+            for (int i = t; i < 189 + (variant ? 144 : 0); i += blockDim.x) {
+                if (i < 189) { const int r = i / 21, c = i % 21; double sq = 0; for (int kk = 0; kk < 9; kk++) sq += S.info_pvr[r * 9 + kk] * S.J1[kk * 21 + c]; S.OJ1[i] = sq; }
+                else { const int ii = i - 189, r = ii / 12, c = ii % 12; double sq = 0; for (int kk = 0; kk < 12; kk++) sq += S.info_prior[r * 12 + kk] * S.J2[kk * 12 + c]; S.OJ2[ii] = sq; }
             }
         }
         __syncthreads();
+        double w1, w2 = 0, rob1, rob2 = 0;
+        { double chi = 0; for (int i = 0; i < 9; i++) chi += S.q[i]; huber(chi, d_pvr, &rob1, &w1); }
+        if (variant) { double chi = 0; for (int i = 0; i < 12; i++) chi += S.q[12 + i]; huber(chi, d_prior, &rob2, &w2); }
         if (t == 0) {
             double tot = 0;
             for (int w = 0; w < 4; w++) { tot += S.red[w][0][27]; if (variant) tot += S.red[w][1][27]; }
-            double chi = 0, r0, r1;
-            for (int i = 0; i < 9; i++) chi += S.q[i];
-            huber(chi, d_pvr, &r0, &r1); tot += r0; S.sc[1] = r1;
-            const d3 eb = (ld3(S.base_ba[0]) + ld3(S.bias[0])) - (ld3(S.base_ba[1]) + ld3(S.bias[1]));
-            huber(bias_info * dot3(eb, eb), d_bias, &r0, &r1); tot += r0;
-            if (lin) {      // bias random-walk factor: J_i = -I (last), J_j = +I (cur)
-                const double w = r1 * bias_info; const double ev[3] = {eb.x, eb.y, eb.z};
-                for (int k = 0; k < 3; k++) {
-                    const int jc = 9 + k, ic = variant ? 21 + k : -1;
-                    Hm[jc * n + jc] += w; bv[jc] -= w * ev[k];
-                    if (ic >= 0) { Hm[ic * n + ic] += w; Hm[ic * n + jc] -= w; Hm[jc * n + ic] -= w; bv[ic] += w * ev[k]; }
-                }
-            }
-            if (variant) {
-                chi = 0; for (int i = 0; i < 12; i++) chi += S.q[12 + i];
-                huber(chi, d_prior, &r0, &r1); tot += r0; S.sc[2] = r1;
-            }
+            tot += rob1; tot += S.sc[8];
+            if (variant) tot += rob2;
             S.sc[0] = tot;
         }
         if (lin) {
-            // Omega*J of both dense factors
-            for (int i = t; i < 189 + (variant ? 144 : 0); i += blockDim.x) {
-                if (i < 189) { const int r = i / 21, c = i % 21; double s = 0; for (int k = 0; k < 9; k++) s += S.info_pvr[r * 9 + k] * S.J1[k * 21 + c]; S.OJ1[i] = s; }
-                else { const int ii = i - 189, r = ii / 12, c = ii % 12; double s = 0; for (int k = 0; k < 12; k++) s += S.info_prior[r * 12 + k] * S.J2[k * 12 + c]; S.OJ2[ii] = s; }
-            }
-            __syncthreads();
-            // H += w J^T (Omega J), b -= w (Omega J)^T e — one output element per thread; the two factors touch
-            // overlapping H entries (last-frame block), so they are applied one after the other
-            const double w1 = S.sc[1];
-            for (int i = t; i < 441 + 21; i += blockDim.x) {
-                if (i < 441) {
-                    const int r = i / 21, c = i % 21;
-                    if (s_map21[r] >= 0 && s_map21[c] >= 0) { double s = 0; for (int k = 0; k < 9; k++) s += S.J1[k * 21 + r] * S.OJ1[k * 21 + c]; Hm[s_map21[r] * n + s_map21[c]] += w1 * s; }
+            const double wb = S.sc[3];
+            for (int i = t; i < n * n + n; i += blockDim.x) {
+                const bool isb = i >= n * n;
+                const int R = isb ? i - n * n : i / n, Cc = isb ? 0 : i - R * n;
+                double v = 0;
+                // reprojection partials: (P, Phi) 6x6 block of each frame
+                const int sideR = R / 12, rr = R - 12 * sideR, r6 = rr < 3 ? rr : (rr >= 6 && rr < 9 ? rr - 3 : -1);
+                if (isb) {
+                    if (r6 >= 0) v += S.red[0][sideR][21 + r6] + S.red[1][sideR][21 + r6] + S.red[2][sideR][21 + r6] + S.red[3][sideR][21 + r6];
                 } else {
-                    const int r = i - 441;
-                    if (s_map21[r] >= 0) { double s = 0; for (int k = 0; k < 9; k++) s += S.OJ1[k * 21 + r] * S.e1[k]; bv[s_map21[r]] -= w1 * s; }
+                    const int sideC = Cc / 12, cr = Cc - 12 * sideC, c6 = cr < 3 ? cr : (cr >= 6 && cr < 9 ? cr - 3 : -1);
+                    if (sideR == sideC && r6 >= 0 && c6 >= 0) {
+                        const int lo6 = min(r6, c6), hi6 = max(r6, c6), kk = lo6 * 6 - lo6 * (lo6 - 1) / 2 + (hi6 - lo6);
+                        v += S.red[0][sideR][kk] + S.red[1][sideR][kk] + S.red[2][sideR][kk] + S.red[3][sideR][kk];
+                    }
                 }
-            }
-            __syncthreads();
-            if (variant) {
-                const double w2 = S.sc[2];
-                for (int i = t; i < 144 + 12; i += blockDim.x) {
-                    if (i < 144) { const int r = i / 12, c = i % 12; double s = 0; for (int k = 0; k < 12; k++) s += S.J2[k * 12 + r] * S.OJ2[k * 12 + c]; Hm[s_map12[r] * n + s_map12[c]] += w2 * s; }
-                    else { const int r = i - 144; double s = 0; for (int k = 0; k < 12; k++) s += S.OJ2[k * 12 + r] * S.e2[k]; bv[s_map12[r]] -= w2 * s; }
+                // IMU factor: column m of J = [last PVR (9) | cur PVR (9) | last bias (3)]
+                const int mR = R < 9 ? 9 + R : (R >= 12 && R < 21 ? R - 12 : (R >= 21 ? 18 + R - 21 : -1));
+                if (isb) {
+                    if (mR >= 0) { double sq = 0; for (int kk = 0; kk < 9; kk++) sq += S.OJ1[kk * 21 + mR] * S.e1[kk]; v -= w1 * sq; }
+                } else {
+                    const int mC = Cc < 9 ? 9 + Cc : (Cc >= 12 && Cc < 21 ? Cc - 12 : (Cc >= 21 ? 18 + Cc - 21 : -1));
+                    if (mR >= 0 && mC >= 0) { double sq = 0; for (int kk = 0; kk < 9; kk++) sq += S.J1[kk * 21 + mR] * S.OJ1[kk * 21 + mC]; v += w1 * sq; }
                 }
+                // prior factor on the last frame's 12 unknowns
+                if (variant && R >= 12) {
+                    if (isb) { double sq = 0; for (int kk = 0; kk < 12; kk++) sq += S.OJ2[kk * 12 + R - 12] * S.e2[kk]; v -= w2 * sq; }
+                    else if (Cc >= 12) { double sq = 0; for (int kk = 0; kk < 12; kk++) sq += S.J2[kk * 12 + R - 12] * S.OJ2[kk * 12 + Cc - 12]; v += w2 * sq; }
+                }
+                // bias random-walk factor: J_i = -I (last bias), J_j = +I (cur bias)
+                const int bR = (R >= 9 && R < 12) ? R - 9 : (R >= 21 ? R - 21 : -1);
+                if (bR >= 0) {
+                    const bool curR = R < 12;
+                    if (isb) v += (curR ? -wb : wb) * S.sc[4 + bR];
+                    else {
+                        const int bC = (Cc >= 9 && Cc < 12) ? Cc - 9 : (Cc >= 21 ? Cc - 21 : -1);
+                        if (bC == bR) v += ((Cc < 12) == curR) ? wb : -wb;
+                    }
+                }
+                if (isb) bv[R] = v; else Hm[i] = v;
             }
         }
         __syncthreads();
