@@ -134,6 +134,7 @@ def main():
     TLM = not args.no_track_local_map
     trs = [BatchedTracker(cam, gw, Sg, W_IMG, H_IMG, NFEAT, th=15.0, device=local_rank, compute_marg=True, track_local_map=TLM) for _ in range(G)]
     for g, tr in enumerate(trs):
+        tr.skip_input_wait = bool(os.environ.get('SKIPWAIT'))
         tr.bootstrap(fr_g[g][0], pt_g[g][0], tf_g[g][0], ns_g[g][0], mci0[sl[g]].contiguous())
 
     def run_step(k):
@@ -156,6 +157,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         run_step(k); k += 1
+    t_enq = time.perf_counter() - t0                   # host time to enqueue all steps (the device may still be working)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -213,7 +215,7 @@ def main():
                                     if TLM else " with marginal  [TrackWithIMU only]"),
                        "track_local_map": TLM, "mean_local_matches_last_step": round(float(n_loc.mean()), 1),
                        "streams_per_gpu": S, "stream_groups_per_gpu": G, "frames_per_step": S * world, "solver_dtype": "f64",
-                       "tracked_streams_last_step": tracked, "mean_matches_last_step": round(float(nm.mean()), 1),
+                       "host_enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 3), "tracked_streams_last_step": tracked, "mean_matches_last_step": round(float(nm.mean()), 1),
                        "mean_inliers_last_step": round(float(info[:, 0].mean()), 1), "status_ok": status_ok},
             "roofline": roof, "cpu_baseline": cpu,
         }

@@ -257,8 +257,20 @@ int viorb_synth_local_points_device(viorb_frontend* h, const viorb_keypoint* kps
 /* Workload support for bench.py / tests (no reference counterpart): map points of the synthetic plane
  * world (viorb_amd/synth.py) for all keypoints of a frame; pose12 = Rcw(9) tcw(3) in double per stream.
  * Writes Pw[b][cap][3] and flags[b][cap] = 1|4 (map point with observations), 0 beyond count[b]. */
+/* "mLastFrame = Frame(mCurrentFrame)" for the batched harness in one launch: shifts the local-map tables ([b][local_frames][cap]:
+ * pts_f, descriptors, flags; slot 0 = newest) by one frame and puts the outgoing last frame's points (last_pts_f, last_desc,
+ * last_flags) into slot 0 when shift_local != 0, copies the current frame's keypoints / descriptors / count over the last frame's,
+ * and carries ns_src -> last_ns and prior_ns, t_src -> t_last, marg_src -> marg_dst (both NULL: skipped). loc_* may be NULL. */
+int viorb_frontend_roll_device(viorb_frontend* h, const viorb_keypoint* cur_kps, const uint8_t* cur_desc, const int32_t* cur_count,
+                               viorb_keypoint* last_kps, uint8_t* last_desc, int32_t* last_count, const float* last_pts_f,
+                               const uint8_t* last_flags, float* loc_pts_f, uint8_t* loc_desc, uint8_t* loc_flags,
+                               int local_frames, int shift_local, const double* ns_src, double* last_ns, double* prior_ns,
+                               const double* t_src, double* t_last, const double* marg_src, double* marg_dst, int batch,
+                               void* stream);
+
 int viorb_synth_plane_points_device(viorb_frontend* h, const viorb_keypoint* kps, const int32_t* count,
-                                    const double* pose12, double z0, int batch, float* Pw, uint8_t* flags, void* stream);
+                                    const double* pose12, double z0, int batch, float* Pw, uint8_t* flags,
+                                    int32_t* self_index /* [b][cap]: i for i < count[b], else -1; may be NULL */, void* stream);
 
 /* hipMemcpyAsync(device -> device) on `stream`, for callers that hold raw device addresses. */
 int viorb_memcpy_dtod_async(void* dst, const void* src, size_t bytes, void* stream);

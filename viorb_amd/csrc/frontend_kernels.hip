@@ -647,15 +647,59 @@ __global__ void k_synth_local_points(const viorb_keypoint* __restrict__ kps, con
     out[6] = (float)mind; out[7] = (float)maxd;
 }
 
+// "mLastFrame = Frame(mCurrentFrame)" (reference src/Tracking.cc, end of Track()) for the batched harness, in ONE launch: the
+// outgoing last frame's map points enter the local map (newest first, older slots shift back), the current frame's keypoints and
+// descriptors become the last frame's, and the per-stream scalars (NavState, prior, time stamp, marginal) are carried over.
+struct RollArgs {
+    const viorb_keypoint* cur_kps; const uint8_t* cur_desc; const int* cur_count;
+    viorb_keypoint* last_kps; uint8_t* last_desc; int* last_count;
+    const float* last_pts_f; const uint8_t* last_flags;                  // the OUTGOING last frame's points (read before being replaced)
+    float* loc_pts_f; uint8_t* loc_desc; uint8_t* loc_flags; int local_frames;      // [B][local_frames][cap] tables, or null
+    const double* ns_src; double* last_ns; double* prior_ns; const double* t_src; double* t_last;
+    const double* marg_src; double* marg_dst;                            // [B][144], or null
+    int cap, shift_local;
+};
+__global__ __launch_bounds__(256) void k_roll(RollArgs A) {
+    const int b = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x, cap = A.cap;
+    if (i < cap) {
+        const size_t o = (size_t)b * cap + i;
+        if (A.loc_pts_f && A.shift_local) {
+            const int R = A.local_frames;
+            const size_t base = (size_t)b * R * cap + i;
+            for (int r = R - 1; r >= 1; r--) {
+                const size_t d = base + (size_t)r * cap, sidx = d - cap;
+                for (int k = 0; k < 8; k++) A.loc_pts_f[d * 8 + k] = A.loc_pts_f[sidx * 8 + k];
+                const uint4* sd = reinterpret_cast<const uint4*>(A.loc_desc + sidx * 32); uint4* dd = reinterpret_cast<uint4*>(A.loc_desc + d * 32);
+                dd[0] = sd[0]; dd[1] = sd[1];
+                A.loc_flags[d] = A.loc_flags[sidx];
+            }
+            for (int k = 0; k < 8; k++) A.loc_pts_f[base * 8 + k] = A.last_pts_f[o * 8 + k];
+            const uint4* sd = reinterpret_cast<const uint4*>(A.last_desc + o * 32); uint4* dd = reinterpret_cast<uint4*>(A.loc_desc + base * 32);
+            dd[0] = sd[0]; dd[1] = sd[1];
+            A.loc_flags[base] = A.last_flags[o];
+        }
+        A.last_kps[o] = A.cur_kps[o];
+        const uint4* sd = reinterpret_cast<const uint4*>(A.cur_desc + o * 32); uint4* dd = reinterpret_cast<uint4*>(A.last_desc + o * 32);
+        dd[0] = sd[0]; dd[1] = sd[1];
+    }
+    if (blockIdx.x == 0) {
+        const int t = threadIdx.x;
+        if (t < 22) { const double v = A.ns_src[(size_t)b * 22 + t]; A.last_ns[(size_t)b * 22 + t] = v; A.prior_ns[(size_t)b * 22 + t] = v; }
+        if (t == 32) { A.last_count[b] = A.cur_count[b]; A.t_last[b] = A.t_src[b]; }
+        if (A.marg_src && t >= 64 && t < 64 + 144) A.marg_dst[(size_t)b * 144 + t - 64] = A.marg_src[(size_t)b * 144 + t - 64];
+    }
+}
+
 // Workload support (not a reference function): map points for the keypoints of a frame of the
 // synthetic plane world of viorb_amd/synth.py — intersects the pixel ray with the plane z = z0 using
 // the given camera pose (Rcw, tcw) in double, writes float world points and flags = 1|4.
 __global__ void k_synth_plane_points(const viorb_keypoint* __restrict__ kps, const int* __restrict__ count, int cap,
                                      const double* __restrict__ pose12, double fx, double fy, double cx, double cy, double z0,
-                                     float* __restrict__ Pw, uint8_t* __restrict__ flags) {
+                                     float* __restrict__ Pw, uint8_t* __restrict__ flags, int* __restrict__ self_index) {
     const int b = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= cap) return;
     const size_t o = (size_t)b * cap + i;
+    if (self_index) self_index[o] = i < count[b] ? i : -1;        // "keypoint i holds map point i": the match array of the frame's own points
     if (i >= count[b]) { flags[o] = 0; return; }
     const double* T = pose12 + (size_t)b * 12;
     const double dx = (kps[o].x - cx) / fx, dy = (kps[o].y - cy) / fy;
@@ -1527,6 +1571,27 @@ int viorb_synth_local_points_device(viorb_frontend* h, const viorb_keypoint* kps
     return VIORB_OK;
 }
 
+int viorb_frontend_roll_device(viorb_frontend* h, const viorb_keypoint* cur_kps, const uint8_t* cur_desc, const int32_t* cur_count,
+                               viorb_keypoint* last_kps, uint8_t* last_desc, int32_t* last_count, const float* last_pts_f,
+                               const uint8_t* last_flags, float* loc_pts_f, uint8_t* loc_desc, uint8_t* loc_flags, int local_frames,
+                               int shift_local, const double* ns_src, double* last_ns, double* prior_ns, const double* t_src, double* t_last,
+                               const double* marg_src, double* marg_dst, int batch, void* stream) {
+    FE_CHECK_BATCH(h, batch);
+    VIORB_REQUIRE(cur_kps && cur_desc && cur_count && last_kps && last_desc && last_count && ns_src && last_ns && prior_ns && t_src && t_last, "null array");
+    VIORB_REQUIRE(!loc_pts_f || (loc_desc && loc_flags && last_pts_f && last_flags && local_frames >= 1), "incomplete local-map tables");
+    VIORB_REQUIRE((marg_src == nullptr) == (marg_dst == nullptr), "marg_src / marg_dst");
+    RollArgs A;
+    A.cur_kps = cur_kps; A.cur_desc = cur_desc; A.cur_count = cur_count; A.last_kps = last_kps; A.last_desc = last_desc; A.last_count = last_count;
+    A.last_pts_f = last_pts_f; A.last_flags = last_flags; A.loc_pts_f = loc_pts_f; A.loc_desc = loc_desc; A.loc_flags = loc_flags;
+    A.local_frames = local_frames; A.shift_local = shift_local;
+    A.ns_src = ns_src; A.last_ns = last_ns; A.prior_ns = prior_ns; A.t_src = t_src; A.t_last = t_last; A.marg_src = marg_src; A.marg_dst = marg_dst;
+    A.cap = h->cap;
+    ProfScope ps("k_roll", (hipStream_t)stream);
+    hipLaunchKernelGGL(k_roll, dim3((h->cap + 255) / 256, batch), dim3(256), 0, (hipStream_t)stream, A);
+    VIORB_HIP_TRY(hipGetLastError());
+    return VIORB_OK;
+}
+
 int viorb_frontend_pose_opt_device(viorb_frontend* h, int variant, int compute_marg, const double* cur_ns, const double* last_ns,
                                    const double* prior_ns, const double* marg_cov_inv, const double* preint, const double* obs_cur,
                                    const int32_t* n_cur, const double* obs_last, const int32_t* n_last, int batch, double* out_ns,
@@ -1550,12 +1615,12 @@ int viorb_frontend_pose_opt_device(viorb_frontend* h, int variant, int compute_m
 }
 
 int viorb_synth_plane_points_device(viorb_frontend* h, const viorb_keypoint* kps, const int32_t* count, const double* pose12,
-                                    double z0, int batch, float* Pw, uint8_t* flags, void* stream) {
+                                    double z0, int batch, float* Pw, uint8_t* flags, int32_t* self_index, void* stream) {
     FE_CHECK_BATCH(h, batch);
     VIORB_REQUIRE(kps && count && pose12 && Pw && flags, "null array");
     ProfScope ps("k_synth_plane_points", (hipStream_t)stream);
     hipLaunchKernelGGL(k_synth_plane_points, dim3((h->cap + 255) / 256, batch), dim3(256), 0, (hipStream_t)stream, kps, count, h->cap,
-                       pose12, h->cfg.cam[0], h->cfg.cam[1], h->cfg.cam[2], h->cfg.cam[3], z0, Pw, flags);
+                       pose12, h->cfg.cam[0], h->cfg.cam[1], h->cfg.cam[2], h->cfg.cam[3], z0, Pw, flags, self_index);
     VIORB_HIP_TRY(hipGetLastError());
     return VIORB_OK;
 }

@@ -108,37 +108,24 @@ class BatchedTracker:
     def _cur_ptrs(self):
         return self.ex.results_device()            # kps, desc, count, status, cap
 
-    def _roll(self, true_pose12, t_cur, ns_for_last, stream=None):
-        """Make the frame just processed the new last frame and give its keypoints map points.
-        Runs on the current torch stream (the tracking stream when overlapping)."""
-        torch = self.torch
+    def _roll(self, true_pose12, t_cur, ns_for_last, marg_src=None, stream=None):
+        """Make the frame just processed the new last frame (one fused kernel: local-map shift, keypoint / descriptor / state copies)
+        and give its keypoints map points. Runs on the current torch stream (the tracking stream when overlapping)."""
         kps, desc, count, _, cap = self._cur_ptrs()
         L = lib()
         st = Frontend._st(stream)
-        nb = self.B * cap
-        if self.track_local_map and self.k_rolls > 0:                     # the outgoing last frame's points join the local map
-            B, R = self.B, self.LOCAL_FRAMES
-            for tbl, new, w in ((self.loc_pts_f, self.last_pts_f, 8), (self.loc_desc, self.last_desc, 32)):
-                v = tbl.view(B, R, cap, w)
-                if R > 1:
-                    v[:, 1:] = v[:, :-1].clone()
-                v[:, 0] = new.view(B, cap, w)
-            vf = self.loc_flags.view(B, R, cap)
-            if R > 1:
-                vf[:, 1:] = vf[:, :-1].clone()
-            vf[:, 0] = self.last_flags
-        for dst, src, nbytes in ((self.last_kps, kps, nb * KP_DTYPE.itemsize), (self.last_desc, desc, nb * 32), (self.last_count, count, self.B * 4)):
-            rc = _hip_memcpy_dtod_async(dst.data_ptr(), src, nbytes, st)
-            assert rc == 0
-        check(L.viorb_synth_plane_points_device(self.fe.h, C.c_void_p(self.last_kps.data_ptr()), C.c_void_p(self.last_count.data_ptr()),
-                                                ptr(true_pose12), synth.PLANE_Z0, self.B, ptr(self.last_Pw), ptr(self.last_flags), st))
-        self.last_ns.copy_(ns_for_last, non_blocking=True)
-        self.prior_ns.copy_(ns_for_last, non_blocking=True)
-        self.t_last.copy_(t_cur, non_blocking=True)
-        self.last_self.copy_(torch.where(self.last_flags > 0, self.iota, torch.full_like(self.iota, -1)))
-        if self.track_local_map:
+        tlm = self.track_local_map
+        vp = lambda tns: C.c_void_p(tns.data_ptr()) if tns is not None else None
+        check(L.viorb_frontend_roll_device(
+            self.fe.h, C.c_void_p(kps), C.c_void_p(desc), C.c_void_p(count), vp(self.last_kps), vp(self.last_desc), vp(self.last_count),
+            vp(self.last_pts_f) if tlm else None, vp(self.last_flags), vp(self.loc_pts_f) if tlm else None, vp(self.loc_desc) if tlm else None,
+            vp(self.loc_flags) if tlm else None, self.LOCAL_FRAMES, int(tlm and self.k_rolls > 0), vp(ns_for_last), vp(self.last_ns), vp(self.prior_ns),
+            vp(t_cur), vp(self.t_last), vp(marg_src), vp(self.marg_cov_inv) if marg_src is not None else None, self.B, st))
+        check(L.viorb_synth_plane_points_device(self.fe.h, vp(self.last_kps), vp(self.last_count), ptr(true_pose12), synth.PLANE_Z0, self.B,
+                                                ptr(self.last_Pw), ptr(self.last_flags), vp(self.last_self), st))
+        if tlm:
             self.fe.synth_local_points(self.last_kps.data_ptr(), self.last_count.data_ptr(), true_pose12, self.last_Pw, self.B, self.last_pts_f)
-            self.k_rolls += 1
+        self.k_rolls += 1
 
     def bootstrap(self, images, true_pose12, t0, ns0, marg_cov_inv):
         """First frame of every stream: extract, adopt as last frame with ground-truth state."""
@@ -181,9 +168,8 @@ class BatchedTracker:
                         self.obs_last, self.n_last, B, self.out_ns2, self.out_last_ns, self.outlier_cur2, self.outlier_last, self.marg_out,
                         self.info2)
             final_ns = self.out_ns2
-        if self.compute_marg and chain_estimate:
-            self.marg_cov_inv.copy_(self.marg_out, non_blocking=True)
-        self._roll(true_pose12, t_cur if t_next_last is None else t_next_last, final_ns if chain_estimate else true_ns)
+        self._roll(true_pose12, t_cur if t_next_last is None else t_next_last, final_ns if chain_estimate else true_ns,
+                   marg_src=self.marg_out if (self.compute_marg and chain_estimate) else None)
 
     def step(self, images, imu, t_cur, true_pose12, chain_estimate=True, true_ns=None, t_next_last=None):
         """One tracking step for all streams. images [B,h,w] u8, imu [B,n,7] f64, t_cur [B] f64,
