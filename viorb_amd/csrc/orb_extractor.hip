@@ -85,6 +85,8 @@ struct LevelDev {
 };
 struct CellDesc {              // one FAST cell = sub-image [x0,x0+cw) x [y0,y0+ch) of its level
     int16_t level, x0, y0, cw, ch, shx, shy, pad;
+    uint32_t src_off;          // byte offset, inside one image's plane block, of the aligned dword holding pixel (x0, y0)
+    int32_t stride;            // row pitch of the level (so the kernel needs no second, dependent table look-up)
 };
 
 static inline int host_cv_round(double v) { return (int)nearbyint(v); }
@@ -228,17 +230,15 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t* __restrict__ p
     uint16_t* corn = surv + list_cap;                                    // [list_cap] corners (strength >= minTh)
     const int lane = threadIdx.x;
     const CellDesc c = cells[blockIdx.x];
-    const LevelDev L = lv[c.level];
-    const uint8_t* img = planes + (size_t)blockIdx.y * frame_bytes + L.plane_off;
     const int x0a = c.x0 & ~3, xoff = c.x0 - x0a;
     const int ndw = ((c.x0 + c.cw - 1 - x0a) >> 2) + 1;
     const int pitch_dw = tile_pitch >> 2;
     {
         const int st_r = 64 / pitch_dw, st_q = 64 - st_r * pitch_dw;      // one division per wave instead of one per dword
         int r = lane / pitch_dw, q = lane - r * pitch_dw;
-        const uint8_t* src = img + (size_t)c.y0 * L.stride + x0a;
+        const uint8_t* src = planes + (size_t)blockIdx.y * frame_bytes + c.src_off;
         for (int i = lane; i < c.ch * pitch_dw; i += 64) {
-            if (q < ndw) s_mem[i] = *reinterpret_cast<const uint32_t*>(src + r * L.stride + 4 * q);
+            if (q < ndw) s_mem[i] = *reinterpret_cast<const uint32_t*>(src + r * c.stride + 4 * q);
             r += st_r; q += st_q;
             if (q >= pitch_dw) { q -= pitch_dw; r++; }
         }
@@ -1054,6 +1054,7 @@ static int configure(viorb_extractor* h, int w, int hgt) {
                     c.level = (int16_t)l; c.x0 = (int16_t)iniX; c.y0 = (int16_t)iniY;
                     c.cw = (int16_t)((int)maxX - (int)iniX); c.ch = (int16_t)((int)maxY - (int)iniY);
                     c.shx = (int16_t)(j * wCell); c.shy = (int16_t)(i * hCell); c.pad = 0;
+                    c.src_off = (uint32_t)(L.plane_off + (size_t)c.y0 * L.stride + (size_t)(c.x0 & ~3)); c.stride = L.stride;
                     if (c.cw < 7 || c.ch < 7) continue;            // cv::FAST finds nothing in such a sub-image
                     h->cells.push_back(c);
                     max_cw = std::max(max_cw, (int)c.cw); max_ch = std::max(max_ch, (int)c.ch);
