@@ -358,6 +358,41 @@ int viorb_search_by_bow(const viorb_keypoint* kf_kps, const uint8_t* kf_desc, co
                         const int32_t* f_node, int nf, float nnratio, int check_orientation, int32_t* match,
                         int* nmatches);
 
+/* ---- Key-frame side matchers LocalMapping runs around the local BA (reference src/LocalMapping.cc:1296, 1522, 1547) ------------
+ * ORBmatcher::SearchForTriangulation(pKF1, pKF2, F12, vMatchedPairs, bOnlyStereo) (src/ORBmatcher.cc:657-823): node1 / node2 are
+ * the FeatureVector nodes per feature (-1 absent), has_point = GetMapPoint(i) != NULL, uright = mvuRight (< 0 mono), F12 row-major
+ * (LocalMapping::ComputeF12), Cw1 = pKF1->GetCameraCenter(), pose12_2 = pKF2's Tcw, intr4 / scale_factors2 / level_sigma2_2 =
+ * pKF2's fx fy cx cy, mvScaleFactors, mvLevelSigma2. match12[i1] = i2 or -1 (the vMatchedPairs list is its non-negative entries
+ * in i1 order). Device form: arrays [b*cap + i], n1[b] / n2[b] counts, F12 [b][9], Cw1 [b][3], pose12_2 [b][12]. */
+int viorb_search_for_triangulation_device(const viorb_keypoint* k1, const uint8_t* d1, const uint8_t* has_point1,
+                                          const float* uright1, const int32_t* node1, const int32_t* n1,
+                                          const viorb_keypoint* k2, const uint8_t* d2, const uint8_t* has_point2,
+                                          const float* uright2, const int32_t* node2, const int32_t* n2, const float* F12,
+                                          const float* Cw1, const float* pose12_2, const float intr4[4],
+                                          const float* scale_factors2, const float* level_sigma2_2, int nlevels, int only_stereo,
+                                          int check_orientation, int cap, int batch, int32_t* match12, int32_t* nmatches,
+                                          void* stream);
+int viorb_search_for_triangulation(const viorb_keypoint* k1, const uint8_t* d1, const uint8_t* has_point1, const float* uright1,
+                                   const int32_t* node1, int n1, const viorb_keypoint* k2, const uint8_t* d2,
+                                   const uint8_t* has_point2, const float* uright2, const int32_t* node2, int n2,
+                                   const float F12[9], const float Cw1[3], const float pose12_2[12], const float intr4[4],
+                                   const float* scale_factors2, const float* level_sigma2_2, int nlevels, int only_stereo,
+                                   int check_orientation, int32_t* match12, int* nmatches);
+
+/* ORBmatcher::Fuse(KeyFrame* pKF, const vector<MapPoint*>& vpMapPoints, th) (src/ORBmatcher.cc:825-975): pts_f[p][8] = Pw3 normal3
+ * minDist maxDist (GetWorldPos, GetNormal, mfMinDistance, mfMaxDistance), pts_valid[p] = pMP && !isBad() && !IsInKeyFrame(pKF),
+ * pts_desc = GetDescriptor(); uright = pKF->mvuRight, bf = pKF->mbf, cell_start / cell_idx = the key frame's 64x48 grid
+ * (viorb_frontend_grid_device). best_idx[p] = the feature the point fuses with (descriptor distance <= TH_LOW) or -1; the caller
+ * then replaces / adds observations in point order as :956-972 do. nfused = number of non-negative entries. */
+int viorb_frontend_fuse_device(viorb_frontend* h, const viorb_keypoint* kps, const uint8_t* desc, const float* uright,
+                               const int32_t* count, const int32_t* cell_start, const int32_t* cell_idx, const float* pose12,
+                               const float* pts_f, const uint8_t* pts_valid, const uint8_t* pts_desc, const int32_t* pts_count,
+                               int pcap, float th, float bf, int batch, int32_t* best_idx, int32_t* nfused, void* stream);
+int viorb_fuse(const viorb_keypoint* kps, const uint8_t* desc, const float* uright, int n, const float bounds4[4],
+               const float pose12[12], const float intr5[5], const float* scale_factors, const float* inv_level_sigma2, int nlevels,
+               const float* pts_f, const uint8_t* pts_valid, const uint8_t* pts_desc, int npts, float th, int32_t* best_idx,
+               int* nfused);
+
 /* Host-only test hooks (no GPU needed; used by the CPU test-suite to compare product host code with
  * the oracle): the flat-array formulation of DistributeOctTree that the device kernel mirrors
  * (keys packed x | y<<12 | score<<24, border-relative), and the scalar math shared with the kernels. */

@@ -436,3 +436,31 @@ def search_by_bow(kf_desc, kf_angle, kf_node, kf_has_point, f_desc, f_angle, f_n
                             _p(np.ascontiguousarray(kf_has_point, np.uint8)), len(kd), _p(fd), _p(np.ascontiguousarray(f_angle, np.float32)),
                             _p(np.ascontiguousarray(f_node, np.int32)), len(fd), float(nnratio), int(check_orientation), _p(m))
     return n, m[:len(fd)]
+
+
+def search_for_triangulation(k1, d1, hp1, ur1, node1, k2, d2, hp2, ur2, node2, F12, Cw1, pose12_2, intr4, sf2, level_sigma2_2,
+                             only_stereo=False, check_orientation=True):
+    """ORBmatcher::SearchForTriangulation. Returns (nmatches, match12[N1]) with match12[i1] = i2 or -1."""
+    L = lib()
+    L.ora_search_for_triangulation.argtypes = [C.c_void_p] * 5 + [C.c_int] + [C.c_void_p] * 5 + [C.c_int] + [C.c_void_p] * 6 + [C.c_int, C.c_int, C.c_void_p]
+    k1 = np.ascontiguousarray(k1, KP_DTYPE); k2 = np.ascontiguousarray(k2, KP_DTYPE)
+    u8 = lambda a: np.ascontiguousarray(a, np.uint8); f32 = lambda a: np.ascontiguousarray(a, np.float32); i32 = lambda a: np.ascontiguousarray(a, np.int32)
+    m = np.full(max(len(k1), 1), -1, np.int32)
+    n = L.ora_search_for_triangulation(_p(k1), _p(u8(d1)), _p(u8(hp1)), _p(f32(ur1)), _p(i32(node1)), len(k1), _p(k2), _p(u8(d2)), _p(u8(hp2)),
+                                       _p(f32(ur2)), _p(i32(node2)), len(k2), _p(f32(F12)), _p(f32(Cw1)), _p(f32(pose12_2)), _p(f32(intr4)),
+                                       _p(f32(sf2)), _p(f32(level_sigma2_2)), int(only_stereo), int(check_orientation), _p(m))
+    return n, m[:len(k1)]
+
+
+def fuse(kps, desc, uright, bounds, pose12, intr5, scale_factors, inv_level_sigma2, log_scale_factor, pts_f, pts_valid, pts_desc, th=3.0):
+    """ORBmatcher::Fuse(KeyFrame*, vpMapPoints, th): best_idx per map point (-1: not fused). Returns (nFused, best_idx)."""
+    L = lib()
+    L.ora_fuse.argtypes = [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 5 + [C.c_int, C.c_float, C.c_int] + [C.c_void_p] * 3 + [C.c_float, C.c_void_p]
+    kps = np.ascontiguousarray(kps, KP_DTYPE)
+    f32 = lambda a: np.ascontiguousarray(a, np.float32)
+    pts_f = f32(pts_f).reshape(-1, 8); sf = f32(scale_factors)
+    bi = np.full(max(len(pts_f), 1), -1, np.int32)
+    n = L.ora_fuse(_p(kps), _p(np.ascontiguousarray(desc, np.uint8)), _p(f32(uright)), len(kps), _p(f32(bounds)), _p(f32(pose12)), _p(f32(intr5)),
+                   _p(sf), _p(f32(inv_level_sigma2)), len(sf), float(log_scale_factor), len(pts_f), _p(pts_f), _p(np.ascontiguousarray(pts_valid, np.uint8)),
+                   _p(np.ascontiguousarray(pts_desc, np.uint8)), float(th), _p(bi))
+    return n, bi[:len(pts_f)]

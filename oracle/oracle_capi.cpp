@@ -360,3 +360,39 @@ int ora_search_by_bow(const uint8_t* kf_desc, const float* kf_angle, const int* 
     return n;
 }
 } // extern "C"
+
+#include "kf_matcher.h"
+extern "C" {
+int ora_search_for_triangulation(const ora::KeyPoint* k1, const uint8_t* d1, const uint8_t* hp1, const float* ur1, const int* node1, int n1,
+                                 const ora::KeyPoint* k2, const uint8_t* d2, const uint8_t* hp2, const float* ur2, const int* node2, int n2,
+                                 const float* F12, const float* Cw1, const float* pose12_2, const float* intr4, const float* sf2,
+                                 const float* level_sigma2_2, int only_stereo, int check_ori, int* match12) {
+    ora::KfView a, b;
+    a.N = n1; a.kps = k1; a.desc = d1; a.has_point = hp1; a.uright = ur1; a.node = node1;
+    b.N = n2; b.kps = k2; b.desc = d2; b.has_point = hp2; b.uright = ur2; b.node = node2;
+    ora::PoseF T; for (int i = 0; i < 9; i++) T.Rcw[i] = pose12_2[i]; for (int i = 0; i < 3; i++) T.tcw[i] = pose12_2[9 + i];
+    T.fx = intr4[0]; T.fy = intr4[1]; T.cx = intr4[2]; T.cy = intr4[3];
+    std::vector<int> m;
+    const int n = ora::search_for_triangulation(a, b, F12, Cw1, T, sf2, level_sigma2_2, only_stereo != 0, check_ori != 0, m);
+    for (int i = 0; i < n1; i++) match12[i] = m[i];
+    return n;
+}
+// pts_f[n][8] = Pw3 normal3 minDist maxDist; pts_valid[n]; intr5 = fx fy cx cy bf
+int ora_fuse(const ora::KeyPoint* kps, const uint8_t* desc, const float* uright, int n, const float* bounds4, const float* pose12,
+             const float* intr5, const float* sf, const float* inv_level_sigma2, int nlevels, float log_scale_factor, int npts,
+             const float* pts_f, const uint8_t* pts_valid, const uint8_t* pts_desc, float th, int* best_idx) {
+    ora::FrameGrid g; g.build(kps, desc, n, bounds4[0], bounds4[1], bounds4[2], bounds4[3]);
+    ora::PoseF T; for (int i = 0; i < 9; i++) T.Rcw[i] = pose12[i]; for (int i = 0; i < 3; i++) T.tcw[i] = pose12[9 + i];
+    T.fx = intr5[0]; T.fy = intr5[1]; T.cx = intr5[2]; T.cy = intr5[3];
+    std::vector<ora::FusePoint> pts(npts);
+    for (int i = 0; i < npts; i++) {
+        pts[i].valid = pts_valid[i];
+        for (int k = 0; k < 3; k++) { pts[i].Pw[k] = pts_f[8 * i + k]; pts[i].normal[k] = pts_f[8 * i + 3 + k]; }
+        pts[i].min_dist = pts_f[8 * i + 6]; pts[i].max_dist = pts_f[8 * i + 7]; pts[i].desc = pts_desc + (size_t)32 * i;
+    }
+    std::vector<int> bi;
+    const int nf = ora::fuse(g, uright, T, intr5[4], sf, inv_level_sigma2, nlevels, log_scale_factor, pts, th, bi);
+    for (int i = 0; i < npts; i++) best_idx[i] = bi[i];
+    return nf;
+}
+} // extern "C"

@@ -74,6 +74,10 @@ SIGNATURES = {
     "viorb_frontend_pose_from_navstate_device": (i32, [vp, vp, i32, vp, vp]),
     "viorb_frontend_build_observations2_device": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp]),
     "viorb_synth_local_points_device": (i32, [vp, vp, vp, vp, vp, i32, vp, vp]),
+    "viorb_search_for_triangulation_device": (i32, [vp] * 18 + [i32, i32, i32, i32, i32, vp, vp, vp]),
+    "viorb_search_for_triangulation": (i32, [vp] * 5 + [i32] + [vp] * 5 + [i32] + [vp] * 6 + [i32, i32, i32, vp, PP(i32)]),
+    "viorb_frontend_fuse_device": (i32, [vp] * 12 + [i32, f32, f32, i32, vp, vp, vp]),
+    "viorb_fuse": (i32, [vp, vp, vp, i32, vp, vp, vp, vp, vp, i32, vp, vp, vp, i32, f32, vp, PP(i32)]),
     "viorb_synth_plane_points_device": (i32, [vp, vp, vp, vp, C.c_double, i32, vp, vp, vp, vp]),
     "viorb_frontend_roll_device": (i32, [vp] * 12 + [i32, i32] + [vp] * 7 + [i32, vp]),
     "viorb_memcpy_dtod_async": (i32, [vp, vp, sz, vp]),

@@ -170,6 +170,127 @@ __global__ __launch_bounds__(256) void k_search_by_bow(BowSearchArgs A) {
     if (t == 0) A.nmatches[b] = s_nm;
 }
 
+// ---------------------------------------------------------------------------------------------
+// ORBmatcher::SearchForTriangulation (reference src/ORBmatcher.cc:657-823, CheckDistEpipolarLine :138-156): for every key-frame-1
+// feature without a map point, the lowest-Hamming key-frame-2 feature of the same vocabulary node that has no map point, is not
+// too close to the epipole (mono) and lies on the epipolar line within 3.84 sigma^2; rotation-histogram filter at the end. The
+// reference never sets vbMatched2, so key-frame-1 features do not compete: one thread per feature. Key frame 2's features are
+// sorted by (node, index) in LDS so that a node is a contiguous run walked in index order ("dist > bestDist -> continue" lets
+// the LAST of equal-distance candidates win).
+struct TriArgs {
+    const viorb_keypoint *k1, *k2; const uint8_t *d1, *d2, *hp1, *hp2; const float *ur1, *ur2; const int *node1, *node2, *n1, *n2;
+    const float *F12, *Cw1, *pose2;
+    int* match12; int* nmatches;
+    int cap, sort_n, only_stereo, check_ori;
+    float fx, fy, cx, cy, scale[16], level_sigma2[16];
+};
+__host__ __device__ inline size_t tri_lds_bytes(int cap, int sort_n) { return (size_t)sort_n * 8 + (size_t)cap + 256; }
+
+__global__ __launch_bounds__(256) void k_search_triangulation(TriArgs A) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int b = blockIdx.x, t = threadIdx.x, cap = A.cap, sn = A.sort_n;
+    unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);          // [sn] ((node + 1) << 32 | index), absent nodes sort first
+    unsigned char* s_bin = reinterpret_cast<unsigned char*>(keys + sn);              // [cap]
+    __shared__ int s_hist[BOW_HISTO], s_keep[BOW_HISTO], s_nm;
+    __shared__ float s_e[2];
+    const int N1 = min(A.n1[b], cap), N2 = min(A.n2[b], cap);
+    const size_t o = (size_t)b * cap;
+    for (int i = t; i < sn; i += blockDim.x)
+        keys[i] = i < N2 ? (((unsigned long long)(unsigned)(A.node2[o + i] + 1) << 32) | (unsigned)i) : ~0ull;
+    if (t < BOW_HISTO) { s_hist[t] = 0; s_keep[t] = 1; }
+    if (t == 0) {
+        s_nm = 0;
+        const float* P = A.pose2 + (size_t)b * 12; const float* C = A.Cw1 + (size_t)b * 3;
+        float c2[3];
+        for (int r = 0; r < 3; r++) { const float tt = P[3 * r] * C[0] + P[3 * r + 1] * C[1] + P[3 * r + 2] * C[2]; c2[r] = tt + P[9 + r]; }
+        const float invz = 1.0f / c2[2];
+        s_e[0] = A.fx * c2[0] * invz + A.cx; s_e[1] = A.fy * c2[1] * invz + A.cy;
+    }
+    __syncthreads();
+    for (int k = 2; k <= sn; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int q = t; q < (sn >> 1); q += blockDim.x) {
+                const int lo = ((q & ~(j - 1)) << 1) | (q & (j - 1)), hi = lo | j;
+                const bool up = (lo & k) == 0;
+                const unsigned long long x = keys[lo], y = keys[hi];
+                if ((x > y) == up) { keys[lo] = y; keys[hi] = x; }
+            }
+            __syncthreads();
+        }
+    const float ex = s_e[0], ey = s_e[1];
+    const float* F = A.F12 + (size_t)b * 9;
+    const float factor = 1.0f / BOW_HISTO;
+    for (int i1 = t; i1 < cap; i1 += blockDim.x) {
+        int bestIdx2 = -1;
+        if (i1 < N1) {
+            const int nd = A.node1[o + i1];
+            const bool st1 = A.ur1[o + i1] >= 0;
+            if (nd >= 0 && !A.hp1[o + i1] && !(A.only_stereo && !st1)) {
+                const viorb_keypoint kp1 = A.k1[o + i1];
+                const float la = kp1.x * F[0] + kp1.y * F[3] + F[6], lb = kp1.x * F[1] + kp1.y * F[4] + F[7], lc = kp1.x * F[2] + kp1.y * F[5] + F[8];
+                const float den = la * la + lb * lb;
+                const uint4* p1 = reinterpret_cast<const uint4*>(A.d1 + (o + i1) * 32);
+                const uint4 da = p1[0], db = p1[1];
+                const unsigned long long want = (unsigned long long)(unsigned)(nd + 1) << 32;
+                int lo = 0, hi = N2;
+                while (lo < hi) { const int mid = (lo + hi) >> 1; if (keys[mid] < want) lo = mid + 1; else hi = mid; }
+                int bestDist = BOW_TH_LOW;
+                for (int k = lo; k < N2 && (keys[k] >> 32) == (unsigned)(nd + 1); k++) {
+                    const int i2 = (int)(keys[k] & 0xffffffffu);
+                    if (A.hp2[o + i2]) continue;
+                    const bool st2 = A.ur2[o + i2] >= 0;
+                    if (A.only_stereo && !st2) continue;
+                    const uint4* p2 = reinterpret_cast<const uint4*>(A.d2 + (o + i2) * 32);
+                    const uint4 ea = p2[0], eb = p2[1];
+                    const int dist = __popc(da.x ^ ea.x) + __popc(da.y ^ ea.y) + __popc(da.z ^ ea.z) + __popc(da.w ^ ea.w) +
+                                     __popc(db.x ^ eb.x) + __popc(db.y ^ eb.y) + __popc(db.z ^ eb.z) + __popc(db.w ^ eb.w);
+                    if (dist > BOW_TH_LOW || dist > bestDist) continue;
+                    const viorb_keypoint kp2 = A.k2[o + i2];
+                    if (!st1 && !st2) {
+                        const float dx = ex - kp2.x, dy = ey - kp2.y;
+                        if (dx * dx + dy * dy < 100 * A.scale[kp2.octave]) continue;
+                    }
+                    const float num = la * kp2.x + lb * kp2.y + lc;
+                    if (den == 0) continue;
+                    const float dsqr = num * num / den;
+                    if ((double)dsqr < 3.84 * (double)A.level_sigma2[kp2.octave]) { bestIdx2 = i2; bestDist = dist; }
+                }
+                if (bestIdx2 >= 0) {
+                    float rot = kp1.angle - A.k2[o + bestIdx2].angle;
+                    if (rot < 0.0f) rot += 360.0f;
+                    int bin = (int)roundf(rot * factor);
+                    if (bin == BOW_HISTO) bin = 0;
+                    s_bin[i1] = (unsigned char)bin;
+                    atomicAdd(&s_nm, 1);
+                    if (A.check_ori) atomicAdd(&s_hist[bin], 1);
+                }
+            }
+        }
+        A.match12[o + i1] = bestIdx2;
+    }
+    __syncthreads();
+    if (A.check_ori) {
+        if (t == 0) {                                                // ComputeThreeMaxima, src/ORBmatcher.cc:1602-1643
+            int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
+            for (int i = 0; i < BOW_HISTO; i++) {
+                const int sz = s_hist[i];
+                if (sz > max1) { max3 = max2; max2 = max1; max1 = sz; ind3 = ind2; ind2 = ind1; ind1 = i; }
+                else if (sz > max2) { max3 = max2; max2 = sz; ind3 = ind2; ind2 = i; }
+                else if (sz > max3) { max3 = sz; ind3 = i; }
+            }
+            if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+            else if (max3 < 0.1f * (float)max1) { ind3 = -1; }
+            int removed = 0;
+            for (int i = 0; i < BOW_HISTO; i++) { const int keep = (i == ind1 || i == ind2 || i == ind3); s_keep[i] = keep; if (!keep) removed += s_hist[i]; }
+            s_nm -= removed;
+        }
+        __syncthreads();
+        for (int i1 = t; i1 < N1; i1 += blockDim.x)
+            if (A.match12[o + i1] >= 0 && !s_keep[s_bin[i1]]) A.match12[o + i1] = -1;
+    }
+    if (t == 0) A.nmatches[b] = s_nm;
+}
+
 } // namespace viorb
 
 using namespace viorb;
@@ -304,6 +425,65 @@ int viorb_search_by_bow(const viorb_keypoint* kf_kps, const uint8_t* kf_desc, co
     VIORB_HIP_TRY(hipDeviceSynchronize());
     VIORB_HIP_TRY(hipMemcpy(match, d_m, sizeof(int) * nf, hipMemcpyDeviceToHost));
     VIORB_HIP_TRY(hipMemcpy(nmatches, d_nm, sizeof(int), hipMemcpyDeviceToHost));
+    return VIORB_OK;
+}
+
+int viorb_search_for_triangulation_device(const viorb_keypoint* k1, const uint8_t* d1, const uint8_t* has_point1, const float* uright1,
+                                          const int32_t* node1, const int32_t* n1, const viorb_keypoint* k2, const uint8_t* d2,
+                                          const uint8_t* has_point2, const float* uright2, const int32_t* node2, const int32_t* n2,
+                                          const float* F12, const float* Cw1, const float* pose12_2, const float intr4[4],
+                                          const float* scale_factors2, const float* level_sigma2_2, int nlevels, int only_stereo,
+                                          int check_orientation, int cap, int batch, int32_t* match12, int32_t* nmatches, void* stream) {
+    VIORB_REQUIRE(k1 && d1 && has_point1 && uright1 && node1 && n1 && k2 && d2 && has_point2 && uright2 && node2 && n2 && F12 && Cw1 && pose12_2 &&
+                  intr4 && scale_factors2 && level_sigma2_2 && match12 && nmatches, "null array");
+    VIORB_REQUIRE(cap >= 1 && cap <= 16384 && batch >= 1 && nlevels >= 1 && nlevels <= 16, "1 <= cap <= 16384, 1 <= nlevels <= 16");
+    int sn = 1; while (sn < cap) sn <<= 1;
+    const size_t lds = tri_lds_bytes(cap, sn);
+    if (lds > 160 * 1024) { set_error("cap %d needs %zu B of LDS for SearchForTriangulation", cap, lds); return VIORB_ERR_UNSUPPORTED; }
+    if (lds > 64 * 1024) VIORB_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_search_triangulation), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    TriArgs A;
+    A.k1 = k1; A.k2 = k2; A.d1 = d1; A.d2 = d2; A.hp1 = has_point1; A.hp2 = has_point2; A.ur1 = uright1; A.ur2 = uright2; A.node1 = node1; A.node2 = node2;
+    A.n1 = n1; A.n2 = n2; A.F12 = F12; A.Cw1 = Cw1; A.pose2 = pose12_2; A.match12 = match12; A.nmatches = nmatches;
+    A.cap = cap; A.sort_n = sn; A.only_stereo = only_stereo; A.check_ori = check_orientation;
+    A.fx = intr4[0]; A.fy = intr4[1]; A.cx = intr4[2]; A.cy = intr4[3];
+    for (int i = 0; i < 16; i++) { A.scale[i] = scale_factors2[i < nlevels ? i : nlevels - 1]; A.level_sigma2[i] = level_sigma2_2[i < nlevels ? i : nlevels - 1]; }
+    ProfScope ps("k_search_triangulation", (hipStream_t)stream);
+    hipLaunchKernelGGL(k_search_triangulation, dim3(batch), dim3(256), lds, (hipStream_t)stream, A);
+    VIORB_HIP_TRY(hipGetLastError());
+    return VIORB_OK;
+}
+
+int viorb_search_for_triangulation(const viorb_keypoint* k1, const uint8_t* d1, const uint8_t* has_point1, const float* uright1,
+                                   const int32_t* node1, int n1, const viorb_keypoint* k2, const uint8_t* d2, const uint8_t* has_point2,
+                                   const float* uright2, const int32_t* node2, int n2, const float F12[9], const float Cw1[3],
+                                   const float pose12_2[12], const float intr4[4], const float* scale_factors2,
+                                   const float* level_sigma2_2, int nlevels, int only_stereo, int check_orientation, int32_t* match12,
+                                   int* nmatches) {
+    VIORB_REQUIRE(nmatches && n1 >= 0 && n2 >= 0, "null array");
+    *nmatches = 0;
+    for (int i = 0; i < n1; i++) match12[i] = -1;
+    if (n1 == 0 || n2 == 0) return VIORB_OK;
+    VIORB_REQUIRE(k1 && d1 && has_point1 && uright1 && node1 && k2 && d2 && has_point2 && uright2 && node2 && F12 && Cw1 && pose12_2 && match12, "null array");
+    if (viorb_device_count() < 1) { set_error("no HIP device: libviorb_hip has no CPU fallback"); return VIORB_ERR_NO_DEVICE; }
+    const int cap = std::max(n1, n2);
+    BowBuf B; viorb_keypoint *dk1, *dk2; uint8_t *dd1, *dd2, *dh1, *dh2; float *du1, *du2, *dF, *dC, *dP; int *dn1, *dn2, *dc1, *dc2, *dm, *dnm;
+    bool ok = B.up(&dk1, (const viorb_keypoint*)nullptr, cap) && B.up(&dk2, (const viorb_keypoint*)nullptr, cap) && B.up(&dd1, (const uint8_t*)nullptr, (size_t)32 * cap) &&
+              B.up(&dd2, (const uint8_t*)nullptr, (size_t)32 * cap) && B.up(&dh1, (const uint8_t*)nullptr, cap) && B.up(&dh2, (const uint8_t*)nullptr, cap) &&
+              B.up(&du1, (const float*)nullptr, cap) && B.up(&du2, (const float*)nullptr, cap) && B.up(&dF, F12, 9) && B.up(&dC, Cw1, 3) && B.up(&dP, pose12_2, 12) &&
+              B.up(&dn1, (const int*)nullptr, cap) && B.up(&dn2, (const int*)nullptr, cap) && B.up(&dc1, &n1, 1) && B.up(&dc2, &n2, 1) &&
+              B.up(&dm, (const int*)nullptr, cap) && B.up(&dnm, (const int*)nullptr, 1);
+    if (!ok) { set_error("device allocation / upload failed"); return VIORB_ERR_HIP; }
+    VIORB_HIP_TRY(hipMemcpy(dk1, k1, sizeof(viorb_keypoint) * n1, hipMemcpyHostToDevice)); VIORB_HIP_TRY(hipMemcpy(dk2, k2, sizeof(viorb_keypoint) * n2, hipMemcpyHostToDevice));
+    VIORB_HIP_TRY(hipMemcpy(dd1, d1, (size_t)32 * n1, hipMemcpyHostToDevice)); VIORB_HIP_TRY(hipMemcpy(dd2, d2, (size_t)32 * n2, hipMemcpyHostToDevice));
+    VIORB_HIP_TRY(hipMemcpy(dh1, has_point1, n1, hipMemcpyHostToDevice)); VIORB_HIP_TRY(hipMemcpy(dh2, has_point2, n2, hipMemcpyHostToDevice));
+    VIORB_HIP_TRY(hipMemcpy(du1, uright1, sizeof(float) * n1, hipMemcpyHostToDevice)); VIORB_HIP_TRY(hipMemcpy(du2, uright2, sizeof(float) * n2, hipMemcpyHostToDevice));
+    VIORB_HIP_TRY(hipMemcpy(dn1, node1, sizeof(int) * n1, hipMemcpyHostToDevice)); VIORB_HIP_TRY(hipMemcpy(dn2, node2, sizeof(int) * n2, hipMemcpyHostToDevice));
+    int rc = viorb_search_for_triangulation_device(dk1, dd1, dh1, du1, dn1, dc1, dk2, dd2, dh2, du2, dn2, dc2, dF, dC, dP, intr4, scale_factors2, level_sigma2_2,
+                                                   nlevels, only_stereo, check_orientation, cap, 1, dm, dnm, nullptr);
+    if (rc != VIORB_OK) return rc;
+    VIORB_HIP_TRY(hipDeviceSynchronize());
+    VIORB_HIP_TRY(hipMemcpy(match12, dm, sizeof(int) * n1, hipMemcpyDeviceToHost));
+    VIORB_HIP_TRY(hipMemcpy(nmatches, dnm, sizeof(int), hipMemcpyDeviceToHost));
     return VIORB_OK;
 }
 

@@ -647,6 +647,102 @@ __global__ void k_synth_local_points(const viorb_keypoint* __restrict__ kps, con
     out[6] = (float)mind; out[7] = (float)maxd;
 }
 
+// ORBmatcher::Fuse(KeyFrame* pKF, const vector<MapPoint*>&, th) (reference src/ORBmatcher.cc:825-975): one thread per map point —
+// projection, image / distance / viewing-angle gates, MapPoint::PredictScale, then the best-Hamming key-frame feature of levels
+// [l-1, l] inside the window that passes the chi-square reprojection gate (5.99 mono, 7.8 stereo). best_idx[p] = that feature when
+// its distance is <= TH_LOW, else -1. The Replace / AddObservation bookkeeping is the caller's (map management). Candidates are
+// visited in KeyFrame::GetFeaturesInArea order (src/KeyFrame.cc:906-945), so the first minimum wins as in the reference.
+struct FuseArgs {
+    const viorb_keypoint* kps; const uint8_t* desc; const float* uright; const int* count; const int* cell_start; const int* cell_idx;
+    const float* pose12; const float* pts_f; const uint8_t* pts_valid; const uint8_t* pts_desc; const int* pts_count;
+    int* best_idx; int* nfused;
+    int cap, pcap, nlevels;
+    float minX, maxX, minY, maxY, wInv, hInv, fx, fy, cx, cy, bf, th, log_sf;
+    float scale[16], inv_sigma2[16];
+};
+__global__ __launch_bounds__(256) void k_fuse(FuseArgs A) {
+    __shared__ int s_n;
+    const int b = blockIdx.x, t = threadIdx.x, cap = A.cap, pcap = A.pcap;
+    const int npts = min(A.pts_count[b], pcap);
+    const float* P = A.pose12 + (size_t)b * 12;
+    const viorb_keypoint* kp = A.kps + (size_t)b * cap;
+    const int* cs = A.cell_start + (size_t)b * (GRID_CELLS + 1);
+    const int* ci = A.cell_idx + (size_t)b * cap;
+    if (t == 0) s_n = 0;
+    __syncthreads();
+    float Ow[3];
+#pragma unroll
+    for (int r = 0; r < 3; r++) { const float tt = P[r] * P[9] + P[3 + r] * P[10] + P[6 + r] * P[11]; Ow[r] = -tt; }
+    int mine = 0;
+    for (int i = t; i < pcap; i += blockDim.x) {
+        int best = -1;
+        if (i < npts && A.pts_valid[(size_t)b * pcap + i]) {
+            const float* X = A.pts_f + ((size_t)b * pcap + i) * 8;
+            float pc[3];
+#pragma unroll
+            for (int r = 0; r < 3; r++) { const float tt = P[3 * r] * X[0] + P[3 * r + 1] * X[1] + P[3 * r + 2] * X[2]; pc[r] = tt + P[9 + r]; }
+            bool ok = !(pc[2] < 0.0f);
+            const float invz = 1.0f / pc[2];
+            const float x = pc[0] * invz, y = pc[1] * invz;
+            const float u = A.fx * x + A.cx, v = A.fy * y + A.cy;
+            ok = ok && (u >= A.minX && u < A.maxX && v >= A.minY && v < A.maxY);
+            const float ur = u - A.bf * invz;
+            const float maxD = 1.2f * X[7], minD = 0.8f * X[6];
+            const float PO0 = X[0] - Ow[0], PO1 = X[1] - Ow[1], PO2 = X[2] - Ow[2];
+            const float dist3D = (float)sqrt((double)PO0 * PO0 + (double)PO1 * PO1 + (double)PO2 * PO2);
+            ok = ok && !(dist3D < minD || dist3D > maxD);
+            const double dotp = (double)PO0 * X[3] + (double)PO1 * X[4] + (double)PO2 * X[5];
+            ok = ok && !(dotp < 0.5 * (double)dist3D);
+            if (ok) {
+                const float ratio = X[7] / dist3D;
+                int lvl = (int)ceilf(viorb_logf(ratio) / A.log_sf);
+                lvl = lvl < 0 ? 0 : (lvl >= A.nlevels ? A.nlevels - 1 : lvl);
+                const float radius = A.th * A.scale[lvl];
+                const int x0 = max(0, (int)floorf((u - A.minX - radius) * A.wInv));
+                const int x1 = min((int)GRID_COLS - 1, (int)ceilf((u - A.minX + radius) * A.wInv));
+                const int y0 = max(0, (int)floorf((v - A.minY - radius) * A.hInv));
+                const int y1 = min((int)GRID_ROWS - 1, (int)ceilf((v - A.minY + radius) * A.hInv));
+                if (x0 < GRID_COLS && x1 >= 0 && y0 < GRID_ROWS && y1 >= 0) {
+                    const uint4* dl = reinterpret_cast<const uint4*>(A.pts_desc + ((size_t)b * pcap + i) * 32);
+                    const uint4 da = dl[0], db = dl[1];
+                    int bestDist = 256;
+                    for (int ix = x0; ix <= x1; ix++) {
+                        const int pbeg = cs[ix * GRID_ROWS + y0], pend = cs[ix * GRID_ROWS + y1 + 1];
+                        for (int q = pbeg; q < pend; q++) {
+                            const int idx = ci[q];
+                            const viorb_keypoint k = kp[idx];
+                            if (!(fabsf(k.x - u) < radius && fabsf(k.y - v) < radius)) continue;
+                            const int kl = k.octave;
+                            if (kl < lvl - 1 || kl > lvl) continue;
+                            const float kr = A.uright[(size_t)b * cap + idx];
+                            const float ex = u - k.x, ey = v - k.y;
+                            if (kr >= 0) {
+                                const float er = ur - kr;
+                                const float e2 = ex * ex + ey * ey + er * er;
+                                if ((double)(e2 * A.inv_sigma2[kl]) > 7.8) continue;
+                            } else {
+                                const float e2 = ex * ex + ey * ey;
+                                if ((double)(e2 * A.inv_sigma2[kl]) > 5.99) continue;
+                            }
+                            const uint4* dc = reinterpret_cast<const uint4*>(A.desc + ((size_t)b * cap + idx) * 32);
+                            const uint4 ea = dc[0], eb = dc[1];
+                            const int dist = __popc(da.x ^ ea.x) + __popc(da.y ^ ea.y) + __popc(da.z ^ ea.z) + __popc(da.w ^ ea.w) +
+                                             __popc(db.x ^ eb.x) + __popc(db.y ^ eb.y) + __popc(db.z ^ eb.z) + __popc(db.w ^ eb.w);
+                            if (dist < bestDist) { bestDist = dist; best = idx; }
+                        }
+                    }
+                    if (bestDist > 50) best = -1;                       // TH_LOW
+                }
+            }
+        }
+        A.best_idx[(size_t)b * pcap + i] = best;
+        mine += best >= 0;
+    }
+    if (mine) atomicAdd(&s_n, mine);
+    __syncthreads();
+    if (t == 0) A.nfused[b] = s_n;
+}
+
 // "mLastFrame = Frame(mCurrentFrame)" (reference src/Tracking.cc, end of Track()) for the batched harness, in ONE launch: the
 // outgoing last frame's map points enter the local map (newest first, older slots shift back), the current frame's keypoints and
 // descriptors become the last frame's, and the per-stream scalars (NavState, prior, time stamp, marginal) are carried over.
@@ -1592,6 +1688,28 @@ int viorb_frontend_roll_device(viorb_frontend* h, const viorb_keypoint* cur_kps,
     return VIORB_OK;
 }
 
+int viorb_frontend_fuse_device(viorb_frontend* h, const viorb_keypoint* kps, const uint8_t* desc, const float* uright, const int32_t* count,
+                               const int32_t* cell_start, const int32_t* cell_idx, const float* pose12, const float* pts_f,
+                               const uint8_t* pts_valid, const uint8_t* pts_desc, const int32_t* pts_count, int pcap, float th, float bf, int batch,
+                               int32_t* best_idx, int32_t* nfused, void* stream) {
+    FE_CHECK_BATCH(h, batch);
+    VIORB_REQUIRE(kps && desc && uright && count && cell_start && cell_idx && pose12 && pts_f && pts_valid && pts_desc && pts_count && best_idx && nfused,
+                  "null array");
+    VIORB_REQUIRE(pcap >= 1, "pcap >= 1");
+    FuseArgs A;
+    A.kps = kps; A.desc = desc; A.uright = uright; A.count = count; A.cell_start = cell_start; A.cell_idx = cell_idx; A.pose12 = pose12;
+    A.pts_f = pts_f; A.pts_valid = pts_valid; A.pts_desc = pts_desc; A.pts_count = pts_count; A.best_idx = best_idx; A.nfused = nfused;
+    A.cap = h->cap; A.pcap = pcap; A.nlevels = h->cfg.nlevels;
+    A.minX = h->cfg.min_x; A.maxX = h->cfg.max_x; A.minY = h->cfg.min_y; A.maxY = h->cfg.max_y; A.wInv = h->wInv; A.hInv = h->hInv;
+    A.fx = h->cfg.fx; A.fy = h->cfg.fy; A.cx = h->cfg.cx; A.cy = h->cfg.cy; A.bf = bf; A.th = th;
+    A.log_sf = (float)log((double)h->cfg.scale_factors[h->cfg.nlevels > 1 ? 1 : 0]);
+    for (int i = 0; i < 16; i++) { A.scale[i] = h->cfg.scale_factors[i]; A.inv_sigma2[i] = h->cfg.inv_level_sigma2[i]; }
+    ProfScope ps("k_fuse", (hipStream_t)stream);
+    hipLaunchKernelGGL(k_fuse, dim3(batch), dim3(256), 0, (hipStream_t)stream, A);
+    VIORB_HIP_TRY(hipGetLastError());
+    return VIORB_OK;
+}
+
 int viorb_frontend_pose_opt_device(viorb_frontend* h, int variant, int compute_marg, const double* cur_ns, const double* last_ns,
                                    const double* prior_ns, const double* marg_cov_inv, const double* preint, const double* obs_cur,
                                    const int32_t* n_cur, const double* obs_last, const int32_t* n_last, int batch, double* out_ns,
@@ -1712,6 +1830,36 @@ int viorb_search_by_projection_frame(const viorb_keypoint* cur_kps, const uint8_
     VIORB_HIP_TRY(hipMemcpy(nmatches, d_nm, sizeof(int), hipMemcpyDeviceToHost));
     VIORB_HIP_TRY(hipMemcpy(&st, d_st, sizeof(int), hipMemcpyDeviceToHost));
     if (st != VIORB_OK) { set_error("more than %d grid candidates for one point", (int)CAND_CAP); return st; }
+    return VIORB_OK;
+}
+
+int viorb_fuse(const viorb_keypoint* kps, const uint8_t* desc, const float* uright, int n, const float bounds4[4], const float pose12[12],
+               const float intr5[5], const float* scale_factors, const float* inv_level_sigma2, int nlevels, const float* pts_f,
+               const uint8_t* pts_valid, const uint8_t* pts_desc, int npts, float th, int32_t* best_idx, int* nfused) {
+    VIORB_REQUIRE(bounds4 && pose12 && intr5 && scale_factors && inv_level_sigma2 && nfused && n >= 0 && npts >= 0, "null array");
+    VIORB_REQUIRE(nlevels >= 1 && nlevels <= 16, "nlevels must be 1..16");
+    *nfused = 0;
+    for (int i = 0; i < npts; i++) best_idx[i] = -1;
+    if (n == 0 || npts == 0) return VIORB_OK;
+    VIORB_REQUIRE(kps && desc && uright && pts_f && pts_valid && pts_desc && best_idx, "null array");
+    viorb_frontend_config c = default_cfg();
+    c.min_x = bounds4[0]; c.max_x = bounds4[1]; c.min_y = bounds4[2]; c.max_y = bounds4[3];
+    c.fx = intr5[0]; c.fy = intr5[1]; c.cx = intr5[2]; c.cy = intr5[3];
+    c.nlevels = nlevels;
+    for (int i = 0; i < 16; i++) { c.scale_factors[i] = scale_factors[i < nlevels ? i : nlevels - 1]; c.inv_level_sigma2[i] = inv_level_sigma2[i < nlevels ? i : nlevels - 1]; }
+    viorb_frontend* h = nullptr;
+    FE_TRY(viorb_frontend_create(&c, 1, n, 0, &h));
+    struct Guard { viorb_frontend* h; ~Guard() { viorb_frontend_destroy(h); } } g{h};
+    DevBuf B; viorb_keypoint* d_k; uint8_t *d_d, *d_pv, *d_pd; float *d_ur, *d_pose, *d_pf; int *d_c, *d_cs, *d_ci, *d_pc, *d_bi, *d_nf;
+    FE_TRY(B.up(&d_k, kps, (size_t)n)); FE_TRY(B.up(&d_d, desc, (size_t)n * 32)); FE_TRY(B.up(&d_ur, uright, (size_t)n));
+    FE_TRY(B.up(&d_pose, pose12, 12)); FE_TRY(B.up(&d_c, &n, 1)); FE_TRY(B.up(&d_cs, (const int*)nullptr, GRID_CELLS + 1)); FE_TRY(B.up(&d_ci, (const int*)nullptr, (size_t)n));
+    FE_TRY(B.up(&d_pf, pts_f, (size_t)npts * 8)); FE_TRY(B.up(&d_pv, pts_valid, (size_t)npts)); FE_TRY(B.up(&d_pd, pts_desc, (size_t)npts * 32));
+    FE_TRY(B.up(&d_pc, &npts, 1)); FE_TRY(B.up(&d_bi, (const int*)nullptr, (size_t)npts)); FE_TRY(B.up(&d_nf, (const int*)nullptr, 1));
+    FE_TRY(viorb_frontend_grid_device(h, d_k, d_c, 1, d_cs, d_ci, nullptr));
+    FE_TRY(viorb_frontend_fuse_device(h, d_k, d_d, d_ur, d_c, d_cs, d_ci, d_pose, d_pf, d_pv, d_pd, d_pc, npts, th, intr5[4], 1, d_bi, d_nf, nullptr));
+    VIORB_HIP_TRY(hipDeviceSynchronize());
+    VIORB_HIP_TRY(hipMemcpy(best_idx, d_bi, sizeof(int) * npts, hipMemcpyDeviceToHost));
+    VIORB_HIP_TRY(hipMemcpy(nfused, d_nf, sizeof(int), hipMemcpyDeviceToHost));
     return VIORB_OK;
 }
 

@@ -147,6 +147,32 @@ def SearchByBoW(kf_kps, kf_desc, kf_node, kf_has_point, f_kps, f_desc, f_node, n
     return n.value, m[:len(fk)]
 
 
+def SearchForTriangulation(k1, d1, has_point1, uright1, node1, k2, d2, has_point2, uright2, node2, F12, Cw1, pose12_2, intr4, scale_factors2,
+                           level_sigma2_2, only_stereo=False, check_orientation=True):
+    """ORBmatcher::SearchForTriangulation (reference src/ORBmatcher.cc:657-823), host buffers. Returns (nmatches, match12[N1])."""
+    k1 = np.ascontiguousarray(k1, capi.KP_DTYPE); k2 = np.ascontiguousarray(k2, capi.KP_DTYPE)
+    u8 = lambda a: np.ascontiguousarray(a, np.uint8); f32 = lambda a: np.ascontiguousarray(a, np.float32); i32 = lambda a: np.ascontiguousarray(a, np.int32)
+    sf = f32(scale_factors2)
+    m = np.full(max(len(k1), 1), -1, np.int32); n = C.c_int(0)
+    check(lib().viorb_search_for_triangulation(ptr(k1), ptr(u8(d1)), ptr(u8(has_point1)), ptr(f32(uright1)), ptr(i32(node1)), len(k1), ptr(k2), ptr(u8(d2)),
+                                               ptr(u8(has_point2)), ptr(f32(uright2)), ptr(i32(node2)), len(k2), ptr(f32(F12)), ptr(f32(Cw1)), ptr(f32(pose12_2)),
+                                               ptr(f32(intr4)), ptr(sf), ptr(f32(level_sigma2_2)), len(sf), int(only_stereo), int(check_orientation), ptr(m),
+                                               C.byref(n)))
+    return n.value, m[:len(k1)]
+
+
+def Fuse(kps, desc, uright, bounds, pose12, intr5, scale_factors, inv_level_sigma2, pts_f, pts_valid, pts_desc, th=3.0):
+    """ORBmatcher::Fuse(KeyFrame*, vpMapPoints, th) (reference src/ORBmatcher.cc:825-975), host buffers: (nFused, best_idx[npts])."""
+    kps = np.ascontiguousarray(kps, capi.KP_DTYPE)
+    f32 = lambda a: np.ascontiguousarray(a, np.float32)
+    pts_f = f32(pts_f).reshape(-1, 8); sf = f32(scale_factors)
+    bi = np.full(max(len(pts_f), 1), -1, np.int32); n = C.c_int(0)
+    check(lib().viorb_fuse(ptr(kps), ptr(np.ascontiguousarray(desc, np.uint8)), ptr(f32(uright)), len(kps), ptr(f32(bounds)), ptr(f32(pose12)), ptr(f32(intr5)),
+                           ptr(sf), ptr(f32(inv_level_sigma2)), len(sf), ptr(pts_f), ptr(np.ascontiguousarray(pts_valid, np.uint8)),
+                           ptr(np.ascontiguousarray(pts_desc, np.uint8)), len(pts_f), float(th), ptr(bi), C.byref(n)))
+    return n.value, bi[:len(pts_f)]
+
+
 class Frontend:
     """Batched device-resident front-end: every method only enqueues kernels on the given torch stream."""
 

@@ -523,3 +523,63 @@ def descriptors_near_words(seed, voc, n, noise_bits=6):
         b = rng.integers(0, 256, n)
         d[np.arange(n), b >> 3] ^= (1 << (b & 7)).astype(np.uint8)
     return d
+
+
+KP_NP = np.dtype([("x", "f4"), ("y", "f4"), ("size", "f4"), ("angle", "f4"), ("response", "f4"), ("octave", "i4"), ("class_id", "i4")])   # == viorb_keypoint / cv::KeyPoint
+
+
+def make_two_view_problem(seed, n1=900, n2=950, n_common=500, stereo_frac=0.0, w=752, h=480):
+    """Two key frames observing a 3-D point cloud, for SearchForTriangulation / Fuse: keypoints (float32 pixel positions with octave
+    and angle), descriptors (noisy copies for common points), vocabulary-like node ids (common points share a node), has_point
+    flags, the fundamental matrix F12 (x1^T F12 x2 = 0, as ORB-SLAM's ComputeF12), poses and camera centre. numpy only."""
+    rng = np.random.Generator(np.random.PCG64(seed + 31337))
+    fx, fy, cx, cy = [np.float32(v) for v in (EUROC_K["fx"], EUROC_K["fy"], EUROC_K["cx"], EUROC_K["cy"])]
+    K = np.array([[fx, 0, cx], [0, fy, cy], [0, 0, 1]], np.float64)
+    R1 = _rotvec_to_R(rng.normal(0, 0.05, 3)); t1 = rng.normal(0, 0.05, 3)
+    R2 = _rotvec_to_R(rng.normal(0, 0.08, 3)) @ R1; t2 = t1 + np.array([0.35, 0.05, 0.02]) + rng.normal(0, 0.02, 3)
+    def project(R, t, X):
+        Pc = (R @ X.T).T + t
+        return np.stack([fx * Pc[:, 0] / Pc[:, 2] + cx, fy * Pc[:, 1] / Pc[:, 2] + cy], 1), Pc[:, 2]
+    # common 3-D points in front of both cameras
+    X = np.stack([rng.uniform(-3, 3, 4 * n_common), rng.uniform(-2, 2, 4 * n_common), rng.uniform(3, 12, 4 * n_common)], 1)
+    uv1, z1 = project(R1, t1, X); uv2, z2 = project(R2, t2, X)
+    ok = (z1 > 0.5) & (z2 > 0.5) & (uv1[:, 0] > 20) & (uv1[:, 0] < w - 20) & (uv1[:, 1] > 20) & (uv1[:, 1] < h - 20) & \
+         (uv2[:, 0] > 20) & (uv2[:, 0] < w - 20) & (uv2[:, 1] > 20) & (uv2[:, 1] < h - 20)
+    X, uv1, uv2 = X[ok][:n_common], uv1[ok][:n_common], uv2[ok][:n_common]
+    nc = len(X)
+    sf = (np.float32(1.2) ** np.arange(8)).astype(np.float32)
+    def frame(n, uvc, salt):
+        r = np.random.Generator(np.random.PCG64(seed * 13 + salt))
+        k = np.zeros(n, KP_NP)
+        k["x"][:nc] = uvc[:, 0] + r.normal(0, 0.7, nc); k["y"][:nc] = uvc[:, 1] + r.normal(0, 0.7, nc)
+        k["x"][nc:] = r.uniform(20, w - 20, n - nc); k["y"][nc:] = r.uniform(20, h - 20, n - nc)
+        k["octave"] = r.integers(0, 8, n); k["angle"] = r.uniform(0, 360, n); k["size"] = 31 * sf[k["octave"]]; k["class_id"] = -1
+        return k
+    k1 = frame(n1, uv1, 1); k2 = frame(n2, uv2, 2)
+    k2["octave"][:nc] = np.clip(k1["octave"][:nc] + rng.integers(-1, 2, nc), 0, 7)
+    k2["angle"][:nc] = (k1["angle"][:nc] + rng.choice([8.0, 8.0, 8.0, 200.0], nc) + rng.normal(0, 3, nc)) % 360
+    d1 = rng.integers(0, 256, (n1, 32), dtype=np.uint8); d2 = rng.integers(0, 256, (n2, 32), dtype=np.uint8)
+    d2[:nc] = d1[:nc]
+    for _ in range(14):
+        b = rng.integers(0, 256, nc); d2[np.arange(nc), b >> 3] ^= (1 << (b & 7)).astype(np.uint8)
+    node1 = rng.integers(0, 60, n1).astype(np.int32); node2 = rng.integers(0, 60, n2).astype(np.int32)
+    node2[:nc] = node1[:nc]
+    node1[rng.random(n1) < 0.02] = -1
+    hp1 = (rng.random(n1) < 0.35).astype(np.uint8); hp2 = (rng.random(n2) < 0.35).astype(np.uint8)
+    ur1 = np.where(rng.random(n1) < stereo_frac, k1["x"] - 20.0, -1.0).astype(np.float32)
+    ur2 = np.where(rng.random(n2) < stereo_frac, k2["x"] - 20.0, -1.0).astype(np.float32)
+    p1 = rng.permutation(n1); p2 = rng.permutation(n2)
+    inv2 = np.empty(n2, np.int64); inv2[p2] = np.arange(n2)
+    truth = np.full(n1, -1, np.int64); truth[:nc] = np.arange(nc)
+    truth = np.where(truth >= 0, inv2[np.maximum(truth, 0)], -1)[p1]
+    k1, d1, node1, hp1, ur1 = k1[p1], d1[p1], node1[p1], hp1[p1], ur1[p1]
+    k2, d2, node2, hp2, ur2 = k2[p2], d2[p2], node2[p2], hp2[p2], ur2[p2]
+    # F12 = K^-T [t12]x R12 K^-1 with R12 = R1 R2^T, t12 = -R1 R2^T t2 + t1 (LocalMapping::ComputeF12), float32 like the cv::Mat
+    R12 = R1 @ R2.T; t12 = -R12 @ t2 + t1
+    tx = np.array([[0, -t12[2], t12[1]], [t12[2], 0, -t12[0]], [-t12[1], t12[0], 0]])
+    F12 = (np.linalg.inv(K).T @ tx @ R12 @ np.linalg.inv(K)).astype(np.float32)
+    Cw1 = (-R1.T @ t1).astype(np.float32)
+    pose2 = np.concatenate([R2.ravel(), t2]).astype(np.float32); pose1 = np.concatenate([R1.ravel(), t1]).astype(np.float32)
+    return dict(k1=k1, d1=d1, node1=node1, hp1=hp1, ur1=ur1, k2=k2, d2=d2, node2=node2, hp2=hp2, ur2=ur2, F12=F12, Cw1=Cw1, pose1=pose1,
+                pose2=pose2, intr4=np.array([fx, fy, cx, cy], np.float32), sf=sf, level_sigma2=(sf * sf).astype(np.float32),
+                inv_level_sigma2=(np.float32(1) / (sf * sf)).astype(np.float32), truth12=truth, X=X)
