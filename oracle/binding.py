@@ -464,3 +464,18 @@ def fuse(kps, desc, uright, bounds, pose12, intr5, scale_factors, inv_level_sigm
                    _p(sf), _p(f32(inv_level_sigma2)), len(sf), float(log_scale_factor), len(pts_f), _p(pts_f), _p(np.ascontiguousarray(pts_valid, np.uint8)),
                    _p(np.ascontiguousarray(pts_desc, np.uint8)), float(th), _p(bi))
     return n, bi[:len(pts_f)]
+
+
+def local_ba_se3(kfs, n_local, points, edge_idx, edge_obs, intr5, stop=None):
+    """Vision-only Optimizer::LocalBundleAdjustment. kfs [NK,7] = qx qy qz qw tx ty tz (Tcw), free ones first; points [NP,3];
+    edge_idx [NE,2] int32 (point, kf) grouped by point; edge_obs [NE,4] = u v uRight(<0 mono) invSigma2; intr5 = fx fy cx cy bf."""
+    L = lib()
+    L.ora_local_ba_se3.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 6
+    kfs = _f64(kfs).reshape(-1, 7); points = _f64(points).reshape(-1, 3)
+    ei = np.ascontiguousarray(edge_idx, np.int32).reshape(-1, 2); eo = _f64(edge_obs).reshape(-1, 4)
+    ko, po = np.zeros((n_local, 7)), np.zeros_like(points)
+    er, info = np.zeros(max(len(ei), 1), np.uint8), np.zeros(6)
+    st = np.ascontiguousarray(stop, np.int32) if stop is not None else None
+    L.ora_local_ba_se3(_p(kfs), len(kfs), n_local, _p(points), len(points), _p(ei), _p(eo), len(ei), _p(_f64(intr5, 5)), _p(st) if st is not None else None,
+                       _p(ko), _p(po), _p(er), _p(info))
+    return dict(kfs=ko, points=po, erase=er[:len(ei)], chi2_first=info[0], chi2_final=info[1], its_first=int(info[2]), its_second=int(info[3]))

@@ -396,3 +396,22 @@ int ora_fuse(const ora::KeyPoint* kps, const uint8_t* desc, const float* uright,
     return nf;
 }
 } // extern "C"
+
+#include "local_ba_se3.h"
+extern "C" {
+// kfs[nk][7] = qx qy qz qw tx ty tz (g2o::SE3Quat of Tcw); edge_idx[ne][2] = (point, kf); edge_obs[ne][4] = u v ur invSigma2; intr5 = fx fy cx cy bf
+int ora_local_ba_se3(const double* kfs, int nk, int n_local, const double* points, int np, const int* edge_idx, const double* edge_obs, int ne,
+                     const double* intr5, const int* stop, double* kfs_out, double* points_out, uint8_t* erase, double* info) {
+    ora::BaSe3Problem P; P.n_local = n_local; P.fx = intr5[0]; P.fy = intr5[1]; P.cx = intr5[2]; P.cy = intr5[3]; P.bf = intr5[4];
+    P.kfs.resize(nk);
+    for (int i = 0; i < nk; i++) { const double* k = kfs + 7 * i; P.kfs[i].r = ora::Quat{k[0], k[1], k[2], k[3]}; P.kfs[i].t = ora::V3{k[4], k[5], k[6]}; }
+    P.points.resize(np); for (int i = 0; i < np; i++) P.points[i] = ora::V3{points[3 * i], points[3 * i + 1], points[3 * i + 2]};
+    P.edges.resize(ne); for (int k = 0; k < ne; k++) P.edges[k] = ora::BaSe3Edge{edge_idx[2 * k], edge_idx[2 * k + 1], edge_obs[4 * k], edge_obs[4 * k + 1], edge_obs[4 * k + 2], edge_obs[4 * k + 3]};
+    const ora::BaSe3Result R = ora::local_ba_se3(P, stop);
+    for (int i = 0; i < n_local; i++) { double* k = kfs_out + 7 * i; k[0] = R.kfs[i].r.x; k[1] = R.kfs[i].r.y; k[2] = R.kfs[i].r.z; k[3] = R.kfs[i].r.w; k[4] = R.kfs[i].t.x; k[5] = R.kfs[i].t.y; k[6] = R.kfs[i].t.z; }
+    for (int i = 0; i < np; i++) { points_out[3 * i] = R.points[i].x; points_out[3 * i + 1] = R.points[i].y; points_out[3 * i + 2] = R.points[i].z; }
+    for (int k = 0; k < ne; k++) erase[k] = R.erase[k];
+    info[0] = R.chi2_after_first; info[1] = R.chi2_final; info[2] = R.its_first; info[3] = R.its_second;
+    return 0;
+}
+} // extern "C"

@@ -97,3 +97,44 @@ def test_local_ba_stop_flag(oracle):
     np.testing.assert_array_equal(r["kfs"], p["kfs"][:5])                       # aborted before the first iteration
     np.testing.assert_array_equal(r["points"], p["points"])
     assert r["its_first"] == 0 and r["its_second"] == 0
+
+
+def test_local_ba_se3_recovers_truth_and_is_the_optimum(oracle):
+    """Vision-only LocalBundleAdjustment (oracle/local_ba_se3.cpp): recovers the synthetic truth, flags the planted outliers, and its
+    final estimate is the optimum of the final objective (plain least squares over the kept edges, re-optimised densely with scipy)."""
+    from viorb_amd.synth import make_local_ba_se3_problem
+    p = make_local_ba_se3_problem(1, W=4, n_fixed=2, n_points=70)
+    r = oracle.local_ba_se3(p["kfs"], p["n_local"], p["points"], p["edge_idx"], p["edge_obs"], p["intr5"])
+    W = p["n_local"]
+    e0 = np.linalg.norm(p["kfs"][:W, 4:] - p["kfs_true"][:W, 4:], axis=1).mean(); e1 = np.linalg.norm(r["kfs"][:, 4:] - p["kfs_true"][:W, 4:], axis=1).mean()
+    assert e1 < 0.5 * e0 and 1 <= r["its_first"] <= 5 and 1 <= r["its_second"] <= 10 and r["chi2_final"] < r["chi2_first"]
+    assert 0.02 * len(r["erase"]) < r["erase"].sum() < 0.2 * len(r["erase"])
+    fx, fy, cx, cy, bf = p["intr5"]
+    keep = r["erase"] == 0
+    ei, eo = p["edge_idx"][keep], p["edge_obs"][keep]
+    kf_all = p["kfs"].copy(); kf_all[:W] = r["kfs"]
+
+    def resid(x):
+        out = []
+        Rs, ts = [], []
+        for i in range(len(kf_all)):
+            R = Rotation.from_quat(kf_all[i, :4]).as_matrix(); t = kf_all[i, 4:]
+            if i < W:
+                dR = Rotation.from_rotvec(x[6 * i:6 * i + 3]).as_matrix(); R = dR @ R; t = dR @ t + x[6 * i + 3:6 * i + 6]
+            Rs.append(R); ts.append(t)
+        pts = r["points"] + x[6 * W:].reshape(-1, 3)
+        for (pi, ki), (u, v, ur, w) in zip(ei, eo):
+            Pc = Rs[ki] @ pts[pi] + ts[ki]
+            out += [(u - (fx * Pc[0] / Pc[2] + cx)) * np.sqrt(w), (v - (fy * Pc[1] / Pc[2] + cy)) * np.sqrt(w)]
+            if ur >= 0:
+                out.append((ur - (fx * Pc[0] / Pc[2] + cx - bf / Pc[2])) * np.sqrt(w))
+        return np.array(out)
+
+    x0 = np.zeros(6 * W + 3 * len(r["points"]))
+    c0 = (resid(x0) ** 2).sum()
+    sol = least_squares(resid, x0, method="trf", x_scale="jac", xtol=1e-12, ftol=1e-12, gtol=1e-12, max_nfev=30)
+    c1 = (sol.fun ** 2).sum()
+    assert c1 <= c0 * (1 + 1e-9) and (c0 - c1) <= 2e-3 * c0, (c0, c1)      # g2o stops on its 1e-3 relative-gain rule: within a few 1e-4 of the optimum
+    stop = np.ones(1, np.int32)
+    r2 = oracle.local_ba_se3(p["kfs"], p["n_local"], p["points"], p["edge_idx"], p["edge_obs"], p["intr5"], stop=stop)
+    assert np.array_equal(r2["kfs"], p["kfs"][:W]) and r2["its_first"] == 0

@@ -583,3 +583,57 @@ def make_two_view_problem(seed, n1=900, n2=950, n_common=500, stereo_frac=0.0, w
     return dict(k1=k1, d1=d1, node1=node1, hp1=hp1, ur1=ur1, k2=k2, d2=d2, node2=node2, hp2=hp2, ur2=ur2, F12=F12, Cw1=Cw1, pose1=pose1,
                 pose2=pose2, intr4=np.array([fx, fy, cx, cy], np.float32), sf=sf, level_sigma2=(sf * sf).astype(np.float32),
                 inv_level_sigma2=(np.float32(1) / (sf * sf)).astype(np.float32), truth12=truth, X=X)
+
+
+def make_local_ba_se3_problem(seed, W=8, n_fixed=3, n_points=600, stereo_frac=0.5, outlier_frac=0.05, pix_sigma=1.5, w=1241, h=376):
+    """A vision-only LocalBundleAdjustment problem (KITTI-shaped camera): W free key frames + n_fixed fixed ones on a forward-moving
+    trajectory, points seen by 3..7 key frames, a mix of mono and stereo observations, Gaussian pixel noise and gross outliers.
+    Returns flat arrays (kfs [NK,7] = qx qy qz qw tx ty tz of Tcw, free first) + truth."""
+    from scipy.spatial.transform import Rotation
+    rng = np.random.Generator(np.random.PCG64(seed + 9090))
+    fx = fy = 718.856; cx, cy, bf = 607.1928, 185.2157, 386.1448
+    nk = W + n_fixed
+    poses = []
+    p = np.zeros(3); yaw = 0.0
+    for k in range(nk):
+        Rwc = Rotation.from_euler("y", yaw).as_matrix() @ _rotvec_to_R(rng.normal(0, 0.01, 3))
+        poses.append((Rwc.T, -Rwc.T @ p))                                     # Tcw
+        p = p + Rwc @ np.array([rng.normal(0, 0.05), rng.normal(0, 0.02), 0.8 + rng.normal(0, 0.1)]); yaw += rng.normal(0, 0.03)
+    order = list(range(n_fixed, nk)) + list(range(n_fixed))                   # free (recent) key frames first, then the fixed (older) ones
+    poses = [poses[i] for i in order]
+    pts, ei, eo = [], [], []
+    sf = np.float32(1.2) ** np.arange(8)
+    while len(pts) < n_points:
+        k0 = int(rng.integers(0, nk)); Rk, tk = poses[k0]
+        z = rng.uniform(4, 40); Xc = np.array([(rng.uniform(20, w - 20) - cx) / fx * z, (rng.uniform(20, h - 20) - cy) / fy * z, z])
+        X = Rk.T @ (Xc - tk)
+        vis = []
+        for k, (R, t) in enumerate(poses):
+            Pc = R @ X + t
+            if Pc[2] < 1.0: continue
+            u, v = fx * Pc[0] / Pc[2] + cx, fy * Pc[1] / Pc[2] + cy
+            if 10 < u < w - 10 and 10 < v < h - 10: vis.append((k, u, v, Pc[2]))
+        if len(vis) < 3: continue
+        sel = sorted(rng.choice(len(vis), int(min(len(vis), rng.integers(3, 8))), replace=False))
+        pid = len(pts); pts.append(X)
+        for si in sel:
+            k, u, v, zc = vis[si]
+            octv = int(rng.integers(0, 8)); sg = pix_sigma * float(sf[octv]) / 1.5
+            ou, ov = u + rng.normal(0, sg), v + rng.normal(0, sg)
+            stereo = rng.random() < stereo_frac and zc < 35
+            our = (u - bf / zc + rng.normal(0, sg)) if stereo else -1.0
+            if rng.random() < outlier_frac: ou += rng.choice([-1, 1]) * rng.uniform(12, 25)
+            ei.append((pid, k)); eo.append((np.float32(ou), np.float32(ov), np.float32(our) if stereo else -1.0, 1.0 / float(np.float32(sf[octv]) ** 2)))
+    pts = np.array(pts)
+    def to7(R, t):
+        q = Rotation.from_matrix(R).as_quat(); q = q if q[3] >= 0 else -q
+        return np.concatenate([q, t])
+    kfs_true = np.stack([to7(R, t) for R, t in poses])
+    kfs = kfs_true.copy()
+    for i in range(W):                                                        # perturb the free key frames
+        R, t = poses[i]
+        Rp = _rotvec_to_R(rng.normal(0, 0.01, 3)) @ R
+        kfs[i] = to7(Rp, t + rng.normal(0, 0.05, 3))
+    points0 = pts + rng.normal(0, 0.1, pts.shape)
+    return dict(kfs=kfs, kfs_true=kfs_true, n_local=W, points=points0, points_true=pts, edge_idx=np.array(ei, np.int32), edge_obs=np.array(eo, np.float64),
+                intr5=np.array([fx, fy, cx, cy, bf]))
