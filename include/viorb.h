@@ -322,6 +322,16 @@ int viorb_local_ba_navstate(const double* kfs, int nk, int n_local, int prev_kf,
                             const double gw[3], const double cam[16], const volatile int* stop, double* kfs_out,
                             double* points_out, uint8_t* erase, double info[6]);
 
+/* Vision-only Optimizer::LocalBundleAdjustment (reference src/Optimizer.cc:3980-4311; BlockSolver_6_3): kfs [nk][7] = g2o::SE3Quat of
+ * each key frame's Tcw as qx qy qz qw tx ty tz (Converter::toSE3Quat), the n_local free ones first, then the fixed ones (lFixedCameras,
+ * and key frame 0 when it is local: :4055); points [np][3]; edge_idx [ne][2] = (point, key frame) sorted by point; edge_obs [ne][4] =
+ * u v uRight invSigma2 with uRight < 0 for a monocular observation (EdgeSE3ProjectXYZ / EdgeStereoSE3ProjectXYZ,
+ * Thirdparty/g2o/g2o/types/types_six_dof_expmap.cpp:66-250); intr5 = fx fy cx cy bf. Same optimize(5) / gate / optimize(10) scheme
+ * and outputs as viorb_local_ba_navstate (chi-square gates 5.991 mono, 7.815 stereo). n_local <= 40 (a 240 x 240 reduced system). */
+int viorb_local_ba_se3(const double* kfs, int nk, int n_local, const double* points, int np, const int32_t* edge_idx,
+                       const double* edge_obs, int ne, const double intr5[5], const volatile int* stop, double* kfs_out,
+                       double* points_out, uint8_t* erase, double info[6]);
+
 /* ---- Bag of words: DBoW2 vocabulary-tree descent and ORBmatcher::SearchByBoW -------------------------------------
  * viorb_vocabulary replaces ORBVocabulary (= DBoW2::TemplatedVocabulary<FORB::TDescriptor, FORB>, reference
  * include/ORBVocabulary.h:30-31) for the one call the trackers make, transform(features, BowVector, FeatureVector, 4)

@@ -62,3 +62,23 @@ def test_local_ba_stop_flag_and_argument_checks(oracle):
         LocalBundleAdjustmentNavState(p["kfs"], p["n_local"], p["prev_kf"], pre, p["points"], bad, p["edge_obs"], p["gw"], p["cam"])
     with pytest.raises(ViorbError):                                           # edges must be sorted by point
         LocalBundleAdjustmentNavState(p["kfs"], p["n_local"], p["prev_kf"], pre, p["points"], p["edge_idx"][::-1], p["edge_obs"][::-1], p["gw"], p["cam"])
+
+
+@pytest.mark.parametrize("seed,W,nfix,npts,stereo", [(1, 8, 3, 600, 0.5), (2, 4, 2, 120, 0.0), (3, 20, 5, 2000, 0.7), (4, 40, 4, 1500, 0.3), (5, 1, 3, 80, 1.0)])
+def test_local_ba_se3_matches_oracle(oracle, seed, W, nfix, npts, stereo):
+    """Vision-only LocalBundleAdjustment (viorb_local_ba_se3) against oracle/local_ba_se3.cpp."""
+    from viorb_amd import LocalBundleAdjustment
+    from viorb_amd.synth import make_local_ba_se3_problem
+    p = make_local_ba_se3_problem(seed, W=W, n_fixed=nfix, n_points=npts, stereo_frac=stereo)
+    a = (p["kfs"], p["n_local"], p["points"], p["edge_idx"], p["edge_obs"], p["intr5"])
+    ref = oracle.local_ba_se3(*a)
+    got = LocalBundleAdjustment(*a)
+    assert (got["its_first"], got["its_second"]) == (ref["its_first"], ref["its_second"])
+    assert abs(got["chi2_first"] - ref["chi2_first"]) <= 1e-5 * ref["chi2_first"]
+    assert abs(got["chi2_final"] - ref["chi2_final"]) <= 1e-5 * ref["chi2_final"]
+    assert np.array_equal(got["erase"], ref["erase"])
+    np.testing.assert_allclose(got["kfs"], ref["kfs"], rtol=0, atol=1e-7)
+    np.testing.assert_allclose(got["points"], ref["points"], rtol=0, atol=1e-5)
+    stop = np.ones(1, np.int32)
+    g2 = LocalBundleAdjustment(*a, stop=stop)
+    assert np.array_equal(g2["kfs"], p["kfs"][:W]) and g2["its_first"] == 0

@@ -64,6 +64,7 @@ SIGNATURES = {
     "viorb_frontend_pose_opt_se3_device": (i32, [vp, vp, vp, vp, C.c_double, i32, vp, vp, vp, vp]),
     "viorb_pose_opt_se3": (i32, [vp, vp, vp, i32, vp, vp, vp]),
     "viorb_local_ba_navstate": (i32, [vp, i32, i32, i32, vp, vp, i32, vp, vp, i32] + [vp] * 7),
+    "viorb_local_ba_se3": (i32, [vp, i32, i32, vp, i32, vp, vp, i32] + [vp] * 6),
     "viorb_vocabulary_create": (i32, [i32, i32, vp, vp, vp, vp, vp, PP(vp)]),
     "viorb_vocabulary_destroy": (i32, [vp]),
     "viorb_bow_transform_device": (i32, [vp, vp, vp, i32, i32, i32, vp, vp, vp, vp]),

@@ -25,6 +25,7 @@ namespace viorb {
 
 struct BaDev {
     int W, NK, NP, NE, np, ld, prev_kf;
+    int pose_dim, rows, kf_stride;  // unknowns per key frame (12: PVR+bias, 6: SE3), residual rows per edge (2, or 3 with stereo), doubles per key-frame state
     double *kf, *kf_bak;            // [NK][22]
     double *pt, *pt_bak;            // [NP][3]
     const int *e_pt, *e_kf;         // [NE]
@@ -50,6 +51,9 @@ __device__ __forceinline__ void ba_edge_geom(const BaDev& D, int k, const double
     Pc = Paux - K.RcbPbc;
 }
 __device__ __forceinline__ int ba_pred(const BaDev& D, int i) { return i == 0 ? D.prev_kf : i - 1; }
+// position, inside a key frame's block of unknowns, of the r-th of the six coordinates a reprojection edge depends on:
+// NavState block = [P V Phi | bias] -> P at 0..2, Phi at 6..8; SE3 block = [omega upsilon] -> 0..5
+__device__ __forceinline__ int ba_loc(const BaDev& D, int r) { return D.pose_dim == 12 ? (r < 3 ? r : r + 3) : r; }
 
 // residuals of the active edges + robust chi2 (mono kernel optional) + IMU / bias factors
 __global__ void k_ba_errors(BaDev D, int mono_kernel) {
@@ -125,24 +129,27 @@ __global__ void k_ba_lin_points(BaDev D, int mono_kernel) {
     for (int a = 0; a < 3; a++) D.bl[(size_t)p * 3 + a] = b[a];
 }
 
-// one workgroup per local key frame: sum of Jk^T w Jk / Jk^T w e over its active edges -> (P, Phi) block of Hpp, bp
+// one workgroup per local key frame: sum of Jk^T w Jk / Jk^T w e over its active edges -> the 6x6 reprojection block of Hpp, bp
 __global__ __launch_bounds__(256) void k_ba_hpp(BaDev D) {
     __shared__ double s_red[4][27];
-    const int i = blockIdx.x, t = threadIdx.x;
+    const int i = blockIdx.x, t = threadIdx.x, rows = D.rows;
     double a[27];
 #pragma unroll
     for (int k = 0; k < 27; k++) a[k] = 0;
     for (int q = D.kf_start[i] + t; q < D.kf_start[i + 1]; q += blockDim.x) {
         const int k = D.kf_list[q];
         if (D.level[k] != 0) continue;
-        const double* J = D.Jk + (size_t)12 * k; const double w = D.wgt[k], e0 = D.err[2 * k], e1 = D.err[2 * k + 1];
-        int c = 0;
+        const double* J = D.Jk + (size_t)6 * rows * k; const double* e = D.err + (size_t)rows * k; const double w = D.wgt[k];
+        for (int row = 0; row < rows; row++) {
+            const double* Jr = J + 6 * row; const double er = e[row];
+            int c = 0;
 #pragma unroll
-        for (int r = 0; r < 6; r++)
+            for (int r = 0; r < 6; r++)
 #pragma unroll
-            for (int cc = r; cc < 6; cc++) a[c++] += w * (J[r] * J[cc] + J[6 + r] * J[6 + cc]);
+                for (int cc = r; cc < 6; cc++) a[c++] += w * (Jr[r] * Jr[cc]);
 #pragma unroll
-        for (int r = 0; r < 6; r++) a[21 + r] -= w * (J[r] * e0 + J[6 + r] * e1);
+            for (int r = 0; r < 6; r++) a[21 + r] -= w * (Jr[r] * er);
+        }
     }
 #pragma unroll
     for (int k = 0; k < 27; k++) {
@@ -154,13 +161,13 @@ __global__ __launch_bounds__(256) void k_ba_hpp(BaDev D) {
     __syncthreads();
     if (t < 27) {
         const double v = s_red[0][t] + s_red[1][t] + s_red[2][t] + s_red[3][t];
-        const int base = 12 * i, loc[6] = {0, 1, 2, 6, 7, 8}, n = D.np;
+        const int base = D.pose_dim * i, n = D.np;
         if (t < 21) {
             int kk = 0, rr = 0, cc = 0;
             for (int r = 0; r < 6; r++) for (int c = r; c < 6; c++) { if (kk == t) { rr = r; cc = c; } kk++; }
-            atomicAdd(&D.Hpp[(size_t)(base + loc[rr]) * n + base + loc[cc]], v);
-            if (rr != cc) atomicAdd(&D.Hpp[(size_t)(base + loc[cc]) * n + base + loc[rr]], v);
-        } else atomicAdd(&D.bp[base + loc[t - 21]], v);
+            atomicAdd(&D.Hpp[(size_t)(base + ba_loc(D, rr)) * n + base + ba_loc(D, cc)], v);
+            if (rr != cc) atomicAdd(&D.Hpp[(size_t)(base + ba_loc(D, cc)) * n + base + ba_loc(D, rr)], v);
+        } else atomicAdd(&D.bp[base + ba_loc(D, t - 21)], v);
     }
 }
 
@@ -244,7 +251,7 @@ __global__ void k_ba_dinv(BaDev D, double lambda) {
 // and bs without global atomics (rows of key frame a belong to this workgroup alone).
 __global__ __launch_bounds__(256) void k_ba_schur(BaDev D) {
     __shared__ double s_row[6][240], s_b[6];
-    const int ka = blockIdx.x, t = threadIdx.x, ld = D.ld, ncol = 12 * (ka + 1);
+    const int ka = blockIdx.x, t = threadIdx.x, ld = D.ld, rows = D.rows, pd = D.pose_dim, ncol = pd * (ka + 1);
     for (int q = t; q < 6 * 240; q += blockDim.x) (&s_row[0][0])[q] = 0.0;
     if (t < 6) s_b[t] = 0.0;
     __syncthreads();
@@ -253,22 +260,26 @@ __global__ __launch_bounds__(256) void k_ba_schur(BaDev D) {
         if (D.level[ea] != 0) continue;
         const int p = D.e_pt[ea];
         const double* Di = D.Dinv + (size_t)p * 9;
-        const double* Ja = D.Jk + (size_t)12 * ea; const double* Pa = D.Jp + (size_t)6 * ea; const double wa = D.wgt[ea];
+        const double* Ja = D.Jk + (size_t)6 * rows * ea; const double* Pa = D.Jp + (size_t)3 * rows * ea; const double wa = D.wgt[ea];
         double BD[18];
 #pragma unroll
         for (int r = 0; r < 6; r++) {
-            const double w0 = wa * (Ja[r] * Pa[0] + Ja[6 + r] * Pa[3]), w1 = wa * (Ja[r] * Pa[1] + Ja[6 + r] * Pa[4]), w2 = wa * (Ja[r] * Pa[2] + Ja[6 + r] * Pa[5]);
+            double w0 = 0, w1 = 0, w2 = 0;
+            for (int row = 0; row < rows; row++) { const double j = Ja[6 * row + r]; w0 += j * Pa[3 * row]; w1 += j * Pa[3 * row + 1]; w2 += j * Pa[3 * row + 2]; }
+            w0 *= wa; w1 *= wa; w2 *= wa;
             BD[r * 3] = w0 * Di[0] + w1 * Di[1] + w2 * Di[2]; BD[r * 3 + 1] = w0 * Di[3] + w1 * Di[4] + w2 * Di[5]; BD[r * 3 + 2] = w0 * Di[6] + w1 * Di[7] + w2 * Di[8];
             atomicAdd(&s_b[r], -(w0 * D.db[3 * p] + w1 * D.db[3 * p + 1] + w2 * D.db[3 * p + 2]));
         }
         for (int eb = D.pt_start[p]; eb < D.pt_start[p + 1]; eb++) {
             const int kb = D.e_kf[eb];
             if (D.level[eb] != 0 || kb > ka) continue;                   // kb > ka: the transposed block, accumulated by key frame kb's workgroup
-            const double* Jb = D.Jk + (size_t)12 * eb; const double* Pb = D.Jp + (size_t)6 * eb; const double wb = D.wgt[eb];
+            const double* Jb = D.Jk + (size_t)6 * rows * eb; const double* Pb = D.Jp + (size_t)3 * rows * eb; const double wb = D.wgt[eb];
 #pragma unroll
             for (int cc = 0; cc < 6; cc++) {
-                const double w0 = wb * (Jb[cc] * Pb[0] + Jb[6 + cc] * Pb[3]), w1 = wb * (Jb[cc] * Pb[1] + Jb[6 + cc] * Pb[4]), w2 = wb * (Jb[cc] * Pb[2] + Jb[6 + cc] * Pb[5]);
-                const int col = 12 * kb + (cc < 3 ? cc : cc + 3);
+                double w0 = 0, w1 = 0, w2 = 0;
+                for (int row = 0; row < rows; row++) { const double j = Jb[6 * row + cc]; w0 += j * Pb[3 * row]; w1 += j * Pb[3 * row + 1]; w2 += j * Pb[3 * row + 2]; }
+                w0 *= wb; w1 *= wb; w2 *= wb;
+                const int col = pd * kb + ba_loc(D, cc);
 #pragma unroll
                 for (int r = 0; r < 6; r++) atomicAdd(&s_row[r][col], -(BD[r * 3] * w0 + BD[r * 3 + 1] * w1 + BD[r * 3 + 2] * w2));
             }
@@ -276,10 +287,10 @@ __global__ __launch_bounds__(256) void k_ba_schur(BaDev D) {
     }
     __syncthreads();
     for (int q = t; q < 6 * ncol; q += blockDim.x) {
-        const int r = q / ncol, c = q - r * ncol, row = 12 * ka + (r < 3 ? r : r + 3);
+        const int r = q / ncol, c = q - r * ncol, row = pd * ka + ba_loc(D, r);
         if (c <= row) D.S[(size_t)row * ld + c] += s_row[r][c];
     }
-    if (t < 6) D.bs[12 * ka + (t < 3 ? t : t + 3)] += s_b[t];
+    if (t < 6) D.bs[pd * ka + ba_loc(D, t)] += s_b[t];
 }
 
 // Dense Cholesky solve S xp = bs of the reduced system by ONE 1024-thread workgroup, blocked by 16 (n <= 240, padded to ld):
@@ -412,16 +423,20 @@ __global__ __launch_bounds__(1024) void k_ba_chol_solve(BaDev D) {
 // xl = Dinv (bl - W^T xp) per point, and the LM scale term sum x (lambda x + b)
 __global__ void k_ba_backsub(BaDev D, double lambda) {
     __shared__ double s_red[4];
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    const int p = blockIdx.x * blockDim.x + threadIdx.x, rows = D.rows;
     double sc = 0;
     if (p < D.NP) {
         double c0 = D.bl[3 * p], c1 = D.bl[3 * p + 1], c2 = D.bl[3 * p + 2];
-        const int loc[6] = {0, 1, 2, 6, 7, 8};
         for (int k = D.pt_start[p]; k < D.pt_start[p + 1]; k++) {
             if (D.level[k] != 0 || D.e_kf[k] >= D.W) continue;
-            const double* J = D.Jk + (size_t)12 * k; const double* Pp = D.Jp + (size_t)6 * k; const double w = D.wgt[k];
-            const int ba = 12 * D.e_kf[k];
-            for (int r = 0; r < 6; r++) { const double x = D.xp[ba + loc[r]]; c0 -= w * (J[r] * Pp[0] + J[6 + r] * Pp[3]) * x; c1 -= w * (J[r] * Pp[1] + J[6 + r] * Pp[4]) * x; c2 -= w * (J[r] * Pp[2] + J[6 + r] * Pp[5]) * x; }
+            const double* J = D.Jk + (size_t)6 * rows * k; const double* Pp = D.Jp + (size_t)3 * rows * k; const double w = D.wgt[k];
+            const int ba = D.pose_dim * D.e_kf[k];
+            for (int r = 0; r < 6; r++) {
+                const double x = D.xp[ba + ba_loc(D, r)];
+                double w0 = 0, w1 = 0, w2 = 0;
+                for (int row = 0; row < rows; row++) { const double j = J[6 * row + r]; w0 += j * Pp[3 * row]; w1 += j * Pp[3 * row + 1]; w2 += j * Pp[3 * row + 2]; }
+                c0 -= w * w0 * x; c1 -= w * w1 * x; c2 -= w * w2 * x;
+            }
         }
         const double* Di = D.Dinv + (size_t)p * 9;
         const double x0 = Di[0] * c0 + Di[1] * c1 + Di[2] * c2, x1 = Di[3] * c0 + Di[4] * c1 + Di[5] * c2, x2 = Di[6] * c0 + Di[7] * c1 + Di[8] * c2;
@@ -455,6 +470,98 @@ __global__ void k_ba_gate(BaDev D, uint8_t* out, int set_level) {
     ba_edge_geom(D, k, D.kf, D.pt, Pc, RT, Paux, K);
     const double chi = D.e_obs[3 * k + 2] * (D.err[2 * k] * D.err[2 * k] + D.err[2 * k + 1] * D.err[2 * k + 1]);
     const int bad = (chi > 5.991 || !(Pc.z > 0.0)) ? 1 : 0;
+    if (set_level) { if (bad) D.level[k] = 1; } else out[k] = (uint8_t)bad;
+}
+
+// ---- vision-only LocalBundleAdjustment (reference src/Optimizer.cc:3980-4311): SE3 key frames (kf = qx qy qz qw tx ty tz of Tcw),
+// EdgeSE3ProjectXYZ / EdgeStereoSE3ProjectXYZ (Thirdparty/g2o/g2o/types/types_six_dof_expmap.cpp:66-250). e_obs[k] = u v uRight invSigma2
+// (uRight < 0: mono); cam[0..4] = fx fy cx cy bf. Three residual rows per edge (the third is zero for mono edges).
+__device__ __forceinline__ se3q ba_ld_se3(const double* k) { se3q s; s.r = mkq(k[0], k[1], k[2], k[3]); s.t = mk3(k[4], k[5], k[6]); return s; }
+__global__ void k_ba_se3_errors(BaDev D, int kernels) {
+    __shared__ double s_red[8];
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    double c = 0;
+    if (k < D.NE && D.level[k] == 0) {
+        const double* ob = D.e_obs + 4 * (size_t)k;
+        double e[3];
+        se3_edge(ba_ld_se3(D.kf + (size_t)D.e_kf[k] * 7), ld3(D.pt + (size_t)D.e_pt[k] * 3), ob[0], ob[1], ob[2], D.cam[0], D.cam[1], D.cam[2], D.cam[3], D.cam[4], false, e, nullptr);
+        D.err[3 * k] = e[0]; D.err[3 * k + 1] = e[1]; D.err[3 * k + 2] = e[2];
+        const double chi = ob[3] * (e[0] * e[0] + e[1] * e[1] + e[2] * e[2]);
+        double r0 = chi, r1;
+        if (kernels) huber(chi, (double)(float)sqrt(ob[2] < 0 ? 5.991 : 7.815), &r0, &r1);
+        c = r0;
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) c += __shfl_xor(c, d);
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) { double t = 0; for (int w = 0; w < (int)(blockDim.x >> 6); w++) t += s_red[w]; atomicAdd(&D.scal[0], t); }
+}
+__global__ void k_ba_se3_lin_points(BaDev D, int kernels) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= D.NP) return;
+    double H[6] = {0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};
+    const double fx = D.cam[0], fy = D.cam[1], bf = D.cam[4];
+    for (int k = D.pt_start[p]; k < D.pt_start[p + 1]; k++) {
+        if (D.level[k] != 0) continue;
+        const double* ob = D.e_obs + 4 * (size_t)k;
+        const bool stereo = !(ob[2] < 0);
+        const se3q T = ba_ld_se3(D.kf + (size_t)D.e_kf[k] * 7);
+        const d3 pc = se3_map(T, ld3(D.pt + (size_t)p * 3));
+        const m33 R = qmat(T.r);
+        const double x = pc.x, y = pc.y, z = pc.z, z_2 = z * z;
+        double Jp[9], Jk[18];
+        const double Rr[9] = {R.a00, R.a01, R.a02, R.a10, R.a11, R.a12, R.a20, R.a21, R.a22};
+        if (!stereo) {
+            const double t0[3] = {fx, 0, -x / z * fx}, t1[3] = {0, fy, -y / z * fy};
+            for (int c = 0; c < 3; c++) {
+                double s0 = 0, s1 = 0;
+                for (int q = 0; q < 3; q++) { s0 += (-1. / z * t0[q]) * Rr[3 * q + c]; s1 += (-1. / z * t1[q]) * Rr[3 * q + c]; }
+                Jp[c] = s0; Jp[3 + c] = s1; Jp[6 + c] = 0;
+            }
+        } else {
+            for (int c = 0; c < 3; c++) {
+                Jp[c] = -fx * Rr[c] / z + fx * x * Rr[6 + c] / z_2;
+                Jp[3 + c] = -fy * Rr[3 + c] / z + fy * y * Rr[6 + c] / z_2;
+                Jp[6 + c] = Jp[c] - bf * Rr[6 + c] / z_2;
+            }
+        }
+        Jk[0] = x * y / z_2 * fx; Jk[1] = -(1 + (x * x / z_2)) * fx; Jk[2] = y / z * fx; Jk[3] = -1. / z * fx; Jk[4] = 0; Jk[5] = x / z_2 * fx;
+        Jk[6] = (1 + y * y / z_2) * fy; Jk[7] = -x * y / z_2 * fy; Jk[8] = -x / z * fy; Jk[9] = 0; Jk[10] = -1. / z * fy; Jk[11] = y / z_2 * fy;
+        if (stereo) { Jk[12] = Jk[0] - bf * y / z_2; Jk[13] = Jk[1] + bf * x / z_2; Jk[14] = Jk[2]; Jk[15] = Jk[3]; Jk[16] = 0; Jk[17] = Jk[5] - bf / z_2; }
+        else { for (int q = 12; q < 18; q++) Jk[q] = 0; }
+        const double e0 = D.err[3 * k], e1 = D.err[3 * k + 1], e2 = D.err[3 * k + 2], is2 = ob[3];
+        double r0, r1 = 1;
+        if (kernels) huber(is2 * (e0 * e0 + e1 * e1 + e2 * e2), (double)(float)sqrt(stereo ? 7.815 : 5.991), &r0, &r1);
+        const double w = r1 * is2;
+        D.wgt[k] = w;
+        for (int a = 0; a < 9; a++) D.Jp[9 * (size_t)k + a] = Jp[a];
+        for (int a = 0; a < 18; a++) D.Jk[18 * (size_t)k + a] = Jk[a];
+        H[0] += w * (Jp[0] * Jp[0] + Jp[3] * Jp[3] + Jp[6] * Jp[6]); H[1] += w * (Jp[0] * Jp[1] + Jp[3] * Jp[4] + Jp[6] * Jp[7]); H[2] += w * (Jp[0] * Jp[2] + Jp[3] * Jp[5] + Jp[6] * Jp[8]);
+        H[3] += w * (Jp[1] * Jp[1] + Jp[4] * Jp[4] + Jp[7] * Jp[7]); H[4] += w * (Jp[1] * Jp[2] + Jp[4] * Jp[5] + Jp[7] * Jp[8]); H[5] += w * (Jp[2] * Jp[2] + Jp[5] * Jp[5] + Jp[8] * Jp[8]);
+        for (int a = 0; a < 3; a++) b[a] -= w * (Jp[a] * e0 + Jp[3 + a] * e1 + Jp[6 + a] * e2);
+    }
+    double* Ho = D.Hll + (size_t)p * 9;
+    Ho[0] = H[0]; Ho[1] = H[1]; Ho[2] = H[2]; Ho[3] = H[1]; Ho[4] = H[3]; Ho[5] = H[4]; Ho[6] = H[2]; Ho[7] = H[4]; Ho[8] = H[5];
+    for (int a = 0; a < 3; a++) D.bl[(size_t)p * 3 + a] = b[a];
+}
+__global__ void k_ba_se3_update(BaDev D) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < D.W) {                                                   // VertexSE3Expmap::oplusImpl: T <- exp(update) * T
+        double* k = D.kf + (size_t)q * 7;
+        const se3q s = se3_mul(se3_exp(D.xp + 6 * q), ba_ld_se3(k));
+        k[0] = s.r.x; k[1] = s.r.y; k[2] = s.r.z; k[3] = s.r.w; k[4] = s.t.x; k[5] = s.t.y; k[6] = s.t.z;
+    }
+    if (q < D.NP) for (int c = 0; c < 3; c++) D.pt[3 * q + c] += D.xl[3 * q + c];
+}
+// chi2 (5.991 mono / 7.815 stereo, stale error on excluded edges) / depth gate, Optimizer.cc:4170-4200 and :4207-4235
+__global__ void k_ba_se3_gate(BaDev D, uint8_t* out, int set_level) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= D.NE) return;
+    const double* ob = D.e_obs + 4 * (size_t)k;
+    const d3 pc = se3_map(ba_ld_se3(D.kf + (size_t)D.e_kf[k] * 7), ld3(D.pt + (size_t)D.e_pt[k] * 3));
+    const double chi = ob[3] * (D.err[3 * k] * D.err[3 * k] + D.err[3 * k + 1] * D.err[3 * k + 1] + D.err[3 * k + 2] * D.err[3 * k + 2]);
+    const int bad = (chi > (ob[2] < 0 ? 5.991 : 7.815) || !(pc.z > 0.0)) ? 1 : 0;
     if (set_level) { if (bad) D.level[k] = 1; } else out[k] = (uint8_t)bad;
 }
 
@@ -522,6 +629,101 @@ bool host_inverse9(const double* a_in, double* inv) {
 }
 } // namespace
 
+// The Levenberg-Marquardt control flow of g2o (optimization_algorithm_levenberg.cpp:61-189) shared by both window solves:
+// optimize(5) -> gate / drop kernels -> optimize(10) -> erase flags. model 0: NavState window, 1: SE3 (vision-only) window.
+static int ba_run(BaDev& D, hipStream_t st, int model, const volatile int* stop, uint8_t* d_erase, double* kfs_out, double* points_out,
+                  uint8_t* erase, double* info) {
+    const int nk = D.NK, npts = D.NP, ne = D.NE, n_local = D.W;
+    const size_t n2 = (size_t)D.np * D.np, nl2 = (size_t)D.ld * D.ld, kf_doubles = (size_t)nk * D.kf_stride;
+    auto terminate = [&]() { return stop && *stop; };
+    const int TB = 256, gE = (ne + TB - 1) / TB, gP = (npts + TB - 1) / TB;
+    int mono_kernel = 1;
+    double h_scal[8];
+    auto eval_chi2 = [&](double* chi) -> int {
+        VIORB_HIP_TRY(hipMemsetAsync(D.scal, 0, sizeof(double), st));
+        if (model == 0) hipLaunchKernelGGL(k_ba_errors, dim3(gE), dim3(TB), 0, st, D, mono_kernel);
+        else hipLaunchKernelGGL(k_ba_se3_errors, dim3(gE), dim3(TB), 0, st, D, mono_kernel);
+        VIORB_HIP_TRY(hipMemcpyAsync(chi, D.scal, sizeof(double), hipMemcpyDeviceToHost, st));
+        VIORB_HIP_TRY(hipStreamSynchronize(st));
+        return VIORB_OK;
+    };
+    auto build_system = [&]() -> int {
+        VIORB_HIP_TRY(hipMemsetAsync(D.Hpp, 0, n2 * sizeof(double), st));
+        VIORB_HIP_TRY(hipMemsetAsync(D.bp, 0, D.np * sizeof(double), st));
+        if (model == 0) hipLaunchKernelGGL(k_ba_lin_points, dim3(gP), dim3(TB), 0, st, D, mono_kernel);
+        else hipLaunchKernelGGL(k_ba_se3_lin_points, dim3(gP), dim3(TB), 0, st, D, mono_kernel);
+        hipLaunchKernelGGL(k_ba_hpp, dim3(n_local), dim3(256), 0, st, D);
+        if (model == 0) hipLaunchKernelGGL(k_ba_imu, dim3(n_local), dim3(256), 0, st, D);
+        return VIORB_OK;
+    };
+    double lambda = 0, ni = 2;
+    int rc = VIORB_OK;
+    auto optimize = [&](int iterations, int& its_done, double& chi_out) -> int {
+        double currentChi = 0; int nBad = 0;
+        for (int it = 0; it < iterations && !terminate(); it++) {
+            if ((rc = eval_chi2(&currentChi)) != VIORB_OK) return rc;
+            const double iniChi = currentChi;
+            if ((rc = build_system()) != VIORB_OK) return rc;
+            if (it == 0) {
+                VIORB_HIP_TRY(hipMemsetAsync(D.scal + 3, 0, sizeof(double), st));
+                hipLaunchKernelGGL(k_ba_max_diag, dim3(32), dim3(256), 0, st, D);
+                VIORB_HIP_TRY(hipMemcpyAsync(h_scal, D.scal, 8 * sizeof(double), hipMemcpyDeviceToHost, st));
+                VIORB_HIP_TRY(hipStreamSynchronize(st));
+                lambda = 1e-5 * h_scal[3]; ni = 2; nBad = 0;
+            }
+            double rho = 0; int qmax = 0;
+            do {
+                VIORB_HIP_TRY(hipMemcpyAsync(D.kf_bak, D.kf, kf_doubles * sizeof(double), hipMemcpyDeviceToDevice, st));
+                VIORB_HIP_TRY(hipMemcpyAsync(D.pt_bak, D.pt, (size_t)npts * 3 * sizeof(double), hipMemcpyDeviceToDevice, st));
+                hipLaunchKernelGGL(k_ba_init_reduced, dim3((unsigned)((nl2 + TB - 1) / TB)), dim3(TB), 0, st, D, lambda);
+                hipLaunchKernelGGL(k_ba_dinv, dim3(gP), dim3(TB), 0, st, D, lambda);
+                hipLaunchKernelGGL(k_ba_schur, dim3(n_local), dim3(256), 0, st, D);
+                hipLaunchKernelGGL(k_ba_chol_solve, dim3(1), dim3(1024), 0, st, D);
+                VIORB_HIP_TRY(hipMemsetAsync(D.scal + 1, 0, sizeof(double), st));
+                hipLaunchKernelGGL(k_ba_backsub, dim3(gP), dim3(TB), 0, st, D, lambda);
+                if (model == 0) hipLaunchKernelGGL(k_ba_update, dim3(std::max(gP, 1)), dim3(TB), 0, st, D);
+                else hipLaunchKernelGGL(k_ba_se3_update, dim3(std::max(gP, 1)), dim3(TB), 0, st, D);
+                double tempChi = 0;
+                if ((rc = eval_chi2(&tempChi)) != VIORB_OK) return rc;
+                VIORB_HIP_TRY(hipMemcpyAsync(h_scal, D.scal, 8 * sizeof(double), hipMemcpyDeviceToHost, st));
+                VIORB_HIP_TRY(hipStreamSynchronize(st));
+                const bool ok2 = h_scal[2] > 0.5;
+                if (!ok2) tempChi = std::numeric_limits<double>::max();
+                const double scale = (ok2 ? h_scal[1] : 0.0) + 1e-3;
+                rho = (currentChi - tempChi) / scale;
+                if (rho > 0 && std::isfinite(tempChi)) { double alpha = 1. - std::pow((2 * rho - 1), 3); alpha = std::min(alpha, 2. / 3.); lambda *= std::max(1. / 3., alpha); ni = 2; currentChi = tempChi; }
+                else {
+                    lambda *= ni; ni *= 2;
+                    VIORB_HIP_TRY(hipMemcpyAsync(D.kf, D.kf_bak, kf_doubles * sizeof(double), hipMemcpyDeviceToDevice, st));
+                    VIORB_HIP_TRY(hipMemcpyAsync(D.pt, D.pt_bak, (size_t)npts * 3 * sizeof(double), hipMemcpyDeviceToDevice, st));
+                }
+                qmax++;
+            } while (rho < 0 && qmax < 10 && !terminate());
+            its_done++; chi_out = currentChi;
+            if (qmax == 10 || rho == 0) break;
+            if ((iniChi - currentChi) * 1e3 < iniChi) nBad++; else nBad = 0;
+            if (nBad >= 3) break;
+        }
+        return VIORB_OK;
+    };
+    int its1 = 0, its2 = 0; double chi1 = 0, chi2v = 0;
+    if ((rc = optimize(5, its1, chi1)) != VIORB_OK) return rc;
+    if (!terminate()) {
+        if (model == 0) hipLaunchKernelGGL(k_ba_gate, dim3(gE), dim3(TB), 0, st, D, d_erase, 1);
+        else hipLaunchKernelGGL(k_ba_se3_gate, dim3(gE), dim3(TB), 0, st, D, d_erase, 1);
+        mono_kernel = 0;
+        if ((rc = optimize(10, its2, chi2v)) != VIORB_OK) return rc;
+    }
+    if (model == 0) hipLaunchKernelGGL(k_ba_gate, dim3(gE), dim3(TB), 0, st, D, d_erase, 0);
+    else hipLaunchKernelGGL(k_ba_se3_gate, dim3(gE), dim3(TB), 0, st, D, d_erase, 0);
+    VIORB_HIP_TRY(hipMemcpyAsync(kfs_out, D.kf, (size_t)n_local * D.kf_stride * sizeof(double), hipMemcpyDeviceToHost, st));
+    VIORB_HIP_TRY(hipMemcpyAsync(points_out, D.pt, (size_t)npts * 3 * sizeof(double), hipMemcpyDeviceToHost, st));
+    VIORB_HIP_TRY(hipMemcpyAsync(erase, d_erase, ne, hipMemcpyDeviceToHost, st));
+    VIORB_HIP_TRY(hipStreamSynchronize(st));
+    info[0] = chi1; info[1] = chi2v; info[2] = its1; info[3] = its2;
+    return VIORB_OK;
+}
+
 extern "C" int viorb_local_ba_navstate(const double* kfs, int nk, int n_local, int prev_kf, const double* preint, const double* points, int npts,
                                        const int32_t* edge_idx, const double* edge_obs, int ne, const double gw[3], const double cam[16],
                                        const volatile int* stop, double* kfs_out, double* points_out, uint8_t* erase, double info[6]) {
@@ -558,6 +760,7 @@ extern "C" int viorb_local_ba_navstate(const double* kfs, int nk, int n_local, i
     hipStream_t st = lease.c->st;
     BaBuf B; BaDev D;
     D.W = n_local; D.NK = nk; D.NP = npts; D.NE = ne; D.np = 12 * n_local; D.prev_kf = prev_kf; D.acc_bias_rw2 = 5e-3 * 5e-3;
+    D.pose_dim = 12; D.rows = 2; D.kf_stride = 22;
     for (int i = 0; i < 16; i++) D.cam[i] = cam[i];
     for (int i = 0; i < 3; i++) D.gw[i] = gw[i];
     int *d_ept, *d_ekf, *d_pts, *d_kfs, *d_kfl; double *d_obs, *d_pre, *d_info; uint8_t* d_erase;
@@ -573,85 +776,54 @@ extern "C" int viorb_local_ba_navstate(const double* kfs, int nk, int n_local, i
               B.alloc(&D.e_pvr, (size_t)n_local * 9) && B.alloc(&D.e_b, (size_t)n_local * 3) && B.alloc(&D.scal, 8) && B.alloc(&d_erase, ne) && B.commit(lease.c);
     if (!ok) { set_error("device allocation / upload failed"); return VIORB_ERR_HIP; }
     D.e_pt = d_ept; D.e_kf = d_ekf; D.e_obs = d_obs; D.pt_start = d_pts; D.kf_start = d_kfs; D.kf_list = d_kfl; D.preint = d_pre; D.info_pvr = d_info;
-    const int TB = 256, gE = (ne + TB - 1) / TB, gP = (npts + TB - 1) / TB;
-    int mono_kernel = 1;
-    double h_scal[8];
-    auto eval_chi2 = [&](double* chi) -> int {
-        VIORB_HIP_TRY(hipMemsetAsync(D.scal, 0, sizeof(double), st));
-        hipLaunchKernelGGL(k_ba_errors, dim3(gE), dim3(TB), 0, st, D, mono_kernel);
-        VIORB_HIP_TRY(hipMemcpyAsync(chi, D.scal, sizeof(double), hipMemcpyDeviceToHost, st));
-        VIORB_HIP_TRY(hipStreamSynchronize(st));
-        return VIORB_OK;
-    };
-    auto build_system = [&]() -> int {
-        VIORB_HIP_TRY(hipMemsetAsync(D.Hpp, 0, n2 * sizeof(double), st));
-        VIORB_HIP_TRY(hipMemsetAsync(D.bp, 0, D.np * sizeof(double), st));
-        hipLaunchKernelGGL(k_ba_lin_points, dim3(gP), dim3(TB), 0, st, D, mono_kernel);
-        hipLaunchKernelGGL(k_ba_hpp, dim3(n_local), dim3(256), 0, st, D);
-        hipLaunchKernelGGL(k_ba_imu, dim3(n_local), dim3(256), 0, st, D);
-        return VIORB_OK;
-    };
-    double lambda = 0, ni = 2;
-    int rc = VIORB_OK;
-    auto optimize = [&](int iterations, int& its_done, double& chi_out) -> int {
-        double currentChi = 0; int nBad = 0;
-        for (int it = 0; it < iterations && !terminate(); it++) {
-            if ((rc = eval_chi2(&currentChi)) != VIORB_OK) return rc;
-            const double iniChi = currentChi;
-            if ((rc = build_system()) != VIORB_OK) return rc;
-            if (it == 0) {
-                VIORB_HIP_TRY(hipMemsetAsync(D.scal + 3, 0, sizeof(double), st));
-                hipLaunchKernelGGL(k_ba_max_diag, dim3(32), dim3(256), 0, st, D);
-                VIORB_HIP_TRY(hipMemcpyAsync(h_scal, D.scal, 8 * sizeof(double), hipMemcpyDeviceToHost, st));
-                VIORB_HIP_TRY(hipStreamSynchronize(st));
-                lambda = 1e-5 * h_scal[3]; ni = 2; nBad = 0;
-            }
-            double rho = 0; int qmax = 0;
-            do {
-                VIORB_HIP_TRY(hipMemcpyAsync(D.kf_bak, D.kf, (size_t)nk * 22 * sizeof(double), hipMemcpyDeviceToDevice, st));
-                VIORB_HIP_TRY(hipMemcpyAsync(D.pt_bak, D.pt, (size_t)npts * 3 * sizeof(double), hipMemcpyDeviceToDevice, st));
-                hipLaunchKernelGGL(k_ba_init_reduced, dim3((unsigned)((nl2 + TB - 1) / TB)), dim3(TB), 0, st, D, lambda);
-                hipLaunchKernelGGL(k_ba_dinv, dim3(gP), dim3(TB), 0, st, D, lambda);
-                hipLaunchKernelGGL(k_ba_schur, dim3(n_local), dim3(256), 0, st, D);
-                hipLaunchKernelGGL(k_ba_chol_solve, dim3(1), dim3(1024), 0, st, D);
-                VIORB_HIP_TRY(hipMemsetAsync(D.scal + 1, 0, sizeof(double), st));
-                hipLaunchKernelGGL(k_ba_backsub, dim3(gP), dim3(TB), 0, st, D, lambda);
-                hipLaunchKernelGGL(k_ba_update, dim3(std::max(gP, 1)), dim3(TB), 0, st, D);
-                double tempChi = 0;
-                if ((rc = eval_chi2(&tempChi)) != VIORB_OK) return rc;
-                VIORB_HIP_TRY(hipMemcpyAsync(h_scal, D.scal, 8 * sizeof(double), hipMemcpyDeviceToHost, st));
-                VIORB_HIP_TRY(hipStreamSynchronize(st));
-                const bool ok2 = h_scal[2] > 0.5;
-                if (!ok2) tempChi = std::numeric_limits<double>::max();
-                const double scale = (ok2 ? h_scal[1] : 0.0) + 1e-3;
-                rho = (currentChi - tempChi) / scale;
-                if (rho > 0 && std::isfinite(tempChi)) { double alpha = 1. - std::pow((2 * rho - 1), 3); alpha = std::min(alpha, 2. / 3.); lambda *= std::max(1. / 3., alpha); ni = 2; currentChi = tempChi; }
-                else {
-                    lambda *= ni; ni *= 2;
-                    VIORB_HIP_TRY(hipMemcpyAsync(D.kf, D.kf_bak, (size_t)nk * 22 * sizeof(double), hipMemcpyDeviceToDevice, st));
-                    VIORB_HIP_TRY(hipMemcpyAsync(D.pt, D.pt_bak, (size_t)npts * 3 * sizeof(double), hipMemcpyDeviceToDevice, st));
-                }
-                qmax++;
-            } while (rho < 0 && qmax < 10 && !terminate());
-            its_done++; chi_out = currentChi;
-            if (qmax == 10 || rho == 0) break;
-            if ((iniChi - currentChi) * 1e3 < iniChi) nBad++; else nBad = 0;
-            if (nBad >= 3) break;
-        }
-        return VIORB_OK;
-    };
-    int its1 = 0, its2 = 0; double chi1 = 0, chi2v = 0;
-    if ((rc = optimize(5, its1, chi1)) != VIORB_OK) return rc;
-    if (!terminate()) {
-        hipLaunchKernelGGL(k_ba_gate, dim3(gE), dim3(TB), 0, st, D, d_erase, 1);
-        mono_kernel = 0;
-        if ((rc = optimize(10, its2, chi2v)) != VIORB_OK) return rc;
+    return ba_run(D, st, 0, stop, d_erase, kfs_out, points_out, erase, info);
+}
+
+extern "C" int viorb_local_ba_se3(const double* kfs, int nk, int n_local, const double* points, int npts, const int32_t* edge_idx,
+                                  const double* edge_obs, int ne, const double intr5[5], const volatile int* stop, double* kfs_out,
+                                  double* points_out, uint8_t* erase, double info[6]) {
+    VIORB_REQUIRE(kfs && points && edge_idx && edge_obs && intr5 && kfs_out && points_out && erase && info, "null array");
+    VIORB_REQUIRE(n_local >= 1 && n_local <= 40 && nk >= n_local && npts >= 1 && ne >= 1, "1 <= n_local <= 40 key frames, at least one point and edge");
+    if (viorb_device_count() < 1) { set_error("no HIP device: libviorb_hip has no CPU fallback"); return VIORB_ERR_NO_DEVICE; }
+    for (int i = 0; i < 6; i++) info[i] = 0;
+    for (int i = 0; i < n_local * 7; i++) kfs_out[i] = kfs[i];
+    for (int i = 0; i < npts * 3; i++) points_out[i] = points[i];
+    for (int k = 0; k < ne; k++) erase[k] = 0;
+    if (stop && *stop) return VIORB_OK;
+    std::vector<int> e_pt(ne), e_kf(ne), pt_start(npts + 1, 0);
+    for (int k = 0; k < ne; k++) {
+        e_pt[k] = edge_idx[2 * k]; e_kf[k] = edge_idx[2 * k + 1];
+        VIORB_REQUIRE(e_pt[k] >= 0 && e_pt[k] < npts && e_kf[k] >= 0 && e_kf[k] < nk, "edge index out of range");
+        VIORB_REQUIRE(k == 0 || e_pt[k] >= e_pt[k - 1], "edges must be grouped by point (ascending point index)");
+        pt_start[e_pt[k] + 1]++;
     }
-    hipLaunchKernelGGL(k_ba_gate, dim3(gE), dim3(TB), 0, st, D, d_erase, 0);
-    VIORB_HIP_TRY(hipMemcpyAsync(kfs_out, D.kf, (size_t)n_local * 22 * sizeof(double), hipMemcpyDeviceToHost, st));
-    VIORB_HIP_TRY(hipMemcpyAsync(points_out, D.pt, (size_t)npts * 3 * sizeof(double), hipMemcpyDeviceToHost, st));
-    VIORB_HIP_TRY(hipMemcpyAsync(erase, d_erase, ne, hipMemcpyDeviceToHost, st));
-    VIORB_HIP_TRY(hipStreamSynchronize(st));
-    info[0] = chi1; info[1] = chi2v; info[2] = its1; info[3] = its2;
-    return VIORB_OK;
+    for (int p = 0; p < npts; p++) pt_start[p + 1] += pt_start[p];
+    std::vector<int> kf_start(n_local + 1, 0), kf_list;
+    for (int k = 0; k < ne; k++) if (e_kf[k] < n_local) kf_start[e_kf[k] + 1]++;
+    for (int i = 0; i < n_local; i++) kf_start[i + 1] += kf_start[i];
+    kf_list.resize(kf_start[n_local]);
+    { std::vector<int> pos(kf_start.begin(), kf_start.end() - 1); for (int k = 0; k < ne; k++) if (e_kf[k] < n_local) kf_list[pos[e_kf[k]]++] = k; }
+    VIORB_HIP_TRY(hipSetDevice(0));
+    BaCtxLease lease;
+    if (!lease.ready()) { set_error("could not create a HIP stream"); return VIORB_ERR_HIP; }
+    hipStream_t st = lease.c->st;
+    BaBuf B; BaDev D;
+    D.W = n_local; D.NK = nk; D.NP = npts; D.NE = ne; D.np = 6 * n_local; D.prev_kf = -1; D.acc_bias_rw2 = 0;
+    D.pose_dim = 6; D.rows = 3; D.kf_stride = 7;
+    for (int i = 0; i < 16; i++) D.cam[i] = i < 5 ? intr5[i] : 0.0;
+    for (int i = 0; i < 3; i++) D.gw[i] = 0;
+    D.ld = (D.np + 15) & ~15;
+    const size_t n2 = (size_t)D.np * D.np, nl2 = (size_t)D.ld * D.ld;
+    int *d_ept, *d_ekf, *d_pts, *d_kfs, *d_kfl; double* d_obs; uint8_t* d_erase;
+    D.preint = nullptr; D.info_pvr = nullptr; D.e_pvr = nullptr; D.e_b = nullptr;
+    bool ok = B.alloc(&D.kf, (size_t)nk * 7, kfs) && B.alloc(&D.kf_bak, (size_t)nk * 7) && B.alloc(&D.pt, (size_t)npts * 3, points) && B.alloc(&D.pt_bak, (size_t)npts * 3) &&
+              B.alloc(&d_ept, ne, e_pt.data()) && B.alloc(&d_ekf, ne, e_kf.data()) && B.alloc(&d_obs, (size_t)ne * 4, edge_obs) && B.alloc(&D.level, ne) &&
+              B.alloc(&D.err, (size_t)ne * 3) && B.alloc(&D.Jp, (size_t)ne * 9) && B.alloc(&D.Jk, (size_t)ne * 18) && B.alloc(&D.wgt, ne) &&
+              B.alloc(&d_pts, npts + 1, pt_start.data()) && B.alloc(&d_kfs, n_local + 1, kf_start.data()) && B.alloc(&d_kfl, kf_list.size(), kf_list.data()) &&
+              B.alloc(&D.Hll, (size_t)npts * 9) && B.alloc(&D.bl, (size_t)npts * 3) && B.alloc(&D.Dinv, (size_t)npts * 9) &&
+              B.alloc(&D.Hpp, n2) && B.alloc(&D.bp, D.np) && B.alloc(&D.S, nl2 + (size_t)16 * D.ld + (size_t)(D.ld / 16) * 256) && B.alloc(&D.bs, D.ld) && B.alloc(&D.xp, D.ld) &&
+              B.alloc(&D.db, (size_t)npts * 3) && B.alloc(&D.xl, (size_t)npts * 3) && B.alloc(&D.scal, 8) && B.alloc(&d_erase, ne) && B.commit(lease.c);
+    if (!ok) { set_error("device allocation / upload failed"); return VIORB_ERR_HIP; }
+    D.e_pt = d_ept; D.e_kf = d_ekf; D.e_obs = d_obs; D.pt_start = d_pts; D.kf_start = d_kfs; D.kf_list = d_kfl;
+    return ba_run(D, st, 1, stop, d_erase, kfs_out, points_out, erase, info);
 }

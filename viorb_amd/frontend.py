@@ -95,6 +95,18 @@ def LocalBundleAdjustmentNavState(kfs, n_local, prev_kf, preint, points, edge_id
     return dict(kfs=ko, points=po, erase=er[:len(ei)], chi2_first=info[0], chi2_final=info[1], its_first=int(info[2]), its_second=int(info[3]))
 
 
+def LocalBundleAdjustment(kfs, n_local, points, edge_idx, edge_obs, intr5, stop=None):
+    """Vision-only Optimizer::LocalBundleAdjustment (reference src/Optimizer.cc:3980-4311) with host buffers, solved on the GPU.
+    kfs [NK,7] = qx qy qz qw tx ty tz (Tcw), free ones first; edge_obs [NE,4] = u v uRight(<0 mono) invSigma2; intr5 = fx fy cx cy bf."""
+    kfs = np.ascontiguousarray(kfs, np.float64).reshape(-1, 7); points = np.ascontiguousarray(points, np.float64).reshape(-1, 3)
+    ei = np.ascontiguousarray(edge_idx, np.int32).reshape(-1, 2); eo = np.ascontiguousarray(edge_obs, np.float64).reshape(-1, 4)
+    ko, po = np.zeros((n_local, 7)), np.zeros_like(points)
+    er, info = np.zeros(max(len(ei), 1), np.uint8), np.zeros(6)
+    check(lib().viorb_local_ba_se3(ptr(kfs), len(kfs), n_local, ptr(points), len(points), ptr(ei), ptr(eo), len(ei), ptr(np.ascontiguousarray(intr5, np.float64)),
+                                   ptr(stop) if stop is not None else None, ptr(ko), ptr(po), ptr(er), ptr(info)))
+    return dict(kfs=ko, points=po, erase=er[:len(ei)], chi2_first=info[0], chi2_final=info[1], its_first=int(info[2]), its_second=int(info[3]))
+
+
 class ORBVocabulary:
     """The part of ORBVocabulary (DBoW2::TemplatedVocabulary<FORB>, reference include/ORBVocabulary.h:30-31) the trackers use:
     transform(features, BowVector, FeatureVector, levelsup). `voc` = flat tree arrays (layout of viorb_vocabulary_create)."""
