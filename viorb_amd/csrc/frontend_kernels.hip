@@ -100,7 +100,10 @@ __host__ __device__ inline size_t search_lds_bytes(int cap) {
     return (size_t)(GRID_CELLS + 1) * 2 + 2 /*pad*/ + (size_t)cap * (2 + 8 + 4 + 1 + 3 /*pad to 4*/) + (size_t)cap * SEARCH_SLOT * 4 + (size_t)cap * 4 * 4 + 64;
 }
 
-__global__ __launch_bounds__(256) void k_search_projection(SearchArgs A) {
+// 1024 threads per stream: the kernel is a chain of LDS / L2 latencies per point (grid walk, descriptor fetch), so it wants every
+// point of a ~1000-point frame on its own thread and 16 waves per CU to hide them (256 threads: 0.32 ms per 256 streams)
+#define SEARCH_THREADS 1024
+__global__ __launch_bounds__(SEARCH_THREADS) void k_search_projection(SearchArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
     const int b = blockIdx.x, cap = A.cap, t = threadIdx.x, lane = t & 63;
     const int ncur = min(A.cur_count[b], cap), nlast = min(A.last_count[b], cap);
@@ -297,7 +300,7 @@ __host__ __device__ inline size_t local_search_lds_bytes(int cap, int pcap) {
     return (size_t)pcap * (LOCAL_SLOT * 4 + 4 + 4) + (size_t)cap * (4 + 8 + 2 + 1 + 1) + (size_t)(GRID_CELLS + 2) * 2 + 64;
 }
 
-__global__ __launch_bounds__(256) void k_search_local_points(LocalSearchArgs A) {
+__global__ __launch_bounds__(SEARCH_THREADS) void k_search_local_points(LocalSearchArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
     const int b = blockIdx.x, cap = A.cap, pcap = A.pcap, t = threadIdx.x, lane = t & 63;
     const int ncur = min(A.cur_count[b], cap), npts = min(A.pts_count[b], pcap);
@@ -1565,7 +1568,7 @@ int viorb_frontend_search_projection_device(viorb_frontend* h, const viorb_keypo
     A.check_ori = h->cfg.check_orientation;
     VIORB_HIP_TRY(hipMemsetAsync(status, 0, sizeof(int32_t) * batch, (hipStream_t)stream));
     ProfScope ps("k_search_projection", (hipStream_t)stream);
-    hipLaunchKernelGGL(k_search_projection, dim3(batch), dim3(256), search_lds_bytes(h->cap), (hipStream_t)stream, A);
+    hipLaunchKernelGGL(k_search_projection, dim3(batch), dim3(SEARCH_THREADS), search_lds_bytes(h->cap), (hipStream_t)stream, A);
     VIORB_HIP_TRY(hipGetLastError());
     return VIORB_OK;
 }
@@ -1603,7 +1606,7 @@ int viorb_frontend_search_local_points_device(viorb_frontend* h, const viorb_key
     A.nlevels = h->cfg.nlevels;
     VIORB_HIP_TRY(hipMemsetAsync(status, 0, sizeof(int32_t) * batch, (hipStream_t)stream));
     ProfScope ps("k_search_local_points", (hipStream_t)stream);
-    hipLaunchKernelGGL(k_search_local_points, dim3(batch), dim3(256), lds, (hipStream_t)stream, A);
+    hipLaunchKernelGGL(k_search_local_points, dim3(batch), dim3(SEARCH_THREADS), lds, (hipStream_t)stream, A);
     VIORB_HIP_TRY(hipGetLastError());
     return VIORB_OK;
 }
