@@ -819,7 +819,7 @@ struct StereoArgs {
 };
 __host__ __device__ inline size_t stereo_lds_bytes(int cap, int sort_n) { return (size_t)sort_n * (8 + 4 + 4 + 4) + (size_t)cap * 4 + 64; }
 
-__global__ __launch_bounds__(256) void k_stereo_match(StereoArgs A) {
+__global__ __launch_bounds__(1024) void k_stereo_match(StereoArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_st[];
     const int p = blockIdx.x, t = threadIdx.x, cap = A.cap, sn = A.sort_n;
     unsigned long long* keys = reinterpret_cast<unsigned long long*>(s_st);            // [sn] (ybits << 32 | iR)
@@ -1479,7 +1479,7 @@ int viorb_stereo_match_device(const viorb_extractor* L, int left_index, const vi
     if (lds > 160 * 1024) { set_error("stereo matcher needs %zu B of LDS", lds); return VIORB_ERR_UNSUPPORTED; }
     if (lds > 64 * 1024) VIORB_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_stereo_match), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     ProfScope ps("k_stereo_match", (hipStream_t)stream);
-    hipLaunchKernelGGL(k_stereo_match, dim3(pairs), dim3(256), lds, (hipStream_t)stream, A);
+    hipLaunchKernelGGL(k_stereo_match, dim3(pairs), dim3(1024), lds, (hipStream_t)stream, A);
     VIORB_HIP_TRY(hipGetLastError());
     return VIORB_OK;
 }
