@@ -186,7 +186,7 @@ struct TriArgs {
 };
 __host__ __device__ inline size_t tri_lds_bytes(int cap, int sort_n) { return (size_t)sort_n * 8 + (size_t)cap + 256; }
 
-__global__ __launch_bounds__(256) void k_search_triangulation(TriArgs A) {
+__global__ __launch_bounds__(1024) void k_search_triangulation(TriArgs A) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int b = blockIdx.x, t = threadIdx.x, cap = A.cap, sn = A.sort_n;
     unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);          // [sn] ((node + 1) << 32 | index), absent nodes sort first
@@ -448,7 +448,7 @@ int viorb_search_for_triangulation_device(const viorb_keypoint* k1, const uint8_
     A.fx = intr4[0]; A.fy = intr4[1]; A.cx = intr4[2]; A.cy = intr4[3];
     for (int i = 0; i < 16; i++) { A.scale[i] = scale_factors2[i < nlevels ? i : nlevels - 1]; A.level_sigma2[i] = level_sigma2_2[i < nlevels ? i : nlevels - 1]; }
     ProfScope ps("k_search_triangulation", (hipStream_t)stream);
-    hipLaunchKernelGGL(k_search_triangulation, dim3(batch), dim3(256), lds, (hipStream_t)stream, A);
+    hipLaunchKernelGGL(k_search_triangulation, dim3(batch), dim3(1024), lds, (hipStream_t)stream, A);
     VIORB_HIP_TRY(hipGetLastError());
     return VIORB_OK;
 }

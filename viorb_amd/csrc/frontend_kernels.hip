@@ -663,7 +663,7 @@ struct FuseArgs {
     float minX, maxX, minY, maxY, wInv, hInv, fx, fy, cx, cy, bf, th, log_sf;
     float scale[16], inv_sigma2[16];
 };
-__global__ __launch_bounds__(256) void k_fuse(FuseArgs A) {
+__global__ __launch_bounds__(1024) void k_fuse(FuseArgs A) {
     __shared__ int s_n;
     const int b = blockIdx.x, t = threadIdx.x, cap = A.cap, pcap = A.pcap;
     const int npts = min(A.pts_count[b], pcap);
@@ -1708,7 +1708,7 @@ int viorb_frontend_fuse_device(viorb_frontend* h, const viorb_keypoint* kps, con
     A.log_sf = (float)log((double)h->cfg.scale_factors[h->cfg.nlevels > 1 ? 1 : 0]);
     for (int i = 0; i < 16; i++) { A.scale[i] = h->cfg.scale_factors[i]; A.inv_sigma2[i] = h->cfg.inv_level_sigma2[i]; }
     ProfScope ps("k_fuse", (hipStream_t)stream);
-    hipLaunchKernelGGL(k_fuse, dim3(batch), dim3(256), 0, (hipStream_t)stream, A);
+    hipLaunchKernelGGL(k_fuse, dim3(batch), dim3(1024), 0, (hipStream_t)stream, A);
     VIORB_HIP_TRY(hipGetLastError());
     return VIORB_OK;
 }
