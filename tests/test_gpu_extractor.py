@@ -139,3 +139,15 @@ def test_properties_full_size(gpu):
     kw, dw = ex(warp_image(img, 3.0, -2.0, 1.0, seed=3))
     bits = np.unpackbits(d1[:, None, :] ^ dw[None, :, :], axis=2).sum(axis=2)
     assert (bits.min(axis=1) <= 50).mean() > 0.5
+
+
+@pytest.mark.parametrize("w,h,nf,sf,nl,ini,mn", [(640, 480, 800, 1.2, 1, 20, 7), (640, 480, 1200, 1.1, 12, 20, 7), (500, 375, 600, 1.5, 4, 30, 10),
+                                                 (96, 80, 100, 1.2, 3, 20, 7), (131, 97, 150, 1.2, 8, 12, 5), (1280, 720, 1500, 1.2, 8, 20, 7)])
+def test_constructor_parameter_variations(gpu, oracle, w, h, nf, sf, nl, ini, mn):
+    """Other pyramid depths / scale factors / thresholds / tiny images (one or two large FAST cells per level, vanishing upper
+    levels) and the 1280x720 / 1500-feature configuration of BASELINE.json: keypoints and descriptors bit-exact."""
+    img = make_image(900 + w + nl, w, h)
+    k, d = viorb_amd.ORBextractor(nf, sf, nl, ini, mn)(img)
+    ok, od = oracle.Extractor(nf, sf, nl, ini, mn)(img)
+    np.testing.assert_array_equal(k, ok)
+    np.testing.assert_array_equal(d, od)
