@@ -117,3 +117,94 @@ def test_fuse_finds_the_planted_points(oracle):
     hit = bi[valid == 1] == partner[valid == 1]
     assert n == (bi >= 0).sum() and hit.mean() > 0.6, (n, hit.mean())     # level gate + chi gate reject some; none may land elsewhere
     assert ((bi[valid == 1] == -1) | hit).mean() > 0.97
+
+
+def literal_fuse(p, pts_f, valid, desc, intr5, th):
+    """Pure-Python restatement of ORBmatcher::Fuse (float32 arithmetic spelled out; candidates in KeyFrame::GetFeaturesInArea order)."""
+    k2 = p["k2"]; n = len(k2)
+    R, t = p["pose2"][:9].reshape(3, 3), p["pose2"][9:]
+    fx, fy, cx, cy, bf = [f32(v) for v in intr5]
+    minX, maxX, minY, maxY = f32(0), f32(752), f32(0), f32(480)
+    wInv, hInv = f32(64) / f32(maxX - minX), f32(48) / f32(maxY - minY)
+    # grid (Frame::AssignFeaturesToGrid: round() to cell, insertion order)
+    grid = [[[] for _ in range(48)] for _ in range(64)]
+    for i in range(n):
+        gx = int(np.floor(float(f32(f32(k2["x"][i] - minX) * wInv)) + 0.5)); gy = int(np.floor(float(f32(f32(k2["y"][i] - minY) * hInv)) + 0.5))
+        if 0 <= gx < 64 and 0 <= gy < 48:
+            grid[gx][gy].append(i)
+    Ow = np.array([-f32(f32(f32(R[0, r] * t[0]) + f32(R[1, r] * t[1])) + f32(R[2, r] * t[2])) for r in range(3)], f32)
+    log_sf = f32(np.log(np.float64(p["sf"][1])))
+    out = np.full(len(pts_f), -1, np.int64)
+    for i in range(len(pts_f)):
+        if not valid[i]:
+            continue
+        X = pts_f[i, :3]; nrm = pts_f[i, 3:6]; mind, maxd = pts_f[i, 6], pts_f[i, 7]
+        pc = [f32((np.float64(f32(f32(f32(R[r, 0] * X[0]) + f32(R[r, 1] * X[1])) + f32(R[r, 2] * X[2]))) + np.float64(t[r]))) for r in range(3)]
+        if pc[2] < 0:
+            continue
+        invz = f32(1) / pc[2]
+        u = f32(f32(fx * f32(pc[0] * invz)) + cx); v = f32(f32(fy * f32(pc[1] * invz)) + cy)
+        if not (u >= minX and u < maxX and v >= minY and v < maxY):
+            continue
+        ur = f32(u - f32(bf * invz))
+        PO = (X - Ow).astype(f32)
+        dist = f32(np.sqrt(np.float64(PO[0]) ** 2 + np.float64(PO[1]) ** 2 + np.float64(PO[2]) ** 2))
+        if dist < f32(f32(0.8) * mind) or dist > f32(f32(1.2) * maxd):
+            continue
+        if float(np.float64(PO[0]) * nrm[0] + np.float64(PO[1]) * nrm[1] + np.float64(PO[2]) * nrm[2]) < 0.5 * float(dist):
+            continue
+        lvl = int(np.ceil(f32(f32(np.log(np.float64(f32(maxd / dist)))) / log_sf)))
+        lvl = 0 if lvl < 0 else (7 if lvl >= 8 else lvl)
+        r = f32(f32(th) * p["sf"][lvl])
+        x0 = max(0, int(np.floor(f32(f32(f32(u - minX) - r) * wInv)))); x1 = min(63, int(np.ceil(f32(f32(f32(u - minX) + r) * wInv))))
+        y0 = max(0, int(np.floor(f32(f32(f32(v - minY) - r) * hInv)))); y1 = min(47, int(np.ceil(f32(f32(f32(v - minY) + r) * hInv))))
+        if x0 >= 64 or x1 < 0 or y0 >= 48 or y1 < 0:
+            continue
+        best, bi = 256, -1
+        for ix in range(x0, x1 + 1):
+            for iy in range(y0, y1 + 1):
+                for idx in grid[ix][iy]:
+                    kx, ky, kl = k2["x"][idx], k2["y"][idx], int(k2["octave"][idx])
+                    if not (abs(f32(kx - u)) < r and abs(f32(ky - v)) < r):
+                        continue
+                    if kl < lvl - 1 or kl > lvl:
+                        continue
+                    ex, ey = f32(u - kx), f32(v - ky)
+                    if p["ur2"][idx] >= 0:
+                        er = f32(ur - p["ur2"][idx])
+                        e2 = f32(f32(f32(ex * ex) + f32(ey * ey)) + f32(er * er))
+                        if float(f32(e2 * p["inv_level_sigma2"][kl])) > 7.8:
+                            continue
+                    else:
+                        e2 = f32(f32(ex * ex) + f32(ey * ey))
+                        if float(f32(e2 * p["inv_level_sigma2"][kl])) > 5.99:
+                            continue
+                    d = ham(desc[i], p["d2"][idx])
+                    if d < best:
+                        best, bi = d, idx
+        if best <= 50:
+            out[i] = bi
+    return int((out >= 0).sum()), out
+
+
+@pytest.mark.parametrize("seed,stereo,th", [(11, 0.0, 3.0), (12, 0.5, 6.0)])
+def test_fuse_matches_literal(oracle, seed, stereo, th):
+    p = make_two_view_problem(seed, 300, 330, 200, stereo_frac=stereo)
+    rng = np.random.default_rng(seed)
+    R2, t2 = p["pose2"][:9].reshape(3, 3).astype(np.float64), p["pose2"][9:].astype(np.float64)
+    fx, fy, cx, cy = [float(v) for v in p["intr4"]]
+    X = np.concatenate([p["X"], np.stack([rng.uniform(-4, 4, 60), rng.uniform(-3, 3, 60), rng.uniform(1, 15, 60)], 1)])
+    uv2 = (R2 @ X.T).T + t2; uv2 = np.stack([fx * uv2[:, 0] / uv2[:, 2] + cx, fy * uv2[:, 1] / uv2[:, 2] + cy], 1)
+    k2xy = np.stack([p["k2"]["x"], p["k2"]["y"]], 1).astype(np.float64)
+    partner = np.array([int(np.argmin(((k2xy - q) ** 2).sum(1))) for q in uv2])
+    pts_f = local_points_f32(p["k2"]["octave"][partner], p["pose1"].astype(np.float64), X.astype(np.float32), p["sf"])
+    valid = (rng.random(len(X)) < 0.9).astype(np.uint8)
+    desc = p["d2"][partner].copy()
+    for _ in range(8):
+        b = rng.integers(0, 256, len(X)); desc[np.arange(len(X)), b >> 3] ^= (1 << (b & 7)).astype(np.uint8)
+    intr5 = np.concatenate([p["intr4"], [np.float32(40.0)]]).astype(np.float32)
+    log_sf = np.float32(np.log(np.float64(p["sf"][1])))
+    n, bi = oracle.fuse(p["k2"], p["d2"], p["ur2"], (0.0, 752.0, 0.0, 480.0), p["pose2"], intr5, p["sf"], p["inv_level_sigma2"], log_sf, pts_f, valid, desc, th)
+    n2, bi2 = literal_fuse(p, pts_f, valid, desc, intr5, th)
+    assert n == n2 and np.array_equal(bi, bi2)
+    assert n > 30
