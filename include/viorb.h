@@ -188,6 +188,15 @@ int viorb_frontend_search_projection_device(viorb_frontend* h, const viorb_keypo
                                             const uint8_t* last_flags, const float* last_Pw, const uint8_t* last_desc,
                                             float th, int batch, int32_t* cur_match, int32_t* nmatches, int32_t* status,
                                             void* stream);
+/* The same search run again only for the streams whose nmatches[b] is below retry_below (the others keep their results):
+ * TrackWithIMU's "if(nmatches<20) ... SearchByProjection(..., 2*th, ...)" (reference src/Tracking.cc:440-444) for a batch —
+ * call with th = 2 * th and retry_below = 20 right after the first search. retry_below <= 0: every stream is searched. */
+int viorb_frontend_search_projection_retry_device(viorb_frontend* h, const viorb_keypoint* cur_kps, const uint8_t* cur_desc,
+                                            const int32_t* cur_count, const int32_t* cell_start, const int32_t* cell_idx,
+                                            const float* pose12, const viorb_keypoint* last_kps, const int32_t* last_count,
+                                            const uint8_t* last_flags, const float* last_Pw, const uint8_t* last_desc,
+                                            float th, int retry_below, int batch, int32_t* cur_match, int32_t* nmatches, int32_t* status,
+                                            void* stream);
 
 /* Tracking::SearchLocalPoints (reference src/Tracking.cc:1904-1958): Frame::isInFrustum(pMP, 0.5) for every local map
  * point that is valid and not yet matched in this frame, then ORBmatcher::SearchByProjection(F, vpMapPoints, th)

@@ -43,6 +43,9 @@ class OracleTracker:
         pose12 = ora.pose_from_navstate(cur_ns, self.cam)
         nm, match = ora.search_by_projection_frame(kps, desc, self.bounds, pose12, self.cam[:4], self.tab["scale"], self.last_flags,
                                                    self.last_Pw, self.last_desc, self.last_kps["octave"], self.last_kps["angle"], self.th)
+        if nm < 20:                                          # Tracking.cc:440-444: wider window when few matches
+            nm, match = ora.search_by_projection_frame(kps, desc, self.bounds, pose12, self.cam[:4], self.tab["scale"], self.last_flags,
+                                                       self.last_Pw, self.last_desc, self.last_kps["octave"], self.last_kps["angle"], 2 * self.th)
         sel = np.nonzero(match >= 0)[0]
         inv_s2 = self.tab["inv_sigma2"]
         obs_cur = np.concatenate([self.last_Pw[match[sel]].astype(np.float64),

@@ -325,3 +325,46 @@ def test_pose_optimisation_se3_matches_oracle(torch_cuda, oracle, stereo_frac):
     g = viorb_amd.PoseOptimizationSE3(p["pose0"], p["intr5"].astype(np.float32), p["obs7"][:2])
     assert g["n_inliers"] == 0
     np.testing.assert_array_equal(g["pose12"], p["pose0"])
+
+
+def test_search_projection_retry_only_touches_streams_below_the_limit(oracle):
+    """TrackWithIMU's 2*th retry as a batched launch: streams with >= retry_below matches keep their first-pass result bit for bit,
+    the others get exactly what SearchByProjection(..., 2*th) returns."""
+    import torch, ctypes as C
+    import viorb_amd
+    from viorb_amd.frontend import Frontend
+    from viorb_amd.synth import make_periodic_stream, plane_points_f32
+    from viorb_amd.capi import KP_DTYPE
+    B = 3
+    streams = [make_periodic_stream(70 + b, 2) for b in range(B)]
+    ex = viorb_amd.ORBextractor(1000, 1.2, 8, 20, 7, max_batch=B)
+    tab = ex.tables()
+    fe = Frontend(streams[0]["cam"], streams[0]["gw"], tab["scale"], tab["inv_sigma2"], max_batch=B, cap=ex.cap)
+    dev = torch.device("cuda", 0); cap = ex.cap
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    # last frame = frame 0 (features + plane points), current = frame 1 with the true pose as the prediction
+    last = [oracle.Extractor(1000)(s["frames"][0]) for s in streams]
+    lk = np.zeros((B, cap), KP_DTYPE); ld = np.zeros((B, cap, 32), np.uint8); lc = np.zeros(B, np.int32); lP = np.zeros((B, cap, 3), np.float32); lf = np.zeros((B, cap), np.uint8)
+    for b, (k, d) in enumerate(last):
+        n = len(k); lk[b, :n] = k; ld[b, :n] = d; lc[b] = n; lf[b, :n] = 1 | 4
+        lP[b, :n] = plane_points_f32(np.stack([k["x"], k["y"]], 1), streams[b]["pose_true"][0], streams[b]["cam"])
+    lf[1, 40:] = 0                                               # stream 1 keeps 40 map points only: few matches at th = 15
+    ex.extract_batch_device(up(np.stack([s["frames"][1] for s in streams])))
+    kps, desc, count, _, _ = ex.results_device()
+    cs = torch.zeros((B, 64 * 48 + 1), dtype=torch.int32, device=dev); ci = torch.zeros((B, cap), dtype=torch.int32, device=dev)
+    fe.grid(kps, count, B, cs, ci)
+    pose = up(np.stack([s["pose_true"][1] for s in streams]).astype(np.float32))
+    m = torch.zeros((B, cap), dtype=torch.int32, device=dev); nm = torch.zeros(B, dtype=torch.int32, device=dev); st = torch.zeros(B, dtype=torch.int32, device=dev)
+    tl = [up(x) for x in (lk.view(np.uint8).reshape(B, -1), lc, lf, lP, ld)]
+    args = (kps, desc, count, cs, ci, pose, tl[0].data_ptr(), tl[1].data_ptr(), tl[2], tl[3], tl[4].data_ptr())
+    fe.search_projection(*args, 15.0, B, m, nm, st)
+    torch.cuda.synchronize(); m1, n1 = m.cpu().numpy().copy(), nm.cpu().numpy().copy()
+    limit = int(n1[1]) + 1                                       # only stream 1 is below the limit
+    assert n1[0] >= limit and n1[2] >= limit
+    fe.search_projection(*args, 30.0, B, m, nm, st, retry_below=limit)
+    torch.cuda.synchronize(); m2, n2 = m.cpu().numpy(), nm.cpu().numpy()
+    assert np.array_equal(m2[0], m1[0]) and np.array_equal(m2[2], m1[2]) and n2[0] == n1[0] and n2[2] == n1[2]
+    ck, cd = ex.download(1)
+    r_n, r_m = oracle.search_by_projection_frame(ck, cd, (0.0, 752.0, 0.0, 480.0), streams[1]["pose_true"][1].astype(np.float32), streams[1]["cam"][:4],
+                                                 tab["scale"], lf[1, :lc[1]], lP[1, :lc[1]], ld[1, :lc[1]], lk[1, :lc[1]]["octave"], lk[1, :lc[1]]["angle"], 30.0)
+    assert n2[1] == r_n and np.array_equal(m2[1, :len(ck)], r_m) and (st.cpu().numpy() == 0).all()

@@ -90,6 +90,7 @@ struct SearchArgs {
     float minX, maxX, minY, maxY, wInv, hInv, fx, fy, cx, cy, th;
     float scale[16];
     int check_ori;
+    int skip_if_at_least;     // > 0: leave streams whose nmatches[b] is already >= this untouched (TrackWithIMU's retry with 2*th)
 };
 
 // LDS plan (dynamic, per workgroup): the current frame's grid (u16 CSR), keypoint x/y/octave/angle, the first
@@ -106,6 +107,7 @@ __host__ __device__ inline size_t search_lds_bytes(int cap) {
 __global__ __launch_bounds__(SEARCH_THREADS) void k_search_projection(SearchArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
     const int b = blockIdx.x, cap = A.cap, t = threadIdx.x, lane = t & 63;
+    if (A.skip_if_at_least > 0 && A.nmatches[b] >= A.skip_if_at_least) return;       // uniform per workgroup, before any barrier
     const int ncur = min(A.cur_count[b], cap), nlast = min(A.last_count[b], cap);
     // carve LDS (4-byte aligned sections first)
     uint32_t* slot = reinterpret_cast<uint32_t*>(s_raw);                 // [cap][SLOT] dist<<16 | idx
@@ -272,7 +274,7 @@ __global__ __launch_bounds__(SEARCH_THREADS) void k_search_projection(SearchArgs
     }
     int* out = A.cur_match + (size_t)b * cap;
     for (int c = t; c < cap; c += blockDim.x) out[c] = (c < ncur && !rej[c]) ? owner[c] : -1;
-    if (t == 0) { A.nmatches[b] = s_nm; if (s_overflow) A.status[b] = VIORB_ERR_CAPACITY; }
+    if (t == 0) { A.nmatches[b] = s_nm; A.status[b] = s_overflow ? VIORB_ERR_CAPACITY : VIORB_OK; }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1549,11 +1551,12 @@ int viorb_frontend_imu_predict_device(viorb_frontend* h, const double* imu, int 
     return VIORB_OK;
 }
 
-int viorb_frontend_search_projection_device(viorb_frontend* h, const viorb_keypoint* cur_kps, const uint8_t* cur_desc,
-                                            const int32_t* cur_count, const int32_t* cell_start, const int32_t* cell_idx,
-                                            const float* pose12, const viorb_keypoint* last_kps, const int32_t* last_count,
-                                            const uint8_t* last_flags, const float* last_Pw, const uint8_t* last_desc, float th,
-                                            int batch, int32_t* cur_match, int32_t* nmatches, int32_t* status, void* stream) {
+int viorb_frontend_search_projection_retry_device(viorb_frontend* h, const viorb_keypoint* cur_kps, const uint8_t* cur_desc,
+                                                  const int32_t* cur_count, const int32_t* cell_start, const int32_t* cell_idx,
+                                                  const float* pose12, const viorb_keypoint* last_kps, const int32_t* last_count,
+                                                  const uint8_t* last_flags, const float* last_Pw, const uint8_t* last_desc, float th,
+                                                  int retry_below, int batch, int32_t* cur_match, int32_t* nmatches, int32_t* status,
+                                                  void* stream) {
     FE_CHECK_BATCH(h, batch);
     VIORB_REQUIRE(cur_kps && cur_desc && cur_count && cell_start && cell_idx && pose12 && last_kps && last_count && last_flags &&
                   last_Pw && last_desc && cur_match && nmatches && status, "null array");
@@ -1566,11 +1569,20 @@ int viorb_frontend_search_projection_device(viorb_frontend* h, const viorb_keypo
     A.fx = h->cfg.fx; A.fy = h->cfg.fy; A.cx = h->cfg.cx; A.cy = h->cfg.cy; A.th = th;
     for (int i = 0; i < 16; i++) A.scale[i] = h->cfg.scale_factors[i];
     A.check_ori = h->cfg.check_orientation;
-    VIORB_HIP_TRY(hipMemsetAsync(status, 0, sizeof(int32_t) * batch, (hipStream_t)stream));
+    A.skip_if_at_least = retry_below > 0 ? retry_below : 0;
     ProfScope ps("k_search_projection", (hipStream_t)stream);
     hipLaunchKernelGGL(k_search_projection, dim3(batch), dim3(SEARCH_THREADS), search_lds_bytes(h->cap), (hipStream_t)stream, A);
     VIORB_HIP_TRY(hipGetLastError());
     return VIORB_OK;
+}
+
+int viorb_frontend_search_projection_device(viorb_frontend* h, const viorb_keypoint* cur_kps, const uint8_t* cur_desc,
+                                            const int32_t* cur_count, const int32_t* cell_start, const int32_t* cell_idx,
+                                            const float* pose12, const viorb_keypoint* last_kps, const int32_t* last_count,
+                                            const uint8_t* last_flags, const float* last_Pw, const uint8_t* last_desc, float th,
+                                            int batch, int32_t* cur_match, int32_t* nmatches, int32_t* status, void* stream) {
+    return viorb_frontend_search_projection_retry_device(h, cur_kps, cur_desc, cur_count, cell_start, cell_idx, pose12, last_kps, last_count, last_flags,
+                                                         last_Pw, last_desc, th, 0, batch, cur_match, nmatches, status, stream);
 }
 
 int viorb_frontend_search_local_points_device(viorb_frontend* h, const viorb_keypoint* cur_kps, const uint8_t* cur_desc, const int32_t* cur_count,

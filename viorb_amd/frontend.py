@@ -229,12 +229,13 @@ class Frontend:
                                                        ptr(cur_ns), ptr(pose12), self._st(stream)))
 
     def search_projection(self, cur_kps_ptr, cur_desc_ptr, cur_count_ptr, cell_start, cell_idx, pose12, last_kps, last_count,
-                          last_flags, last_Pw, last_desc, th, batch, cur_match, nmatches, status, stream=None):
+                          last_flags, last_Pw, last_desc, th, batch, cur_match, nmatches, status, stream=None, retry_below=0):
+        """retry_below > 0: only the streams whose nmatches is below it are searched again (TrackWithIMU's 2*th retry)."""
         p = lambda a: a if isinstance(a, C.c_void_p) else (C.c_void_p(a) if isinstance(a, int) else ptr(a))
-        check(self.L.viorb_frontend_search_projection_device(
+        check(self.L.viorb_frontend_search_projection_retry_device(
             self.h, p(cur_kps_ptr), p(cur_desc_ptr), p(cur_count_ptr), ptr(cell_start), ptr(cell_idx), ptr(pose12), p(last_kps),
-            p(last_count), ptr(last_flags), ptr(last_Pw), p(last_desc), float(th), batch, ptr(cur_match), ptr(nmatches), ptr(status),
-            self._st(stream)))
+            p(last_count), ptr(last_flags), ptr(last_Pw), p(last_desc), float(th), int(retry_below), batch, ptr(cur_match), ptr(nmatches),
+            ptr(status), self._st(stream)))
 
     def search_local_points(self, cur_kps_ptr, cur_desc_ptr, cur_count_ptr, cell_start, cell_idx, pose12, pts_f, pts_flags, pts_desc,
                             pts_count, th, nnratio, cur_owner_obs, batch, match, nmatches, frustum, status, stream=None):

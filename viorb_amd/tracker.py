@@ -148,6 +148,10 @@ class BatchedTracker:
         fe.search_projection(kps, desc, count, self.cell_start, self.cell_idx, self.pose12, self.last_kps.data_ptr(),
                              self.last_count.data_ptr(), self.last_flags, self.last_Pw, self.last_desc.data_ptr(), self.th, B,
                              self.cur_match, self.nmatches, self.status)
+        # "if(nmatches<20) ... SearchByProjection(..., 2*th, ...)" (reference src/Tracking.cc:440-444): a no-op for streams with >= 20 matches
+        fe.search_projection(kps, desc, count, self.cell_start, self.cell_idx, self.pose12, self.last_kps.data_ptr(),
+                             self.last_count.data_ptr(), self.last_flags, self.last_Pw, self.last_desc.data_ptr(), 2 * self.th, B,
+                             self.cur_match, self.nmatches, self.status, retry_below=20)
         fe.build_observations(kps, count, self.cur_match, self.last_Pw, B, self.obs_cur, self.idx_cur, self.n_cur)
         fe.build_observations(self.last_kps.data_ptr(), self.last_count.data_ptr(), self.last_self, self.last_Pw, B, self.obs_last,
                               self.idx_last, self.n_last)
