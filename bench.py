@@ -107,10 +107,14 @@ def main():
     from viorb_amd.tracker import BatchedTracker
     if viorb_amd.lib().viorb_device_count() < 1:
         raise SystemExit("bench.py needs a HIP device (viorb_amd has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # VIORB_BENCH_REHEARSAL=1: run the N > 1 code path on a box with fewer GPUs than ranks (ranks share devices, gloo instead of
+    # RCCL, which refuses two ranks on one device) — a functional rehearsal, never a measurement
+    rehearsal = bool(os.environ.get("VIORB_BENCH_REHEARSAL"))
+    dev_index = local_rank % torch.cuda.device_count() if rehearsal else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
-        dist_init("nccl", dev)                               # "nccl" is RCCL on ROCm
+        dist_init("gloo" if rehearsal else "nccl", None if rehearsal else dev)       # "nccl" is RCCL on ROCm
     up = lambda a, dt=None: torch.from_numpy(np.ascontiguousarray(a)).to(dev) if dt is None else torch.from_numpy(np.ascontiguousarray(a)).to(dev, dt)
     frames = up(np.stack([s["frames"] for s in streams], 1))                   # [F, S, h, w] u8
     imu = up(np.stack([s["imu"] for s in streams], 1))                         # [F, S, n, 7] f64
@@ -132,7 +136,7 @@ def main():
     pt_g = [cut(pose_true, g) for g in range(G)]; ns_g = [cut(ns_true, g) for g in range(G)]; tp_g = [t_period[sl[g]].contiguous() for g in range(G)]
     zeros_g = zeros_t[:Sg].contiguous()
     TLM = not args.no_track_local_map
-    trs = [BatchedTracker(cam, gw, Sg, W_IMG, H_IMG, NFEAT, th=15.0, device=local_rank, compute_marg=True, track_local_map=TLM) for _ in range(G)]
+    trs = [BatchedTracker(cam, gw, Sg, W_IMG, H_IMG, NFEAT, th=15.0, device=dev_index, compute_marg=True, track_local_map=TLM) for _ in range(G)]
     for g, tr in enumerate(trs):
         tr.skip_input_wait = bool(os.environ.get('SKIPWAIT'))
         tr.bootstrap(fr_g[g][0], pt_g[g][0], tf_g[g][0], ns_g[g][0], mci0[sl[g]].contiguous())
@@ -181,7 +185,7 @@ def main():
     dom = max(ext, key=lambda kname: ext[kname][0]) if ext else None
 
     # ---- reduce over ranks: total frames, max time ----------------------------------------------------------
-    frames_done, elapsed = reduce_throughput(S * args.steps, elapsed, dev)
+    frames_done, elapsed = reduce_throughput(S * args.steps, elapsed, None if rehearsal else dev)
 
     if rank == 0:
         roof = None
