@@ -325,7 +325,8 @@ int viorb_pose_opt_se3(const float pose12[12], const float intr5[5], const doubl
  * key frame i, points [np][3], edge_idx [ne][2] = (point, key frame) sorted by point, edge_obs [ne][3] = u v invSigma2.
  * stop: the reference's pbStopFlag (polled between LM trials; may be NULL). Outputs: kfs_out [n_local][22],
  * points_out [np][3], erase [ne], info = chi2 after optimize(5), final chi2, iterations of both runs, 0, 0.
- * Host buffers in and out (the caller is the LocalMapping thread); all arithmetic runs on the GPU in FP64. */
+ * Host buffers in and out (the caller is the LocalMapping thread); all arithmetic runs on the GPU in FP64, on HIP device 0 of the
+ * calling process (select the GPU with HIP_VISIBLE_DEVICES). Re-entrant: concurrent callers get their own stream and device arena. */
 int viorb_local_ba_navstate(const double* kfs, int nk, int n_local, int prev_kf, const double* preint,
                             const double* points, int np, const int32_t* edge_idx, const double* edge_obs, int ne,
                             const double gw[3], const double cam[16], const volatile int* stop, double* kfs_out,
