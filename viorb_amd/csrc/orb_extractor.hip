@@ -359,8 +359,29 @@ struct OctLds {
 
 __device__ __forceinline__ unsigned long long lanemask_lt(int lane) { return (1ull << lane) - 1ull; }
 
-// Expand node i (DivideNode): stable 4-way partition of its key segment; children appended.
-__device__ __forceinline__ void oct_expand(const OctLds& S, int i, int lane, int& nn, int& live, int& n_to_expand) {
+// DivideNode. Every expansion owns FOUR consecutive node slots [slot, slot + 4): child c goes to slot + c, an empty child is written
+// as a tombstone, and the stable compaction that closes a round removes tombstones and dead parents alike — so the surviving
+// order is exactly the reference's "push the non-empty children to the list front in n1..n4 order". Fixed slots make expansions
+// independent of each other: a round's small nodes are expanded one per LANE (64 at a time), only big nodes take the whole wave.
+#define OCT_LANE_LIMIT 64                     // points a lane-local expansion handles (child codes live in two 64-bit registers)
+struct OctExpandResult { int off, nexp; };    // non-empty children, children with more than one point
+
+__device__ __forceinline__ void oct_write_children(const OctLds& S, const OctNode& p, int i, int slot, int mx, int my, int sb,
+                                                   const int tc[4], const int sc4[4]) {
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        OctNode o;
+        o.x0 = (c & 1) ? (int16_t)mx : p.x0; o.x1 = (c & 1) ? p.x1 : (int16_t)mx;
+        o.y0 = (c & 2) ? (int16_t)my : p.y0; o.y1 = (c & 2) ? p.y1 : (int16_t)my;
+        o.begin = (uint16_t)sc4[c]; o.count = (uint16_t)tc[c];
+        o.flags = tc[c] > 0 ? (uint16_t)((sb ^ 1) | (tc[c] == 1 ? OCT_NOMORE : 0)) : (uint16_t)OCT_DEAD; o.pad = 0;
+        S.nd[slot + c] = o;
+    }
+    S.nd[i].flags = p.flags | OCT_DEAD;
+}
+
+// whole wave on one node: stable 4-way partition of its key segment with ballots
+__device__ __forceinline__ OctExpandResult oct_expand_wave(const OctLds& S, int i, int slot, int lane) {
     const OctNode p = S.nd[i];
     const int mx = p.x0 + ((p.x1 - p.x0 + 1) >> 1), my = p.y0 + ((p.y1 - p.y0 + 1) >> 1);
     const int sb = p.flags & OCT_BUF;
@@ -370,9 +391,8 @@ __device__ __forceinline__ void oct_expand(const OctLds& S, int i, int lane, int
     int t0 = 0, t1 = 0, t2 = 0, t3 = 0;
     for (int o = 0; o < cnt; o += 64) {
         const int idx = o + lane;
-        const bool valid = idx < cnt;
         int c = -1;
-        if (valid) {
+        if (idx < cnt) {
             const uint32_t key = S.keys[src[beg + idx]];
             c = ((int)(key & 0xfff) < mx ? 0 : 1) | ((int)((key >> 12) & 0xfff) < my ? 0 : 2);
         }
@@ -383,10 +403,9 @@ __device__ __forceinline__ void oct_expand(const OctLds& S, int i, int lane, int
     int r0 = 0, r1 = 0, r2 = 0, r3 = 0;
     for (int o = 0; o < cnt; o += 64) {
         const int idx = o + lane;
-        const bool valid = idx < cnt;
         int c = -1;
         uint16_t id = 0;
-        if (valid) {
+        if (idx < cnt) {
             id = src[beg + idx];
             const uint32_t key = S.keys[id];
             c = ((int)(key & 0xfff) < mx ? 0 : 1) | ((int)((key >> 12) & 0xfff) < my ? 0 : 2);
@@ -399,29 +418,39 @@ __device__ __forceinline__ void oct_expand(const OctLds& S, int i, int lane, int
         else if (c == 3) dst[s3 + r3 + __popcll(m3 & lt)] = id;
         r0 += __popcll(m0); r1 += __popcll(m1); r2 += __popcll(m2); r3 += __popcll(m3);
     }
-    // append the non-empty children in n1..n4 order (lane j builds child j)
-    const int tc[4] = {t0, t1, t2, t3};
-    const int sc4[4] = {s0, s1, s2, s3};
-    int off = 0;
-#pragma unroll
-    for (int c = 0; c < 4; c++) {
-        if (tc[c] > 0) {
-            if (lane == 0) {
-                OctNode o;
-                o.x0 = (c & 1) ? (int16_t)mx : p.x0; o.x1 = (c & 1) ? p.x1 : (int16_t)mx;
-                o.y0 = (c & 2) ? (int16_t)my : p.y0; o.y1 = (c & 2) ? p.y1 : (int16_t)my;
-                o.begin = (uint16_t)sc4[c]; o.count = (uint16_t)tc[c];
-                o.flags = (uint16_t)((sb ^ 1) | (tc[c] == 1 ? OCT_NOMORE : 0)); o.pad = 0;
-                S.nd[nn + off] = o;
-            }
-            off++;
-            if (tc[c] > 1) n_to_expand++;
-        }
+    const int tc[4] = {t0, t1, t2, t3}, sc4[4] = {s0, s1, s2, s3};
+    if (lane == 0) oct_write_children(S, p, i, slot, mx, my, sb, tc, sc4);
+    OctExpandResult r; r.off = (t0 > 0) + (t1 > 0) + (t2 > 0) + (t3 > 0); r.nexp = (t0 > 1) + (t1 > 1) + (t2 > 1) + (t3 > 1);
+    return r;
+}
+
+// one lane on one node (count <= OCT_LANE_LIMIT): counting pass (child codes kept in registers), then the stable scatter
+__device__ __forceinline__ void oct_lane_count(const OctLds& S, const OctNode& p, int mx, int my, unsigned long long& lo, unsigned long long& hi, int tc[4]) {
+    const uint16_t* src = (p.flags & OCT_BUF) ? S.perm1 : S.perm0;
+    lo = 0; hi = 0; tc[0] = tc[1] = tc[2] = tc[3] = 0;
+    for (int k = 0; k < (int)p.count; k++) {
+        const uint32_t key = S.keys[src[p.begin + k]];
+        const int cx = (int)(key & 0xfff) < mx ? 0 : 1, cy = (int)((key >> 12) & 0xfff) < my ? 0 : 1;
+        lo |= (unsigned long long)cx << k; hi |= (unsigned long long)cy << k;
+        const int c = cx | (cy << 1);
+        tc[0] += c == 0; tc[1] += c == 1; tc[2] += c == 2; tc[3] += c == 3;
     }
-    if (lane == 0) S.nd[i].flags = p.flags | OCT_DEAD;
-    nn += off;
-    live += off - 1;
-    WAVE_SYNC();
+}
+__device__ __forceinline__ void oct_lane_scatter(const OctLds& S, const OctNode& p, int i, int slot, int mx, int my, unsigned long long lo,
+                                                 unsigned long long hi, const int tc[4]) {
+    const int sb = p.flags & OCT_BUF;
+    const uint16_t* src = sb ? S.perm1 : S.perm0;
+    uint16_t* dst = sb ? S.perm0 : S.perm1;
+    const int sc4[4] = {p.begin, p.begin + tc[0], p.begin + tc[0] + tc[1], p.begin + tc[0] + tc[1] + tc[2]};
+    int w0 = sc4[0], w1 = sc4[1], w2 = sc4[2], w3 = sc4[3];
+    for (int k = 0; k < (int)p.count; k++) {
+        const uint16_t id = src[p.begin + k];
+        const int c = (int)((lo >> k) & 1) | ((int)((hi >> k) & 1) << 1);
+        const int pos = c == 0 ? w0 : (c == 1 ? w1 : (c == 2 ? w2 : w3));
+        dst[pos] = id;
+        w0 += c == 0; w1 += c == 1; w2 += c == 2; w3 += c == 3;
+    }
+    oct_write_children(S, p, i, slot, mx, my, sb, tc, sc4);
 }
 
 // Stable in-place removal of dead nodes; returns the new node count; first_new = new index of `upto`.
@@ -557,17 +586,48 @@ __global__ __launch_bounds__(64) void k_octree(const LevelDev* __restrict__ lv, 
     int guard = 0;
     while (!finish && guard++ < 64) {
         const int prev = live, nn0 = nn;
-        int n_to_expand = 0;
-        for (int i = nn0 - 1; i >= 0; i--) {
-            const int fl = S.nd[i].flags;
-            if (!(fl & (OCT_NOMORE | OCT_DEAD))) {
-                if (nn + 4 > nodecap) { overflow = true; finish = true; break; }
-                oct_expand(S, i, lane, nn, live, n_to_expand);
-            }
+        // every expandable node of the list, front to back (array downwards): the e-th one owns slots nn0 + 4e .. nn0 + 4e + 3
+        int ne = 0;
+        for (int base = 0; base < nn0; base += 64) {
+            const int i = nn0 - 1 - (base + lane);
+            ne += __popcll(__ballot(i >= 0 && !(S.nd[max(i, 0)].flags & (OCT_NOMORE | OCT_DEAD))));
         }
+        if (nn0 + 4 * ne > nodecap) { overflow = true; break; }
+        int n_to_expand = 0, e_base = 0;
+        for (int base = 0; base < nn0; base += 64) {
+            const int i = nn0 - 1 - (base + lane);
+            OctNode p; p.flags = OCT_DEAD; p.count = 0;
+            if (i >= 0) p = S.nd[i];
+            const bool ex = i >= 0 && !(p.flags & (OCT_NOMORE | OCT_DEAD));
+            const unsigned long long m = __ballot(ex);
+            const int e = e_base + __popcll(m & lanemask_lt(lane));
+            const bool small = ex && p.count <= OCT_LANE_LIMIT;
+            int off = 0, nexp = 0;
+            if (small) {
+                const int mx = p.x0 + ((p.x1 - p.x0 + 1) >> 1), my = p.y0 + ((p.y1 - p.y0 + 1) >> 1);
+                unsigned long long lo, hi; int tc[4];
+                oct_lane_count(S, p, mx, my, lo, hi, tc);
+                oct_lane_scatter(S, p, i, nn0 + 4 * e, mx, my, lo, hi, tc);
+                off = (tc[0] > 0) + (tc[1] > 0) + (tc[2] > 0) + (tc[3] > 0); nexp = (tc[0] > 1) + (tc[1] > 1) + (tc[2] > 1) + (tc[3] > 1);
+            }
+            unsigned long long mb = __ballot(ex && !small);
+            int big_off = 0, big_nexp = 0;
+            while (mb) {                                          // big nodes: the whole wave on each, in list order
+                const int l = __ffsll((long long)mb) - 1;
+                mb &= mb - 1;
+                const OctExpandResult r = oct_expand_wave(S, nn0 - 1 - (base + l), nn0 + 4 * __shfl(e, l), lane);
+                big_off += r.off - 1; big_nexp += r.nexp;
+            }
+            int d_live = small ? off - 1 : 0, d_exp = nexp;
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) { d_live += __shfl_xor(d_live, d); d_exp += __shfl_xor(d_exp, d); }
+            live += d_live + big_off; n_to_expand += d_exp + big_nexp;
+            e_base += __popcll(m);
+        }
+        nn = nn0 + 4 * ne;
+        WAVE_SYNC();
         int first_new;
         nn = oct_compact(S, nn, nn0, lane, first_new);
-        if (finish) break;
         if (live >= N || live == prev) {
             finish = true;
         } else if (live + n_to_expand * 3 > N) {
@@ -589,13 +649,44 @@ __global__ __launch_bounds__(64) void k_octree(const LevelDev* __restrict__ lv, 
                 for (int i = m + lane; i < mp; i += 64) S.sortb[i] = 0;      // pad sorts to the front
                 WAVE_SYNC();
                 oct_sort(S.sortb, mp, lane);
+                // largest first (sortb from the top); candidate q owns slots nn1 + 4q ..; stop after the expansion that reaches N
                 const int nn1 = nn;
-                int dummy = 0;
-                for (int j = mp - 1; j >= mp - m; j--) {
-                    if (nn + 4 > nodecap) { overflow = true; finish = true; break; }
-                    oct_expand(S, (int)(S.sortb[j] & 0xffff), lane, nn, live, dummy);
-                    if (live >= N) break;
+                int processed = 0;
+                bool reached = false;
+                for (int base = 0; base < m && !reached && !finish; base += 64) {
+                    const int q = base + lane;
+                    const bool valid = q < m;
+                    const int i = valid ? (int)(S.sortb[mp - 1 - q] & 0xffff) : 0;
+                    OctNode p; p.flags = OCT_DEAD; p.count = 0;
+                    if (valid) p = S.nd[i];
+                    if (__any(valid && p.count > OCT_LANE_LIMIT)) {           // rare: big nodes this late -> one at a time on the whole wave
+                        for (int l = 0; l < 64 && base + l < m; l++) {
+                            if (nn1 + 4 * (processed + 1) > nodecap) { overflow = true; finish = true; break; }
+                            const OctExpandResult r = oct_expand_wave(S, (int)(S.sortb[mp - 1 - (base + l)] & 0xffff), nn1 + 4 * processed, lane);
+                            processed++; live += r.off - 1;
+                            if (live >= N) { reached = true; break; }
+                        }
+                        continue;
+                    }
+                    const int mx = p.x0 + ((p.x1 - p.x0 + 1) >> 1), my = p.y0 + ((p.y1 - p.y0 + 1) >> 1);
+                    unsigned long long lo = 0, hi = 0; int tc[4] = {0, 0, 0, 0};
+                    if (valid) oct_lane_count(S, p, mx, my, lo, hi, tc);
+                    const int inc = valid ? (tc[0] > 0) + (tc[1] > 0) + (tc[2] > 0) + (tc[3] > 0) - 1 : 0;
+                    int incl = inc;
+#pragma unroll
+                    for (int d = 1; d < 64; d <<= 1) { const int v = __shfl_up(incl, d); if (lane >= d) incl += v; }
+                    const unsigned long long mh = __ballot(valid && live + incl >= N);
+                    const int nvalid = min(64, m - base);
+                    int cut = mh ? __ffsll((long long)mh) - 1 : nvalid - 1;   // last candidate of this chunk that is expanded
+                    // node capacity: candidate q needs slots up to nn1 + 4 (processed + lane + 1)
+                    const int fit = (nodecap - nn1) / 4 - processed;          // candidates of this chunk that still fit
+                    if (fit < cut + 1) { overflow = true; finish = true; cut = fit - 1; }
+                    if (valid && lane <= cut) oct_lane_scatter(S, p, i, nn1 + 4 * (processed + lane), mx, my, lo, hi, tc);
+                    if (cut >= 0) { live += __shfl(incl, cut); processed += cut + 1; }
+                    if (mh) reached = true;
                 }
+                nn = nn1 + 4 * processed;
+                WAVE_SYNC();
                 nn = oct_compact(S, nn, nn1, lane, first_new);
                 if (live >= N || live == prev2) finish = true;
             }
