@@ -30,7 +30,7 @@ def build(force=False, verbose=False):
     if not force and not needs_build():
         return SO
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + FLAGS + ["-I", os.path.join(ROOT, "include"), "-o", SO] + sources()
+    cmd = [hipcc] + FLAGS + os.environ.get("VIORB_HIPCC_FLAGS", "").split() + ["-I", os.path.join(ROOT, "include"), "-o", SO] + sources()
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

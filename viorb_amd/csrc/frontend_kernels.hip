@@ -7,6 +7,7 @@
 //   k_build_observations  the edge-construction loops of PoseOptimization  src/Optimizer.cc:493-589
 //   k_pose_opt_vi         Optimizer::PoseOptimization(Frame*, KeyFrame*|Frame*, ...) with g2o's LM
 //                         reference src/Optimizer.cc:323-1112 + Thirdparty/g2o (see vio_core.h)
+#include <atomic>
 #include <hip/hip_runtime.h>
 #include <vector>
 #include <algorithm>
@@ -826,6 +827,7 @@ struct PoseOptArgs {
     double *out_ns, *out_last_ns, *marg_out, *info;
     uint8_t *outlier_cur, *outlier_last;
     double acc_bias_rw2;
+    int obs_lds;                 // 1: the launch carries 2 * cap * 25 bytes of dynamic LDS for the observations and their outlier flags
 };
 
 struct PoseOptShared {
@@ -839,6 +841,8 @@ struct PoseOptShared {
     double bak[2][10], bakb[2][3];
     double base_ba[2][3];                               // BiasAcc of cur / last (constant)
     double sc[16];                                      // 0 chi total, 1 w_imu, 2 w_prior, 3 ok, 7 last chi
+    double pre[64];                                     // dP dV dR JPg JPa JVg JVa JRg (60) + dT: what the IMU factor reads every evaluation
+    double gw[3], dbg[3];                               // gravity, the last frame's gyro-bias delta
     int flag[4];
 };
 
@@ -925,9 +929,103 @@ __device__ bool wave_solve_reg(const double* __restrict__ H, const double* __res
 __device__ __forceinline__ pvr sh_pvr(const double* p) { pvr s; s.P = ld3(p); s.V = ld3(p + 3); s.q = mkq(p[6], p[7], p[8], p[9]); return s; }
 __device__ __forceinline__ void sh_put(double* p, const pvr& s) { st3(p, s.P); st3(p + 3, s.V); p[6] = s.q.x; p[7] = s.q.y; p[8] = s.q.z; p[9] = s.q.w; }
 
+
+// Reprojection edge of the pose solver's linearisation pass: proj_edge()'s error and the two 6-entry Jacobian rows over
+// (dP, dPhi), written with explicit fma and without the products by hat()'s structural zeros — 106 instead of ~170 f64 instructions
+// per edge. Same formulas, fewer roundings; the solver's parity bar is the 1e-5 relative cost tolerance, not bit-exactness.
+__device__ __forceinline__ d3 mulv_fma(const m33& a, d3 v) {
+    return mk3(fma(a.a02, v.z, fma(a.a01, v.y, a.a00 * v.x)), fma(a.a12, v.z, fma(a.a11, v.y, a.a10 * v.x)), fma(a.a22, v.z, fma(a.a21, v.y, a.a20 * v.x)));
+}
+__device__ __forceinline__ void proj_edge_lin(const cam_t& k, const m33& RwbT, d3 Pwb, d3 Pw, double u, double v, double& e0, double& e1,
+                                              double* __restrict__ j0, double* __restrict__ j1) {
+    const d3 Paux = mulv_fma(k.Rcb, mulv_fma(RwbT, Pw - Pwb));
+    const d3 Pc = Paux - k.RcbPbc;
+    const double iz = 1.0 / Pc.z, xz = Pc.x * iz, yz = Pc.y * iz;
+    e0 = u - fma(xz, k.fx, k.cx);
+    e1 = v - fma(yz, k.fy, k.cy);
+    const double j00 = k.fx * iz, j02 = -xz * j00, j11 = k.fy * iz, j12 = -yz * j11;
+    const m33& R = k.Rcb;
+    j0[0] = fma(j02, R.a20, j00 * R.a00); j0[1] = fma(j02, R.a21, j00 * R.a01); j0[2] = fma(j02, R.a22, j00 * R.a02);
+    j1[0] = fma(j12, R.a20, j11 * R.a10); j1[1] = fma(j12, R.a21, j11 * R.a11); j1[2] = fma(j12, R.a22, j11 * R.a12);
+    // HR = hat(Paux) * Rcb, row by row
+    const double x = Paux.x, y = Paux.y, z = Paux.z;
+    const double h00 = fma(y, R.a20, -z * R.a10), h01 = fma(y, R.a21, -z * R.a11), h02 = fma(y, R.a22, -z * R.a12);
+    const double h10 = fma(z, R.a00, -x * R.a20), h11 = fma(z, R.a01, -x * R.a21), h12 = fma(z, R.a02, -x * R.a22);
+    const double h20 = fma(x, R.a10, -y * R.a00), h21 = fma(x, R.a11, -y * R.a01), h22 = fma(x, R.a12, -y * R.a02);
+    j0[3] = -fma(j02, h20, j00 * h00); j0[4] = -fma(j02, h21, j00 * h01); j0[5] = -fma(j02, h22, j00 * h02);
+    j1[3] = -fma(j12, h20, j11 * h10); j1[4] = -fma(j12, h21, j11 * h11); j1[5] = -fma(j12, h22, j11 * h12);
+}
+
+// Phase timing for development (-DVIORB_POSE_TIMING, VIORB_HIPCC_FLAGS in viorb_amd/build.py): workgroup 0 prints its accumulated
+// s_memtime ticks per phase.
+#ifdef VIORB_POSE_TIMING
+#define PT_DECL unsigned long long pt_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pt_t0 = 0; int pt_n = 0
+#define PT_START() pt_t0 = __builtin_amdgcn_s_memtime()
+#define PT_LAP(k) do { const unsigned long long pt_now = __builtin_amdgcn_s_memtime(); pt_acc[k] += pt_now - pt_t0; pt_t0 = pt_now; } while (0)
+#define PT_COUNT() pt_n++
+#else
+#define PT_DECL
+#define PT_START()
+#define PT_LAP(k)
+#define PT_COUNT()
+#endif
+
+// The IMU factor of vio_core.h's pvr_edge() — same operations in the same order per value — cut into three independent pieces that
+// the solver runs on the first lanes of three different waves (a single lane took ~15 k cycles per evaluation, as long as its wave's
+// whole share of the reprojection edges). est_i / est_j: P V q (10 doubles); every operand is read from LDS where it is used.
+// J (9 x 21, row-major) keeps its static zero pattern; each piece writes its own blocks.
+__device__ __forceinline__ void imu_put(double* J, int r0, int c0, const m33& B, double s) {
+    const double v[9] = {B.a00, B.a01, B.a02, B.a10, B.a11, B.a12, B.a20, B.a21, B.a22};
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) J[(r0 + r) * 21 + c0 + c] = s * v[3 * r + c];
+}
+// piece 1: position and velocity residuals, their rotation-column blocks and the accelerometer-bias blocks
+__device__ __forceinline__ void imu_piece_pv(const double* est_i, const double* est_j, const double* dbg_i_p, const double* dba_i_p, const double* pre,
+                                             const double* gw_p, double* e, double* J) {
+    const double dT = pre[60], dT2 = dT * dT;
+    const pvr si = sh_pvr(est_i); const d3 Pj = ld3(est_j), Vj = ld3(est_j + 3), gw = ld3(gw_p), dbg_i = ld3(dbg_i_p), dba_i = ld3(dba_i_p);
+    const quat RiT = qnorm(qconj(si.q));
+    const d3 aP = qrot(RiT, Pj - si.P - si.V * dT - gw * (0.5 * dT2));
+    const d3 aV = qrot(RiT, Vj - si.V - gw * dT);
+    const m33 JPa = ldm(pre + 24), JVa = ldm(pre + 42);
+    const d3 rP = aP - (ld3(pre) + mulv(ldm(pre + 15), dbg_i) + mulv(JPa, dba_i));
+    const d3 rV = aV - (ld3(pre + 3) + mulv(ldm(pre + 33), dbg_i) + mulv(JVa, dba_i));
+    e[0] = rP.x; e[1] = rP.y; e[2] = rP.z; e[3] = rV.x; e[4] = rV.y; e[5] = rV.z;
+    if (!J) return;
+    imu_put(J, 0, 6, hat3(aP), 1); imu_put(J, 3, 6, hat3(aV), 1);
+    imu_put(J, 0, 18, JPa, -1); imu_put(J, 3, 18, JVa, -1);
+}
+// piece 2: rotation residual and the two blocks that carry Jr^-1
+__device__ __forceinline__ void imu_piece_rot(const double* est_i, const double* est_j, const double* dbg_i_p, const double* pre, double* e, double* J) {
+    const quat qi = mkq(est_i[6], est_i[7], est_i[8], est_i[9]), qj = mkq(est_j[6], est_j[7], est_j[8], est_j[9]);
+    const quat RiT = qnorm(qconj(qi));
+    const quat dRij = qnorm(mat2q(ldm(pre + 6)));
+    const quat corr = so3_mul(dRij, so3_exp(mulv(ldm(pre + 51), ld3(dbg_i_p))));
+    const quat rR = so3_mul(so3_mul(qnorm(qconj(corr)), RiT), qj);
+    const d3 rPhi = so3_log(rR);
+    e[6] = rPhi.x; e[7] = rPhi.y; e[8] = rPhi.z;
+    if (!J) return;
+    const m33 JrInv = so3_jr_inv(rPhi);
+    imu_put(J, 6, 15, JrInv, 1);
+    imu_put(J, 6, 6, mul(mul(JrInv, tr(qmat(qj))), qmat(qi)), -1);
+}
+// piece 3: the blocks built from Ri^T alone
+__device__ __forceinline__ void imu_piece_blocks(const double* est_i, const double* est_j, const double* pre, double* J) {
+    const double dT = pre[60];
+    const quat qi = mkq(est_i[6], est_i[7], est_i[8], est_i[9]), qj = mkq(est_j[6], est_j[7], est_j[8], est_j[9]);
+    const m33 RiTm = tr(qmat(qi));
+    imu_put(J, 0, 0, eye3(), -1); imu_put(J, 0, 3, RiTm, -dT); imu_put(J, 3, 3, RiTm, -1); imu_put(J, 3, 12, RiTm, 1);
+    imu_put(J, 0, 9, mul(RiTm, qmat(qj)), 1);
+}
+
 __global__ __launch_bounds__(256) void k_pose_opt_vi(PoseOptArgs A) {
     __shared__ PoseOptShared S;
     __shared__ int s_map21[21], s_map12[12];
+#ifdef VIORB_POSE_TIMING
+    const unsigned long long pt_begin = __builtin_amdgcn_s_memtime();
+#endif
     const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6, cap = A.cap;
     const int variant = A.variant, n = variant ? 24 : 12;
     const int ncur = min(A.n_cur[b], cap), nlast = variant ? min(A.n_last[b], cap) : 0;
@@ -940,14 +1038,41 @@ __global__ __launch_bounds__(256) void k_pose_opt_vi(PoseOptArgs A) {
     const double* pre = A.preint + (size_t)b * 142;
     const double* priorns = variant ? A.prior_ns + (size_t)b * 22 : nullptr;
     const cam_t K = ld_cam(A.cam);
-    const d3 gw = ld3(A.gw);
-    const d3 last_dbg = ld3(lastns + 16);
     const double d_mono = (double)(float)sqrt(5.991), d_pvr = (double)(float)sqrt(21.666), d_bias = (double)(float)sqrt(16.812),
                  d_prior = (double)(float)sqrt(30.5779);
     const double bias_info = 1.0 / A.acc_bias_rw2 / pre[141];
     // ---- setup
     for (int i = t; i < ncur; i += blockDim.x) out_c[i] = 0;
     for (int i = t; i < nlast; i += blockDim.x) out_l[i] = 0;
+    // The observations are read by every one of the ~25 evaluations, one wave per SIMD with nothing to hide a global load behind: keep
+    // them in LDS. In the tracking sequence every value is a float widened to double (map points, keypoint coordinates, 1/sigma2), so
+    // the LDS copy is float, 24 bytes per edge, and exact; any other input (checked here, value by value) keeps the global path.
+    extern __shared__ float s_obs[];                                    // [2][cap][6] floats, then [2][cap] outlier flags
+    uint8_t* s_out = reinterpret_cast<uint8_t*>(s_obs + (size_t)2 * cap * 6);
+    bool use_lds = false;
+    if (A.obs_lds) {
+        bool exact = true;
+        for (int side = 0; side < (variant ? 2 : 1); side++) {
+            const double* ob = side ? obs_l : obs_c; const int ne = side ? nlast : ncur;
+            for (int i = t; i < ne * 6; i += blockDim.x) {
+                const double d = ob[i]; const float f = (float)d;
+                exact = exact && ((double)f == d);
+                s_obs[(size_t)side * cap * 6 + i] = f;
+            }
+            for (int i = t; i < ne; i += blockDim.x) s_out[side * cap + i] = 0;
+        }
+        use_lds = __syncthreads_and(exact) != 0;
+    }
+    struct obs_t { d3 X; double u, v, is2; };
+    auto load_obs = [&](int side, const double* ob, int i) {
+        obs_t o;
+        if (use_lds) {
+            const float2* f = reinterpret_cast<const float2*>(s_obs + ((size_t)side * cap + i) * 6);
+            const float2 f0 = f[0], f1 = f[1], f2 = f[2];
+            o.X = mk3((double)f0.x, (double)f0.y, (double)f1.x); o.u = (double)f1.y; o.v = (double)f2.x; o.is2 = (double)f2.y;
+        } else { o.X = ld3(ob + 6 * i); o.u = ob[6 * i + 3]; o.v = ob[6 * i + 4]; o.is2 = ob[6 * i + 5]; }
+        return o;
+    };
     // information of the IMU factor: cov^-1 + diag(1e2,1,1e2) (x) I3, by Gauss-Jordan over all threads
     {
         double* a = S.Lm; double* inv = S.Hb[0];              // scratch: [9x9 | 9x9]
@@ -979,6 +1104,8 @@ __global__ __launch_bounds__(256) void k_pose_opt_vi(PoseOptArgs A) {
         }
     }
     for (int i = t; i < 189; i += blockDim.x) S.J1[i] = 0;          // the factors' Jacobians keep a static zero pattern
+    if (t < 61) S.pre[t] = t < 60 ? pre[t] : pre[141];
+    else if (t >= 64 && t < 67) { S.gw[t - 64] = A.gw[t - 64]; S.dbg[t - 64] = lastns[16 + t - 64]; }
     for (int i = t; i < 144; i += blockDim.x) S.J2[i] = 0;
     if (t == 0) {
         for (int k = 0; k < 3; k++) { S.base_ba[0][k] = curns[13 + k]; S.base_ba[1][k] = lastns[13 + k]; }
@@ -998,8 +1125,8 @@ __global__ __launch_bounds__(256) void k_pose_opt_vi(PoseOptArgs A) {
         return;
     }
     const int n_edges_total = ncur + nlast + (variant ? 3 : 2);
-    const int edge_nslot = t < 128 ? 1 : 2, edge_slot0 = t < 128 ? t : 128 + 2 * (t - 128);
     int kernel_on = 1;           // mono edges keep their Huber kernel until the end of round 3
+    PT_DECL;
     int hb_last = 0;
     int nbad = 0;
 
@@ -1008,13 +1135,16 @@ __global__ __launch_bounds__(256) void k_pose_opt_vi(PoseOptArgs A) {
     // wave 0, prior on wave 1) and the bias factor. Leaves H, b (when lin) and the total robust chi2 in S.sc[0].
     auto evaluate = [&](bool lin, double* Hm, double* bv) -> double {
         // dense factors: residuals (+ Jacobians) by one lane of two different waves
-        if (t == 0) {
-            const pvr sc = sh_pvr(S.est[0]), sl = sh_pvr(S.est[1]);
-            pvr_edge(sl, sc, last_dbg, ld3(S.bias[1]), pre, gw, S.e1, lin ? S.J1 : nullptr, false);
-        } else if (t == 64 && variant) {
-            const pvr sl = sh_pvr(S.est[1]);
-            prior_edge(sl, ld3(S.base_ba[1]) + ld3(S.bias[1]), priorns, S.e2, lin ? S.J2 : nullptr, false);
+        PT_START();
+        if (lane == 0) {
+            if (wave == 0) imu_piece_pv(S.est[1], S.est[0], S.dbg, S.bias[1], S.pre, S.gw, S.e1, lin ? S.J1 : nullptr);
+            else if (wave == 1) {
+                if (variant) { const pvr sl = sh_pvr(S.est[1]); prior_edge(sl, ld3(S.base_ba[1]) + ld3(S.bias[1]), priorns, S.e2, lin ? S.J2 : nullptr, false); }
+            }
+            else if (wave == 2) imu_piece_rot(S.est[1], S.est[0], S.dbg, S.pre, S.e1, lin ? S.J1 : nullptr);
+            else if (lin) imu_piece_blocks(S.est[1], S.est[0], S.pre, S.J1);
         }
+        PT_LAP(0);
         for (int side = 0; side < (variant ? 2 : 1); side++) {
             const pvr s = sh_pvr(S.est[side]);
             const m33 RT = tr(qmat(s.q));
@@ -1022,30 +1152,46 @@ __global__ __launch_bounds__(256) void k_pose_opt_vi(PoseOptArgs A) {
             double a[28];
 #pragma unroll
             for (int k = 0; k < 28; k++) a[k] = 0;
-            // waves 0 and 1 reach this loop late (their first lanes have just evaluated the IMU / prior factors: ~13 k cycles by
-            // s_memtime, about 70 % of a wave's even share of the edges), so waves 2 and 3 take two edge slots per thread and
-            // waves 0 and 1 one: 384 slots per trip
-            for (int i = edge_slot0; i < ne; i += ((i - edge_slot0) % 384 + 1 < edge_nslot) ? 1 : 385 - edge_nslot) {
-                if (ol[i]) continue;
-                double e[2], JP[6], JR[6];
-                proj_edge(K, RT, s.P, ld3(ob + 6 * i), ob[6 * i + 3], ob[6 * i + 4], lin, e, JP, JR);
-                const double is2 = ob[6 * i + 5];
-                const double chi = is2 * (e[0] * e[0] + e[1] * e[1]);
-                double r0 = chi, r1 = 1;
-                if (kernel_on) huber(chi, d_mono, &r0, &r1);
-                a[27] += r0;
+            // Two edges per thread and trip (i and i + 256), both in the same straight-line code: one wave per SIMD has nothing else to
+            // fill the f64 pipeline's dependent-issue gaps with. A switched-off edge (outlier, or past the end) is computed on a harmless
+            // stand-in — a point on the optical axis at unit depth — with weight 0.
+            const double dsq_mono = d_mono * d_mono;
+            const d3 Xoff = s.P + mulv(tr(RT), mulv(tr(K.Rcb), K.RcbPbc + mk3(0, 0, 1)));        // projects to camera coordinates (0, 0, 1)
+            for (int i0 = t; i0 < ne; i0 += 512) {
+                const int i1 = min(i0 + 256, ne - 1);
+                const uint8_t* fl = use_lds ? s_out + side * cap : ol;
+                const bool on0 = fl[i0] == 0, on1 = (i0 + 256 < ne) && fl[i1] == 0;
+                if (!(on0 || on1)) continue;
+                const obs_t o0 = load_obs(side, ob, i0), o1 = load_obs(side, ob, i1);
+                const d3 X0 = on0 ? o0.X : Xoff, X1 = on1 ? o1.X : Xoff;
+                const double u0 = o0.u, v0 = o0.v, u1 = o1.u, v1 = o1.v;
+                const double is0 = on0 ? o0.is2 : 0.0, is1 = on1 ? o1.is2 : 0.0;
+                double ea0, ea1, eb0, eb1, ja0[6], ja1[6], jb0[6], jb1[6];
+                proj_edge_lin(K, RT, s.P, X0, u0, v0, ea0, ea1, ja0, ja1);
+                proj_edge_lin(K, RT, s.P, X1, u1, v1, eb0, eb1, jb0, jb1);
+                const double chi0 = is0 * fma(ea0, ea0, ea1 * ea1), chi1 = is1 * fma(eb0, eb0, eb1 * eb1);
+                double ra0 = chi0, ra1 = 1, rb0 = chi1, rb1 = 1;
+                if (kernel_on && (chi0 > dsq_mono || chi1 > dsq_mono)) {          // RobustKernelHuber::robustify
+                    const double sq0 = sqrt(chi0), sq1 = sqrt(chi1);
+                    if (chi0 > dsq_mono) { ra0 = 2 * sq0 * d_mono - dsq_mono; ra1 = d_mono / sq0; }
+                    if (chi1 > dsq_mono) { rb0 = 2 * sq1 * d_mono - dsq_mono; rb1 = d_mono / sq1; }
+                }
+                a[27] += ra0; a[27] += rb0;
                 if (lin) {
-                    const double w = r1 * is2;
-                    const double j0[6] = {JP[0], JP[1], JP[2], JR[0], JR[1], JR[2]}, j1[6] = {JP[3], JP[4], JP[5], JR[3], JR[4], JR[5]};
+                    const double w0 = ra1 * is0, w1 = rb1 * is1;
+                    double wa0[6], wa1[6], wb0[6], wb1[6];
+#pragma unroll
+                    for (int r = 0; r < 6; r++) { wa0[r] = w0 * ja0[r]; wa1[r] = w0 * ja1[r]; wb0[r] = w1 * jb0[r]; wb1[r] = w1 * jb1[r]; }
                     int k = 0;
 #pragma unroll
                     for (int r = 0; r < 6; r++)
 #pragma unroll
-                        for (int c = r; c < 6; c++) a[k++] += w * (j0[r] * j0[c] + j1[r] * j1[c]);
+                        for (int c = r; c < 6; c++, k++) a[k] = fma(wb1[r], jb1[c], fma(wb0[r], jb0[c], fma(wa1[r], ja1[c], fma(wa0[r], ja0[c], a[k]))));
 #pragma unroll
-                    for (int r = 0; r < 6; r++) a[21 + r] -= w * (j0[r] * e[0] + j1[r] * e[1]);
+                    for (int r = 0; r < 6; r++) a[21 + r] = fma(-wb1[r], eb1, fma(-wb0[r], eb0, fma(-wa1[r], ea1, fma(-wa0[r], ea0, a[21 + r]))));
                 }
             }
+            PT_LAP(6);
             if (lin) {
                 // transpose-reduce 32 padded values over the 64 lanes: 16+8+4+2+1 exchanges leave lane l with the
                 // wave total of value (l >> 1) & 31, one more exchange pairs the two copies
@@ -1075,7 +1221,9 @@ __global__ __launch_bounds__(256) void k_pose_opt_vi(PoseOptArgs A) {
                 if (lane == 0) S.red[wave][side][27] = vv;
             }
         }
+        PT_LAP(1);
         __syncthreads();
+        PT_LAP(2);
         // ---- assembly. Step 1 (parallel): quadratic forms q[r] = e_r (Omega e)_r of the dense factors, Omega*J of both, and the
         // bias random-walk factor's weight; step 2: every thread derives the two Huber weights itself and builds complete H / b
         // entries from all their sources (reprojection partials, IMU factor, prior factor, bias factor) — one pass, no zeroing.
@@ -1147,17 +1295,20 @@ __global__ __launch_bounds__(256) void k_pose_opt_vi(PoseOptArgs A) {
             }
         }
         __syncthreads();
+        PT_LAP(3); PT_COUNT();
         return S.sc[0];
     };
 
     // (H + lambda I) x = b on wave 0, matrix rows in registers (wave_solve_reg). S.flag[0] = success.
     auto solve = [&](double lambda, const double* Hm, const double* bv) {
+        PT_START();
         if (wave == 0) {
             const bool ok = variant ? wave_solve_reg<24>(Hm, bv, lambda, S.Lm, S.x, lane) : wave_solve_reg<12>(Hm, bv, lambda, S.Lm, S.x, lane);
             if (!ok && lane < n) S.x[lane] = 0;
             if (lane == 0) S.flag[0] = ok ? 1 : 0;
         }
         __syncthreads();
+        PT_LAP(4);
     };
 
     for (int round = 0; round < 4; round++) {
@@ -1223,6 +1374,7 @@ __global__ __launch_bounds__(256) void k_pose_opt_vi(PoseOptArgs A) {
         }
         __syncthreads();
         // ---- re-classify every mono edge by its chi2 at the new estimate (Optimizer.cc:622-688)
+        PT_START();
         {
             int bad_local = 0;
             for (int side = 0; side < (variant ? 2 : 1); side++) {
@@ -1230,11 +1382,13 @@ __global__ __launch_bounds__(256) void k_pose_opt_vi(PoseOptArgs A) {
                 const m33 RT = tr(qmat(s.q));
                 const double* ob = side ? obs_l : obs_c; uint8_t* ol = side ? out_l : out_c; const int ne = side ? nlast : ncur;
                 for (int i = t; i < ne; i += blockDim.x) {
+                    const obs_t o = load_obs(side, ob, i);
                     double e[2];
-                    proj_edge(K, RT, s.P, ld3(ob + 6 * i), ob[6 * i + 3], ob[6 * i + 4], false, e, nullptr, nullptr);
-                    const float chi2 = (float)(ob[6 * i + 5] * (e[0] * e[0] + e[1] * e[1]));
+                    proj_edge(K, RT, s.P, o.X, o.u, o.v, false, e, nullptr, nullptr);
+                    const float chi2 = (float)(o.is2 * (e[0] * e[0] + e[1] * e[1]));
                     const int bad = chi2 > 5.991f;
                     ol[i] = (uint8_t)bad;
+                    if (use_lds) s_out[side * cap + i] = (uint8_t)bad;
                     if (side == 0) bad_local += bad;
                 }
             }
@@ -1249,8 +1403,14 @@ __global__ __launch_bounds__(256) void k_pose_opt_vi(PoseOptArgs A) {
         }
         if (round == 2) kernel_on = 0;
         __syncthreads();
+        PT_LAP(5);
         if (n_edges_total < 10) break;
     }
+#ifdef VIORB_POSE_TIMING
+    if (b == 0 && lane == 0)
+        printf("pose_opt wave=%d total=%llu evals=%d dense=%llu edges=%llu wait=%llu asm=%llu solve=%llu classify=%llu loop=%llu\n", wave,
+               __builtin_amdgcn_s_memtime() - pt_begin, pt_n, pt_acc[0], pt_acc[1], pt_acc[2], pt_acc[3], pt_acc[4], pt_acc[5], pt_acc[6]);
+#endif
     // ---- outputs
     if (t == 0) {
         double* o = A.out_ns + (size_t)b * 22;
@@ -1741,8 +1901,19 @@ int viorb_frontend_pose_opt_device(viorb_frontend* h, int variant, int compute_m
     A.gw = h->d_gw; A.cam = h->d_cam; A.obs_cur = obs_cur; A.obs_last = variant ? obs_last : nullptr; A.n_cur = n_cur; A.n_last = n_last;
     A.out_ns = out_ns; A.out_last_ns = out_last_ns; A.marg_out = marg_out; A.info = info;
     A.outlier_cur = outlier_cur; A.outlier_last = variant ? outlier_last : nullptr; A.acc_bias_rw2 = h->cfg.acc_bias_rw2;
+    // observations + outlier flags in LDS when they fit next to the solver's static 26 KB
+    size_t lds = (((size_t)2 * h->cap * 25) + 15) & ~(size_t)15;
+    A.obs_lds = lds <= 120 * 1024;
+    if (!A.obs_lds) lds = 0;
+    else {
+        static std::atomic<int> lds_allowed{0};                  // the attribute belongs to the function, not to a handle: keep the maximum
+        if ((int)lds > lds_allowed.load()) {
+            VIORB_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pose_opt_vi), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            lds_allowed.store((int)lds);
+        }
+    }
     ProfScope ps("k_pose_opt_vi", (hipStream_t)stream);
-    hipLaunchKernelGGL(k_pose_opt_vi, dim3(batch), dim3(256), 0, (hipStream_t)stream, A);
+    hipLaunchKernelGGL(k_pose_opt_vi, dim3(batch), dim3(256), lds, (hipStream_t)stream, A);
     VIORB_HIP_TRY(hipGetLastError());
     return VIORB_OK;
 }
