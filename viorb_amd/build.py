@@ -10,7 +10,11 @@ SO = os.path.join(HERE, "libviorb_hip.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
          # every float a*b+c in the kernels is two roundings unless fma() is written out: bit-exact
          # parity with the CPU oracle depends on it
-         "-ffp-contract=off"]
+         "-ffp-contract=off",
+         # Machine LICM hoists the f64 literal pairs of every inlined sin/cos/atan/sqrt expansion out of the solvers' loops and keeps them
+         # live across the whole kernel (k_pose_opt_vi: 375 registers per lane with it, 194 without, and at a 256 cap the "constants"
+         # were spilled to scratch and reloaded inside the polynomial chains). Nothing else in the library gains from it.
+         "-mllvm", "-disable-machine-licm"]
 
 
 def sources():

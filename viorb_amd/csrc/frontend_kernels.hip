@@ -836,13 +836,14 @@ struct PoseOptShared {
     double J2[12 * 12], OJ2[12 * 12], e2[12];          // prior factor
     double q[32];                                       // per-row terms of the quadratic forms
     double info_pvr[81], info_prior[144];
-    double red[4][2][28];                               // per wave, per side: 21 H + 6 b + chi
+    double red[8][2][28];                               // per wave, per side: 21 H + 6 b + chi
     double est[2][10], bias[2][3];                      // PVR (P V q) and dBias_acc of cur / last
     double bak[2][10], bakb[2][3];
     double base_ba[2][3];                               // BiasAcc of cur / last (constant)
     double sc[16];                                      // 0 chi total, 1 w_imu, 2 w_prior, 3 ok, 7 last chi
     double pre[64];                                     // dP dV dR JPg JPa JVg JVa JRg (60) + dT: what the IMU factor reads every evaluation
     double gw[3], dbg[3];                               // gravity, the last frame's gyro-bias delta
+    double cpv[6], corrT[4], pri[13];                   // constant parts of the IMU and prior factors (imu_constants, prior_constants)
     int flag[4];
 };
 
@@ -981,35 +982,68 @@ __device__ __forceinline__ void imu_put(double* J, int r0, int c0, const m33& B,
 #pragma unroll
         for (int c = 0; c < 3; c++) J[(r0 + r) * 21 + c0 + c] = s * v[3 * r + c];
 }
+// Constant parts (they depend on the pre-integration and on the last frame's fixed gyro-bias delta only), computed once per solve:
+// cpv = [dP + JPg*dbg | dV + JVg*dbg], corrT = (dRij * Exp(JRg*dbg))^-1 as pvr_edge() forms it.
+__device__ __forceinline__ void imu_constants(const double* pre, const double* dbg_i_p, double* cpv, double* corrT) {
+    const d3 dbg_i = ld3(dbg_i_p);
+    st3(cpv, ld3(pre) + mulv(ldm(pre + 15), dbg_i));
+    st3(cpv + 3, ld3(pre + 3) + mulv(ldm(pre + 33), dbg_i));
+    const quat dRij = qnorm(mat2q(ldm(pre + 6)));
+    const quat corr = so3_mul(dRij, so3_exp(mulv(ldm(pre + 51), dbg_i)));
+    const quat c = qnorm(qconj(corr));
+    corrT[0] = c.x; corrT[1] = c.y; corrT[2] = c.z; corrT[3] = c.w;
+}
 // piece 1: position and velocity residuals, their rotation-column blocks and the accelerometer-bias blocks
-__device__ __forceinline__ void imu_piece_pv(const double* est_i, const double* est_j, const double* dbg_i_p, const double* dba_i_p, const double* pre,
+__device__ __forceinline__ void imu_piece_pv(const double* est_i, const double* est_j, const double* cpv, const double* dba_i_p, const double* pre,
                                              const double* gw_p, double* e, double* J) {
     const double dT = pre[60], dT2 = dT * dT;
-    const pvr si = sh_pvr(est_i); const d3 Pj = ld3(est_j), Vj = ld3(est_j + 3), gw = ld3(gw_p), dbg_i = ld3(dbg_i_p), dba_i = ld3(dba_i_p);
+    const pvr si = sh_pvr(est_i); const d3 Pj = ld3(est_j), Vj = ld3(est_j + 3), gw = ld3(gw_p), dba_i = ld3(dba_i_p);
     const quat RiT = qnorm(qconj(si.q));
     const d3 aP = qrot(RiT, Pj - si.P - si.V * dT - gw * (0.5 * dT2));
     const d3 aV = qrot(RiT, Vj - si.V - gw * dT);
     const m33 JPa = ldm(pre + 24), JVa = ldm(pre + 42);
-    const d3 rP = aP - (ld3(pre) + mulv(ldm(pre + 15), dbg_i) + mulv(JPa, dba_i));
-    const d3 rV = aV - (ld3(pre + 3) + mulv(ldm(pre + 33), dbg_i) + mulv(JVa, dba_i));
+    const d3 rP = aP - (ld3(cpv) + mulv(JPa, dba_i));
+    const d3 rV = aV - (ld3(cpv + 3) + mulv(JVa, dba_i));
     e[0] = rP.x; e[1] = rP.y; e[2] = rP.z; e[3] = rV.x; e[4] = rV.y; e[5] = rV.z;
     if (!J) return;
     imu_put(J, 0, 6, hat3(aP), 1); imu_put(J, 3, 6, hat3(aV), 1);
     imu_put(J, 0, 18, JPa, -1); imu_put(J, 3, 18, JVa, -1);
 }
 // piece 2: rotation residual and the two blocks that carry Jr^-1
-__device__ __forceinline__ void imu_piece_rot(const double* est_i, const double* est_j, const double* dbg_i_p, const double* pre, double* e, double* J) {
+__device__ __forceinline__ void imu_piece_rot(const double* est_i, const double* est_j, const double* corrT, double* e, double* J) {
     const quat qi = mkq(est_i[6], est_i[7], est_i[8], est_i[9]), qj = mkq(est_j[6], est_j[7], est_j[8], est_j[9]);
     const quat RiT = qnorm(qconj(qi));
-    const quat dRij = qnorm(mat2q(ldm(pre + 6)));
-    const quat corr = so3_mul(dRij, so3_exp(mulv(ldm(pre + 51), ld3(dbg_i_p))));
-    const quat rR = so3_mul(so3_mul(qnorm(qconj(corr)), RiT), qj);
+    const quat rR = so3_mul(so3_mul(mkq(corrT[0], corrT[1], corrT[2], corrT[3]), RiT), qj);
     const d3 rPhi = so3_log(rR);
     e[6] = rPhi.x; e[7] = rPhi.y; e[8] = rPhi.z;
     if (!J) return;
     const m33 JrInv = so3_jr_inv(rPhi);
     imu_put(J, 6, 15, JrInv, 1);
     imu_put(J, 6, 6, mul(mul(JrInv, tr(qmat(qj))), qmat(qi)), -1);
+}
+// the prior factor (vio_core.h prior_edge()) with its constant parts hoisted: pri = [P | V | conj(q) normalised | bias_acc + dbias_acc]
+// of the prior NavState; J (12 x 12) keeps its static pattern, including the four constant -1 diagonals written at setup.
+__device__ __forceinline__ void prior_constants(const double* prior22, double* pri) {
+    const pvr pr = ld_pvr(prior22);
+    st3(pri, pr.P); st3(pri + 3, pr.V);
+    const quat c = qnorm(qconj(pr.q));
+    pri[6] = c.x; pri[7] = c.y; pri[8] = c.z; pri[9] = c.w;
+    st3(pri + 10, ld3(prior22 + 13) + ld3(prior22 + 19));
+}
+__device__ __forceinline__ void prior_piece(const double* est, d3 ba_plus_dba, const double* pri, double* e, double* J) {
+    const pvr s = sh_pvr(est);
+    const d3 eP = ld3(pri) - s.P, eV = ld3(pri + 3) - s.V;
+    const d3 eR = so3_log(so3_mul(mkq(pri[6], pri[7], pri[8], pri[9]), s.q));
+    const d3 eB = ld3(pri + 10) - ba_plus_dba;
+    e[0] = eP.x; e[1] = eP.y; e[2] = eP.z; e[3] = eV.x; e[4] = eV.y; e[5] = eV.z; e[6] = eR.x; e[7] = eR.y; e[8] = eR.z; e[9] = eB.x; e[10] = eB.y; e[11] = eB.z;
+    if (!J) return;
+    const m33 R = qmat(s.q), Ji = so3_jr_inv(eR);
+    const double rv[9] = {R.a00, R.a01, R.a02, R.a10, R.a11, R.a12, R.a20, R.a21, R.a22};
+    const double jv[9] = {Ji.a00, Ji.a01, Ji.a02, Ji.a10, Ji.a11, Ji.a12, Ji.a20, Ji.a21, Ji.a22};
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) { J[r * 12 + c] = -rv[3 * r + c]; J[(6 + r) * 12 + 6 + c] = jv[3 * r + c]; }
 }
 // piece 3: the blocks built from Ri^T alone
 __device__ __forceinline__ void imu_piece_blocks(const double* est_i, const double* est_j, const double* pre, double* J) {
@@ -1020,7 +1054,12 @@ __device__ __forceinline__ void imu_piece_blocks(const double* est_i, const doub
     imu_put(J, 0, 9, mul(RiTm, qmat(qj)), 1);
 }
 
-__global__ __launch_bounds__(256) void k_pose_opt_vi(PoseOptArgs A) {
+// 256 threads, one wave per SIMD, <= 200 registers per lane. Measured at 256 streams beside the extraction stream: 512 threads finish
+// one solve 9 % sooner but hold twice the register file while they run, and the step gets 8 % slower (90.6 k vs 98.3 k frames/s):
+// what this kernel costs the other stream is registers x time, so it stays small.
+#define POSE_THREADS 256
+#define POSE_WAVES (POSE_THREADS / 64)
+__global__ __launch_bounds__(POSE_THREADS, 2) void k_pose_opt_vi(PoseOptArgs A) {
     __shared__ PoseOptShared S;
     __shared__ int s_map21[21], s_map12[12];
 #ifdef VIORB_POSE_TIMING
@@ -1116,6 +1155,12 @@ __global__ __launch_bounds__(256) void k_pose_opt_vi(PoseOptArgs A) {
         S.flag[1] = 0;                                                   // LM iteration counter
     }
     __syncthreads();
+    if (t == 0) imu_constants(S.pre, S.dbg, S.cpv, S.corrT);
+    else if (t == 64 && variant) {
+        prior_constants(priorns, S.pri);
+        for (int r = 0; r < 3; r++) { S.J2[(3 + r) * 12 + 3 + r] = -1; S.J2[(9 + r) * 12 + 9 + r] = -1; }
+    }
+    __syncthreads();
     if (ncur < 3) {                                                      // "if(nInitialCorrespondences<3) return 0"
         if (t == 0) {
             double* o = A.out_ns + (size_t)b * 22; for (int k = 0; k < 22; k++) o[k] = curns[k];
@@ -1137,11 +1182,11 @@ __global__ __launch_bounds__(256) void k_pose_opt_vi(PoseOptArgs A) {
         // dense factors: residuals (+ Jacobians) by one lane of two different waves
         PT_START();
         if (lane == 0) {
-            if (wave == 0) imu_piece_pv(S.est[1], S.est[0], S.dbg, S.bias[1], S.pre, S.gw, S.e1, lin ? S.J1 : nullptr);
+            if (wave == 0) imu_piece_pv(S.est[1], S.est[0], S.cpv, S.bias[1], S.pre, S.gw, S.e1, lin ? S.J1 : nullptr);
             else if (wave == 1) {
-                if (variant) { const pvr sl = sh_pvr(S.est[1]); prior_edge(sl, ld3(S.base_ba[1]) + ld3(S.bias[1]), priorns, S.e2, lin ? S.J2 : nullptr, false); }
+                if (variant) prior_piece(S.est[1], ld3(S.base_ba[1]) + ld3(S.bias[1]), S.pri, S.e2, lin ? S.J2 : nullptr);
             }
-            else if (wave == 2) imu_piece_rot(S.est[1], S.est[0], S.dbg, S.pre, S.e1, lin ? S.J1 : nullptr);
+            else if (wave == 2) imu_piece_rot(S.est[1], S.est[0], S.corrT, S.e1, lin ? S.J1 : nullptr);
             else if (lin) imu_piece_blocks(S.est[1], S.est[0], S.pre, S.J1);
         }
         PT_LAP(0);
@@ -1152,43 +1197,29 @@ __global__ __launch_bounds__(256) void k_pose_opt_vi(PoseOptArgs A) {
             double a[28];
 #pragma unroll
             for (int k = 0; k < 28; k++) a[k] = 0;
-            // Two edges per thread and trip (i and i + 256), both in the same straight-line code: one wave per SIMD has nothing else to
-            // fill the f64 pipeline's dependent-issue gaps with. A switched-off edge (outlier, or past the end) is computed on a harmless
-            // stand-in — a point on the optical axis at unit depth — with weight 0.
             const double dsq_mono = d_mono * d_mono;
-            const d3 Xoff = s.P + mulv(tr(RT), mulv(tr(K.Rcb), K.RcbPbc + mk3(0, 0, 1)));        // projects to camera coordinates (0, 0, 1)
-            for (int i0 = t; i0 < ne; i0 += 512) {
-                const int i1 = min(i0 + 256, ne - 1);
+            for (int i0 = t; i0 < ne; i0 += POSE_THREADS) {
                 const uint8_t* fl = use_lds ? s_out + side * cap : ol;
-                const bool on0 = fl[i0] == 0, on1 = (i0 + 256 < ne) && fl[i1] == 0;
-                if (!(on0 || on1)) continue;
-                const obs_t o0 = load_obs(side, ob, i0), o1 = load_obs(side, ob, i1);
-                const d3 X0 = on0 ? o0.X : Xoff, X1 = on1 ? o1.X : Xoff;
-                const double u0 = o0.u, v0 = o0.v, u1 = o1.u, v1 = o1.v;
-                const double is0 = on0 ? o0.is2 : 0.0, is1 = on1 ? o1.is2 : 0.0;
-                double ea0, ea1, eb0, eb1, ja0[6], ja1[6], jb0[6], jb1[6];
-                proj_edge_lin(K, RT, s.P, X0, u0, v0, ea0, ea1, ja0, ja1);
-                proj_edge_lin(K, RT, s.P, X1, u1, v1, eb0, eb1, jb0, jb1);
-                const double chi0 = is0 * fma(ea0, ea0, ea1 * ea1), chi1 = is1 * fma(eb0, eb0, eb1 * eb1);
-                double ra0 = chi0, ra1 = 1, rb0 = chi1, rb1 = 1;
-                if (kernel_on && (chi0 > dsq_mono || chi1 > dsq_mono)) {          // RobustKernelHuber::robustify
-                    const double sq0 = sqrt(chi0), sq1 = sqrt(chi1);
-                    if (chi0 > dsq_mono) { ra0 = 2 * sq0 * d_mono - dsq_mono; ra1 = d_mono / sq0; }
-                    if (chi1 > dsq_mono) { rb0 = 2 * sq1 * d_mono - dsq_mono; rb1 = d_mono / sq1; }
-                }
-                a[27] += ra0; a[27] += rb0;
+                if (fl[i0]) continue;
+                const obs_t o0 = load_obs(side, ob, i0);
+                double ea0, ea1, ja0[6], ja1[6];
+                proj_edge_lin(K, RT, s.P, o0.X, o0.u, o0.v, ea0, ea1, ja0, ja1);
+                const double chi0 = o0.is2 * fma(ea0, ea0, ea1 * ea1);
+                double ra0 = chi0, ra1 = 1;
+                if (kernel_on && chi0 > dsq_mono) { const double sq0 = sqrt(chi0); ra0 = 2 * sq0 * d_mono - dsq_mono; ra1 = d_mono / sq0; }
+                a[27] += ra0;
                 if (lin) {
-                    const double w0 = ra1 * is0, w1 = rb1 * is1;
-                    double wa0[6], wa1[6], wb0[6], wb1[6];
+                    const double w0 = ra1 * o0.is2;
+                    double wa0[6], wa1[6];
 #pragma unroll
-                    for (int r = 0; r < 6; r++) { wa0[r] = w0 * ja0[r]; wa1[r] = w0 * ja1[r]; wb0[r] = w1 * jb0[r]; wb1[r] = w1 * jb1[r]; }
+                    for (int r = 0; r < 6; r++) { wa0[r] = w0 * ja0[r]; wa1[r] = w0 * ja1[r]; }
                     int k = 0;
 #pragma unroll
                     for (int r = 0; r < 6; r++)
 #pragma unroll
-                        for (int c = r; c < 6; c++, k++) a[k] = fma(wb1[r], jb1[c], fma(wb0[r], jb0[c], fma(wa1[r], ja1[c], fma(wa0[r], ja0[c], a[k]))));
+                        for (int c = r; c < 6; c++, k++) a[k] = fma(wa1[r], ja1[c], fma(wa0[r], ja0[c], a[k]));
 #pragma unroll
-                    for (int r = 0; r < 6; r++) a[21 + r] = fma(-wb1[r], eb1, fma(-wb0[r], eb0, fma(-wa1[r], ea1, fma(-wa0[r], ea0, a[21 + r]))));
+                    for (int r = 0; r < 6; r++) a[21 + r] = fma(-wa1[r], ea1, fma(-wa0[r], ea0, a[21 + r]));
                 }
             }
             PT_LAP(6);
@@ -1246,7 +1277,7 @@ __global__ __launch_bounds__(256) void k_pose_opt_vi(PoseOptArgs A) {
         if (variant) { double chi = 0; for (int i = 0; i < 12; i++) chi += S.q[12 + i]; huber(chi, d_prior, &rob2, &w2); }
         if (t == 0) {
             double tot = 0;
-            for (int w = 0; w < 4; w++) { tot += S.red[w][0][27]; if (variant) tot += S.red[w][1][27]; }
+            for (int w = 0; w < POSE_WAVES; w++) { tot += S.red[w][0][27]; if (variant) tot += S.red[w][1][27]; }
             tot += rob1; tot += S.sc[8];
             if (variant) tot += rob2;
             S.sc[0] = tot;
@@ -1260,12 +1291,12 @@ __global__ __launch_bounds__(256) void k_pose_opt_vi(PoseOptArgs A) {
                 // reprojection partials: (P, Phi) 6x6 block of each frame
                 const int sideR = R / 12, rr = R - 12 * sideR, r6 = rr < 3 ? rr : (rr >= 6 && rr < 9 ? rr - 3 : -1);
                 if (isb) {
-                    if (r6 >= 0) v += S.red[0][sideR][21 + r6] + S.red[1][sideR][21 + r6] + S.red[2][sideR][21 + r6] + S.red[3][sideR][21 + r6];
+                    if (r6 >= 0) { for (int w = 0; w < POSE_WAVES; w++) v += S.red[w][sideR][21 + r6]; }
                 } else {
                     const int sideC = Cc / 12, cr = Cc - 12 * sideC, c6 = cr < 3 ? cr : (cr >= 6 && cr < 9 ? cr - 3 : -1);
                     if (sideR == sideC && r6 >= 0 && c6 >= 0) {
                         const int lo6 = min(r6, c6), hi6 = max(r6, c6), kk = lo6 * 6 - lo6 * (lo6 - 1) / 2 + (hi6 - lo6);
-                        v += S.red[0][sideR][kk] + S.red[1][sideR][kk] + S.red[2][sideR][kk] + S.red[3][sideR][kk];
+                        for (int w = 0; w < POSE_WAVES; w++) v += S.red[w][sideR][kk];
                     }
                 }
                 // IMU factor: column m of J = [last PVR (9) | cur PVR (9) | last bias (3)]
@@ -1311,6 +1342,9 @@ __global__ __launch_bounds__(256) void k_pose_opt_vi(PoseOptArgs A) {
         PT_LAP(4);
     };
 
+#ifdef VIORB_POSE_TIMING
+    const unsigned long long pt_setup = __builtin_amdgcn_s_memtime() - pt_begin;
+#endif
     for (int round = 0; round < 4; round++) {
         // reset the estimates to the frames' NavStates (Optimizer.cc:614-617 / :984-985)
         if (t == 0) {
@@ -1408,8 +1442,8 @@ __global__ __launch_bounds__(256) void k_pose_opt_vi(PoseOptArgs A) {
     }
 #ifdef VIORB_POSE_TIMING
     if (b == 0 && lane == 0)
-        printf("pose_opt wave=%d total=%llu evals=%d dense=%llu edges=%llu wait=%llu asm=%llu solve=%llu classify=%llu loop=%llu\n", wave,
-               __builtin_amdgcn_s_memtime() - pt_begin, pt_n, pt_acc[0], pt_acc[1], pt_acc[2], pt_acc[3], pt_acc[4], pt_acc[5], pt_acc[6]);
+        printf("pose_opt wave=%d total=%llu evals=%d dense=%llu edges=%llu wait=%llu asm=%llu solve=%llu classify=%llu loop=%llu setup=%llu\n", wave,
+               __builtin_amdgcn_s_memtime() - pt_begin, pt_n, pt_acc[0], pt_acc[1], pt_acc[2], pt_acc[3], pt_acc[4], pt_acc[5], pt_acc[6], pt_setup);
 #endif
     // ---- outputs
     if (t == 0) {
@@ -1913,7 +1947,7 @@ int viorb_frontend_pose_opt_device(viorb_frontend* h, int variant, int compute_m
         }
     }
     ProfScope ps("k_pose_opt_vi", (hipStream_t)stream);
-    hipLaunchKernelGGL(k_pose_opt_vi, dim3(batch), dim3(256), lds, (hipStream_t)stream, A);
+    hipLaunchKernelGGL(k_pose_opt_vi, dim3(batch), dim3(POSE_THREADS), lds, (hipStream_t)stream, A);
     VIORB_HIP_TRY(hipGetLastError());
     return VIORB_OK;
 }
