@@ -844,6 +844,7 @@ struct PoseOptShared {
     double pre[64];                                     // dP dV dR JPg JPa JVg JVa JRg (60) + dT: what the IMU factor reads every evaluation
     double gw[3], dbg[3];                               // gravity, the last frame's gyro-bias delta
     double cpv[6], corrT[4], pri[13];                   // constant parts of the IMU and prior factors (imu_constants, prior_constants)
+    uint32_t tab[324][2];                               // where each lower-triangle H entry / b entry gets its terms from (built once per solve)
     int flag[4];
 };
 
@@ -881,8 +882,8 @@ __device__ __forceinline__ double readlane_d(double v, int l) {
 // 1/sqrt(d) to full double precision: hardware estimate + two Newton steps
 __device__ __forceinline__ double rsqrt_nr(double d) {
     double y = __builtin_amdgcn_rsq(d);
-    y = y * (1.5 - 0.5 * d * y * y);
-    y = y * (1.5 - 0.5 * d * y * y);
+    y = fma(0.5 * y, fma(-(d * y), y, 1.0), y);          // y (1 + (1 - d y^2) / 2): three dependent operations per step instead of five
+    y = fma(0.5 * y, fma(-(d * y), y, 1.0), y);
     return y;
 }
 // Cholesky solve of (H + lambda I) x = b for ONE wavefront with lane i holding row i of the matrix in
@@ -904,12 +905,12 @@ __device__ bool wave_solve_reg(const double* __restrict__ H, const double* __res
         ok = ok && (d > 0.0) && isfinite(d);
         const double inv = rsqrt_nr(d);
         invd[j] = inv;
-        const double lij = (lane == j) ? d * inv : a[j] * inv;
+        const double lij = a[j] * inv;                           // lane j: d / sqrt(d)
         a[j] = lij;
         const double yj = readlane_d(rhs, j) * inv;              // forward substitution rides along
-        if (lane == j) rhs = yj; else if (lane > j) rhs -= lij * yj;
+        if (lane == j) rhs = yj; else if (lane > j) rhs = fma(-lij, yj, rhs);
 #pragma unroll
-        for (int k = j + 1; k < N; k++) a[k] -= lij * readlane_d(lij, k);
+        for (int k = j + 1; k < N; k++) a[k] = fma(-lij, readlane_d(lij, k), a[k]);
     }
 #pragma unroll
     for (int c = 0; c < N; c++) Lt[li * N + c] = a[c];
@@ -921,7 +922,7 @@ __device__ bool wave_solve_reg(const double* __restrict__ H, const double* __res
 #pragma unroll
     for (int j = N - 1; j >= 0; j--) {
         const double xj = readlane_d(acc, j) * invd[j];
-        if (lane == j) acc = xj; else if (lane < j) acc -= col[j] * xj;
+        if (lane == j) acc = xj; else if (lane < j) acc = fma(-col[j], xj, acc);
     }
     if (lane < N) x[lane] = acc;
     return ok;
@@ -1061,7 +1062,6 @@ __device__ __forceinline__ void imu_piece_blocks(const double* est_i, const doub
 #define POSE_WAVES (POSE_THREADS / 64)
 __global__ __launch_bounds__(POSE_THREADS, 2) void k_pose_opt_vi(PoseOptArgs A) {
     __shared__ PoseOptShared S;
-    __shared__ int s_map21[21], s_map12[12];
 #ifdef VIORB_POSE_TIMING
     const unsigned long long pt_begin = __builtin_amdgcn_s_memtime();
 #endif
@@ -1148,13 +1148,47 @@ __global__ __launch_bounds__(POSE_THREADS, 2) void k_pose_opt_vi(PoseOptArgs A) 
     for (int i = t; i < 144; i += blockDim.x) S.J2[i] = 0;
     if (t == 0) {
         for (int k = 0; k < 3; k++) { S.base_ba[0][k] = curns[13 + k]; S.base_ba[1][k] = lastns[13 + k]; }
-        // column maps: IMU factor J = [i(9) | j(9) | bias_i(3)] with i = last, j = cur
-        for (int k = 0; k < 9; k++) { s_map21[k] = variant ? 12 + k : -1; s_map21[9 + k] = k; }
-        for (int k = 0; k < 3; k++) s_map21[18 + k] = variant ? 21 + k : -1;
-        for (int k = 0; k < 12; k++) s_map12[k] = 12 + k;              // prior: [last PVR | last bias]
         S.flag[1] = 0;                                                   // LM iteration counter
     }
     __syncthreads();
+    // Assembly table: work item q < n(n+1)/2 is the lower-triangle entry (R, C), the next n items are b[R]. Word 0: R | C<<5 | isb<<10 |
+    // red index<<11 (31 = no reprojection term) | side<<16 | IMU column of R<<17 | IMU column of C<<22 (31 = none) | bias sign<<27
+    // (0 none, 1 +, 2 -) | bias component<<29; word 1: prior column of R | prior column of C<<4 (15 = none).
+    {
+        const int ntri = n * (n + 1) / 2;
+        for (int q = t; q < ntri + n; q += blockDim.x) {
+            const bool isb = q >= ntri;
+            int R, Cc;
+            if (isb) { R = q - ntri; Cc = 0; }
+            else {
+                R = (int)((sqrtf(8.0f * (float)q + 1.0f) - 1.0f) * 0.5f);
+                while (R * (R + 1) / 2 > q) R--;
+                while ((R + 1) * (R + 2) / 2 <= q) R++;
+                Cc = q - R * (R + 1) / 2;
+            }
+            auto six = [](int x) { const int r = x % 12; return r < 3 ? r : (r >= 6 && r < 9 ? r - 3 : -1); };
+            auto imu_col = [](int x) { return x < 9 ? 9 + x : (x >= 12 && x < 21 ? x - 12 : (x >= 21 ? 18 + x - 21 : 31)); };
+            auto bias_of = [](int x) { return (x >= 9 && x < 12) ? x - 9 : (x >= 21 ? x - 21 : -1); };
+            const int sideR = R / 12, r6 = six(R);
+            int redk = 31;
+            if (isb) { if (r6 >= 0) redk = 21 + r6; }
+            else {
+                const int c6 = six(Cc);
+                if (sideR == Cc / 12 && r6 >= 0 && c6 >= 0) { const int lo6 = min(r6, c6), hi6 = max(r6, c6); redk = lo6 * 6 - lo6 * (lo6 - 1) / 2 + (hi6 - lo6); }
+            }
+            const int mR = imu_col(R), mC = isb ? 31 : imu_col(Cc);
+            const int bR = bias_of(R);
+            int bsign = 0;
+            if (bR >= 0) {
+                if (isb) bsign = R < 12 ? 2 : 1;
+                else if (bias_of(Cc) == bR) bsign = ((Cc < 12) == (R < 12)) ? 1 : 2;
+            }
+            const int pR = (variant && R >= 12) ? R - 12 : 15, pC = (!isb && variant && Cc >= 12) ? Cc - 12 : 15;
+            S.tab[q][0] = (uint32_t)R | ((uint32_t)Cc << 5) | ((uint32_t)isb << 10) | ((uint32_t)redk << 11) | ((uint32_t)sideR << 16) | ((uint32_t)mR << 17) |
+                          ((uint32_t)mC << 22) | ((uint32_t)bsign << 27) | ((uint32_t)(bR < 0 ? 0 : bR) << 29);
+            S.tab[q][1] = (uint32_t)pR | ((uint32_t)pC << 4);
+        }
+    }
     if (t == 0) imu_constants(S.pre, S.dbg, S.cpv, S.corrT);
     else if (t == 64 && variant) {
         prior_constants(priorns, S.pri);
@@ -1272,6 +1306,7 @@ __global__ __launch_bounds__(POSE_THREADS, 2) void k_pose_opt_vi(PoseOptArgs A) 
             }
         }
         __syncthreads();
+        PT_LAP(7);
         double w1, w2 = 0, rob1, rob2 = 0;
         { double chi = 0; for (int i = 0; i < 9; i++) chi += S.q[i]; huber(chi, d_pvr, &rob1, &w1); }
         if (variant) { double chi = 0; for (int i = 0; i < 12; i++) chi += S.q[12 + i]; huber(chi, d_prior, &rob2, &w2); }
@@ -1284,45 +1319,25 @@ __global__ __launch_bounds__(POSE_THREADS, 2) void k_pose_opt_vi(PoseOptArgs A) 
         }
         if (lin) {
             const double wb = S.sc[3];
-            for (int i = t; i < n * n + n; i += blockDim.x) {
-                const bool isb = i >= n * n;
-                const int R = isb ? i - n * n : i / n, Cc = isb ? 0 : i - R * n;
+            const int nitems = n * (n + 1) / 2 + n;
+            for (int q = t; q < nitems; q += blockDim.x) {
+                const uint32_t d0 = S.tab[q][0], d1 = S.tab[q][1];
+                const int R = d0 & 31, Cc = (d0 >> 5) & 31, redk = (d0 >> 11) & 31, sideR = (d0 >> 16) & 1, mR = (d0 >> 17) & 31, mC = (d0 >> 22) & 31;
+                const int bsign = (d0 >> 27) & 3, bR = d0 >> 29, pR = d1 & 15, pC = (d1 >> 4) & 15;
+                const bool isb = (d0 >> 10) & 1;
                 double v = 0;
-                // reprojection partials: (P, Phi) 6x6 block of each frame
-                const int sideR = R / 12, rr = R - 12 * sideR, r6 = rr < 3 ? rr : (rr >= 6 && rr < 9 ? rr - 3 : -1);
+                if (redk != 31) { for (int w = 0; w < POSE_WAVES; w++) v += S.red[w][sideR][redk]; }      // reprojection partials
                 if (isb) {
-                    if (r6 >= 0) { for (int w = 0; w < POSE_WAVES; w++) v += S.red[w][sideR][21 + r6]; }
+                    if (mR != 31) { double sq = 0; for (int kk = 0; kk < 9; kk++) sq += S.OJ1[kk * 21 + mR] * S.e1[kk]; v -= w1 * sq; }
+                    if (pR != 15) { double sq = 0; for (int kk = 0; kk < 12; kk++) sq += S.OJ2[kk * 12 + pR] * S.e2[kk]; v -= w2 * sq; }
+                    if (bsign) v += (bsign == 2 ? -wb : wb) * S.sc[4 + bR];
+                    bv[R] = v;
                 } else {
-                    const int sideC = Cc / 12, cr = Cc - 12 * sideC, c6 = cr < 3 ? cr : (cr >= 6 && cr < 9 ? cr - 3 : -1);
-                    if (sideR == sideC && r6 >= 0 && c6 >= 0) {
-                        const int lo6 = min(r6, c6), hi6 = max(r6, c6), kk = lo6 * 6 - lo6 * (lo6 - 1) / 2 + (hi6 - lo6);
-                        for (int w = 0; w < POSE_WAVES; w++) v += S.red[w][sideR][kk];
-                    }
+                    if (mR != 31 && mC != 31) { double sq = 0; for (int kk = 0; kk < 9; kk++) sq += S.J1[kk * 21 + mR] * S.OJ1[kk * 21 + mC]; v += w1 * sq; }
+                    if (pR != 15 && pC != 15) { double sq = 0; for (int kk = 0; kk < 12; kk++) sq += S.J2[kk * 12 + pR] * S.OJ2[kk * 12 + pC]; v += w2 * sq; }
+                    if (bsign) v += bsign == 1 ? wb : -wb;
+                    Hm[R * n + Cc] = v; Hm[Cc * n + R] = v;          // both triangles: the marginal at the end reads the full matrix
                 }
-                // IMU factor: column m of J = [last PVR (9) | cur PVR (9) | last bias (3)]
-                const int mR = R < 9 ? 9 + R : (R >= 12 && R < 21 ? R - 12 : (R >= 21 ? 18 + R - 21 : -1));
-                if (isb) {
-                    if (mR >= 0) { double sq = 0; for (int kk = 0; kk < 9; kk++) sq += S.OJ1[kk * 21 + mR] * S.e1[kk]; v -= w1 * sq; }
-                } else {
-                    const int mC = Cc < 9 ? 9 + Cc : (Cc >= 12 && Cc < 21 ? Cc - 12 : (Cc >= 21 ? 18 + Cc - 21 : -1));
-                    if (mR >= 0 && mC >= 0) { double sq = 0; for (int kk = 0; kk < 9; kk++) sq += S.J1[kk * 21 + mR] * S.OJ1[kk * 21 + mC]; v += w1 * sq; }
-                }
-                // prior factor on the last frame's 12 unknowns
-                if (variant && R >= 12) {
-                    if (isb) { double sq = 0; for (int kk = 0; kk < 12; kk++) sq += S.OJ2[kk * 12 + R - 12] * S.e2[kk]; v -= w2 * sq; }
-                    else if (Cc >= 12) { double sq = 0; for (int kk = 0; kk < 12; kk++) sq += S.J2[kk * 12 + R - 12] * S.OJ2[kk * 12 + Cc - 12]; v += w2 * sq; }
-                }
-                // bias random-walk factor: J_i = -I (last bias), J_j = +I (cur bias)
-                const int bR = (R >= 9 && R < 12) ? R - 9 : (R >= 21 ? R - 21 : -1);
-                if (bR >= 0) {
-                    const bool curR = R < 12;
-                    if (isb) v += (curR ? -wb : wb) * S.sc[4 + bR];
-                    else {
-                        const int bC = (Cc >= 9 && Cc < 12) ? Cc - 9 : (Cc >= 21 ? Cc - 21 : -1);
-                        if (bC == bR) v += ((Cc < 12) == curR) ? wb : -wb;
-                    }
-                }
-                if (isb) bv[R] = v; else Hm[i] = v;
             }
         }
         __syncthreads();
@@ -1389,7 +1404,8 @@ __global__ __launch_bounds__(POSE_THREADS, 2) void k_pose_opt_vi(PoseOptArgs A) 
                 rho = (currentChi - tempChi) / scale;
                 accepted = rho > 0 && isfinite(tempChi);
                 if (accepted) {
-                    double alpha = 1. - pow(2 * rho - 1, 3);
+                    const double tr1 = 2 * rho - 1;
+                    double alpha = 1. - tr1 * tr1 * tr1;               // g2o: 1 - pow(2*rho-1, 3)
                     alpha = fmin(alpha, 2. / 3.);
                     lambda *= fmax(1. / 3., alpha); ni = 2; currentChi = tempChi;
                 } else {
@@ -1442,8 +1458,8 @@ __global__ __launch_bounds__(POSE_THREADS, 2) void k_pose_opt_vi(PoseOptArgs A) 
     }
 #ifdef VIORB_POSE_TIMING
     if (b == 0 && lane == 0)
-        printf("pose_opt wave=%d total=%llu evals=%d dense=%llu edges=%llu wait=%llu asm=%llu solve=%llu classify=%llu loop=%llu setup=%llu\n", wave,
-               __builtin_amdgcn_s_memtime() - pt_begin, pt_n, pt_acc[0], pt_acc[1], pt_acc[2], pt_acc[3], pt_acc[4], pt_acc[5], pt_acc[6], pt_setup);
+        printf("pose_opt wave=%d total=%llu evals=%d dense=%llu edges=%llu wait=%llu asm=%llu solve=%llu classify=%llu loop=%llu setup=%llu asm1=%llu\n", wave,
+               __builtin_amdgcn_s_memtime() - pt_begin, pt_n, pt_acc[0], pt_acc[1], pt_acc[2], pt_acc[3], pt_acc[4], pt_acc[5], pt_acc[6], pt_setup, pt_acc[7]);
 #endif
     // ---- outputs
     if (t == 0) {
