@@ -7,7 +7,6 @@
 //   k_build_observations  the edge-construction loops of PoseOptimization  src/Optimizer.cc:493-589
 //   k_pose_opt_vi         Optimizer::PoseOptimization(Frame*, KeyFrame*|Frame*, ...) with g2o's LM
 //                         reference src/Optimizer.cc:323-1112 + Thirdparty/g2o (see vio_core.h)
-#include <atomic>
 #include <hip/hip_runtime.h>
 #include <vector>
 #include <algorithm>
@@ -827,7 +826,6 @@ struct PoseOptArgs {
     double *out_ns, *out_last_ns, *marg_out, *info;
     uint8_t *outlier_cur, *outlier_last;
     double acc_bias_rw2;
-    int obs_lds;                 // 1: the launch carries 2 * cap * 25 bytes of dynamic LDS for the observations and their outlier flags
 };
 
 struct PoseOptShared {
@@ -1083,33 +1081,11 @@ __global__ __launch_bounds__(POSE_THREADS, 2) void k_pose_opt_vi(PoseOptArgs A) 
     // ---- setup
     for (int i = t; i < ncur; i += blockDim.x) out_c[i] = 0;
     for (int i = t; i < nlast; i += blockDim.x) out_l[i] = 0;
-    // The observations are read by every one of the ~25 evaluations, one wave per SIMD with nothing to hide a global load behind: keep
-    // them in LDS. In the tracking sequence every value is a float widened to double (map points, keypoint coordinates, 1/sigma2), so
-    // the LDS copy is float, 24 bytes per edge, and exact; any other input (checked here, value by value) keeps the global path.
-    extern __shared__ float s_obs[];                                    // [2][cap][6] floats, then [2][cap] outlier flags
-    uint8_t* s_out = reinterpret_cast<uint8_t*>(s_obs + (size_t)2 * cap * 6);
-    bool use_lds = false;
-    if (A.obs_lds) {
-        bool exact = true;
-        for (int side = 0; side < (variant ? 2 : 1); side++) {
-            const double* ob = side ? obs_l : obs_c; const int ne = side ? nlast : ncur;
-            for (int i = t; i < ne * 6; i += blockDim.x) {
-                const double d = ob[i]; const float f = (float)d;
-                exact = exact && ((double)f == d);
-                s_obs[(size_t)side * cap * 6 + i] = f;
-            }
-            for (int i = t; i < ne; i += blockDim.x) s_out[side * cap + i] = 0;
-        }
-        use_lds = __syncthreads_and(exact) != 0;
-    }
     struct obs_t { d3 X; double u, v, is2; };
-    auto load_obs = [&](int side, const double* ob, int i) {
-        obs_t o;
-        if (use_lds) {
-            const float2* f = reinterpret_cast<const float2*>(s_obs + ((size_t)side * cap + i) * 6);
-            const float2 f0 = f[0], f1 = f[1], f2 = f[2];
-            o.X = mk3((double)f0.x, (double)f0.y, (double)f1.x); o.u = (double)f1.y; o.v = (double)f2.x; o.is2 = (double)f2.y;
-        } else { o.X = ld3(ob + 6 * i); o.u = ob[6 * i + 3]; o.v = ob[6 * i + 4]; o.is2 = ob[6 * i + 5]; }
+    // Observations stay in global memory (L2): an LDS copy (24 B per edge as float) made one solve 4 % faster alone and the whole
+    // step 9 % slower, because 50 KB more LDS per workgroup keep the extraction stream's workgroups off the CU while this kernel runs.
+    auto load_obs = [&](const double* ob, int i) {
+        obs_t o; o.X = ld3(ob + 6 * i); o.u = ob[6 * i + 3]; o.v = ob[6 * i + 4]; o.is2 = ob[6 * i + 5];
         return o;
     };
     // information of the IMU factor: cov^-1 + diag(1e2,1,1e2) (x) I3, by Gauss-Jordan over all threads
@@ -1233,9 +1209,8 @@ __global__ __launch_bounds__(POSE_THREADS, 2) void k_pose_opt_vi(PoseOptArgs A) 
             for (int k = 0; k < 28; k++) a[k] = 0;
             const double dsq_mono = d_mono * d_mono;
             for (int i0 = t; i0 < ne; i0 += POSE_THREADS) {
-                const uint8_t* fl = use_lds ? s_out + side * cap : ol;
-                if (fl[i0]) continue;
-                const obs_t o0 = load_obs(side, ob, i0);
+                if (ol[i0]) continue;
+                const obs_t o0 = load_obs(ob, i0);
                 double ea0, ea1, ja0[6], ja1[6];
                 proj_edge_lin(K, RT, s.P, o0.X, o0.u, o0.v, ea0, ea1, ja0, ja1);
                 const double chi0 = o0.is2 * fma(ea0, ea0, ea1 * ea1);
@@ -1432,13 +1407,12 @@ __global__ __launch_bounds__(POSE_THREADS, 2) void k_pose_opt_vi(PoseOptArgs A) 
                 const m33 RT = tr(qmat(s.q));
                 const double* ob = side ? obs_l : obs_c; uint8_t* ol = side ? out_l : out_c; const int ne = side ? nlast : ncur;
                 for (int i = t; i < ne; i += blockDim.x) {
-                    const obs_t o = load_obs(side, ob, i);
+                    const obs_t o = load_obs(ob, i);
                     double e[2];
                     proj_edge(K, RT, s.P, o.X, o.u, o.v, false, e, nullptr, nullptr);
                     const float chi2 = (float)(o.is2 * (e[0] * e[0] + e[1] * e[1]));
                     const int bad = chi2 > 5.991f;
                     ol[i] = (uint8_t)bad;
-                    if (use_lds) s_out[side * cap + i] = (uint8_t)bad;
                     if (side == 0) bad_local += bad;
                 }
             }
@@ -1951,19 +1925,8 @@ int viorb_frontend_pose_opt_device(viorb_frontend* h, int variant, int compute_m
     A.gw = h->d_gw; A.cam = h->d_cam; A.obs_cur = obs_cur; A.obs_last = variant ? obs_last : nullptr; A.n_cur = n_cur; A.n_last = n_last;
     A.out_ns = out_ns; A.out_last_ns = out_last_ns; A.marg_out = marg_out; A.info = info;
     A.outlier_cur = outlier_cur; A.outlier_last = variant ? outlier_last : nullptr; A.acc_bias_rw2 = h->cfg.acc_bias_rw2;
-    // observations + outlier flags in LDS when they fit next to the solver's static 26 KB
-    size_t lds = (((size_t)2 * h->cap * 25) + 15) & ~(size_t)15;
-    A.obs_lds = lds <= 120 * 1024;
-    if (!A.obs_lds) lds = 0;
-    else {
-        static std::atomic<int> lds_allowed{0};                  // the attribute belongs to the function, not to a handle: keep the maximum
-        if ((int)lds > lds_allowed.load()) {
-            VIORB_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pose_opt_vi), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            lds_allowed.store((int)lds);
-        }
-    }
     ProfScope ps("k_pose_opt_vi", (hipStream_t)stream);
-    hipLaunchKernelGGL(k_pose_opt_vi, dim3(batch), dim3(POSE_THREADS), lds, (hipStream_t)stream, A);
+    hipLaunchKernelGGL(k_pose_opt_vi, dim3(batch), dim3(POSE_THREADS), 0, (hipStream_t)stream, A);
     VIORB_HIP_TRY(hipGetLastError());
     return VIORB_OK;
 }
