@@ -183,28 +183,49 @@ __global__ __launch_bounds__(256) void k_resize(uint8_t* __restrict__ planes, si
 // FAST-9-16 corner strength of the pixel at p (byte pointer into an LDS tile with `pitch` bytes per
 // row): max over the 16 arcs of 9 contiguous ring pixels of min(v - ring) and of min(ring - v),
 // minus 1 == cv::cornerScore<16>; the pixel is a FAST corner at threshold t iff strength >= t.
+typedef short short2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_min16(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(short2v, a), __builtin_bit_cast(short2v, b)));
+}
+__device__ __forceinline__ uint32_t pk_max16(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(short2v, a), __builtin_bit_cast(short2v, b)));
+}
+__device__ __forceinline__ uint32_t pk_sub16(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, __builtin_bit_cast(short2v, a) - __builtin_bit_cast(short2v, b));
+}
+__device__ __forceinline__ uint32_t swap16(uint32_t a) { return __builtin_amdgcn_alignbit(a, a, 16); }
+// The ring differences d[k] = v - ring[k] fit 16 bits, and the 16 arcs come in opposite pairs: register k holds (d[k], d[k+8]), so
+// every min / max of the arc recurrence is one packed 16-bit instruction for two arcs (integer min/max issue at quarter rate on
+// CDNA4, which is what bounds this kernel), with a half-swap wherever an index wraps past 15.
 __device__ __forceinline__ int fast_strength(const uint8_t* p, int pitch) {
-    const int v = p[0];
-    int d[16];
-    d[0] = v - p[3 * pitch];       d[1] = v - p[3 * pitch + 1];   d[2] = v - p[2 * pitch + 2];
-    d[3] = v - p[pitch + 3];       d[4] = v - p[3];               d[5] = v - p[-pitch + 3];
-    d[6] = v - p[-2 * pitch + 2];  d[7] = v - p[-3 * pitch + 1];  d[8] = v - p[-3 * pitch];
-    d[9] = v - p[-3 * pitch - 1];  d[10] = v - p[-2 * pitch - 2]; d[11] = v - p[-pitch - 3];
-    d[12] = v - p[-3];             d[13] = v - p[pitch - 3];      d[14] = v - p[2 * pitch - 2];
-    d[15] = v - p[3 * pitch - 1];
-    int lo2[16], hi2[16], lo4[16], hi4[16];
+    const uint32_t v = p[0], vv = v | (v << 16);
+    uint32_t P[8];
+    P[0] = pk_sub16(vv, (uint32_t)p[3 * pitch] | ((uint32_t)p[-3 * pitch] << 16));
+    P[1] = pk_sub16(vv, (uint32_t)p[3 * pitch + 1] | ((uint32_t)p[-3 * pitch - 1] << 16));
+    P[2] = pk_sub16(vv, (uint32_t)p[2 * pitch + 2] | ((uint32_t)p[-2 * pitch - 2] << 16));
+    P[3] = pk_sub16(vv, (uint32_t)p[pitch + 3] | ((uint32_t)p[-pitch - 3] << 16));
+    P[4] = pk_sub16(vv, (uint32_t)p[3] | ((uint32_t)p[-3] << 16));
+    P[5] = pk_sub16(vv, (uint32_t)p[-pitch + 3] | ((uint32_t)p[pitch - 3] << 16));
+    P[6] = pk_sub16(vv, (uint32_t)p[-2 * pitch + 2] | ((uint32_t)p[2 * pitch - 2] << 16));
+    P[7] = pk_sub16(vv, (uint32_t)p[-3 * pitch + 1] | ((uint32_t)p[3 * pitch - 1] << 16));
+    uint32_t S[8], lo2[8], hi2[8], lo4[8], hi4[8];
 #pragma unroll
-    for (int k = 0; k < 16; k++) { lo2[k] = min(d[k], d[(k + 1) & 15]); hi2[k] = max(d[k], d[(k + 1) & 15]); }
+    for (int k = 0; k < 8; k++) S[k] = swap16(P[k]);                       // (d[k+8], d[k])
 #pragma unroll
-    for (int k = 0; k < 16; k++) { lo4[k] = min(lo2[k], lo2[(k + 2) & 15]); hi4[k] = max(hi2[k], hi2[(k + 2) & 15]); }
-    int a = -256, bq = 256;
+    for (int k = 0; k < 8; k++) { const uint32_t nx = k < 7 ? P[k + 1] : S[0]; lo2[k] = pk_min16(P[k], nx); hi2[k] = pk_max16(P[k], nx); }
 #pragma unroll
-    for (int k = 0; k < 16; k++) {
-        const int lo9 = min(min(lo4[k], lo4[(k + 4) & 15]), d[(k + 8) & 15]);
-        const int hi9 = max(max(hi4[k], hi4[(k + 4) & 15]), d[(k + 8) & 15]);
-        a = max(a, lo9);
-        bq = min(bq, hi9);
+    for (int k = 0; k < 8; k++) {
+        const uint32_t nl = k < 6 ? lo2[k + 2] : swap16(lo2[k - 6]), nh = k < 6 ? hi2[k + 2] : swap16(hi2[k - 6]);
+        lo4[k] = pk_min16(lo2[k], nl); hi4[k] = pk_max16(hi2[k], nh);
     }
+    uint32_t A = 0x80008000u, B = 0x7fff7fffu;                               // (-32768, -32768), (32767, 32767)
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const uint32_t nl = k < 4 ? lo4[k + 4] : swap16(lo4[k - 4]), nh = k < 4 ? hi4[k + 4] : swap16(hi4[k - 4]);
+        A = pk_max16(A, pk_min16(pk_min16(lo4[k], nl), S[k]));
+        B = pk_min16(B, pk_max16(pk_max16(hi4[k], nh), S[k]));
+    }
+    const int a = max((int)(short)(A & 0xffff), (int)(short)(A >> 16)), bq = min((int)(short)(B & 0xffff), (int)(short)(B >> 16));
     return max(a, -bq) - 1;
 }
 
@@ -258,7 +279,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t* __restrict__ p
             // A lane takes one aligned dword = 4 horizontally adjacent pixels of a row (lanes run over (row, dword) in row-major
             // order, so lane order x byte order is cv::FAST's keypoint order): five dword LDS reads (centre, left, right, three rows
             // up, three rows down) instead of twenty byte reads, and the address / stepping / compaction overhead is paid once per
-            // four pixels. The kernel is VALU-issue bound (integer min/max are 4-cycle ops), so instructions per pixel is the lever.
+            // four pixels. The kernel is VALU-issue bound, so instructions per pixel is the lever.
             const int g0 = (xoff + 3) >> 2;                                  // tile dword holding the first interior pixel
             const int G = ((xoff + 3 + dw - 1) >> 2) - g0 + 1;               // dwords per interior row
             const int step_r = 64 / G, step_g = 64 - step_r * G;
@@ -273,16 +294,29 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t* __restrict__ p
                 const uint32_t W = __builtin_amdgcn_alignbyte(C, Lf, 1);     // pixels 3 to the left of C's four
                 const uint32_t E = __builtin_amdgcn_alignbyte(Rt, C, 3);     // pixels 3 to the right
                 const int q0 = 4 * (g0 + g) - (xoff + 3);                    // interior column of byte 0 (may be < 0 in the first dword)
-                uint32_t bits = 0;
+                // Four pixels at once, bytes widened to 16-bit fields (even bytes in one register, odd bytes in another): with
+                // c1 = 0x8000 + t - v and c2 = 0x8000 - t - 1 - v per field, bit 15 of (p + c1) says "p is NOT darker than v - t" and
+                // bit 15 of (p + c2) says "p is brighter than v + t"; no field can carry into its neighbour. Some adjacent pair of the four
+                // compass pixels (0, 4, 8, 12) is dark-dark iff (dark0 | dark8) & (dark4 | dark12), same for bright: plain and/or/add
+                // at full rate instead of four extract + sixteen min/max per pixel.
+                const uint32_t M = 0x00ff00ffu, Hb = 0x80008000u;
+                const uint32_t K1 = Hb + (uint32_t)min_th * 0x00010001u, K2 = Hb - (uint32_t)(min_th + 1) * 0x00010001u;
+                uint32_t cand[2];
 #pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const int v = (int)((C >> (8 * k)) & 0xff);
-                    const int d0 = v - (int)((D >> (8 * k)) & 0xff), d4 = v - (int)((E >> (8 * k)) & 0xff);
-                    const int d8 = v - (int)((U >> (8 * k)) & 0xff), d12 = v - (int)((W >> (8 * k)) & 0xff);
-                    const int lo = min(min(max(d0, d4), max(d4, d8)), min(max(d8, d12), max(d12, d0)));   // some adjacent pair both < -t
-                    const int hi = max(max(min(d0, d4), min(d4, d8)), max(min(d8, d12), min(d12, d0)));   // some adjacent pair both >  t
-                    const uint32_t ok = (uint32_t)((hi > min_th) | (lo < -min_th)) & (uint32_t)((unsigned)(q0 + k) < (unsigned)dw);
-                    bits |= ok << k;
+                for (int half = 0; half < 2; half++) {
+                    const int sh = 8 * half;
+                    const uint32_t v2 = (C >> sh) & M, c1 = K1 - v2, c2 = K2 - v2;
+                    const uint32_t p0 = (D >> sh) & M, p4 = (E >> sh) & M, p8 = (U >> sh) & M, p12 = (W >> sh) & M;
+                    const uint32_t nd = ((p0 + c1) & (p8 + c1)) | ((p4 + c1) & (p12 + c1));      // bit 15: no adjacent dark pair
+                    const uint32_t br = ((p0 + c2) | (p8 + c2)) & ((p4 + c2) | (p12 + c2));      // bit 15: an adjacent bright pair
+                    cand[half] = (~nd | br) & Hb;
+                }
+                // pixel k of the dword: k = 0, 2 in cand[0] bits 15, 31; k = 1, 3 in cand[1] bits 15, 31
+                uint32_t bits = ((cand[0] >> 15) & 1u) | ((cand[1] >> 14) & 2u) | ((cand[0] >> 29) & 4u) | ((cand[1] >> 28) & 8u);
+                {   // columns outside the interior
+                    const int lo = max(0, -q0), hi = min(4, dw - q0);                            // valid k in [lo, hi)
+                    const uint32_t rng = hi > lo ? (((1u << hi) - 1u) & ~((1u << lo) - 1u)) : 0u;
+                    bits &= rng;
                 }
                 if (r >= dh) bits = 0;
                 // ordered compaction: position = survivors in lower lanes + survivors in lower bytes of this lane
