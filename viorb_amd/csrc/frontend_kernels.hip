@@ -959,7 +959,7 @@ __device__ __forceinline__ void proj_edge_lin(const cam_t& k, const m33& RwbT, d
 // Phase timing for development (-DVIORB_POSE_TIMING, VIORB_HIPCC_FLAGS in viorb_amd/build.py): workgroup 0 prints its accumulated
 // s_memtime ticks per phase.
 #ifdef VIORB_POSE_TIMING
-#define PT_DECL unsigned long long pt_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pt_t0 = 0; int pt_n = 0
+#define PT_DECL unsigned long long pt_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, pt_t0 = 0; int pt_n = 0
 #define PT_START() pt_t0 = __builtin_amdgcn_s_memtime()
 #define PT_LAP(k) do { const unsigned long long pt_now = __builtin_amdgcn_s_memtime(); pt_acc[k] += pt_now - pt_t0; pt_t0 = pt_now; } while (0)
 #define PT_COUNT() pt_n++
@@ -1208,17 +1208,15 @@ __global__ __launch_bounds__(POSE_THREADS, 2) void k_pose_opt_vi(PoseOptArgs A) 
 #pragma unroll
             for (int k = 0; k < 28; k++) a[k] = 0;
             const double dsq_mono = d_mono * d_mono;
-            for (int i0 = t; i0 < ne; i0 += POSE_THREADS) {
-                if (ol[i0]) continue;
-                const obs_t o0 = load_obs(ob, i0);
+            auto accumulate = [&](const obs_t& o) {
                 double ea0, ea1, ja0[6], ja1[6];
-                proj_edge_lin(K, RT, s.P, o0.X, o0.u, o0.v, ea0, ea1, ja0, ja1);
-                const double chi0 = o0.is2 * fma(ea0, ea0, ea1 * ea1);
+                proj_edge_lin(K, RT, s.P, o.X, o.u, o.v, ea0, ea1, ja0, ja1);
+                const double chi0 = o.is2 * fma(ea0, ea0, ea1 * ea1);
                 double ra0 = chi0, ra1 = 1;
                 if (kernel_on && chi0 > dsq_mono) { const double sq0 = sqrt(chi0); ra0 = 2 * sq0 * d_mono - dsq_mono; ra1 = d_mono / sq0; }
                 a[27] += ra0;
                 if (lin) {
-                    const double w0 = ra1 * o0.is2;
+                    const double w0 = ra1 * o.is2;
                     double wa0[6], wa1[6];
 #pragma unroll
                     for (int r = 0; r < 6; r++) { wa0[r] = w0 * ja0[r]; wa1[r] = w0 * ja1[r]; }
@@ -1229,6 +1227,27 @@ __global__ __launch_bounds__(POSE_THREADS, 2) void k_pose_opt_vi(PoseOptArgs A) 
                         for (int c = r; c < 6; c++, k++) a[k] = fma(wa1[r], ja1[c], fma(wa0[r], ja0[c], a[k]));
 #pragma unroll
                     for (int r = 0; r < 6; r++) a[21 + r] = fma(-wa1[r], ea1, fma(-wa0[r], ea0, a[21 + r]));
+                }
+            };
+            // software pipeline, two register sets in turn: the next trip's outlier flag and observation are requested before this
+            // trip's arithmetic (an L2 round trip is as long as the arithmetic of one edge, and one wave per SIMD has nothing else to run)
+            // (the loads are unconditional, from a clamped index: behind a branch the compiler can no longer count how many newer loads
+            // are outstanding and waits for all of them before the arithmetic)
+            int i0 = t;
+            if (ne > 0) {
+                const int last = ne - 1;
+                int fA = ol[min(i0, last)]; obs_t oA = load_obs(ob, min(i0, last));
+                if (i0 >= ne) fA = 1;
+                while (i0 < ne) {
+                    const int iB = i0 + POSE_THREADS, cB = min(iB, last);
+                    int fB = ol[cB]; const obs_t oB = load_obs(ob, cB);
+                    if (!fA) accumulate(oA);
+                    const int iA = iB + POSE_THREADS, cA = min(iA, last);
+                    fA = ol[cA]; oA = load_obs(ob, cA);
+                    if (iB >= ne) fB = 1;
+                    if (!fB) accumulate(oB);
+                    if (iA >= ne) fA = 1;
+                    i0 = iA;
                 }
             }
             PT_LAP(6);
@@ -1372,9 +1391,18 @@ __global__ __launch_bounds__(POSE_THREADS, 2) void k_pose_opt_vi(PoseOptArgs A) 
                     for (int k = 0; k < 3; k++) S.bias[1][k] += S.x[21 + k];
                 }
                 __syncthreads();
+                PT_LAP(8);
                 double tempChi = evaluate(true, S.Hb[cur ^ 1], S.bb[cur ^ 1]);
+                PT_START();
                 if (!ok2) tempChi = 1.7976931348623157e308;
-                double scale = 0; for (int j = 0; j < n; j++) scale += S.x[j] * (lambda * S.x[j] + bc[j]);
+                double scale = 0;                                    // g2o computeScale(): sum_j x_j (lambda x_j + b_j), in order
+                {
+                    double xs[24], bs[24];
+#pragma unroll
+                    for (int j = 0; j < 24; j++) { xs[j] = S.x[j < n ? j : 0]; bs[j] = bc[j < n ? j : 0]; }
+#pragma unroll
+                    for (int j = 0; j < 24; j++) if (j < n) scale += xs[j] * (lambda * xs[j] + bs[j]);
+                }
                 scale += 1e-3;
                 rho = (currentChi - tempChi) / scale;
                 accepted = rho > 0 && isfinite(tempChi);
@@ -1388,6 +1416,7 @@ __global__ __launch_bounds__(POSE_THREADS, 2) void k_pose_opt_vi(PoseOptArgs A) 
                     if (t < 20) S.est[t / 10][t % 10] = S.bak[t / 10][t % 10]; else if (t < 26) S.bias[(t - 20) / 3][(t - 20) % 3] = S.bakb[(t - 20) / 3][(t - 20) % 3];
                 }
                 __syncthreads();
+                PT_LAP(9);
                 qmax++;
             } while (rho < 0 && qmax < 10);
             if (accepted) { cur ^= 1; have_lin = true; chi_lin = currentChi; }      // the speculative buffer is the next iteration's system
@@ -1432,8 +1461,8 @@ __global__ __launch_bounds__(POSE_THREADS, 2) void k_pose_opt_vi(PoseOptArgs A) 
     }
 #ifdef VIORB_POSE_TIMING
     if (b == 0 && lane == 0)
-        printf("pose_opt wave=%d total=%llu evals=%d dense=%llu edges=%llu wait=%llu asm=%llu solve=%llu classify=%llu loop=%llu setup=%llu asm1=%llu\n", wave,
-               __builtin_amdgcn_s_memtime() - pt_begin, pt_n, pt_acc[0], pt_acc[1], pt_acc[2], pt_acc[3], pt_acc[4], pt_acc[5], pt_acc[6], pt_setup, pt_acc[7]);
+        printf("pose_opt wave=%d total=%llu evals=%d dense=%llu edges=%llu wait=%llu asm=%llu solve=%llu classify=%llu loop=%llu setup=%llu asm1=%llu update=%llu post=%llu\n", wave,
+               __builtin_amdgcn_s_memtime() - pt_begin, pt_n, pt_acc[0], pt_acc[1], pt_acc[2], pt_acc[3], pt_acc[4], pt_acc[5], pt_acc[6], pt_setup, pt_acc[7], pt_acc[8], pt_acc[9]);
 #endif
     // ---- outputs
     if (t == 0) {
