@@ -899,7 +899,12 @@ __device__ bool wave_solve_reg(const double* __restrict__ H, const double* __res
     bool ok = true;
 #pragma unroll
     for (int j = 0; j < N; j++) {
+        // Row j of the (symmetric, fully updated) trailing matrix sits in lane j's registers: A[j][k] = A[k][j] is the multiplier column
+        // k needs, and reading it from lane j does not wait for this step's pivot arithmetic (reading l_kj from lane k would).
         const double d = readlane_d(a[j], j);
+        double row[N];
+#pragma unroll
+        for (int k = j + 1; k < N; k++) row[k] = readlane_d(a[k], j);
         ok = ok && (d > 0.0) && isfinite(d);
         const double inv = rsqrt_nr(d);
         invd[j] = inv;
@@ -907,8 +912,9 @@ __device__ bool wave_solve_reg(const double* __restrict__ H, const double* __res
         a[j] = lij;
         const double yj = readlane_d(rhs, j) * inv;              // forward substitution rides along
         if (lane == j) rhs = yj; else if (lane > j) rhs = fma(-lij, yj, rhs);
+        const double m = lij * inv;                              // l_ij l_kj = (a_ij / d) a_jk
 #pragma unroll
-        for (int k = j + 1; k < N; k++) a[k] = fma(-lij, readlane_d(lij, k), a[k]);
+        for (int k = j + 1; k < N; k++) a[k] = fma(-m, row[k], a[k]);
     }
 #pragma unroll
     for (int c = 0; c < N; c++) Lt[li * N + c] = a[c];
@@ -1383,12 +1389,20 @@ __global__ __launch_bounds__(POSE_THREADS, 2) void k_pose_opt_vi(PoseOptArgs A) 
                 if (t < 20) S.bak[t / 10][t % 10] = S.est[t / 10][t % 10]; else if (t < 26) S.bakb[(t - 20) / 3][(t - 20) % 3] = S.bias[(t - 20) / 3][(t - 20) % 3];
                 solve(lambda, Hc, bc);
                 const int ok2 = S.flag[0];
-                if (t == 0) {
-                    sh_put(S.est[0], inc_small_pvr(sh_pvr(S.est[0]), S.x));
-                    for (int k = 0; k < 3; k++) S.bias[0][k] += S.x[9 + k];
-                } else if (t == 64 && variant) {
-                    sh_put(S.est[1], inc_small_pvr(sh_pvr(S.est[1]), S.x + 12));
-                    for (int k = 0; k < 3; k++) S.bias[1][k] += S.x[21 + k];
+                // NavState::IncSmallPVR + the bias increment, one frame per wave pair: the rotation (Exp, two normalisations) on one lane,
+                // position / velocity / bias on another; both read the pre-update state from the backup copy made above
+                if (lane == 0 && ((wave & 1) == 0 || variant)) {
+                    const int side = wave & 1;
+                    const double* u = S.x + 12 * side; const double* old = S.bak[side];
+                    const quat q0 = mkq(old[6], old[7], old[8], old[9]);
+                    if (wave < 2) {
+                        const quat r = so3_mul(q0, so3_exp(mk3(u[6], u[7], u[8])));
+                        S.est[side][6] = r.x; S.est[side][7] = r.y; S.est[side][8] = r.z; S.est[side][9] = r.w;
+                    } else {
+                        st3(S.est[side], ld3(old) + mulv(qmat(q0), mk3(u[0], u[1], u[2])));
+                        st3(S.est[side] + 3, ld3(old + 3) + mk3(u[3], u[4], u[5]));
+                        for (int k = 0; k < 3; k++) S.bias[side][k] += u[9 + k];
+                    }
                 }
                 __syncthreads();
                 PT_LAP(8);
