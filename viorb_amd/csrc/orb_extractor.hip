@@ -273,108 +273,114 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t* __restrict__ p
     if (dw > 0 && dh > 0) {
         const int npx = dw * dh;
         const unsigned long long lt = (1ull << lane) - 1ull;
-        // ---- pass 1
-        int nsurv = 0;
-        {
-            // A lane takes one aligned dword = 4 horizontally adjacent pixels of a row (lanes run over (row, dword) in row-major
-            // order, so lane order x byte order is cv::FAST's keypoint order): five dword LDS reads (centre, left, right, three rows
-            // up, three rows down) instead of twenty byte reads, and the address / stepping / compaction overhead is paid once per
-            // four pixels. The kernel is VALU-issue bound, so instructions per pixel is the lever.
-            const int g0 = (xoff + 3) >> 2;                                  // tile dword holding the first interior pixel
-            const int G = ((xoff + 3 + dw - 1) >> 2) - g0 + 1;               // dwords per interior row
-            const int step_r = 64 / G, step_g = 64 - step_r * G;
-            int r = lane / G, g = lane - r * G;
-            const int ntrip = (dh * G + 63) >> 6;
-            for (int trip = 0; trip < ntrip; trip++) {
-                const int rc = min(r, dh - 1);                                // lanes past the last row read a valid address and are masked
-                const uint32_t* pc = reinterpret_cast<const uint32_t*>(tile + (rc + 3) * tile_pitch) + g0 + g;
-                const uint32_t C = pc[0], Lf = pc[-1], Rt = pc[1];
-                const uint32_t U = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(pc) - 3 * tile_pitch);
-                const uint32_t D = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(pc) + 3 * tile_pitch);
-                const uint32_t W = __builtin_amdgcn_alignbyte(C, Lf, 1);     // pixels 3 to the left of C's four
-                const uint32_t E = __builtin_amdgcn_alignbyte(Rt, C, 3);     // pixels 3 to the right
-                const int q0 = 4 * (g0 + g) - (xoff + 3);                    // interior column of byte 0 (may be < 0 in the first dword)
-                // Four pixels at once, bytes widened to 16-bit fields (even bytes in one register, odd bytes in another): with
-                // c1 = 0x8000 + t - v and c2 = 0x8000 - t - 1 - v per field, bit 15 of (p + c1) says "p is NOT darker than v - t" and
-                // bit 15 of (p + c2) says "p is brighter than v + t"; no field can carry into its neighbour. Some adjacent pair of the four
-                // compass pixels (0, 4, 8, 12) is dark-dark iff (dark0 | dark8) & (dark4 | dark12), same for bright: plain and/or/add
-                // at full rate instead of four extract + sixteen min/max per pixel.
-                const uint32_t M = 0x00ff00ffu, Hb = 0x80008000u;
-                const uint32_t K1 = Hb + (uint32_t)min_th * 0x00010001u, K2 = Hb - (uint32_t)(min_th + 1) * 0x00010001u;
-                uint32_t cand[2];
-#pragma unroll
-                for (int half = 0; half < 2; half++) {
-                    const int sh = 8 * half;
-                    const uint32_t v2 = (C >> sh) & M, c1 = K1 - v2, c2 = K2 - v2;
-                    const uint32_t p0 = (D >> sh) & M, p4 = (E >> sh) & M, p8 = (U >> sh) & M, p12 = (W >> sh) & M;
-                    const uint32_t nd = ((p0 + c1) & (p8 + c1)) | ((p4 + c1) & (p12 + c1));      // bit 15: no adjacent dark pair
-                    const uint32_t br = ((p0 + c2) | (p8 + c2)) & ((p4 + c2) | (p12 + c2));      // bit 15: an adjacent bright pair
-                    cand[half] = (~nd | br) & Hb;
+        // The reference detects at iniThFAST and only when a cell comes back empty again at minThFAST (:797-807). Same here: the pre-test,
+        // the exact strengths and the NMS run at iniThFAST first — the weak threshold lets three to four times as many pixels through
+        // the pre-test — and the whole cell is redone at minThFAST only if nothing survived (the score map keeps what it already has).
+        for (int attempt = 0; attempt < 2 && total == 0; attempt++) {
+            const int th = attempt ? min_th : ini_th;
+            // ---- pass 1
+            int nsurv = 0;
+            {
+                // A lane takes one aligned dword = 4 horizontally adjacent pixels of a row (lanes run over (row, dword) in row-major
+                // order, so lane order x byte order is cv::FAST's keypoint order): five dword LDS reads (centre, left, right, three rows
+                // up, three rows down) instead of twenty byte reads, and the address / stepping / compaction overhead is paid once per
+                // four pixels. The kernel is VALU-issue bound, so instructions per pixel is the lever.
+                const int g0 = (xoff + 3) >> 2;                                  // tile dword holding the first interior pixel
+                const int G = ((xoff + 3 + dw - 1) >> 2) - g0 + 1;               // dwords per interior row
+                const int step_r = 64 / G, step_g = 64 - step_r * G;
+                int r = lane / G, g = lane - r * G;
+                const int ntrip = (dh * G + 63) >> 6;
+                for (int trip = 0; trip < ntrip; trip++) {
+                    const int rc = min(r, dh - 1);                                // lanes past the last row read a valid address and are masked
+                    const uint32_t* pc = reinterpret_cast<const uint32_t*>(tile + (rc + 3) * tile_pitch) + g0 + g;
+                    const uint32_t C = pc[0], Lf = pc[-1], Rt = pc[1];
+                    const uint32_t U = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(pc) - 3 * tile_pitch);
+                    const uint32_t D = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(pc) + 3 * tile_pitch);
+                    const uint32_t W = __builtin_amdgcn_alignbyte(C, Lf, 1);     // pixels 3 to the left of C's four
+                    const uint32_t E = __builtin_amdgcn_alignbyte(Rt, C, 3);     // pixels 3 to the right
+                    const int q0 = 4 * (g0 + g) - (xoff + 3);                    // interior column of byte 0 (may be < 0 in the first dword)
+                    // Four pixels at once, bytes widened to 16-bit fields (even bytes in one register, odd bytes in another): with
+                    // c1 = 0x8000 + t - v and c2 = 0x8000 - t - 1 - v per field, bit 15 of (p + c1) says "p is NOT darker than v - t" and
+                    // bit 15 of (p + c2) says "p is brighter than v + t"; no field can carry into its neighbour. Some adjacent pair of the four
+                    // compass pixels (0, 4, 8, 12) is dark-dark iff (dark0 | dark8) & (dark4 | dark12), same for bright: plain and/or/add
+                    // at full rate instead of four extract + sixteen min/max per pixel.
+                    const uint32_t M = 0x00ff00ffu, Hb = 0x80008000u;
+                    const uint32_t K1 = Hb + (uint32_t)th * 0x00010001u, K2 = Hb - (uint32_t)(th + 1) * 0x00010001u;
+                    uint32_t cand[2];
+    #pragma unroll
+                    for (int half = 0; half < 2; half++) {
+                        const int sh = 8 * half;
+                        const uint32_t v2 = (C >> sh) & M, c1 = K1 - v2, c2 = K2 - v2;
+                        const uint32_t p0 = (D >> sh) & M, p4 = (E >> sh) & M, p8 = (U >> sh) & M, p12 = (W >> sh) & M;
+                        const uint32_t nd = ((p0 + c1) & (p8 + c1)) | ((p4 + c1) & (p12 + c1));      // bit 15: no adjacent dark pair
+                        const uint32_t br = ((p0 + c2) | (p8 + c2)) & ((p4 + c2) | (p12 + c2));      // bit 15: an adjacent bright pair
+                        cand[half] = (~nd | br) & Hb;
+                    }
+                    // pixel k of the dword: k = 0, 2 in cand[0] bits 15, 31; k = 1, 3 in cand[1] bits 15, 31
+                    uint32_t bits = ((cand[0] >> 15) & 1u) | ((cand[1] >> 14) & 2u) | ((cand[0] >> 29) & 4u) | ((cand[1] >> 28) & 8u);
+                    {   // columns outside the interior
+                        const int lo = max(0, -q0), hi = min(4, dw - q0);                            // valid k in [lo, hi)
+                        const uint32_t rng = hi > lo ? (((1u << hi) - 1u) & ~((1u << lo) - 1u)) : 0u;
+                        bits &= rng;
+                    }
+                    if (r >= dh) bits = 0;
+                    // ordered compaction: position = survivors in lower lanes + survivors in lower bytes of this lane
+                    const unsigned long long m0 = __ballot(bits & 1), m1 = __ballot(bits & 2), m2 = __ballot(bits & 4), m3 = __ballot(bits & 8);
+                    int pos = nsurv + __popcll(m0 & lt) + __popcll(m1 & lt) + __popcll(m2 & lt) + __popcll(m3 & lt);
+                    const uint32_t rq0 = ((uint32_t)r << 8) + (uint32_t)q0;
+    #pragma unroll
+                    for (int k = 0; k < 4; k++)
+                        if (bits & (1u << k)) { surv[pos] = (uint16_t)(rq0 + k); pos++; }
+                    nsurv += __popcll(m0) + __popcll(m1) + __popcll(m2) + __popcll(m3);
+                    r += step_r; g += step_g;
+                    if (g >= G) { g -= G; r++; }
                 }
-                // pixel k of the dword: k = 0, 2 in cand[0] bits 15, 31; k = 1, 3 in cand[1] bits 15, 31
-                uint32_t bits = ((cand[0] >> 15) & 1u) | ((cand[1] >> 14) & 2u) | ((cand[0] >> 29) & 4u) | ((cand[1] >> 28) & 8u);
-                {   // columns outside the interior
-                    const int lo = max(0, -q0), hi = min(4, dw - q0);                            // valid k in [lo, hi)
-                    const uint32_t rng = hi > lo ? (((1u << hi) - 1u) & ~((1u << lo) - 1u)) : 0u;
-                    bits &= rng;
-                }
-                if (r >= dh) bits = 0;
-                // ordered compaction: position = survivors in lower lanes + survivors in lower bytes of this lane
-                const unsigned long long m0 = __ballot(bits & 1), m1 = __ballot(bits & 2), m2 = __ballot(bits & 4), m3 = __ballot(bits & 8);
-                int pos = nsurv + __popcll(m0 & lt) + __popcll(m1 & lt) + __popcll(m2 & lt) + __popcll(m3 & lt);
-                const uint32_t rq0 = ((uint32_t)r << 8) + (uint32_t)q0;
-#pragma unroll
-                for (int k = 0; k < 4; k++)
-                    if (bits & (1u << k)) { surv[pos] = (uint16_t)(rq0 + k); pos++; }
-                nsurv += __popcll(m0) + __popcll(m1) + __popcll(m2) + __popcll(m3);
-                r += step_r; g += step_g;
-                if (g >= G) { g -= G; r++; }
             }
-        }
-        __syncthreads();
-        // ---- pass 2
-        int ncorn = 0;
-        for (int base = 0; base < nsurv; base += 64) {
-            bool is_c = false;
-            uint16_t rq = 0;
-            if (base + lane < nsurv) {
-                rq = surv[base + lane];
-                const int r = rq >> 8, q = rq & 0xff;
-                const int s = fast_strength(tile + (r + 3) * tile_pitch + xoff + q + 3, tile_pitch);
-                if (s >= min_th) { is_c = true; sc[(r + 1) * sp + q + 1] = (uint8_t)s; }
-            }
-            const unsigned long long m = __ballot(is_c);
-            if (is_c) corn[ncorn + __popcll(m & lt)] = rq;
-            ncorn += __popcll(m);
-        }
-        __syncthreads();
-        // ---- pass 3
-        for (int pass = 0; pass < 2 && total == 0; pass++) {
-            const int th = pass == 0 ? ini_th : min_th;
-            for (int base = 0; base < ncorn; base += 64) {
-                bool keep = false;
-                int r = 0, q = 0, s = 0;
-                if (base + lane < ncorn) {
-                    const uint16_t rq = corn[base + lane];
-                    r = rq >> 8; q = rq & 0xff;
-                    const uint8_t* z = sc + (r + 1) * sp + q + 1;
-                    s = z[0];
-                    // all eight neighbours are read before any is tested: one LDS round trip instead of a short-circuit chain of eight
-                    int nb[8];
-                    nb[0] = z[-sp - 1]; nb[1] = z[-sp]; nb[2] = z[-sp + 1]; nb[3] = z[-1]; nb[4] = z[1]; nb[5] = z[sp - 1]; nb[6] = z[sp]; nb[7] = z[sp + 1];
-                    int mx = 0;                                       // neighbours below th do not count (they are not corners at th)
-#pragma unroll
-                    for (int k = 0; k < 8; k++) mx = max(mx, nb[k] >= th ? nb[k] : 0);
-                    keep = (s >= th) & (s > mx);
+            __syncthreads();
+            // ---- pass 2
+            int ncorn = 0;
+            for (int base = 0; base < nsurv; base += 64) {
+                bool is_c = false;
+                uint16_t rq = 0;
+                if (base + lane < nsurv) {
+                    rq = surv[base + lane];
+                    const int r = rq >> 8, q = rq & 0xff;
+                    const int s = fast_strength(tile + (r + 3) * tile_pitch + xoff + q + 3, tile_pitch);
+                    if (s >= th) { is_c = true; sc[(r + 1) * sp + q + 1] = (uint8_t)s; }
                 }
-                const unsigned long long m = __ballot(keep);
-                if (keep) {
-                    const int pos = total + __popcll(m & lt);
-                    if (pos < slot_cap)
-                        my_slots[pos] = (uint32_t)(q + 3 + c.shx) | ((uint32_t)(r + 3 + c.shy) << 12) | ((uint32_t)s << 24);
-                }
-                total += __popcll(m);
+                const unsigned long long m = __ballot(is_c);
+                if (is_c) corn[ncorn + __popcll(m & lt)] = rq;
+                ncorn += __popcll(m);
             }
+            __syncthreads();
+            // ---- pass 3
+            {
+                for (int base = 0; base < ncorn; base += 64) {
+                    bool keep = false;
+                    int r = 0, q = 0, s = 0;
+                    if (base + lane < ncorn) {
+                        const uint16_t rq = corn[base + lane];
+                        r = rq >> 8; q = rq & 0xff;
+                        const uint8_t* z = sc + (r + 1) * sp + q + 1;
+                        s = z[0];
+                        // all eight neighbours are read before any is tested: one LDS round trip instead of a short-circuit chain of eight
+                        int nb[8];
+                        nb[0] = z[-sp - 1]; nb[1] = z[-sp]; nb[2] = z[-sp + 1]; nb[3] = z[-1]; nb[4] = z[1]; nb[5] = z[sp - 1]; nb[6] = z[sp]; nb[7] = z[sp + 1];
+                        int mx = 0;
+    #pragma unroll
+                        for (int k = 0; k < 8; k++) mx = max(mx, nb[k]);           // the map only holds corners at the current threshold
+                        keep = s > mx;
+                    }
+                    const unsigned long long m = __ballot(keep);
+                    if (keep) {
+                        const int pos = total + __popcll(m & lt);
+                        if (pos < slot_cap)
+                            my_slots[pos] = (uint32_t)(q + 3 + c.shx) | ((uint32_t)(r + 3 + c.shy) << 12) | ((uint32_t)s << 24);
+                    }
+                    total += __popcll(m);
+                }
+            }
+            __syncthreads();
         }
     }
     if (lane == 0) cell_cnt[(size_t)blockIdx.y * ncells_total + blockIdx.x] = min(total, slot_cap);
