@@ -101,9 +101,10 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 
 // Level 0 = the input image re-pitched into the plane buffer.
 __global__ void k_copy_level0(const uint8_t* __restrict__ src, int w, int h, int sstride, size_t spitch,
-                              uint8_t* __restrict__ planes, size_t frame_bytes, int dstride) {
+                              uint8_t* __restrict__ planes, size_t frame_bytes, int dstride, int* __restrict__ status) {
     const int b = blockIdx.z;
     const int y = blockIdx.y;
+    if (blockIdx.x == 0 && y == 0 && threadIdx.x == 0) status[b] = 0;      // per-image status word of this extraction (one launch less than a memset)
     const int x = (blockIdx.x * blockDim.x + threadIdx.x) * 16;
     if (x >= dstride) return;
     const uint8_t* s = src + (size_t)b * spitch + (size_t)y * sstride;
@@ -1335,11 +1336,10 @@ static int launch_all(viorb_extractor* h, const uint8_t* d_images, int batch, in
     const int nl = h->p.nlevels;
     const int ncells = (int)h->cells.size();
     const LevelDev& L0 = h->lv[0];
-    VIORB_HIP_TRY(hipMemsetAsync(h->d_status, 0, sizeof(int) * batch, st));
     {
         dim3 grid((L0.stride / 16 + 63) / 64, L0.h, batch);
         ProfScope ps("k_copy_level0", st);
-        hipLaunchKernelGGL(k_copy_level0, grid, dim3(64), 0, st, d_images, L0.w, L0.h, stride, pitch, h->d_planes, h->frame_bytes, L0.stride);
+        hipLaunchKernelGGL(k_copy_level0, grid, dim3(64), 0, st, d_images, L0.w, L0.h, stride, pitch, h->d_planes, h->frame_bytes, L0.stride, h->d_status);
     }
     for (int l = 1; l < nl; l++) {
         const LevelDev& L = h->lv[l];
