@@ -239,6 +239,7 @@ __device__ __forceinline__ int fast_strength(const uint8_t* p, int pitch) {
 //   3. cv::FAST's strict 3x3 NMS at iniThFAST over the corner list and, only if that leaves the cell
 //      empty, again at minThFAST. Survivors go to the cell's slot as packed (x | y<<12 | score<<24) with
 //      the reference's j*wCell / i*hCell shift applied.
+#define FAST_FETCH_TRIPS 7
 __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t* __restrict__ planes, size_t frame_bytes,
                                                    const LevelDev* __restrict__ lv,
                                                    const CellDesc* __restrict__ cells, int ini_th, int min_th,
@@ -259,7 +260,21 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t* __restrict__ p
         const int st_r = 64 / pitch_dw, st_q = 64 - st_r * pitch_dw;      // one division per wave instead of one per dword
         int r = lane / pitch_dw, q = lane - r * pitch_dw;
         const uint8_t* src = planes + (size_t)blockIdx.y * frame_bytes + c.src_off;
-        for (int i = lane; i < c.ch * pitch_dw; i += 64) {
+        const int ntile = c.ch * pitch_dw;
+        // all of the tile's loads are issued before the first is waited for (a 36-row cell is 7 trips of 64 dwords; as a plain loop
+        // they were seven dependent L2 round trips per wave, the largest single item of this kernel's time)
+        uint32_t v[FAST_FETCH_TRIPS]; int at[FAST_FETCH_TRIPS];
+#pragma unroll
+        for (int k = 0; k < FAST_FETCH_TRIPS; k++) {
+            const int i = lane + 64 * k;
+            at[k] = (i < ntile && q < ndw) ? i : -1;
+            v[k] = *reinterpret_cast<const uint32_t*>(src + min(r, c.ch - 1) * c.stride + 4 * min(q, ndw - 1));      // unconditional, clamped: no branch per load
+            r += st_r; q += st_q;
+            if (q >= pitch_dw) { q -= pitch_dw; r++; }
+        }
+#pragma unroll
+        for (int k = 0; k < FAST_FETCH_TRIPS; k++) if (at[k] >= 0) s_mem[at[k]] = v[k];
+        for (int i = lane + 64 * FAST_FETCH_TRIPS; i < ntile; i += 64) {          // larger tiles than the default geometry
             if (q < ndw) s_mem[i] = *reinterpret_cast<const uint32_t*>(src + r * c.stride + 4 * q);
             r += st_r; q += st_q;
             if (q >= pitch_dw) { q -= pitch_dw; r++; }
