@@ -564,19 +564,25 @@ __global__ __launch_bounds__(64) void k_octree(const LevelDev* __restrict__ lv, 
     const int N = L.quota;
     // ---- 0. this launch only takes the (image, level) pairs with n_above < candidates <= n_upto: the common case runs
     //         with a small LDS footprint (4 workgroups per CU), a second launch with the full capacity takes the rest
+    const int* cc = cell_cnt + (size_t)b * ncells_total + L.cell_base;
     {
-        const int* cc = cell_cnt + (size_t)b * ncells_total + L.cell_base;
         int tot = 0;
-        for (int ci = lane; ci < L.ncells; ci += 64) tot += cc[ci];
+        for (int c0 = 0; c0 < L.ncells; c0 += 512) {                 // eight independent loads in flight per lane
+            int part[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) { const int ci = c0 + 64 * j + lane; part[j] = cc[min(ci, L.ncells - 1)]; if (ci >= L.ncells) part[j] = 0; }
+#pragma unroll
+            for (int j = 0; j < 8; j++) tot += part[j];
+        }
 #pragma unroll
         for (int d = 32; d > 0; d >>= 1) tot += __shfl_xor(tot, d);
         if (tot <= n_above || tot > n_upto) return;
     }
-    // ---- 1. gather candidates in the reference's push order (cell-major, row-major inside a cell)
+    // ---- 1. gather candidates in the reference's push order (cell-major, row-major inside a cell): one cell per lane, eight of its
+    //         slots requested before the first is stored (the slot loop used to be one L2 round trip per slot)
     int n = 0;
     bool overflow = false;
     {
-        const int* cc = cell_cnt + (size_t)b * ncells_total + L.cell_base;
         const uint32_t* sl = slots + ((size_t)b * ncells_total + L.cell_base) * slot_cap;
         for (int base = 0; base < L.ncells; base += 64) {
             const int ci = base + lane;
@@ -586,9 +592,16 @@ __global__ __launch_bounds__(64) void k_octree(const LevelDev* __restrict__ lv, 
 #pragma unroll
             for (int d = 1; d < 64; d <<= 1) { const int v = __shfl_up(incl, d); if (lane >= d) incl += v; }
             const int start = n + incl - cnt;
-            for (int k = 0; k < cnt; k++) {
-                const int pos = start + k;
-                if (pos < ncap) S.keys[pos] = sl[(size_t)ci * slot_cap + k];
+            const uint32_t* mine = sl + (size_t)min(ci, L.ncells - 1) * slot_cap;
+            for (int k0 = 0; __any(k0 < cnt); k0 += 8) {
+                uint32_t v[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) v[u] = mine[min(k0 + u, slot_cap - 1)];
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const int pos = start + k0 + u;
+                    if (k0 + u < cnt && pos < ncap) S.keys[pos] = v[u];
+                }
             }
             n += __shfl(incl, 63);
         }
