@@ -807,19 +807,31 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t* __restrict__ planes
     const uint8_t* src = planes + (size_t)blockIdx.y * frame_bytes + L.plane_off;
     uint8_t* dst = blur + (size_t)blockIdx.y * frame_bytes + L.plane_off;
     const int x0 = t.y, y0 = t.z;
-    for (int i = threadIdx.x; i < (BL_TH + 6) * BL_IPD; i += 256) {
-        const int r = i / BL_IPD, c = i - r * BL_IPD;
-        const int yy = reflect101(y0 + r - 3, L.h);
-        const int xb = x0 - 4 + 4 * c;
-        const uint8_t* row = src + (size_t)yy * L.stride;
-        uint32_t v;
-        if (xb >= 0 && xb + 3 < L.w) v = *reinterpret_cast<const uint32_t*>(row + xb);
-        else {
-            v = 0;
+    {
+        // every thread's five input dwords are requested before the first is used (a plain loop made them five dependent round
+        // trips); dwords that straddle the image border are patched byte by byte afterwards (BORDER_REFLECT_101)
+        constexpr int NIN = (BL_TH + 6) * BL_IPD, TRIPS = (NIN + 255) / 256;
+        uint32_t v[TRIPS]; int xbs[TRIPS]; const uint8_t* rows[TRIPS];
 #pragma unroll
-            for (int j = 0; j < 4; j++) v |= (uint32_t)row[reflect101(xb + j, L.w)] << (8 * j);
+        for (int k = 0; k < TRIPS; k++) {
+            const int i = min((int)threadIdx.x + 256 * k, NIN - 1);
+            const int r = i / BL_IPD, c = i - r * BL_IPD;
+            rows[k] = src + (size_t)reflect101(y0 + r - 3, L.h) * L.stride;
+            xbs[k] = x0 - 4 + 4 * c;
+            v[k] = *reinterpret_cast<const uint32_t*>(rows[k] + min(max(xbs[k], 0), L.stride - 4));
         }
-        s_in[i] = v;
+#pragma unroll
+        for (int k = 0; k < TRIPS; k++) {
+            const int i = (int)threadIdx.x + 256 * k;
+            if (i >= NIN) continue;
+            uint32_t w = v[k];
+            if (!(xbs[k] >= 0 && xbs[k] + 3 < L.w)) {
+                w = 0;
+#pragma unroll
+                for (int j = 0; j < 4; j++) w |= (uint32_t)rows[k][reflect101(xbs[k] + j, L.w)] << (8 * j);
+            }
+            s_in[i] = w;
+        }
     }
     __syncthreads();
     const uint32_t T0 = (uint32_t)c_gauss[0] | ((uint32_t)c_gauss[1] << 8) | ((uint32_t)c_gauss[2] << 16) | ((uint32_t)c_gauss[3] << 24);
