@@ -152,10 +152,24 @@ __global__ __launch_bounds__(256) void k_resize(uint8_t* __restrict__ planes, si
     const int xs0 = (xtab[tx0].x & 0xffff) & ~3, xs1 = xtab[tx1].x >> 16;
     const int ndw = ((xs1 - xs0) >> 2) + 1, nrows = ys1 - ys0 + 1;
     // host guarantees ndw <= lds_pitch_dw and nrows <= lds_rows
-    for (int i = threadIdx.x; i < nrows * lds_pitch_dw; i += 256) {
-        const int r = i / lds_pitch_dw, c = i - r * lds_pitch_dw;
-        if (c < ndw)
-            s_tile[i] = *reinterpret_cast<const uint32_t*>(src + (size_t)(ys0 + r) * P.stride + xs0 + 4 * c);
+    {
+        // two trips cover the default geometry (scale 1.2: 21 x 21 dwords); both loads are in flight before the first store
+        const int total = nrows * lds_pitch_dw;
+        uint32_t v[2]; int at[2];
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const int i = threadIdx.x + 256 * k, ic = min(i, total - 1);
+            const int r = ic / lds_pitch_dw, c = ic - r * lds_pitch_dw;
+            at[k] = (i < total && c < ndw) ? i : -1;
+            v[k] = *reinterpret_cast<const uint32_t*>(src + (size_t)(ys0 + r) * P.stride + xs0 + 4 * min(c, ndw - 1));
+        }
+#pragma unroll
+        for (int k = 0; k < 2; k++) if (at[k] >= 0) s_tile[at[k]] = v[k];
+        for (int i = threadIdx.x + 512; i < total; i += 256) {
+            const int r = i / lds_pitch_dw, c = i - r * lds_pitch_dw;
+            if (c < ndw)
+                s_tile[i] = *reinterpret_cast<const uint32_t*>(src + (size_t)(ys0 + r) * P.stride + xs0 + 4 * c);
+        }
     }
     __syncthreads();
     const uint8_t* t8 = reinterpret_cast<const uint8_t*>(s_tile);
