@@ -84,7 +84,7 @@ struct LevelDev {
     int pad;
 };
 struct CellDesc {              // one FAST cell = sub-image [x0,x0+cw) x [y0,y0+ch) of its level
-    int16_t level, x0, y0, cw, ch, shx, shy, pad;
+    int32_t level, x0, y0, cw, ch, shx, shy, pad;   // 32-bit fields: the wave-uniform descriptor then arrives by scalar loads (16-bit fields took a vector-memory round trip)
     uint32_t src_off;          // byte offset, inside one image's plane block, of the aligned dword holding pixel (x0, y0)
     int32_t stride;            // row pitch of the level (so the kernel needs no second, dependent table look-up)
 };
@@ -1237,9 +1237,9 @@ static int configure(viorb_extractor* h, int w, int hgt) {
                     if (iniX >= maxBX - 6) continue;
                     if (maxX > maxBX) maxX = (float)maxBX;
                     CellDesc c;
-                    c.level = (int16_t)l; c.x0 = (int16_t)iniX; c.y0 = (int16_t)iniY;
-                    c.cw = (int16_t)((int)maxX - (int)iniX); c.ch = (int16_t)((int)maxY - (int)iniY);
-                    c.shx = (int16_t)(j * wCell); c.shy = (int16_t)(i * hCell); c.pad = 0;
+                    c.level = l; c.x0 = (int)iniX; c.y0 = (int)iniY;
+                    c.cw = (int)maxX - (int)iniX; c.ch = (int)maxY - (int)iniY;
+                    c.shx = j * wCell; c.shy = i * hCell; c.pad = 0;
                     c.src_off = (uint32_t)(L.plane_off + (size_t)c.y0 * L.stride + (size_t)(c.x0 & ~3)); c.stride = L.stride;
                     if (c.cw < 7 || c.ch < 7) continue;            // cv::FAST finds nothing in such a sub-image
                     h->cells.push_back(c);
