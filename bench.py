@@ -28,6 +28,7 @@ W_IMG, H_IMG, NFEAT, NLEVELS = 752, 480, 1000, 8
 N_FRAMES = 8                                  # frames per (periodic) synthetic stream
 P_PIXELS = 1117367                            # sum of level pixels, SURVEY.md §8 table (config E)
 HBM_PEAK_GBS = 8000.0                         # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+ROOFLINE_KERNEL = "k_fast_cells"
 # algorithmic bytes per frame of each extractor kernel (B_ext = 4 P + K (709 + 961 + 60))
 ALGO_BYTES = {
     "k_fast_cells": P_PIXELS,                                  # 1 P read by FAST
@@ -89,6 +90,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip the per-kernel HIP events (roofline becomes null); dev aid "
                     "to measure what the events themselves cost")
+    ap.add_argument("--all-kernel-events", action="store_true", help="time every kernel of the step, not only the roofline kernel: fills "
+                    "roofline.kernel_ms_per_step for all of them and costs ~5 %% of the step (an event pair is ~8 us of stream time)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -154,6 +157,8 @@ def main():
         run_step(k); k += 1
     torch.cuda.synchronize()
     L = viorb_amd.lib()
+    # the dominant extractor kernel (profiles/*_kernel_stats.csv) is the one the roofline object is about; only its launches carry events
+    L.viorb_profile_select(None if args.all_kernel_events else ROOFLINE_KERNEL.encode())
     L.viorb_profile_reset(); L.viorb_profile_enable(0 if args.no_kernel_events else 1)
     if world > 1:
         dist.barrier()
@@ -182,7 +187,7 @@ def main():
     L.viorb_profile_read(names, 4096, ms, calls, 64, C.byref(n))
     prof = {nm_: (ms[i], calls[i]) for i, nm_ in enumerate(names.value.decode().split("\n")[:n.value])}
     ext = {kname: v for kname, v in prof.items() if kname in ALGO_BYTES}
-    dom = max(ext, key=lambda kname: ext[kname][0]) if ext else None
+    dom = ROOFLINE_KERNEL if ROOFLINE_KERNEL in ext else None
 
     # ---- reduce over ranks: total frames, max time ----------------------------------------------------------
     frames_done, elapsed = reduce_throughput(S * args.steps, elapsed, None if rehearsal else dev)
@@ -200,7 +205,7 @@ def main():
             roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
                     "avg_launch_us": round(avg_s * 1e6, 2), "algorithmic_bytes_per_launch": int(bytes_per_launch),
-                    "extractor_all_kernels_GBps": round(ext_bytes / (ext_ms * 1e-3) / 1e9, 2),
+                    "extractor_all_kernels_GBps": round(ext_bytes / (ext_ms * 1e-3) / 1e9, 2) if args.all_kernel_events else None,
                     "kernel_ms_per_step": {kname: round(v[0] / args.steps, 4) for kname, v in sorted(prof.items())}}
         cpu = None
         if not args.no_cpu_baseline:

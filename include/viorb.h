@@ -289,6 +289,9 @@ int viorb_memcpy_dtod_async(void* dst, const void* src, size_t bytes, void* stre
  * total_ms[i] / calls[i] the summed duration and launch count of name i since the last reset. */
 int viorb_profile_enable(int on);
 int viorb_profile_reset(void);
+/* Restrict the timing to one kernel name (NULL or "" = every kernel). An event pair around a kernel costs about 8 us of stream
+ * time, so timing all ~30 launches of a tracking step slows the step by ~5 %; bench.py times only its roofline kernel. */
+int viorb_profile_select(const char* kernel_name);
 int viorb_profile_read(char* names_buf, int names_cap, double* total_ms, int* calls, int cap, int* n);
 
 /* Host-buffer drop-ins for single calls (they stage through the device and include the PCIe copies). */

@@ -85,6 +85,7 @@ SIGNATURES = {
     "viorb_memcpy_dtod_async": (i32, [vp, vp, sz, vp]),
     "viorb_profile_enable": (i32, [i32]),
     "viorb_profile_reset": (i32, []),
+    "viorb_profile_select": (i32, [C.c_char_p]),
     "viorb_profile_read": (i32, [C.c_char_p, i32, vp, vp, i32, PP(i32)]),
     "viorb_descriptor_distance": (i32, [vp, vp]),
     "viorb_search_by_projection_frame": (i32, [vp, vp, i32, vp, vp, vp, vp, i32, vp, i32, vp, vp, vp, f32, i32, vp, PP(i32)]),

@@ -38,6 +38,7 @@ namespace {
 struct ProfRec { hipEvent_t a, b; int slot; };
 struct Profiler {
     bool enabled = false;
+    std::string only;                 // when not empty: only this kernel is timed (an event pair costs ~8 us of stream time)
     std::vector<std::string> names;
     std::vector<ProfRec> recs;
     size_t used = 0;
@@ -45,6 +46,7 @@ struct Profiler {
 }
 ProfScope::ProfScope(const char* name, hipStream_t s) : idx(-1), st(s) {
     if (!g_prof.enabled) return;
+    if (!g_prof.only.empty() && g_prof.only != name) return;
     if (g_prof.used >= g_prof.recs.size()) {
         if (g_prof.recs.size() >= 16384) return;
         ProfRec r; r.slot = -1;
@@ -1460,6 +1462,10 @@ int viorb_profile_enable(int on) {
 }
 int viorb_profile_reset(void) {
     g_prof.used = 0;
+    return VIORB_OK;
+}
+int viorb_profile_select(const char* kernel_name) {
+    g_prof.only = kernel_name ? kernel_name : "";
     return VIORB_OK;
 }
 // Synchronises the device and sums the recorded intervals per kernel name. names_buf receives the
