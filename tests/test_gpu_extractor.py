@@ -125,6 +125,22 @@ def test_edge_inputs(gpu, oracle):
     np.testing.assert_array_equal(d, od)
 
 
+def test_two_threshold_cells(gpu, oracle):
+    """Reference :797-807: a cell is detected at iniThFAST and, only when that leaves it empty, again at minThFAST. A low-contrast image
+    (nearly every corner weaker than 20) takes the second pass in almost every cell; a half-and-half image mixes both kinds of cells in one frame."""
+    base = make_image(11, 480, 360)
+    weak = (base.astype(np.int32) // 8 + 100).astype(np.uint8)
+    mixed = base.copy(); mixed[:, 240:] = weak[:, 240:]
+    for img, nf in ((weak, 500), (mixed, 700)):
+        k, d = viorb_amd.ORBextractor(nf, 1.2, 8, 20, 7)(img)
+        ok, od = oracle.Extractor(nf, 1.2, 8, 20, 7)(img)
+        assert len(ok) > 30
+        np.testing.assert_array_equal(k, ok)
+        np.testing.assert_array_equal(d, od)
+    kw, _ = viorb_amd.ORBextractor(500, 1.2, 8, 20, 7)(weak)
+    assert (kw["response"] < 20).mean() > 0.8, "most cells of the low-contrast image must come from the minThFAST pass"
+
+
 def test_properties_full_size(gpu):
     """Size-independent checks at the bench configuration: determinism, bounds, and that a warped view
     of the same scene re-detects most features with small Hamming distance."""
