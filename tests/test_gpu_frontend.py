@@ -163,6 +163,18 @@ def test_pose_optimisation_matches_oracle(torch_cuda, oracle, variant, seed):
     np.testing.assert_allclose(M, Mo, rtol=1e-4, atol=1e-6 * np.abs(Mo).max())
 
 
+@pytest.mark.parametrize("n_points", [3, 63, 255, 256, 257, 511, 512, 513, 769])
+def test_pose_optimisation_edge_counts_around_the_thread_count(torch_cuda, oracle, n_points):
+    """The solver's edge loop takes 256 edges per trip, two register sets in turn: counts at and around the trip boundaries."""
+    p = make_vio_problem(7, n_points=n_points)
+    o, g = _gpu_pose_opt(p, oracle, 1, True)
+    assert g["n_inliers"] == o["n_inliers"] and g["lm_iterations"] == o["lm_iterations"]
+    assert abs(g["final_chi2"] - o["final_chi2"]) <= 1e-5 * abs(o["final_chi2"]) + 1e-12
+    np.testing.assert_array_equal(g["outlier_cur"], o["outlier_cur"])
+    np.testing.assert_array_equal(g["outlier_last"], o["outlier_last"])
+    np.testing.assert_allclose(g["ns"], o["ns"], rtol=0, atol=1e-7)
+
+
 def test_pose_optimisation_edge_cases(torch_cuda, oracle):
     p = make_vio_problem(5)
     last = p["ns_last"]
