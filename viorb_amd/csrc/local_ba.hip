@@ -683,10 +683,13 @@ static int ba_run(BaDev& D, hipStream_t st, int model, const volatile int* stop,
                 hipLaunchKernelGGL(k_ba_backsub, dim3(gP), dim3(TB), 0, st, D, lambda);
                 if (model == 0) hipLaunchKernelGGL(k_ba_update, dim3(std::max(gP, 1)), dim3(TB), 0, st, D);
                 else hipLaunchKernelGGL(k_ba_se3_update, dim3(std::max(gP, 1)), dim3(TB), 0, st, D);
-                double tempChi = 0;
-                if ((rc = eval_chi2(&tempChi)) != VIORB_OK) return rc;
+                // chi2 of the trial state, the solver's flag and the gain denominator come back in one copy / one synchronisation
+                VIORB_HIP_TRY(hipMemsetAsync(D.scal, 0, sizeof(double), st));
+                if (model == 0) hipLaunchKernelGGL(k_ba_errors, dim3(gE), dim3(TB), 0, st, D, mono_kernel);
+                else hipLaunchKernelGGL(k_ba_se3_errors, dim3(gE), dim3(TB), 0, st, D, mono_kernel);
                 VIORB_HIP_TRY(hipMemcpyAsync(h_scal, D.scal, 8 * sizeof(double), hipMemcpyDeviceToHost, st));
                 VIORB_HIP_TRY(hipStreamSynchronize(st));
+                double tempChi = h_scal[0];
                 const bool ok2 = h_scal[2] > 0.5;
                 if (!ok2) tempChi = std::numeric_limits<double>::max();
                 const double scale = (ok2 ? h_scal[1] : 0.0) + 1e-3;
