@@ -304,6 +304,19 @@ __global__ __launch_bounds__(256) void k_ba_schur(BaDev D) {
 // fails the solve like the reference's LLT (linear_solver_eigen.h / Eigen info()).
 typedef double v4d __attribute__((ext_vector_type(4)));
 #define BA_MAX_TILES_PER_WAVE 9              // ceil(16 * 17 / 2 / 16) trailing tiles per wave at ld = 256 (+ the rhs block row)
+// lane broadcast of a double and a full-precision reciprocal square root (hardware estimate + two Newton steps) for the factorisation's
+// diagonal blocks
+__device__ __forceinline__ double ba_readlane(double v, int l) {
+    union { double d; int i[2]; } u; u.d = v;
+    u.i[0] = __builtin_amdgcn_readlane(u.i[0], l); u.i[1] = __builtin_amdgcn_readlane(u.i[1], l);
+    return u.d;
+}
+__device__ __forceinline__ double ba_rsqrt(double d) {
+    double y = __builtin_amdgcn_rsq(d);
+    y = fma(0.5 * y, fma(-(d * y), y, 1.0), y);
+    y = fma(0.5 * y, fma(-(d * y), y, 1.0), y);
+    return y;
+}
 __global__ __launch_bounds__(1024) void k_ba_chol_solve(BaDev D) {
     __shared__ double s_L[16][17], s_P[256][17], s_y[256], s_rd[16];
     __shared__ int s_ok;
@@ -316,26 +329,32 @@ __global__ __launch_bounds__(1024) void k_ba_chol_solve(BaDev D) {
     __syncthreads();
     for (int kb = 0; kb < nb; kb++) {
         const int k0 = kb << 4;
-        if (wv == 0) {                                           // (1) diagonal block
-            for (int q = lane; q < 256; q += 64) s_L[q >> 4][q & 15] = A[(size_t)(k0 + (q >> 4)) * ld + k0 + (q & 15)];
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            for (int j = 0; j < 16; j++) {
-                const double d = s_L[j][j];
-                const bool good = (d > 0) && isfinite(d);
-                if (!good && lane == 0) s_ok = 0;
-                const double dj = sqrt(good ? d : 1.0);
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                if (lane >= j && lane < 16) s_L[lane][j] = (lane == j) ? dj : s_L[lane][j] / dj;
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (wv == 0) {                                           // (1) diagonal block: row (lane & 15) of it in registers, pivots and
+            const int li = lane & 15;                            //     multipliers by v_readlane, 1/sqrt by rsq + two Newton steps
+            double a[16];
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const int q = lane + 64 * u, r = q >> 4, c = q & 15;
-                    if (c > j && c <= r) s_L[r][c] -= s_L[r][j] * s_L[c][j];
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            for (int c = 0; c < 16; c++) a[c] = A[(size_t)(k0 + li) * ld + k0 + c];
+            bool good = true;
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                const double d = ba_readlane(a[j], j);
+                const bool gj = (d > 0) && isfinite(d);
+                good = good && gj;
+                const double inv = ba_rsqrt(gj ? d : 1.0);
+                const double lij = a[j] * inv;                   // rows >= j; the rest never reaches a result
+                a[j] = lij;
+                if (lane == j) s_rd[j] = inv;                    // the panel rows multiply by the reciprocal pivots
+#pragma unroll
+                for (int k = j + 1; k < 16; k++) a[k] = fma(-lij, ba_readlane(lij, k), a[k]);
             }
-            for (int q = lane; q < 256; q += 64) if ((q & 15) <= (q >> 4)) A[(size_t)(k0 + (q >> 4)) * ld + k0 + (q & 15)] = s_L[q >> 4][q & 15];
-            if (lane < 16) s_rd[lane] = 1.0 / s_L[lane][lane];          // the panel rows multiply by the reciprocal pivots
+            if (!good && lane == 0) s_ok = 0;
+            if (lane < 16) {
+#pragma unroll
+                for (int c = 0; c < 16; c++) {
+                    s_L[li][c] = a[c];
+                    if (c <= li) A[(size_t)(k0 + li) * ld + k0 + c] = a[c];
+                }
+            }
         }
         __syncthreads();
         const int below = rows - k0 - 16;                        // rows under the diagonal block (the rhs block row included)
@@ -631,6 +650,14 @@ bool host_inverse9(const double* a_in, double* inv) {
 
 // The Levenberg-Marquardt control flow of g2o (optimization_algorithm_levenberg.cpp:61-189) shared by both window solves:
 // optimize(5) -> gate / drop kernels -> optimize(10) -> erase flags. model 0: NavState window, 1: SE3 (vision-only) window.
+// The LM driver reads three scalars per trial: it polls the stream instead of blocking in hipStreamSynchronize (whose wake-up costs more
+// than the kernels of a trial take).
+static hipError_t ba_wait(hipStream_t st) {
+    for (;;) {
+        const hipError_t e = hipStreamQuery(st);
+        if (e != hipErrorNotReady) return e;
+    }
+}
 static int ba_run(BaDev& D, hipStream_t st, int model, const volatile int* stop, uint8_t* d_erase, double* kfs_out, double* points_out,
                   uint8_t* erase, double* info) {
     const int nk = D.NK, npts = D.NP, ne = D.NE, n_local = D.W;
@@ -644,7 +671,7 @@ static int ba_run(BaDev& D, hipStream_t st, int model, const volatile int* stop,
         if (model == 0) hipLaunchKernelGGL(k_ba_errors, dim3(gE), dim3(TB), 0, st, D, mono_kernel);
         else hipLaunchKernelGGL(k_ba_se3_errors, dim3(gE), dim3(TB), 0, st, D, mono_kernel);
         VIORB_HIP_TRY(hipMemcpyAsync(chi, D.scal, sizeof(double), hipMemcpyDeviceToHost, st));
-        VIORB_HIP_TRY(hipStreamSynchronize(st));
+        VIORB_HIP_TRY(ba_wait(st));
         return VIORB_OK;
     };
     auto build_system = [&]() -> int {
@@ -668,7 +695,7 @@ static int ba_run(BaDev& D, hipStream_t st, int model, const volatile int* stop,
                 VIORB_HIP_TRY(hipMemsetAsync(D.scal + 3, 0, sizeof(double), st));
                 hipLaunchKernelGGL(k_ba_max_diag, dim3(32), dim3(256), 0, st, D);
                 VIORB_HIP_TRY(hipMemcpyAsync(h_scal, D.scal, 8 * sizeof(double), hipMemcpyDeviceToHost, st));
-                VIORB_HIP_TRY(hipStreamSynchronize(st));
+                VIORB_HIP_TRY(ba_wait(st));
                 lambda = 1e-5 * h_scal[3]; ni = 2; nBad = 0;
             }
             double rho = 0; int qmax = 0;
@@ -688,7 +715,7 @@ static int ba_run(BaDev& D, hipStream_t st, int model, const volatile int* stop,
                 if (model == 0) hipLaunchKernelGGL(k_ba_errors, dim3(gE), dim3(TB), 0, st, D, mono_kernel);
                 else hipLaunchKernelGGL(k_ba_se3_errors, dim3(gE), dim3(TB), 0, st, D, mono_kernel);
                 VIORB_HIP_TRY(hipMemcpyAsync(h_scal, D.scal, 8 * sizeof(double), hipMemcpyDeviceToHost, st));
-                VIORB_HIP_TRY(hipStreamSynchronize(st));
+                VIORB_HIP_TRY(ba_wait(st));
                 double tempChi = h_scal[0];
                 const bool ok2 = h_scal[2] > 0.5;
                 if (!ok2) tempChi = std::numeric_limits<double>::max();
@@ -722,7 +749,7 @@ static int ba_run(BaDev& D, hipStream_t st, int model, const volatile int* stop,
     VIORB_HIP_TRY(hipMemcpyAsync(kfs_out, D.kf, (size_t)n_local * D.kf_stride * sizeof(double), hipMemcpyDeviceToHost, st));
     VIORB_HIP_TRY(hipMemcpyAsync(points_out, D.pt, (size_t)npts * 3 * sizeof(double), hipMemcpyDeviceToHost, st));
     VIORB_HIP_TRY(hipMemcpyAsync(erase, d_erase, ne, hipMemcpyDeviceToHost, st));
-    VIORB_HIP_TRY(hipStreamSynchronize(st));
+    VIORB_HIP_TRY(ba_wait(st));
     info[0] = chi1; info[1] = chi2v; info[2] = its1; info[3] = its2;
     return VIORB_OK;
 }
