@@ -923,6 +923,10 @@ __constant__ __attribute__((aligned(16))) uint32_t c_pattern[256];   // x0 | y0<
 __constant__ int c_umax[16];
 __constant__ uint32_t c_orient_mask[256];              // [row 0..31][dword 0..7]: 0xff per byte inside the circle (row 31: 0)
 typedef uint32_t u32_unaligned __attribute__((aligned(1)));
+#define DESC_WIN_HALF 18
+#define DESC_WIN_ROWS 37
+#define DESC_WIN_DW 10
+#define DESC_WIN_TRIPS 6           // ceil(37 * 10 / 64)
 __global__ __launch_bounds__(256) void k_orient_describe(const uint8_t* __restrict__ planes,
                                                          const uint8_t* __restrict__ blur, size_t frame_bytes,
                                                          const LevelDev* __restrict__ lv, int nlevels,
@@ -950,6 +954,19 @@ __global__ __launch_bounds__(256) void k_orient_describe(const uint8_t* __restri
     // slabs cover the 31 rows; the circle is a constant byte-mask table, so the four (unaligned) dword loads are
     // independent and branch-free; sum I and sum (u+15) I come from two v_dot4_u32_u8 per dword.
     const uint8_t* img = planes + (size_t)b * frame_bytes + L.plane_off + (size_t)cy * L.stride + cx;
+    // The 512 descriptor samples of a keypoint lie within +-18 px (the largest pattern radius is 18.38): the 37 x 40-byte window of
+    // the blurred level is requested now, as 370 row-contiguous dwords, and goes through LDS — eight scattered byte loads per lane
+    // touched ~30 cache lines per instruction and made the texture-address unit this kernel's limit.
+    __shared__ uint32_t s_win[4][DESC_WIN_ROWS * DESC_WIN_DW];
+    uint32_t* win = s_win[threadIdx.x >> 6];
+    const uint8_t* bim = blur + (size_t)b * frame_bytes + L.plane_off + (size_t)cy * L.stride + cx;
+    uint32_t wv[DESC_WIN_TRIPS];
+#pragma unroll
+    for (int it = 0; it < DESC_WIN_TRIPS; it++) {
+        const int i = min(lane + 64 * it, DESC_WIN_ROWS * DESC_WIN_DW - 1);
+        const int wr = i / DESC_WIN_DW, wc = i - wr * DESC_WIN_DW;
+        wv[it] = *reinterpret_cast<const u32_unaligned*>(bim + (wr - DESC_WIN_HALF) * L.stride - DESC_WIN_HALF + 4 * wc);
+    }
     int m10 = 0, m01 = 0;
     {
         const int j = lane & 7, r8 = lane >> 3;
@@ -979,7 +996,13 @@ __global__ __launch_bounds__(256) void k_orient_describe(const uint8_t* __restri
     float sn, cs;
     sincos_f32(angle * factor_pi, &sn, &cs);
     const float a = cs, bb = sn;
-    const uint8_t* bim = blur + (size_t)b * frame_bytes + L.plane_off + (size_t)cy * L.stride + cx;
+#pragma unroll
+    for (int it = 0; it < DESC_WIN_TRIPS; it++) {
+        const int i = lane + 64 * it;
+        if (i < DESC_WIN_ROWS * DESC_WIN_DW) win[i] = wv[it];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const uint8_t* w8 = reinterpret_cast<const uint8_t*>(win) + DESC_WIN_HALF * (DESC_WIN_DW * 4) + DESC_WIN_HALF;
     uint32_t nib = 0;
     const uint4 pq = reinterpret_cast<const uint4*>(c_pattern)[lane];
     const uint32_t pqa[4] = {pq.x, pq.y, pq.z, pq.w};
@@ -990,7 +1013,7 @@ __global__ __launch_bounds__(256) void k_orient_describe(const uint8_t* __restri
         const float x1 = (float)(int8_t)((q >> 16) & 0xff), y1 = (float)(int8_t)(q >> 24);
         const int r0 = round_half_even(x0 * bb + y0 * a), c0 = round_half_even(x0 * a - y0 * bb);
         const int r1 = round_half_even(x1 * bb + y1 * a), c1 = round_half_even(x1 * a - y1 * bb);
-        const int t0 = bim[r0 * L.stride + c0], t1 = bim[r1 * L.stride + c1];
+        const int t0 = w8[r0 * (DESC_WIN_DW * 4) + c0], t1 = w8[r1 * (DESC_WIN_DW * 4) + c1];
         nib |= (uint32_t)(t0 < t1) << t;
     }
     // lane i holds bits 4i..4i+3: bytes from lane pairs, dwords from 8-lane groups
