@@ -139,12 +139,19 @@ class BatchedTracker:
         self.k = 0
         self.ev_tr = [None, None]
 
+    def _track_pre(self, imu, t_cur):
+        """The part of a tracking step that does not need the new frame's keypoints: IMU pre-integration + prediction and the last
+        frame's own observations. With overlap it is enqueued before the wait for the extraction."""
+        B = self.B
+        self.fe.imu_predict(imu, self.t_last, t_cur, self.last_ns, self.preint, self.cur_ns, self.pose12)
+        self.fe.build_observations(self.last_kps.data_ptr(), self.last_count.data_ptr(), self.last_self, self.last_Pw, B, self.obs_last,
+                                   self.idx_last, self.n_last)
+
     def _track(self, imu, t_cur, true_pose12, chain_estimate, true_ns, t_next_last):
         B = self.B
         kps, desc, count, _, cap = self._cur_ptrs()
         fe = self.fe
         fe.grid(kps, count, B, self.cell_start, self.cell_idx)
-        fe.imu_predict(imu, self.t_last, t_cur, self.last_ns, self.preint, self.cur_ns, self.pose12)
         fe.search_projection(kps, desc, count, self.cell_start, self.cell_idx, self.pose12, self.last_kps.data_ptr(),
                              self.last_count.data_ptr(), self.last_flags, self.last_Pw, self.last_desc.data_ptr(), self.th, B,
                              self.cur_match, self.nmatches, self.status)
@@ -153,8 +160,6 @@ class BatchedTracker:
                              self.last_count.data_ptr(), self.last_flags, self.last_Pw, self.last_desc.data_ptr(), 2 * self.th, B,
                              self.cur_match, self.nmatches, self.status, retry_below=20)
         fe.build_observations(kps, count, self.cur_match, self.last_Pw, B, self.obs_cur, self.idx_cur, self.n_cur)
-        fe.build_observations(self.last_kps.data_ptr(), self.last_count.data_ptr(), self.last_self, self.last_Pw, B, self.obs_last,
-                              self.idx_last, self.n_last)
         tlm = self.track_local_map
         fe.pose_opt(1, self.compute_marg and not tlm, self.cur_ns, self.last_ns, self.prior_ns, self.marg_cov_inv, self.preint, self.obs_cur,
                     self.n_cur, self.obs_last, self.n_last, B, self.out_ns, self.out_last_ns, self.outlier_cur, self.outlier_last, self.marg_out,
@@ -184,6 +189,7 @@ class BatchedTracker:
         torch = self.torch
         if not self.overlap:
             self.ex.extract_batch_device(images)
+            self._track_pre(imu, t_cur)
             self._track(imu, t_cur, true_pose12, chain_estimate, true_ns, t_next_last)
             return
         slot = self.k % 2
@@ -195,6 +201,8 @@ class BatchedTracker:
         ex.extract_batch_device(images, stream=self.s_ex)
         self.ev_ex[slot].record(self.s_ex)
         self.s_tr.wait_stream(cur)
+        with torch.cuda.stream(self.s_tr):
+            self._track_pre(imu, t_cur)                  # runs while the extraction of this frame is still in flight
         self.s_tr.wait_event(self.ev_ex[slot])
         self.ex = ex
         with torch.cuda.stream(self.s_tr):
