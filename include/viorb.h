@@ -335,6 +335,19 @@ int viorb_local_ba_navstate(const double* kfs, int nk, int n_local, int prev_kf,
                             const double gw[3], const double cam[16], const volatile int* stop, double* kfs_out,
                             double* points_out, uint8_t* erase, double info[6]);
 
+/* Several windows at once (one per camera stream in a multi-stream deployment; the reference runs one LocalMapping thread per system):
+ * each entry carries the arguments of one viorb_local_ba_navstate call and receives its return code in `status`. Up to max_in_flight
+ * windows (<= 0: 16) are kept going concurrently, each on its own HIP stream of device 0, by ONE host thread that resumes a window's
+ * LM driver whenever its stream has drained — a single window is a chain of small latency-bound launches that leaves most of the GPU
+ * idle, and several host threads calling the single-window entry point slow each other down inside the HIP runtime. Results are those
+ * of the individual calls (to rounding: the Schur accumulation uses LDS atomics, whose order is not fixed from run to run). */
+typedef struct viorb_lba_window {
+    const double* kfs; int32_t nk, n_local, prev_kf; const double* preint; const double* points; int32_t np;
+    const int32_t* edge_idx; const double* edge_obs; int32_t ne; const double* gw; const double* cam; const volatile int* stop;
+    double* kfs_out; double* points_out; uint8_t* erase; double* info /* [6] */; int32_t status;
+} viorb_lba_window;
+int viorb_local_ba_navstate_batch(viorb_lba_window* windows, int n_windows, int max_in_flight);
+
 /* Vision-only Optimizer::LocalBundleAdjustment (reference src/Optimizer.cc:3980-4311; BlockSolver_6_3): kfs [nk][7] = g2o::SE3Quat of
  * each key frame's Tcw as qx qy qz qw tx ty tz (Converter::toSE3Quat), the n_local free ones first, then the fixed ones (lFixedCameras,
  * and key frame 0 when it is local: :4055); points [np][3]; edge_idx [ne][2] = (point, key frame) sorted by point; edge_obs [ne][4] =

@@ -35,6 +35,27 @@ def test_local_ba_matches_oracle(oracle, seed, W, npts, extra):
     np.testing.assert_allclose(got["points"], ref["points"], rtol=0, atol=1e-6)
 
 
+def test_local_ba_batch_equals_single_calls(oracle):
+    """viorb_local_ba_navstate_batch: windows of different sizes kept in flight together give what the single
+    calls give (same kernels; the Schur accumulation's LDS atomics make two runs differ in the last bits), in input order."""
+    from viorb_amd import LocalBundleAdjustmentNavState, LocalBundleAdjustmentNavStateBatch
+    probs = []
+    for seed, W, npts in [(11, 6, 300), (12, 10, 500), (13, 3, 90), (14, 8, 400), (15, 6, 300), (16, 12, 700), (17, 2, 60), (18, 5, 200), (19, 9, 450)]:
+        p = make_local_ba_problem(seed, W=W, n_points=npts, n_fixed_extra=2)
+        a = _args(p, _preints(oracle, p))
+        probs.append(dict(kfs=a[0], n_local=a[1], prev_kf=a[2], preint=a[3], points=a[4], edge_idx=a[5], edge_obs=a[6], gw=a[7], cam=a[8]))
+    single = [LocalBundleAdjustmentNavState(**q) for q in probs]
+    for in_flight in (1, 4, 16):
+        batch = LocalBundleAdjustmentNavStateBatch(probs, max_in_flight=in_flight)
+        assert len(batch) == len(single)
+        for g, r in zip(batch, single):
+            assert (g["its_first"], g["its_second"]) == (r["its_first"], r["its_second"])
+            np.testing.assert_array_equal(g["erase"], r["erase"])
+            np.testing.assert_allclose(g["kfs"], r["kfs"], rtol=0, atol=1e-9)          # LDS atomics: run-to-run rounding differences
+            np.testing.assert_allclose(g["points"], r["points"], rtol=0, atol=1e-9)
+            assert abs(g["chi2_final"] - r["chi2_final"]) <= 1e-9 * r["chi2_final"]
+
+
 def test_local_ba_without_prev_keyframe(oracle):
     """prev_kf = -1: the first local key frame has no IMU / bias factor (map start)."""
     from viorb_amd import LocalBundleAdjustmentNavState

@@ -13,6 +13,10 @@
 // k_ba_update. The LM control flow (accept / reject, lambda schedule, stop rule, stop flag) runs on the host and reads
 // three scalars back per trial. The Schur products use FP64 atomics, not MFMA yet.
 #include <hip/hip_runtime.h>
+#include <memory>
+#include <string>
+#include <atomic>
+#include <thread>
 #include <vector>
 #include <algorithm>
 #include <cmath>
@@ -591,7 +595,7 @@ using namespace viorb;
 namespace {
 // A solve borrows a context (a HIP stream + a device arena) from a small pool, so that concurrent callers (the LocalMapping threads
 // of several SLAM instances) run on different streams and no call pays hipMalloc / hipFree, which synchronise the whole device.
-struct BaCtx { hipStream_t st = nullptr; void* arena = nullptr; size_t bytes = 0; };
+struct BaCtx { hipStream_t st = nullptr; void* arena = nullptr; size_t bytes = 0; double* pinned = nullptr; /* 16 doubles of page-locked host memory for the LM scalars */ };
 std::mutex g_ctx_mu;
 std::vector<BaCtx*> g_ctx_free;
 struct BaCtxLease {
@@ -602,34 +606,53 @@ struct BaCtxLease {
     }
     ~BaCtxLease() { if (c) { std::lock_guard<std::mutex> lk(g_ctx_mu); g_ctx_free.push_back(c); } }
     bool ready() {
-        if (!c) { c = new BaCtx(); if (hipStreamCreateWithFlags(&c->st, hipStreamNonBlocking) != hipSuccess) { delete c; c = nullptr; return false; } }
+        if (!c) {
+            c = new BaCtx();
+            if (hipStreamCreateWithFlags(&c->st, hipStreamNonBlocking) != hipSuccess || hipHostMalloc(reinterpret_cast<void**>(&c->pinned), 16 * sizeof(double)) != hipSuccess) {
+                delete c; c = nullptr; return false;
+            }
+        }
         return true;
     }
 };
 // alloc() lays the arrays out in a host mirror (inputs copied, work arrays zero); commit() uploads the mirror into the context's
 // arena in one copy and patches the recorded pointers.
 struct BaBuf {
-    struct Item { void** slot; size_t off; };
+    // Inputs are laid out in a host mirror and uploaded in one copy; work arrays follow them in the arena and are only zeroed on the
+    // device (uploading their zeros from the host was most of the per-window host time of a batch).
+    struct Item { void** slot; size_t off; bool work; };
     std::vector<Item> items;
     std::vector<uint8_t> mirror;
+    size_t work_bytes = 0;
     template <class T> bool alloc(T** d, size_t n, const T* src = nullptr) {
-        const size_t off = (mirror.size() + 255) & ~(size_t)255, bytes = std::max<size_t>(n, 1) * sizeof(T);
-        mirror.resize(off + bytes, 0);
-        if (src && n) memcpy(mirror.data() + off, src, n * sizeof(T));
-        items.push_back({reinterpret_cast<void**>(d), off});
+        const size_t bytes = std::max<size_t>(n, 1) * sizeof(T);
+        if (src) {
+            const size_t off = (mirror.size() + 255) & ~(size_t)255;
+            mirror.resize(off + bytes, 0);
+            if (n) memcpy(mirror.data() + off, src, n * sizeof(T));
+            items.push_back({reinterpret_cast<void**>(d), off, false});
+        } else {
+            const size_t off = (work_bytes + 255) & ~(size_t)255;
+            work_bytes = off + bytes;
+            items.push_back({reinterpret_cast<void**>(d), off, true});
+        }
         *d = nullptr;
         return true;
     }
     bool commit(BaCtx* c) {
-        if (c->bytes < mirror.size()) {
+        const size_t in_bytes = (mirror.size() + 255) & ~(size_t)255, total = in_bytes + work_bytes;
+        if (c->bytes < total) {
             if (c->arena) (void)hipFree(c->arena);
             c->arena = nullptr; c->bytes = 0;
-            const size_t want = mirror.size() + mirror.size() / 4;
+            const size_t want = total + total / 4;
             if (hipMalloc(&c->arena, want) != hipSuccess) { c->arena = nullptr; return false; }
             c->bytes = want;
         }
-        if (hipMemcpyAsync(c->arena, mirror.data(), mirror.size(), hipMemcpyHostToDevice, c->st) != hipSuccess || hipStreamSynchronize(c->st) != hipSuccess) return false;
-        for (const Item& it : items) *it.slot = static_cast<uint8_t*>(c->arena) + it.off;
+        uint8_t* base = static_cast<uint8_t*>(c->arena);
+        if (!mirror.empty() && hipMemcpyAsync(base, mirror.data(), mirror.size(), hipMemcpyHostToDevice, c->st) != hipSuccess) return false;
+        if (work_bytes && hipMemsetAsync(base + in_bytes, 0, work_bytes, c->st) != hipSuccess) return false;
+        if (hipStreamSynchronize(c->st) != hipSuccess) return false;          // the mirror dies with this object
+        for (const Item& it : items) *it.slot = base + (it.work ? in_bytes + it.off : it.off);
         return true;
     }
 };
@@ -658,48 +681,66 @@ static hipError_t ba_wait(hipStream_t st) {
         if (e != hipErrorNotReady) return e;
     }
 }
-static int ba_run(BaDev& D, hipStream_t st, int model, const volatile int* stop, uint8_t* d_erase, double* kfs_out, double* points_out,
-                  uint8_t* erase, double* info) {
-    const int nk = D.NK, npts = D.NP, ne = D.NE, n_local = D.W;
-    const size_t n2 = (size_t)D.np * D.np, nl2 = (size_t)D.ld * D.ld, kf_doubles = (size_t)nk * D.kf_stride;
-    auto terminate = [&]() { return stop && *stop; };
-    const int TB = 256, gE = (ne + TB - 1) / TB, gP = (npts + TB - 1) / TB;
-    int mono_kernel = 1;
-    double h_scal[8];
-    auto eval_chi2 = [&](double* chi) -> int {
-        VIORB_HIP_TRY(hipMemsetAsync(D.scal, 0, sizeof(double), st));
-        if (model == 0) hipLaunchKernelGGL(k_ba_errors, dim3(gE), dim3(TB), 0, st, D, mono_kernel);
-        else hipLaunchKernelGGL(k_ba_se3_errors, dim3(gE), dim3(TB), 0, st, D, mono_kernel);
-        VIORB_HIP_TRY(hipMemcpyAsync(chi, D.scal, sizeof(double), hipMemcpyDeviceToHost, st));
-        VIORB_HIP_TRY(ba_wait(st));
-        return VIORB_OK;
-    };
-    auto build_system = [&]() -> int {
-        VIORB_HIP_TRY(hipMemsetAsync(D.Hpp, 0, n2 * sizeof(double), st));
-        VIORB_HIP_TRY(hipMemsetAsync(D.bp, 0, D.np * sizeof(double), st));
-        if (model == 0) hipLaunchKernelGGL(k_ba_lin_points, dim3(gP), dim3(TB), 0, st, D, mono_kernel);
-        else hipLaunchKernelGGL(k_ba_se3_lin_points, dim3(gP), dim3(TB), 0, st, D, mono_kernel);
-        hipLaunchKernelGGL(k_ba_hpp, dim3(n_local), dim3(256), 0, st, D);
-        if (model == 0) hipLaunchKernelGGL(k_ba_imu, dim3(n_local), dim3(256), 0, st, D);
-        return VIORB_OK;
-    };
-    double lambda = 0, ni = 2;
-    int rc = VIORB_OK;
-    auto optimize = [&](int iterations, int& its_done, double& chi_out) -> int {
-        double currentChi = 0; int nBad = 0;
-        for (int it = 0; it < iterations && !terminate(); it++) {
-            if ((rc = eval_chi2(&currentChi)) != VIORB_OK) return rc;
-            const double iniChi = currentChi;
-            if ((rc = build_system()) != VIORB_OK) return rc;
-            if (it == 0) {
-                VIORB_HIP_TRY(hipMemsetAsync(D.scal + 3, 0, sizeof(double), st));
-                hipLaunchKernelGGL(k_ba_max_diag, dim3(32), dim3(256), 0, st, D);
-                VIORB_HIP_TRY(hipMemcpyAsync(h_scal, D.scal, 8 * sizeof(double), hipMemcpyDeviceToHost, st));
-                VIORB_HIP_TRY(ba_wait(st));
-                lambda = 1e-5 * h_scal[3]; ni = 2; nBad = 0;
-            }
-            double rho = 0; int qmax = 0;
-            do {
+// The LM driver (g2o's optimize(5) -> gate -> optimize(10), reference src/Optimizer.cc:2100-2160 and the vision-only twin) as a
+// resumable state machine: advance() runs the host logic up to the next point where device scalars are needed, enqueues the work on
+// the solve's stream and returns BA_WAIT; the caller resumes it once the stream has drained. One window blocks on its stream between
+// calls; a batch keeps several windows in flight from one host thread (several host threads slow each other down inside the HIP runtime).
+enum { BA_WAIT = 0, BA_DONE = 1 };
+struct BaSolve {
+    BaCtxLease lease;
+    BaDev D; hipStream_t st = nullptr; double* h = nullptr;       // h: 16 page-locked doubles
+    int model = 0; const volatile int* stop = nullptr; uint8_t* d_erase = nullptr;
+    double* kfs_out = nullptr; double* points_out = nullptr; uint8_t* erase = nullptr; double* info = nullptr;
+    // LM state
+    enum State { ST_OPT_BEGIN, ST_ITER_BEGIN, ST_AFTER_CHI, ST_AFTER_DIAG, ST_TRIAL_ENQ, ST_AFTER_TRIAL, ST_FINISH, ST_AFTER_FINAL, ST_DONE } state = ST_OPT_BEGIN;
+    int phase = 0, iterations = 5, it = 0, nBad = 0, qmax = 0, mono_kernel = 1;
+    int its[2] = {0, 0}; double chi[2] = {0, 0};
+    double lambda = 0, ni = 2, currentChi = 0, iniChi = 0, rho = 0;
+    bool terminate() const { return stop && *stop; }
+    int advance() {
+        const int nk = D.NK, npts = D.NP, ne = D.NE, n_local = D.W;
+        const size_t n2 = (size_t)D.np * D.np, nl2 = (size_t)D.ld * D.ld, kf_doubles = (size_t)nk * D.kf_stride;
+        const int TB = 256, gE = (ne + TB - 1) / TB, gP = (npts + TB - 1) / TB;
+        auto enqueue_errors = [&]() -> int {
+            VIORB_HIP_TRY(hipMemsetAsync(D.scal, 0, sizeof(double), st));
+            if (model == 0) hipLaunchKernelGGL(k_ba_errors, dim3(gE), dim3(TB), 0, st, D, mono_kernel);
+            else hipLaunchKernelGGL(k_ba_se3_errors, dim3(gE), dim3(TB), 0, st, D, mono_kernel);
+            return VIORB_OK;
+        };
+        int rc;
+        for (;;) {
+            switch (state) {
+            case ST_OPT_BEGIN:
+                it = 0; currentChi = 0; nBad = 0; state = ST_ITER_BEGIN;
+                break;
+            case ST_ITER_BEGIN:
+                if (it >= iterations || terminate()) { state = ST_FINISH; break; }
+                if ((rc = enqueue_errors()) != VIORB_OK) return rc;
+                VIORB_HIP_TRY(hipMemcpyAsync(h + 8, D.scal, sizeof(double), hipMemcpyDeviceToHost, st));
+                state = ST_AFTER_CHI;
+                return BA_WAIT;
+            case ST_AFTER_CHI:
+                currentChi = h[8]; iniChi = currentChi;
+                VIORB_HIP_TRY(hipMemsetAsync(D.Hpp, 0, n2 * sizeof(double), st));
+                VIORB_HIP_TRY(hipMemsetAsync(D.bp, 0, D.np * sizeof(double), st));
+                if (model == 0) hipLaunchKernelGGL(k_ba_lin_points, dim3(gP), dim3(TB), 0, st, D, mono_kernel);
+                else hipLaunchKernelGGL(k_ba_se3_lin_points, dim3(gP), dim3(TB), 0, st, D, mono_kernel);
+                hipLaunchKernelGGL(k_ba_hpp, dim3(n_local), dim3(256), 0, st, D);
+                if (model == 0) hipLaunchKernelGGL(k_ba_imu, dim3(n_local), dim3(256), 0, st, D);
+                rho = 0; qmax = 0;
+                if (it == 0) {
+                    VIORB_HIP_TRY(hipMemsetAsync(D.scal + 3, 0, sizeof(double), st));
+                    hipLaunchKernelGGL(k_ba_max_diag, dim3(32), dim3(256), 0, st, D);
+                    VIORB_HIP_TRY(hipMemcpyAsync(h, D.scal, 8 * sizeof(double), hipMemcpyDeviceToHost, st));
+                    state = ST_AFTER_DIAG;
+                    return BA_WAIT;
+                }
+                state = ST_TRIAL_ENQ;
+                break;
+            case ST_AFTER_DIAG:
+                lambda = 1e-5 * h[3]; ni = 2; nBad = 0; state = ST_TRIAL_ENQ;
+                break;
+            case ST_TRIAL_ENQ:
                 VIORB_HIP_TRY(hipMemcpyAsync(D.kf_bak, D.kf, kf_doubles * sizeof(double), hipMemcpyDeviceToDevice, st));
                 VIORB_HIP_TRY(hipMemcpyAsync(D.pt_bak, D.pt, (size_t)npts * 3 * sizeof(double), hipMemcpyDeviceToDevice, st));
                 hipLaunchKernelGGL(k_ba_init_reduced, dim3((unsigned)((nl2 + TB - 1) / TB)), dim3(TB), 0, st, D, lambda);
@@ -711,15 +752,15 @@ static int ba_run(BaDev& D, hipStream_t st, int model, const volatile int* stop,
                 if (model == 0) hipLaunchKernelGGL(k_ba_update, dim3(std::max(gP, 1)), dim3(TB), 0, st, D);
                 else hipLaunchKernelGGL(k_ba_se3_update, dim3(std::max(gP, 1)), dim3(TB), 0, st, D);
                 // chi2 of the trial state, the solver's flag and the gain denominator come back in one copy / one synchronisation
-                VIORB_HIP_TRY(hipMemsetAsync(D.scal, 0, sizeof(double), st));
-                if (model == 0) hipLaunchKernelGGL(k_ba_errors, dim3(gE), dim3(TB), 0, st, D, mono_kernel);
-                else hipLaunchKernelGGL(k_ba_se3_errors, dim3(gE), dim3(TB), 0, st, D, mono_kernel);
-                VIORB_HIP_TRY(hipMemcpyAsync(h_scal, D.scal, 8 * sizeof(double), hipMemcpyDeviceToHost, st));
-                VIORB_HIP_TRY(ba_wait(st));
-                double tempChi = h_scal[0];
-                const bool ok2 = h_scal[2] > 0.5;
+                if ((rc = enqueue_errors()) != VIORB_OK) return rc;
+                VIORB_HIP_TRY(hipMemcpyAsync(h, D.scal, 8 * sizeof(double), hipMemcpyDeviceToHost, st));
+                state = ST_AFTER_TRIAL;
+                return BA_WAIT;
+            case ST_AFTER_TRIAL: {
+                double tempChi = h[0];
+                const bool ok2 = h[2] > 0.5;
                 if (!ok2) tempChi = std::numeric_limits<double>::max();
-                const double scale = (ok2 ? h_scal[1] : 0.0) + 1e-3;
+                const double scale = (ok2 ? h[1] : 0.0) + 1e-3;
                 rho = (currentChi - tempChi) / scale;
                 if (rho > 0 && std::isfinite(tempChi)) { double alpha = 1. - std::pow((2 * rho - 1), 3); alpha = std::min(alpha, 2. / 3.); lambda *= std::max(1. / 3., alpha); ni = 2; currentChi = tempChi; }
                 else {
@@ -728,35 +769,53 @@ static int ba_run(BaDev& D, hipStream_t st, int model, const volatile int* stop,
                     VIORB_HIP_TRY(hipMemcpyAsync(D.pt, D.pt_bak, (size_t)npts * 3 * sizeof(double), hipMemcpyDeviceToDevice, st));
                 }
                 qmax++;
-            } while (rho < 0 && qmax < 10 && !terminate());
-            its_done++; chi_out = currentChi;
-            if (qmax == 10 || rho == 0) break;
-            if ((iniChi - currentChi) * 1e3 < iniChi) nBad++; else nBad = 0;
-            if (nBad >= 3) break;
+                if (rho < 0 && qmax < 10 && !terminate()) { state = ST_TRIAL_ENQ; break; }
+                its[phase]++; chi[phase] = currentChi;
+                bool stop_opt = (qmax == 10 || rho == 0);
+                if (!stop_opt) { if ((iniChi - currentChi) * 1e3 < iniChi) nBad++; else nBad = 0; if (nBad >= 3) stop_opt = true; }
+                it++;
+                if (stop_opt) it = iterations;                   // leaves the iteration loop through ST_ITER_BEGIN
+                state = ST_ITER_BEGIN;
+                break;
+            }
+            case ST_FINISH:
+                if (phase == 0 && !terminate()) {
+                    if (model == 0) hipLaunchKernelGGL(k_ba_gate, dim3(gE), dim3(TB), 0, st, D, d_erase, 1);
+                    else hipLaunchKernelGGL(k_ba_se3_gate, dim3(gE), dim3(TB), 0, st, D, d_erase, 1);
+                    mono_kernel = 0; phase = 1; iterations = 10; state = ST_OPT_BEGIN;
+                    break;
+                }
+                if (model == 0) hipLaunchKernelGGL(k_ba_gate, dim3(gE), dim3(TB), 0, st, D, d_erase, 0);
+                else hipLaunchKernelGGL(k_ba_se3_gate, dim3(gE), dim3(TB), 0, st, D, d_erase, 0);
+                VIORB_HIP_TRY(hipMemcpyAsync(kfs_out, D.kf, (size_t)n_local * D.kf_stride * sizeof(double), hipMemcpyDeviceToHost, st));
+                VIORB_HIP_TRY(hipMemcpyAsync(points_out, D.pt, (size_t)npts * 3 * sizeof(double), hipMemcpyDeviceToHost, st));
+                VIORB_HIP_TRY(hipMemcpyAsync(erase, d_erase, ne, hipMemcpyDeviceToHost, st));
+                state = ST_AFTER_FINAL;
+                return BA_WAIT;
+            case ST_AFTER_FINAL:
+                info[0] = chi[0]; info[1] = chi[1]; info[2] = its[0]; info[3] = its[1];
+                state = ST_DONE;
+                return BA_DONE;
+            case ST_DONE:
+                return BA_DONE;
+            }
         }
-        return VIORB_OK;
-    };
-    int its1 = 0, its2 = 0; double chi1 = 0, chi2v = 0;
-    if ((rc = optimize(5, its1, chi1)) != VIORB_OK) return rc;
-    if (!terminate()) {
-        if (model == 0) hipLaunchKernelGGL(k_ba_gate, dim3(gE), dim3(TB), 0, st, D, d_erase, 1);
-        else hipLaunchKernelGGL(k_ba_se3_gate, dim3(gE), dim3(TB), 0, st, D, d_erase, 1);
-        mono_kernel = 0;
-        if ((rc = optimize(10, its2, chi2v)) != VIORB_OK) return rc;
     }
-    if (model == 0) hipLaunchKernelGGL(k_ba_gate, dim3(gE), dim3(TB), 0, st, D, d_erase, 0);
-    else hipLaunchKernelGGL(k_ba_se3_gate, dim3(gE), dim3(TB), 0, st, D, d_erase, 0);
-    VIORB_HIP_TRY(hipMemcpyAsync(kfs_out, D.kf, (size_t)n_local * D.kf_stride * sizeof(double), hipMemcpyDeviceToHost, st));
-    VIORB_HIP_TRY(hipMemcpyAsync(points_out, D.pt, (size_t)npts * 3 * sizeof(double), hipMemcpyDeviceToHost, st));
-    VIORB_HIP_TRY(hipMemcpyAsync(erase, d_erase, ne, hipMemcpyDeviceToHost, st));
-    VIORB_HIP_TRY(ba_wait(st));
-    info[0] = chi1; info[1] = chi2v; info[2] = its1; info[3] = its2;
-    return VIORB_OK;
-}
+    // one window: block on the stream between the steps
+    int run() {
+        for (;;) {
+            const int r = advance();
+            if (r < 0 || r == BA_DONE) return r < 0 ? r : VIORB_OK;
+            VIORB_HIP_TRY(ba_wait(st));
+        }
+    }
+};
 
-extern "C" int viorb_local_ba_navstate(const double* kfs, int nk, int n_local, int prev_kf, const double* preint, const double* points, int npts,
-                                       const int32_t* edge_idx, const double* edge_obs, int ne, const double gw[3], const double cam[16],
-                                       const volatile int* stop, double* kfs_out, double* points_out, uint8_t* erase, double info[6]) {
+// Argument checks, host-side graph bookkeeping and the upload of one NavState window; leaves `S` ready for advance() (or already done
+// when the stop flag was set on entry).
+static int ba_prepare_navstate(BaSolve& S, const double* kfs, int nk, int n_local, int prev_kf, const double* preint, const double* points, int npts,
+                               const int32_t* edge_idx, const double* edge_obs, int ne, const double gw[3], const double cam[16],
+                               const volatile int* stop, double* kfs_out, double* points_out, uint8_t* erase, double info[6]) {
     VIORB_REQUIRE(kfs && preint && points && edge_idx && edge_obs && gw && cam && kfs_out && points_out && erase && info, "null array");
     VIORB_REQUIRE(n_local >= 1 && n_local <= 20 && nk >= n_local && npts >= 1 && ne >= 1, "1 <= n_local <= 20 key frames, at least one point and edge");
     VIORB_REQUIRE(prev_kf == -1 || (prev_kf >= n_local && prev_kf < nk), "prev_kf must index a fixed key frame or be -1");
@@ -766,7 +825,7 @@ extern "C" int viorb_local_ba_navstate(const double* kfs, int nk, int n_local, i
     for (int i = 0; i < npts * 3; i++) points_out[i] = points[i];
     for (int k = 0; k < ne; k++) erase[k] = 0;
     auto terminate = [&]() { return stop && *stop; };
-    if (terminate()) return VIORB_OK;
+    if (terminate()) { S.state = BaSolve::ST_DONE; return VIORB_OK; }
     // ---- host-side graph bookkeeping
     std::vector<int> e_pt(ne), e_kf(ne), pt_start(npts + 1, 0);
     for (int k = 0; k < ne; k++) {
@@ -785,10 +844,9 @@ extern "C" int viorb_local_ba_navstate(const double* kfs, int nk, int n_local, i
     for (int i = 0; i < n_local; i++) if (!host_inverse9(preint + (size_t)i * 142 + 60, &info_pvr[(size_t)i * 81])) { set_error("singular IMU covariance"); return VIORB_ERR_INVALID_ARG; }
 
     VIORB_HIP_TRY(hipSetDevice(0));
-    BaCtxLease lease;
+    BaCtxLease& lease = S.lease;
     if (!lease.ready()) { set_error("could not create a HIP stream"); return VIORB_ERR_HIP; }
-    hipStream_t st = lease.c->st;
-    BaBuf B; BaDev D;
+    BaBuf B; BaDev& D = S.D;
     D.W = n_local; D.NK = nk; D.NP = npts; D.NE = ne; D.np = 12 * n_local; D.prev_kf = prev_kf; D.acc_bias_rw2 = 5e-3 * 5e-3;
     D.pose_dim = 12; D.rows = 2; D.kf_stride = 22;
     for (int i = 0; i < 16; i++) D.cam[i] = cam[i];
@@ -806,7 +864,65 @@ extern "C" int viorb_local_ba_navstate(const double* kfs, int nk, int n_local, i
               B.alloc(&D.e_pvr, (size_t)n_local * 9) && B.alloc(&D.e_b, (size_t)n_local * 3) && B.alloc(&D.scal, 8) && B.alloc(&d_erase, ne) && B.commit(lease.c);
     if (!ok) { set_error("device allocation / upload failed"); return VIORB_ERR_HIP; }
     D.e_pt = d_ept; D.e_kf = d_ekf; D.e_obs = d_obs; D.pt_start = d_pts; D.kf_start = d_kfs; D.kf_list = d_kfl; D.preint = d_pre; D.info_pvr = d_info;
-    return ba_run(D, st, 0, stop, d_erase, kfs_out, points_out, erase, info);
+    S.st = lease.c->st; S.h = lease.c->pinned; S.model = 0; S.stop = stop; S.d_erase = d_erase;
+    S.kfs_out = kfs_out; S.points_out = points_out; S.erase = erase; S.info = info;
+    return VIORB_OK;
+}
+
+extern "C" int viorb_local_ba_navstate(const double* kfs, int nk, int n_local, int prev_kf, const double* preint, const double* points, int npts,
+                                       const int32_t* edge_idx, const double* edge_obs, int ne, const double gw[3], const double cam[16],
+                                       const volatile int* stop, double* kfs_out, double* points_out, uint8_t* erase, double info[6]) {
+    BaSolve S;
+    const int rc = ba_prepare_navstate(S, kfs, nk, n_local, prev_kf, preint, points, npts, edge_idx, edge_obs, ne, gw, cam, stop, kfs_out, points_out, erase, info);
+    return rc != VIORB_OK ? rc : S.run();
+}
+
+extern "C" int viorb_local_ba_navstate_batch(viorb_lba_window* w, int n, int max_in_flight) {
+    VIORB_REQUIRE(w && n >= 0, "null windows");
+    if (viorb_device_count() < 1) { set_error("no HIP device: libviorb_hip has no CPU fallback"); return VIORB_ERR_NO_DEVICE; }
+    if (max_in_flight <= 0) max_in_flight = 16;
+    VIORB_HIP_TRY(hipSetDevice(0));
+    // One host thread keeps up to max_in_flight windows going, each on its own stream: whenever a window's stream has drained, its
+    // driver takes the next LM decision and enqueues the next batch of kernels.
+    std::vector<std::unique_ptr<BaSolve>> live(std::min(max_in_flight, std::max(n, 1)));
+    std::vector<int> which(live.size(), -1);
+    int next = 0, finished = 0, first_error = VIORB_OK;
+    auto start_next = [&](size_t slot) {
+        while (next < n) {
+            const int i = next++;
+            viorb_lba_window& q = w[i];
+            auto S = std::make_unique<BaSolve>();
+            q.status = ba_prepare_navstate(*S, q.kfs, q.nk, q.n_local, q.prev_kf, q.preint, q.points, q.np, q.edge_idx, q.edge_obs, q.ne, q.gw, q.cam,
+                                           q.stop, q.kfs_out, q.points_out, q.erase, q.info);
+            if (q.status == VIORB_OK && S->state != BaSolve::ST_DONE) {
+                const int r = S->advance();                      // first batch of work
+                if (r == BA_WAIT) { live[slot] = std::move(S); which[slot] = i; return; }
+                q.status = r < 0 ? r : VIORB_OK;
+            }
+            if (q.status != VIORB_OK && first_error == VIORB_OK) first_error = q.status;
+            finished++;
+        }
+        live[slot].reset(); which[slot] = -1;
+    };
+    for (size_t k = 0; k < live.size(); k++) start_next(k);
+    while (finished < n) {
+        bool progressed = false;
+        for (size_t k = 0; k < live.size(); k++) {
+            if (!live[k]) continue;
+            const hipError_t e = hipStreamQuery(live[k]->st);
+            if (e == hipErrorNotReady) continue;
+            progressed = true;
+            int r = e == hipSuccess ? live[k]->advance() : VIORB_ERR_HIP;
+            if (e != hipSuccess) set_error("hipStreamQuery failed: %s", hipGetErrorString(e));
+            if (r == BA_WAIT) continue;
+            w[which[k]].status = r < 0 ? r : VIORB_OK;
+            if (r < 0 && first_error == VIORB_OK) first_error = r;
+            finished++;
+            start_next(k);
+        }
+        if (!progressed) for (volatile int spin = 0; spin < 200; spin = spin + 1) {}
+    }
+    return first_error;
 }
 
 extern "C" int viorb_local_ba_se3(const double* kfs, int nk, int n_local, const double* points, int npts, const int32_t* edge_idx,
@@ -834,10 +950,10 @@ extern "C" int viorb_local_ba_se3(const double* kfs, int nk, int n_local, const 
     kf_list.resize(kf_start[n_local]);
     { std::vector<int> pos(kf_start.begin(), kf_start.end() - 1); for (int k = 0; k < ne; k++) if (e_kf[k] < n_local) kf_list[pos[e_kf[k]]++] = k; }
     VIORB_HIP_TRY(hipSetDevice(0));
-    BaCtxLease lease;
+    BaSolve S;
+    BaCtxLease& lease = S.lease;
     if (!lease.ready()) { set_error("could not create a HIP stream"); return VIORB_ERR_HIP; }
-    hipStream_t st = lease.c->st;
-    BaBuf B; BaDev D;
+    BaBuf B; BaDev& D = S.D;
     D.W = n_local; D.NK = nk; D.NP = npts; D.NE = ne; D.np = 6 * n_local; D.prev_kf = -1; D.acc_bias_rw2 = 0;
     D.pose_dim = 6; D.rows = 3; D.kf_stride = 7;
     for (int i = 0; i < 16; i++) D.cam[i] = i < 5 ? intr5[i] : 0.0;
@@ -855,5 +971,7 @@ extern "C" int viorb_local_ba_se3(const double* kfs, int nk, int n_local, const 
               B.alloc(&D.db, (size_t)npts * 3) && B.alloc(&D.xl, (size_t)npts * 3) && B.alloc(&D.scal, 8) && B.alloc(&d_erase, ne) && B.commit(lease.c);
     if (!ok) { set_error("device allocation / upload failed"); return VIORB_ERR_HIP; }
     D.e_pt = d_ept; D.e_kf = d_ekf; D.e_obs = d_obs; D.pt_start = d_pts; D.kf_start = d_kfs; D.kf_list = d_kfl;
-    return ba_run(D, st, 1, stop, d_erase, kfs_out, points_out, erase, info);
+    S.st = lease.c->st; S.h = lease.c->pinned; S.model = 1; S.stop = stop; S.d_erase = d_erase;
+    S.kfs_out = kfs_out; S.points_out = points_out; S.erase = erase; S.info = info;
+    return S.run();
 }

@@ -95,6 +95,31 @@ def LocalBundleAdjustmentNavState(kfs, n_local, prev_kf, preint, points, edge_id
     return dict(kfs=ko, points=po, erase=er[:len(ei)], chi2_first=info[0], chi2_final=info[1], its_first=int(info[2]), its_second=int(info[3]))
 
 
+def LocalBundleAdjustmentNavStateBatch(problems, max_in_flight=16):
+    """Several LocalBundleAdjustmentNavState windows solved concurrently (viorb_local_ba_navstate_batch): `problems` is a list of dicts
+    with the keyword arguments of LocalBundleAdjustmentNavState (kfs, n_local, prev_kf, preint, points, edge_idx, edge_obs, gw, cam);
+    returns the list of result dicts, each identical to what the single call returns."""
+    n = len(problems)
+    W = (capi.LbaWindow * max(n, 1))()
+    keep = []
+    for i, q in enumerate(problems):
+        kfs = np.ascontiguousarray(q["kfs"], np.float64).reshape(-1, 22); preint = np.ascontiguousarray(q["preint"], np.float64).reshape(-1, 142)
+        points = np.ascontiguousarray(q["points"], np.float64).reshape(-1, 3)
+        ei = np.ascontiguousarray(q["edge_idx"], np.int32).reshape(-1, 2); eo = np.ascontiguousarray(q["edge_obs"], np.float64).reshape(-1, 3)
+        gw = np.ascontiguousarray(q["gw"], np.float64); cam = np.ascontiguousarray(q["cam"], np.float64)
+        ko, po = np.zeros((q["n_local"], 22)), np.zeros_like(points)
+        er, info = np.zeros(max(len(ei), 1), np.uint8), np.zeros(6)
+        keep.append((kfs, preint, points, ei, eo, gw, cam, ko, po, er, info))
+        w = W[i]
+        w.kfs = kfs.ctypes.data; w.nk = len(kfs); w.n_local = int(q["n_local"]); w.prev_kf = int(q["prev_kf"]); w.preint = preint.ctypes.data
+        w.points = points.ctypes.data; w.np = len(points); w.edge_idx = ei.ctypes.data; w.edge_obs = eo.ctypes.data; w.ne = len(ei)
+        w.gw = gw.ctypes.data; w.cam = cam.ctypes.data; w.stop = None
+        w.kfs_out = ko.ctypes.data; w.points_out = po.ctypes.data; w.erase = er.ctypes.data; w.info = info.ctypes.data; w.status = 0
+    check(lib().viorb_local_ba_navstate_batch(C.cast(W, C.c_void_p), n, int(max_in_flight)))
+    return [dict(kfs=k[7], points=k[8], erase=k[9][:len(k[3])], chi2_first=k[10][0], chi2_final=k[10][1], its_first=int(k[10][2]),
+                 its_second=int(k[10][3])) for k in keep]
+
+
 def LocalBundleAdjustment(kfs, n_local, points, edge_idx, edge_obs, intr5, stop=None):
     """Vision-only Optimizer::LocalBundleAdjustment (reference src/Optimizer.cc:3980-4311) with host buffers, solved on the GPU.
     kfs [NK,7] = qx qy qz qw tx ty tz (Tcw), free ones first; edge_obs [NE,4] = u v uRight(<0 mono) invSigma2; intr5 = fx fy cx cy bf."""
