@@ -35,7 +35,7 @@ class OracleTracker:
         self.marg_cov_inv = np.asarray(marg_cov_inv, np.float64).reshape(12, 12).copy()
         self._adopt(k, d, pose_true, np.asarray(ns0, np.float64), t0)
 
-    def step(self, image, imu, t_cur, pose_true, t_next_last=None):
+    def step(self, image, imu, t_cur, pose_true, t_next_last=None, reset_ns=None, reset_marg=None):
         kps, desc = self.ex(image)
         last = self.last_ns
         pre = ora.preintegrate(imu, last[10:13], last[13:16], self.t_last, t_cur)
@@ -87,5 +87,10 @@ class OracleTracker:
             r = r2
         if self.compute_marg:
             self.marg_cov_inv = r["marg_cov_inv"].copy()
+        if reset_ns is not None:                       # key-frame boundary of the harness: the next frame starts from the given state / prior
+            if reset_marg is not None:
+                self.marg_cov_inv = np.asarray(reset_marg, np.float64).reshape(12, 12).copy()
+            self._adopt(kps, desc, pose_true, np.asarray(reset_ns, np.float64), t_cur if t_next_last is None else t_next_last)
+            return out
         self._adopt(kps, desc, pose_true, r["ns"], t_cur if t_next_last is None else t_next_last)
         return out
