@@ -53,7 +53,7 @@ def test_tracking_sequence_matches_oracle_step_by_step():
 
 def test_track_local_map_stage_matches_oracle_step_by_step():
     """TrackWithIMU + TrackLocalMapWithIMU per frame (discard outliers -> SearchLocalPoints -> second PoseOptimization with the
-    marginal), chained over frames, against the oracle twin."""
+    marginal), chained over frames and across a key-frame boundary, against the oracle twin."""
     import torch
     from viorb_amd.tracker import BatchedTracker
     from oracle.harness import OracleTracker
@@ -75,10 +75,10 @@ def test_track_local_map_stage_matches_oracle_step_by_step():
     zeros = torch.zeros(B, dtype=torch.float64, device=dev)
     cap = tr.cap
     total_local = 0
-    for k in range(1, 8):
+    for k in range(1, 10):
         j = k % F
-        if j == 0:
-            tr.step(frames[0], imu[0], t_period, pose_true[0], t_next_last=zeros)
+        if j == 0:          # the loop closes: the harness's key-frame boundary (bench.py does the same every 8 frames)
+            tr.step(frames[0], imu[0], t_period, pose_true[0], t_next_last=zeros, chain_estimate=False, true_ns=ns_true[0], marg_reset=mci0)
         else:
             tr.step(frames[j], imu[j], t_frames[j], pose_true[j])
         torch.cuda.synchronize()
@@ -87,7 +87,11 @@ def test_track_local_map_stage_matches_oracle_step_by_step():
         n_map, n_loc, loc_match, info2, out_ns2, n_obs2 = g(tr.n_map), g(tr.n_loc), g(tr.loc_match), g(tr.info2), g(tr.out_ns2), g(tr.n_cur2)
         assert (g(tr.status) == 0).all() and (g(tr.status2) == 0).all()
         for b, s in enumerate(streams):
-            r = ors[b].step(s["frames"][j], s["imu"][j], s["t"][j] if j else s["period"], s["pose_true"][j], t_next_last=0.0 if j == 0 else None)
+            if j:
+                r = ors[b].step(s["frames"][j], s["imu"][j], s["t"][j], s["pose_true"][j])
+            else:
+                r = ors[b].step(s["frames"][0], s["imu"][0], s["period"], s["pose_true"][0], t_next_last=0.0, reset_ns=s["ns_true"][0],
+                                reset_marg=np.eye(12) * 1e3)
             n = r["n_kps"]
             assert nm[b] == r["nmatches"] and int(info[b, 0]) == r["n_inliers"], (k, b)
             np.testing.assert_array_equal(match[b, :n], r["match_after_discard"], err_msg="discard, step %d stream %d" % (k, b))
