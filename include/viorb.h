@@ -358,6 +358,13 @@ int viorb_local_ba_se3(const double* kfs, int nk, int n_local, const double* poi
                        const double* edge_obs, int ne, const double intr5[5], const volatile int* stop, double* kfs_out,
                        double* points_out, uint8_t* erase, double info[6]);
 
+/* The batch form of viorb_local_ba_se3, as viorb_local_ba_navstate_batch is for the NavState window. */
+typedef struct viorb_lba_se3_window {
+    const double* kfs; int32_t nk, n_local; const double* points; int32_t np; const int32_t* edge_idx; const double* edge_obs; int32_t ne;
+    const double* intr5; const volatile int* stop; double* kfs_out; double* points_out; uint8_t* erase; double* info /* [6] */; int32_t status;
+} viorb_lba_se3_window;
+int viorb_local_ba_se3_batch(viorb_lba_se3_window* windows, int n_windows, int max_in_flight);
+
 /* ---- Bag of words: DBoW2 vocabulary-tree descent and ORBmatcher::SearchByBoW -------------------------------------
  * viorb_vocabulary replaces ORBVocabulary (= DBoW2::TemplatedVocabulary<FORB::TDescriptor, FORB>, reference
  * include/ORBVocabulary.h:30-31) for the one call the trackers make, transform(features, BowVector, FeatureVector, 4)

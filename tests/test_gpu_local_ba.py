@@ -103,3 +103,23 @@ def test_local_ba_se3_matches_oracle(oracle, seed, W, nfix, npts, stereo):
     stop = np.ones(1, np.int32)
     g2 = LocalBundleAdjustment(*a, stop=stop)
     assert np.array_equal(g2["kfs"], p["kfs"][:W]) and g2["its_first"] == 0
+
+
+def test_local_ba_se3_batch_equals_single_calls():
+    """viorb_local_ba_se3_batch: several vision-only windows in flight give what the single calls give (to the rounding noise of the
+    Schur accumulation's LDS atomics), in input order."""
+    from viorb_amd import LocalBundleAdjustment, LocalBundleAdjustmentBatch
+    from viorb_amd.synth import make_local_ba_se3_problem
+    probs = []
+    for seed, W, nfix, npts, stereo in [(21, 6, 2, 300, 0.0), (22, 10, 3, 500, 0.5), (23, 3, 1, 90, 1.0), (24, 8, 2, 400, 0.3), (25, 12, 3, 600, 0.0)]:
+        p = make_local_ba_se3_problem(seed, W=W, n_fixed=nfix, n_points=npts, stereo_frac=stereo)
+        probs.append(dict(kfs=p["kfs"], n_local=p["n_local"], points=p["points"], edge_idx=p["edge_idx"], edge_obs=p["edge_obs"], intr5=p["intr5"]))
+    single = [LocalBundleAdjustment(**q) for q in probs]
+    for in_flight in (1, 3, 16):
+        batch = LocalBundleAdjustmentBatch(probs, max_in_flight=in_flight)
+        for g, r in zip(batch, single):
+            assert (g["its_first"], g["its_second"]) == (r["its_first"], r["its_second"])
+            np.testing.assert_array_equal(g["erase"], r["erase"])
+            np.testing.assert_allclose(g["kfs"], r["kfs"], rtol=0, atol=1e-9)
+            np.testing.assert_allclose(g["points"], r["points"], rtol=0, atol=1e-8)
+            assert abs(g["chi2_final"] - r["chi2_final"]) <= 1e-9 * r["chi2_final"]

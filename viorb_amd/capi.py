@@ -36,6 +36,13 @@ class LbaWindow(C.Structure):
                 ("erase", C.c_void_p), ("info", C.c_void_p), ("status", C.c_int32)]
 
 
+class LbaSe3Window(C.Structure):
+    """viorb_lba_se3_window (include/viorb.h)."""
+    _fields_ = [("kfs", C.c_void_p), ("nk", C.c_int32), ("n_local", C.c_int32), ("points", C.c_void_p), ("np", C.c_int32),
+                ("edge_idx", C.c_void_p), ("edge_obs", C.c_void_p), ("ne", C.c_int32), ("intr5", C.c_void_p), ("stop", C.c_void_p),
+                ("kfs_out", C.c_void_p), ("points_out", C.c_void_p), ("erase", C.c_void_p), ("info", C.c_void_p), ("status", C.c_int32)]
+
+
 class ExtractorParams(C.Structure):
     _fields_ = [("nfeatures", C.c_int32), ("scale_factor", C.c_float), ("nlevels", C.c_int32),
                 ("ini_th_fast", C.c_int32), ("min_th_fast", C.c_int32)]
@@ -74,6 +81,7 @@ SIGNATURES = {
     "viorb_pose_opt_se3": (i32, [vp, vp, vp, i32, vp, vp, vp]),
     "viorb_local_ba_navstate": (i32, [vp, i32, i32, i32, vp, vp, i32, vp, vp, i32] + [vp] * 7),
     "viorb_local_ba_navstate_batch": (i32, [vp, i32, i32]),
+    "viorb_local_ba_se3_batch": (i32, [vp, i32, i32]),
     "viorb_local_ba_se3": (i32, [vp, i32, i32, vp, i32, vp, vp, i32] + [vp] * 6),
     "viorb_vocabulary_create": (i32, [i32, i32, vp, vp, vp, vp, vp, PP(vp)]),
     "viorb_vocabulary_destroy": (i32, [vp]),

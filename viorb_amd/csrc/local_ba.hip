@@ -877,29 +877,28 @@ extern "C" int viorb_local_ba_navstate(const double* kfs, int nk, int n_local, i
     return rc != VIORB_OK ? rc : S.run();
 }
 
-extern "C" int viorb_local_ba_navstate_batch(viorb_lba_window* w, int n, int max_in_flight) {
-    VIORB_REQUIRE(w && n >= 0, "null windows");
+// One host thread keeps up to max_in_flight windows going, each on its own stream: whenever a window's stream has drained, its driver
+// takes the next LM decision and enqueues the next batch of kernels. prepare(i, S) fills window i's solve and returns its status.
+template <class Prepare, class SetStatus>
+static int ba_run_batch(int n, int max_in_flight, Prepare prepare, SetStatus set_status) {
     if (viorb_device_count() < 1) { set_error("no HIP device: libviorb_hip has no CPU fallback"); return VIORB_ERR_NO_DEVICE; }
     if (max_in_flight <= 0) max_in_flight = 16;
     VIORB_HIP_TRY(hipSetDevice(0));
-    // One host thread keeps up to max_in_flight windows going, each on its own stream: whenever a window's stream has drained, its
-    // driver takes the next LM decision and enqueues the next batch of kernels.
     std::vector<std::unique_ptr<BaSolve>> live(std::min(max_in_flight, std::max(n, 1)));
     std::vector<int> which(live.size(), -1);
     int next = 0, finished = 0, first_error = VIORB_OK;
     auto start_next = [&](size_t slot) {
         while (next < n) {
             const int i = next++;
-            viorb_lba_window& q = w[i];
             auto S = std::make_unique<BaSolve>();
-            q.status = ba_prepare_navstate(*S, q.kfs, q.nk, q.n_local, q.prev_kf, q.preint, q.points, q.np, q.edge_idx, q.edge_obs, q.ne, q.gw, q.cam,
-                                           q.stop, q.kfs_out, q.points_out, q.erase, q.info);
-            if (q.status == VIORB_OK && S->state != BaSolve::ST_DONE) {
+            int status = prepare(i, *S);
+            if (status == VIORB_OK && S->state != BaSolve::ST_DONE) {
                 const int r = S->advance();                      // first batch of work
                 if (r == BA_WAIT) { live[slot] = std::move(S); which[slot] = i; return; }
-                q.status = r < 0 ? r : VIORB_OK;
+                status = r < 0 ? r : VIORB_OK;
             }
-            if (q.status != VIORB_OK && first_error == VIORB_OK) first_error = q.status;
+            set_status(i, status);
+            if (status != VIORB_OK && first_error == VIORB_OK) first_error = status;
             finished++;
         }
         live[slot].reset(); which[slot] = -1;
@@ -912,10 +911,10 @@ extern "C" int viorb_local_ba_navstate_batch(viorb_lba_window* w, int n, int max
             const hipError_t e = hipStreamQuery(live[k]->st);
             if (e == hipErrorNotReady) continue;
             progressed = true;
-            int r = e == hipSuccess ? live[k]->advance() : VIORB_ERR_HIP;
+            const int r = e == hipSuccess ? live[k]->advance() : VIORB_ERR_HIP;
             if (e != hipSuccess) set_error("hipStreamQuery failed: %s", hipGetErrorString(e));
             if (r == BA_WAIT) continue;
-            w[which[k]].status = r < 0 ? r : VIORB_OK;
+            set_status(which[k], r < 0 ? r : VIORB_OK);
             if (r < 0 && first_error == VIORB_OK) first_error = r;
             finished++;
             start_next(k);
@@ -925,9 +924,20 @@ extern "C" int viorb_local_ba_navstate_batch(viorb_lba_window* w, int n, int max
     return first_error;
 }
 
-extern "C" int viorb_local_ba_se3(const double* kfs, int nk, int n_local, const double* points, int npts, const int32_t* edge_idx,
-                                  const double* edge_obs, int ne, const double intr5[5], const volatile int* stop, double* kfs_out,
-                                  double* points_out, uint8_t* erase, double info[6]) {
+extern "C" int viorb_local_ba_navstate_batch(viorb_lba_window* w, int n, int max_in_flight) {
+    VIORB_REQUIRE(w && n >= 0, "null windows");
+    return ba_run_batch(n, max_in_flight,
+        [&](int i, BaSolve& S) {
+            viorb_lba_window& q = w[i];
+            return ba_prepare_navstate(S, q.kfs, q.nk, q.n_local, q.prev_kf, q.preint, q.points, q.np, q.edge_idx, q.edge_obs, q.ne, q.gw, q.cam, q.stop,
+                                       q.kfs_out, q.points_out, q.erase, q.info);
+        },
+        [&](int i, int status) { w[i].status = status; });
+}
+
+static int ba_prepare_se3(BaSolve& S, const double* kfs, int nk, int n_local, const double* points, int npts, const int32_t* edge_idx,
+                          const double* edge_obs, int ne, const double intr5[5], const volatile int* stop, double* kfs_out,
+                          double* points_out, uint8_t* erase, double info[6]) {
     VIORB_REQUIRE(kfs && points && edge_idx && edge_obs && intr5 && kfs_out && points_out && erase && info, "null array");
     VIORB_REQUIRE(n_local >= 1 && n_local <= 40 && nk >= n_local && npts >= 1 && ne >= 1, "1 <= n_local <= 40 key frames, at least one point and edge");
     if (viorb_device_count() < 1) { set_error("no HIP device: libviorb_hip has no CPU fallback"); return VIORB_ERR_NO_DEVICE; }
@@ -935,7 +945,7 @@ extern "C" int viorb_local_ba_se3(const double* kfs, int nk, int n_local, const 
     for (int i = 0; i < n_local * 7; i++) kfs_out[i] = kfs[i];
     for (int i = 0; i < npts * 3; i++) points_out[i] = points[i];
     for (int k = 0; k < ne; k++) erase[k] = 0;
-    if (stop && *stop) return VIORB_OK;
+    if (stop && *stop) { S.state = BaSolve::ST_DONE; return VIORB_OK; }
     std::vector<int> e_pt(ne), e_kf(ne), pt_start(npts + 1, 0);
     for (int k = 0; k < ne; k++) {
         e_pt[k] = edge_idx[2 * k]; e_kf[k] = edge_idx[2 * k + 1];
@@ -950,7 +960,6 @@ extern "C" int viorb_local_ba_se3(const double* kfs, int nk, int n_local, const 
     kf_list.resize(kf_start[n_local]);
     { std::vector<int> pos(kf_start.begin(), kf_start.end() - 1); for (int k = 0; k < ne; k++) if (e_kf[k] < n_local) kf_list[pos[e_kf[k]]++] = k; }
     VIORB_HIP_TRY(hipSetDevice(0));
-    BaSolve S;
     BaCtxLease& lease = S.lease;
     if (!lease.ready()) { set_error("could not create a HIP stream"); return VIORB_ERR_HIP; }
     BaBuf B; BaDev& D = S.D;
@@ -973,5 +982,23 @@ extern "C" int viorb_local_ba_se3(const double* kfs, int nk, int n_local, const 
     D.e_pt = d_ept; D.e_kf = d_ekf; D.e_obs = d_obs; D.pt_start = d_pts; D.kf_start = d_kfs; D.kf_list = d_kfl;
     S.st = lease.c->st; S.h = lease.c->pinned; S.model = 1; S.stop = stop; S.d_erase = d_erase;
     S.kfs_out = kfs_out; S.points_out = points_out; S.erase = erase; S.info = info;
-    return S.run();
+    return VIORB_OK;
+}
+
+extern "C" int viorb_local_ba_se3(const double* kfs, int nk, int n_local, const double* points, int npts, const int32_t* edge_idx,
+                                  const double* edge_obs, int ne, const double intr5[5], const volatile int* stop, double* kfs_out,
+                                  double* points_out, uint8_t* erase, double info[6]) {
+    BaSolve S;
+    const int rc = ba_prepare_se3(S, kfs, nk, n_local, points, npts, edge_idx, edge_obs, ne, intr5, stop, kfs_out, points_out, erase, info);
+    return rc != VIORB_OK ? rc : S.run();
+}
+
+extern "C" int viorb_local_ba_se3_batch(viorb_lba_se3_window* w, int n, int max_in_flight) {
+    VIORB_REQUIRE(w && n >= 0, "null windows");
+    return ba_run_batch(n, max_in_flight,
+        [&](int i, BaSolve& S) {
+            viorb_lba_se3_window& q = w[i];
+            return ba_prepare_se3(S, q.kfs, q.nk, q.n_local, q.points, q.np, q.edge_idx, q.edge_obs, q.ne, q.intr5, q.stop, q.kfs_out, q.points_out, q.erase, q.info);
+        },
+        [&](int i, int status) { w[i].status = status; });
 }

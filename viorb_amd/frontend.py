@@ -132,6 +132,28 @@ def LocalBundleAdjustment(kfs, n_local, points, edge_idx, edge_obs, intr5, stop=
     return dict(kfs=ko, points=po, erase=er[:len(ei)], chi2_first=info[0], chi2_final=info[1], its_first=int(info[2]), its_second=int(info[3]))
 
 
+def LocalBundleAdjustmentBatch(problems, max_in_flight=16):
+    """Several vision-only LocalBundleAdjustment windows kept in flight together (viorb_local_ba_se3_batch): `problems` is a list of
+    dicts with the keyword arguments of LocalBundleAdjustment (kfs, n_local, points, edge_idx, edge_obs, intr5)."""
+    n = len(problems)
+    W = (capi.LbaSe3Window * max(n, 1))()
+    keep = []
+    for i, q in enumerate(problems):
+        kfs = np.ascontiguousarray(q["kfs"], np.float64).reshape(-1, 7); points = np.ascontiguousarray(q["points"], np.float64).reshape(-1, 3)
+        ei = np.ascontiguousarray(q["edge_idx"], np.int32).reshape(-1, 2); eo = np.ascontiguousarray(q["edge_obs"], np.float64).reshape(-1, 4)
+        intr = np.ascontiguousarray(q["intr5"], np.float64)
+        ko, po = np.zeros((q["n_local"], 7)), np.zeros_like(points)
+        er, info = np.zeros(max(len(ei), 1), np.uint8), np.zeros(6)
+        keep.append((kfs, points, ei, eo, intr, ko, po, er, info))
+        w = W[i]
+        w.kfs = kfs.ctypes.data; w.nk = len(kfs); w.n_local = int(q["n_local"]); w.points = points.ctypes.data; w.np = len(points)
+        w.edge_idx = ei.ctypes.data; w.edge_obs = eo.ctypes.data; w.ne = len(ei); w.intr5 = intr.ctypes.data; w.stop = None
+        w.kfs_out = ko.ctypes.data; w.points_out = po.ctypes.data; w.erase = er.ctypes.data; w.info = info.ctypes.data; w.status = 0
+    check(lib().viorb_local_ba_se3_batch(C.cast(W, C.c_void_p), n, int(max_in_flight)))
+    return [dict(kfs=k[5], points=k[6], erase=k[7][:len(k[2])], chi2_first=k[8][0], chi2_final=k[8][1], its_first=int(k[8][2]),
+                 its_second=int(k[8][3])) for k in keep]
+
+
 class ORBVocabulary:
     """The part of ORBVocabulary (DBoW2::TemplatedVocabulary<FORB>, reference include/ORBVocabulary.h:30-31) the trackers use:
     transform(features, BowVector, FeatureVector, levelsup). `voc` = flat tree arrays (layout of viorb_vocabulary_create)."""
