@@ -255,6 +255,17 @@ __device__ __forceinline__ int fast_strength(const uint8_t* p, int pitch) {
 //   3. cv::FAST's strict 3x3 NMS at iniThFAST over the corner list and, only if that leaves the cell
 //      empty, again at minThFAST. Survivors go to the cell's slot as packed (x | y<<12 | score<<24) with
 //      the reference's j*wCell / i*hCell shift applied.
+// Inclusive prefix sum over the 64 lanes with DPP row shifts and row broadcasts (the gfx9 sequence LLVM's atomic optimiser emits):
+// four shifted adds scan each row of 16, row_bcast:15 carries row 0 / 2 into row 1 / 3, row_bcast:31 carries the lower half into the upper.
+__device__ __forceinline__ int wave_inclusive_scan(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);     // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);     // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);     // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);     // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);     // row_bcast:15 into rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);     // row_bcast:31 into rows 2 and 3
+    return v;
+}
 #define FAST_FETCH_TRIPS 7
 #define FAST_CELLS_PER_WAVE 2         // measured per 256 images: 1: 0.578 ms, 2: 0.553, 4: 0.565, 8: 0.582
 __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t* __restrict__ planes, size_t frame_bytes,
@@ -357,9 +368,10 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t* __restrict__ p
                     uint32_t cand[2];
     #pragma unroll
                     for (int half = 0; half < 2; half++) {
-                        const int sh = 8 * half;
-                        const uint32_t v2 = (C >> sh) & M, c1 = K1 - v2, c2 = K2 - v2;
-                        const uint32_t p0 = (D >> sh) & M, p4 = (E >> sh) & M, p8 = (U >> sh) & M, p12 = (W >> sh) & M;
+                        // even bytes: one and; odd bytes: one v_perm_b32 (bytes 1 and 3 into the low byte of each 16-bit field)
+                        auto field = [&](uint32_t x) { return half ? __builtin_amdgcn_perm(x, x, 0x0c030c01u) : (x & M); };
+                        const uint32_t v2 = field(C), c1 = K1 - v2, c2 = K2 - v2;
+                        const uint32_t p0 = field(D), p4 = field(E), p8 = field(U), p12 = field(W);
                         const uint32_t nd = ((p0 + c1) & (p8 + c1)) | ((p4 + c1) & (p12 + c1));      // bit 15: no adjacent dark pair
                         const uint32_t br = ((p0 + c2) | (p8 + c2)) & ((p4 + c2) | (p12 + c2));      // bit 15: an adjacent bright pair
                         cand[half] = (~nd | br) & Hb;
@@ -372,14 +384,15 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t* __restrict__ p
                         bits &= rng;
                     }
                     if (r >= dh) bits = 0;
-                    // ordered compaction: position = survivors in lower lanes + survivors in lower bytes of this lane
-                    const unsigned long long m0 = __ballot(bits & 1), m1 = __ballot(bits & 2), m2 = __ballot(bits & 4), m3 = __ballot(bits & 8);
-                    int pos = nsurv + __popcll(m0 & lt) + __popcll(m1 & lt) + __popcll(m2 & lt) + __popcll(m3 & lt);
+                    // ordered compaction: position = survivors in lower lanes + survivors in lower bytes of this lane, from a DPP prefix sum
+                    // of the per-lane counts (ten instructions where four ballots with their mbcnt / bcnt pairs took twenty-five)
+                    const int cnt = __popc(bits), incl = wave_inclusive_scan(cnt);
+                    int pos = nsurv + incl - cnt;
                     const uint32_t rq0 = ((uint32_t)r << 8) + (uint32_t)q0;
     #pragma unroll
                     for (int k = 0; k < 4; k++)
                         if (bits & (1u << k)) { surv[pos] = (uint16_t)(rq0 + k); pos++; }
-                    nsurv += __popcll(m0) + __popcll(m1) + __popcll(m2) + __popcll(m3);
+                    nsurv += __builtin_amdgcn_readlane(incl, 63);
                     r += step_r; g += step_g;
                     if (g >= G) { g -= G; r++; }
                 }
