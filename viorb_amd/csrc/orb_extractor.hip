@@ -636,9 +636,7 @@ __global__ __launch_bounds__(64) void k_octree(const LevelDev* __restrict__ lv, 
             const int ci = base + lane;
             const int cnt = ci < L.ncells ? cc[ci] : 0;
             // inclusive wave scan of cnt
-            int incl = cnt;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) { const int v = __shfl_up(incl, d); if (lane >= d) incl += v; }
+            const int incl = wave_inclusive_scan(cnt);
             const int start = n + incl - cnt;
             const uint32_t* mine = sl + (size_t)min(ci, L.ncells - 1) * slot_cap;
             for (int k0 = 0; __any(k0 < cnt); k0 += 8) {
@@ -789,9 +787,7 @@ __global__ __launch_bounds__(64) void k_octree(const LevelDev* __restrict__ lv, 
                     unsigned long long lo = 0, hi = 0; int tc[4] = {0, 0, 0, 0};
                     if (valid) oct_lane_count(S, p, mx, my, lo, hi, tc);
                     const int inc = valid ? (tc[0] > 0) + (tc[1] > 0) + (tc[2] > 0) + (tc[3] > 0) - 1 : 0;
-                    int incl = inc;
-#pragma unroll
-                    for (int d = 1; d < 64; d <<= 1) { const int v = __shfl_up(incl, d); if (lane >= d) incl += v; }
+                    const int incl = wave_inclusive_scan(inc);
                     const unsigned long long mh = __ballot(valid && live + incl >= N);
                     const int nvalid = min(64, m - base);
                     int cut = mh ? __ffsll((long long)mh) - 1 : nvalid - 1;   // last candidate of this chunk that is expanded
