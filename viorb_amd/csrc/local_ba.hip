@@ -440,7 +440,7 @@ __global__ __launch_bounds__(1024) void k_ba_chol_solve(BaDev D) {
         __syncthreads();
     }
     for (int i = t; i < n; i += blockDim.x) D.xp[i] = s_ok ? s_y[i] : 0.0;
-    if (t == 0) D.scal[2] = s_ok ? 1.0 : 0.0;
+    if (t == 0) { D.scal[2] = s_ok ? 1.0 : 0.0; D.scal[1] = 0.0; D.scal[0] = 0.0; }      // [1], [0]: accumulators of k_ba_backsub and k_ba_*_errors, which follow
 }
 
 // xl = Dinv (bl - W^T xp) per point, and the LM scale term sum x (lambda x + b)
@@ -478,11 +478,18 @@ __global__ void k_ba_update(BaDev D) {
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q < D.W) {
         double* k = D.kf + (size_t)q * 22;
+        for (int c = 0; c < 22; c++) D.kf_bak[(size_t)q * 22 + c] = k[c];      // what a rejected LM trial goes back to (k_ba_restore)
         const pvr s = inc_small_pvr(ld_pvr(k), D.xp + 12 * q);
         st_pvr(k, s);
         for (int c = 0; c < 3; c++) k[19 + c] += D.xp[12 * q + 9 + c];
     }
-    if (q < D.NP) for (int c = 0; c < 3; c++) D.pt[3 * q + c] += D.xl[3 * q + c];
+    if (q < D.NP) for (int c = 0; c < 3; c++) { D.pt_bak[3 * q + c] = D.pt[3 * q + c]; D.pt[3 * q + c] += D.xl[3 * q + c]; }
+}
+// a rejected trial: local key frames and points back to what k_ba_update / k_ba_se3_update saved
+__global__ void k_ba_restore(BaDev D) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x, stride = D.kf_stride;
+    if (q < D.W) for (int c = 0; c < stride; c++) D.kf[(size_t)q * stride + c] = D.kf_bak[(size_t)q * stride + c];
+    if (q < D.NP) for (int c = 0; c < 3; c++) D.pt[3 * q + c] = D.pt_bak[3 * q + c];
 }
 
 // chi2 / depth gate on every edge (stale error on excluded edges, fresh depth), Optimizer.cc:2037-2051 and :2105-2118
@@ -572,10 +579,11 @@ __global__ void k_ba_se3_update(BaDev D) {
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q < D.W) {                                                   // VertexSE3Expmap::oplusImpl: T <- exp(update) * T
         double* k = D.kf + (size_t)q * 7;
+        for (int c = 0; c < 7; c++) D.kf_bak[(size_t)q * 7 + c] = k[c];
         const se3q s = se3_mul(se3_exp(D.xp + 6 * q), ba_ld_se3(k));
         k[0] = s.r.x; k[1] = s.r.y; k[2] = s.r.z; k[3] = s.r.w; k[4] = s.t.x; k[5] = s.t.y; k[6] = s.t.z;
     }
-    if (q < D.NP) for (int c = 0; c < 3; c++) D.pt[3 * q + c] += D.xl[3 * q + c];
+    if (q < D.NP) for (int c = 0; c < 3; c++) { D.pt_bak[3 * q + c] = D.pt[3 * q + c]; D.pt[3 * q + c] += D.xl[3 * q + c]; }
 }
 // chi2 (5.991 mono / 7.815 stereo, stale error on excluded edges) / depth gate, Optimizer.cc:4170-4200 and :4207-4235
 __global__ void k_ba_se3_gate(BaDev D, uint8_t* out, int set_level) {
@@ -699,7 +707,7 @@ struct BaSolve {
     bool terminate() const { return stop && *stop; }
     int advance() {
         const int nk = D.NK, npts = D.NP, ne = D.NE, n_local = D.W;
-        const size_t n2 = (size_t)D.np * D.np, nl2 = (size_t)D.ld * D.ld, kf_doubles = (size_t)nk * D.kf_stride;
+        const size_t n2 = (size_t)D.np * D.np, nl2 = (size_t)D.ld * D.ld;
         const int TB = 256, gE = (ne + TB - 1) / TB, gP = (npts + TB - 1) / TB;
         auto enqueue_errors = [&]() -> int {
             VIORB_HIP_TRY(hipMemsetAsync(D.scal, 0, sizeof(double), st));
@@ -741,18 +749,17 @@ struct BaSolve {
                 lambda = 1e-5 * h[3]; ni = 2; nBad = 0; state = ST_TRIAL_ENQ;
                 break;
             case ST_TRIAL_ENQ:
-                VIORB_HIP_TRY(hipMemcpyAsync(D.kf_bak, D.kf, kf_doubles * sizeof(double), hipMemcpyDeviceToDevice, st));
-                VIORB_HIP_TRY(hipMemcpyAsync(D.pt_bak, D.pt, (size_t)npts * 3 * sizeof(double), hipMemcpyDeviceToDevice, st));
                 hipLaunchKernelGGL(k_ba_init_reduced, dim3((unsigned)((nl2 + TB - 1) / TB)), dim3(TB), 0, st, D, lambda);
                 hipLaunchKernelGGL(k_ba_dinv, dim3(gP), dim3(TB), 0, st, D, lambda);
                 hipLaunchKernelGGL(k_ba_schur, dim3(n_local), dim3(256), 0, st, D);
                 hipLaunchKernelGGL(k_ba_chol_solve, dim3(1), dim3(1024), 0, st, D);
-                VIORB_HIP_TRY(hipMemsetAsync(D.scal + 1, 0, sizeof(double), st));
                 hipLaunchKernelGGL(k_ba_backsub, dim3(gP), dim3(TB), 0, st, D, lambda);
                 if (model == 0) hipLaunchKernelGGL(k_ba_update, dim3(std::max(gP, 1)), dim3(TB), 0, st, D);
                 else hipLaunchKernelGGL(k_ba_se3_update, dim3(std::max(gP, 1)), dim3(TB), 0, st, D);
                 // chi2 of the trial state, the solver's flag and the gain denominator come back in one copy / one synchronisation
-                if ((rc = enqueue_errors()) != VIORB_OK) return rc;
+                // (the factorisation kernel has zeroed both accumulators; the state backup is part of the update kernel)
+                if (model == 0) hipLaunchKernelGGL(k_ba_errors, dim3(gE), dim3(TB), 0, st, D, mono_kernel);
+                else hipLaunchKernelGGL(k_ba_se3_errors, dim3(gE), dim3(TB), 0, st, D, mono_kernel);
                 VIORB_HIP_TRY(hipMemcpyAsync(h, D.scal, 8 * sizeof(double), hipMemcpyDeviceToHost, st));
                 state = ST_AFTER_TRIAL;
                 return BA_WAIT;
@@ -765,8 +772,7 @@ struct BaSolve {
                 if (rho > 0 && std::isfinite(tempChi)) { double alpha = 1. - std::pow((2 * rho - 1), 3); alpha = std::min(alpha, 2. / 3.); lambda *= std::max(1. / 3., alpha); ni = 2; currentChi = tempChi; }
                 else {
                     lambda *= ni; ni *= 2;
-                    VIORB_HIP_TRY(hipMemcpyAsync(D.kf, D.kf_bak, kf_doubles * sizeof(double), hipMemcpyDeviceToDevice, st));
-                    VIORB_HIP_TRY(hipMemcpyAsync(D.pt, D.pt_bak, (size_t)npts * 3 * sizeof(double), hipMemcpyDeviceToDevice, st));
+                    hipLaunchKernelGGL(k_ba_restore, dim3(std::max(gP, 1)), dim3(TB), 0, st, D);
                 }
                 qmax++;
                 if (rho < 0 && qmax < 10 && !terminate()) { state = ST_TRIAL_ENQ; break; }
