@@ -387,12 +387,15 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t* __restrict__ p
                     // ordered compaction: position = survivors in lower lanes + survivors in lower bytes of this lane, from a DPP prefix sum
                     // of the per-lane counts (ten instructions where four ballots with their mbcnt / bcnt pairs took twenty-five)
                     const int cnt = __popc(bits), incl = wave_inclusive_scan(cnt);
-                    int pos = nsurv + incl - cnt;
-                    const uint32_t rq0 = ((uint32_t)r << 8) + (uint32_t)q0;
+                    const int trip_total = __builtin_amdgcn_readlane(incl, 63);
+                    if (trip_total) {                                            // wave-uniform: nothing to store on a flat stretch
+                        int pos = nsurv + incl - cnt;
+                        const uint32_t rq0 = ((uint32_t)r << 8) + (uint32_t)q0;
     #pragma unroll
-                    for (int k = 0; k < 4; k++)
-                        if (bits & (1u << k)) { surv[pos] = (uint16_t)(rq0 + k); pos++; }
-                    nsurv += __builtin_amdgcn_readlane(incl, 63);
+                        for (int k = 0; k < 4; k++)
+                            if (bits & (1u << k)) { surv[pos] = (uint16_t)(rq0 + k); pos++; }
+                        nsurv += trip_total;
+                    }
                     r += step_r; g += step_g;
                     if (g >= G) { g -= G; r++; }
                 }
