@@ -175,6 +175,17 @@ def test_pose_optimisation_edge_counts_around_the_thread_count(torch_cuda, oracl
     np.testing.assert_allclose(g["ns"], o["ns"], rtol=0, atol=1e-7)
 
 
+def test_pose_optimisation_random_sweep(torch_cuda, oracle):
+    """Forty random problems per overload: the discrete outcomes (inliers, outlier flags, LM iterations) never differ from the oracle's."""
+    for variant in (0, 1):
+        for seed in range(200, 240):
+            p = make_vio_problem(seed, n_points=150 + 17 * (seed % 30))
+            o, g = _gpu_pose_opt(p, oracle, variant, False)
+            assert g["n_inliers"] == o["n_inliers"] and g["lm_iterations"] == o["lm_iterations"], (variant, seed)
+            np.testing.assert_array_equal(g["outlier_cur"], o["outlier_cur"])
+            assert abs(g["final_chi2"] - o["final_chi2"]) <= 1e-5 * abs(o["final_chi2"]) + 1e-12
+
+
 def test_pose_optimisation_edge_cases(torch_cuda, oracle):
     p = make_vio_problem(5)
     last = p["ns_last"]
