@@ -401,6 +401,17 @@ int viorb_search_by_bow(const viorb_keypoint* kf_kps, const uint8_t* kf_desc, co
                         const int32_t* f_node, int nf, float nnratio, int check_orientation, int32_t* match,
                         int* nmatches);
 
+/* ---- Brute-force Hamming matcher (north_star "Hamming brute-force"; SURVEY.md §8b viorb_match_bruteforce) ---------------------
+ * For every query descriptor q[i] (32 bytes): best[i] / second[i] = the smallest and second-smallest ORBmatcher::DescriptorDistance
+ * (reference src/ORBmatcher.cc:1648-1664) over ALL candidates c[0..nc) and idx[i] = the FIRST candidate at the smallest distance —
+ * the bestDist1 / bestDist2 / bestIdx scan of the reference's searches (e.g. src/ORBmatcher.cc:204-222: "if(dist<bestDist1){
+ * bestDist2=bestDist1; bestDist1=dist; bestIdx=i;} else if(dist<bestDist2) bestDist2=dist;", both initialised to 256) without a
+ * window or a vocabulary node restricting the candidates. nc == 0: best = second = 256, idx = -1. The caller applies its own
+ * TH_LOW / TH_HIGH / nnratio gates. Device form: q_desc[(b*qcap + i)*32], nq[b], c_desc[(b*ccap + j)*32], nc[b]; outputs [b*qcap + i]. */
+int viorb_match_bruteforce_device(const uint8_t* q_desc, const int32_t* nq, int qcap, const uint8_t* c_desc, const int32_t* nc, int ccap,
+                                  int batch, int32_t* best, int32_t* second, int32_t* idx, void* stream);
+int viorb_match_bruteforce(const uint8_t* q, int nq, const uint8_t* c, int nc, int32_t* best, int32_t* second, int32_t* idx);
+
 /* ---- Key-frame side matchers LocalMapping runs around the local BA (reference src/LocalMapping.cc:1296, 1522, 1547) ------------
  * ORBmatcher::SearchForTriangulation(pKF1, pKF2, F12, vMatchedPairs, bOnlyStereo) (src/ORBmatcher.cc:657-823): node1 / node2 are
  * the FeatureVector nodes per feature (-1 absent), has_point = GetMapPoint(i) != NULL, uright = mvuRight (< 0 mono), F12 row-major

@@ -314,6 +314,8 @@ def _match():
     if not _match_ready:
         vp, i, f = C.c_void_p, C.c_int, C.c_float
         L.ora_descriptor_distance.argtypes = [vp, vp]
+        L.ora_match_bruteforce.argtypes = [vp, i, vp, i, vp, vp, vp]
+        L.ora_match_bruteforce.restype = None
         L.ora_frame_grid.argtypes = [vp, i, f, f, f, f, vp, vp]
         L.ora_features_in_area.argtypes = [vp, i, f, f, f, f, f, f, f, i, i, vp, i]
         L.ora_search_by_projection_frame.argtypes = [vp, vp, i, vp, vp, vp, vp, i, vp, vp, vp, vp, vp, f, i, vp]
@@ -324,6 +326,14 @@ def _match():
 
 def descriptor_distance(a, b):
     return _match().ora_descriptor_distance(_p(np.ascontiguousarray(a, np.uint8)), _p(np.ascontiguousarray(b, np.uint8)))
+
+
+def match_bruteforce(q, c):
+    """(best, second, idx) per query over all candidates (strict '<': first candidate wins a tie)."""
+    q = np.ascontiguousarray(q, np.uint8).reshape(-1, 32); c = np.ascontiguousarray(c, np.uint8).reshape(-1, 32)
+    best, second, idx = (np.zeros(len(q), np.int32) for _ in range(3))
+    _match().ora_match_bruteforce(_p(q), len(q), _p(c), len(c), _p(best), _p(second), _p(idx))
+    return best, second, idx
 
 
 def frame_grid(kps, bounds):

@@ -219,6 +219,19 @@ void ora_pose_opt_vi_frame(const double* cur22, const double* last22, const doub
 #include "orb_matcher.h"
 extern "C" {
 int ora_descriptor_distance(const uint8_t* a, const uint8_t* b) { return descriptor_distance(a, b); }
+// The bestDist1 / bestDist2 / bestIdx scan of the reference's searches (src/ORBmatcher.cc:204-222: strict '<', both distances start
+// at 256) over ALL candidates: the brute-force matcher north_star names.
+void ora_match_bruteforce(const uint8_t* q, int nq, const uint8_t* c, int nc, int* best, int* second, int* idx) {
+    for (int i = 0; i < nq; i++) {
+        int bestDist1 = 256, bestIdx = -1, bestDist2 = 256;
+        for (int j = 0; j < nc; j++) {
+            const int dist = descriptor_distance(q + (size_t)32 * i, c + (size_t)32 * j);
+            if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdx = j; }
+            else if (dist < bestDist2) bestDist2 = dist;
+        }
+        best[i] = bestDist1; second[i] = bestDist2; idx[i] = bestIdx;
+    }
+}
 // Grid introspection: CSR of the 64x48 grid in the reference's storage order grid[ix][iy]
 // (cell index = ix*48 + iy): cell_start[64*48+1], cell_idx[N]. Returns number of keypoints binned.
 int ora_frame_grid(const KeyPoint* kps, int n, float minX, float maxX, float minY, float maxY, int* cell_start, int* cell_idx) {

@@ -89,6 +89,8 @@ SIGNATURES = {
     "viorb_bow_transform": (i32, [vp, vp, i32, i32, vp, vp, vp]),
     "viorb_search_by_bow_device": (i32, [vp] * 9 + [i32, i32, f32, i32, vp, vp, vp]),
     "viorb_search_by_bow": (i32, [vp, vp, vp, vp, i32, vp, vp, vp, i32, f32, i32, vp, PP(i32)]),
+    "viorb_match_bruteforce_device": (i32, [vp, vp, i32, vp, vp, i32, i32, vp, vp, vp, vp]),
+    "viorb_match_bruteforce": (i32, [vp, i32, vp, i32, vp, vp, vp]),
     "viorb_frontend_discard_outliers_device": (i32, [vp, vp, vp, vp, vp, vp, i32, vp, vp, vp]),
     "viorb_frontend_pose_from_navstate_device": (i32, [vp, vp, i32, vp, vp]),
     "viorb_frontend_build_observations2_device": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp]),

@@ -842,9 +842,20 @@ struct PoseOptShared {
     double pre[64];                                     // dP dV dR JPg JPa JVg JVa JRg (60) + dT: what the IMU factor reads every evaluation
     double gw[3], dbg[3];                               // gravity, the last frame's gyro-bias delta
     double cpv[6], corrT[4], pri[13];                   // constant parts of the IMU and prior factors (imu_constants, prior_constants)
+    double T6[36], GT[2][36], b6[2][6];                 // edge-Jacobian transform (see evaluate()), G*T and T^T g of both frames
     uint32_t tab[324][2];                               // where each lower-triangle H entry / b entry gets its terms from (built once per solve)
     int flag[4];
 };
+
+// hipcc's scheduler keeps register pressure low by pairing every LDS read with its use: a dot product fed from LDS becomes
+// read -> s_waitcnt lgkmcnt(0) -> fma, once per term (a 27-term H entry took 2.6 k cycles). Where a phase is a handful of short chains
+// fed by many LDS operands the operands are read into registers first and LDS_READS_DONE() keeps the reads above the arithmetic, so
+// that they are all in flight together and the chain pays one LDS latency.
+#define LDS_READS_DONE() __builtin_amdgcn_sched_barrier(0)
+template <int N> __device__ __forceinline__ void lds_get(const double* p, double (&r)[N], int stride = 1) {
+#pragma unroll
+    for (int i = 0; i < N; i++) r[i] = p[i * stride];
+}
 
 // single-wavefront LDS hand-offs: the LDS unit executes one wave's instructions in order, the fence only
 // stops the compiler from moving LDS accesses across the hand-off
@@ -894,8 +905,11 @@ __device__ bool wave_solve_reg(const double* __restrict__ H, const double* __res
     const int li = lane < N ? lane : N - 1;
     double a[N], invd[N];
 #pragma unroll
-    for (int c = 0; c < N; c++) a[c] = H[li * N + c] + ((c == li) ? lambda : 0.0);
+    for (int c = 0; c < N; c++) a[c] = H[li * N + c];
     double rhs = bvec[li];
+    LDS_READS_DONE();
+#pragma unroll
+    for (int c = 0; c < N; c++) a[c] += ((c == li) ? lambda : 0.0);
     bool ok = true;
 #pragma unroll
     for (int j = 0; j < N; j++) {
@@ -922,6 +936,7 @@ __device__ bool wave_solve_reg(const double* __restrict__ H, const double* __res
     double col[N];
 #pragma unroll
     for (int j = 0; j < N; j++) col[j] = Lt[j * N + li];         // L[j][i]: column i of L
+    LDS_READS_DONE();
     double acc = rhs;
 #pragma unroll
     for (int j = N - 1; j >= 0; j--) {
@@ -1001,14 +1016,17 @@ __device__ __forceinline__ void imu_constants(const double* pre, const double* d
 // piece 1: position and velocity residuals, their rotation-column blocks and the accelerometer-bias blocks
 __device__ __forceinline__ void imu_piece_pv(const double* est_i, const double* est_j, const double* cpv, const double* dba_i_p, const double* pre,
                                              const double* gw_p, double* e, double* J) {
+    double ei[10], ej[6], g3[3], db[3], ja[9], jv[9], cp[6];
+    lds_get(est_i, ei); lds_get(est_j, ej); lds_get(gw_p, g3); lds_get(dba_i_p, db); lds_get(pre + 24, ja); lds_get(pre + 42, jv); lds_get(cpv, cp);
     const double dT = pre[60], dT2 = dT * dT;
-    const pvr si = sh_pvr(est_i); const d3 Pj = ld3(est_j), Vj = ld3(est_j + 3), gw = ld3(gw_p), dba_i = ld3(dba_i_p);
+    LDS_READS_DONE();
+    const pvr si = sh_pvr(ei); const d3 Pj = ld3(ej), Vj = ld3(ej + 3), gw = ld3(g3), dba_i = ld3(db);
     const quat RiT = qnorm(qconj(si.q));
     const d3 aP = qrot(RiT, Pj - si.P - si.V * dT - gw * (0.5 * dT2));
     const d3 aV = qrot(RiT, Vj - si.V - gw * dT);
-    const m33 JPa = ldm(pre + 24), JVa = ldm(pre + 42);
-    const d3 rP = aP - (ld3(cpv) + mulv(JPa, dba_i));
-    const d3 rV = aV - (ld3(cpv + 3) + mulv(JVa, dba_i));
+    const m33 JPa = ldm(ja), JVa = ldm(jv);
+    const d3 rP = aP - (ld3(cp) + mulv(JPa, dba_i));
+    const d3 rV = aV - (ld3(cp + 3) + mulv(JVa, dba_i));
     e[0] = rP.x; e[1] = rP.y; e[2] = rP.z; e[3] = rV.x; e[4] = rV.y; e[5] = rV.z;
     if (!J) return;
     imu_put(J, 0, 6, hat3(aP), 1); imu_put(J, 3, 6, hat3(aV), 1);
@@ -1016,9 +1034,12 @@ __device__ __forceinline__ void imu_piece_pv(const double* est_i, const double* 
 }
 // piece 2: rotation residual and the two blocks that carry Jr^-1
 __device__ __forceinline__ void imu_piece_rot(const double* est_i, const double* est_j, const double* corrT, double* e, double* J) {
-    const quat qi = mkq(est_i[6], est_i[7], est_i[8], est_i[9]), qj = mkq(est_j[6], est_j[7], est_j[8], est_j[9]);
+    double qa[4], qb[4], ct[4];
+    lds_get(est_i + 6, qa); lds_get(est_j + 6, qb); lds_get(corrT, ct);
+    LDS_READS_DONE();
+    const quat qi = mkq(qa[0], qa[1], qa[2], qa[3]), qj = mkq(qb[0], qb[1], qb[2], qb[3]);
     const quat RiT = qnorm(qconj(qi));
-    const quat rR = so3_mul(so3_mul(mkq(corrT[0], corrT[1], corrT[2], corrT[3]), RiT), qj);
+    const quat rR = so3_mul(so3_mul(mkq(ct[0], ct[1], ct[2], ct[3]), RiT), qj);
     const d3 rPhi = so3_log(rR);
     e[6] = rPhi.x; e[7] = rPhi.y; e[8] = rPhi.z;
     if (!J) return;
@@ -1036,10 +1057,13 @@ __device__ __forceinline__ void prior_constants(const double* prior22, double* p
     st3(pri + 10, ld3(prior22 + 13) + ld3(prior22 + 19));
 }
 __device__ __forceinline__ void prior_piece(const double* est, d3 ba_plus_dba, const double* pri, double* e, double* J) {
-    const pvr s = sh_pvr(est);
-    const d3 eP = ld3(pri) - s.P, eV = ld3(pri + 3) - s.V;
-    const d3 eR = so3_log(so3_mul(mkq(pri[6], pri[7], pri[8], pri[9]), s.q));
-    const d3 eB = ld3(pri + 10) - ba_plus_dba;
+    double es[10], pr[13];
+    lds_get(est, es); lds_get(pri, pr);
+    LDS_READS_DONE();
+    const pvr s = sh_pvr(es);
+    const d3 eP = ld3(pr) - s.P, eV = ld3(pr + 3) - s.V;
+    const d3 eR = so3_log(so3_mul(mkq(pr[6], pr[7], pr[8], pr[9]), s.q));
+    const d3 eB = ld3(pr + 10) - ba_plus_dba;
     e[0] = eP.x; e[1] = eP.y; e[2] = eP.z; e[3] = eV.x; e[4] = eV.y; e[5] = eV.z; e[6] = eR.x; e[7] = eR.y; e[8] = eR.z; e[9] = eB.x; e[10] = eB.y; e[11] = eB.z;
     if (!J) return;
     const m33 R = qmat(s.q), Ji = so3_jr_inv(eR);
@@ -1052,8 +1076,11 @@ __device__ __forceinline__ void prior_piece(const double* est, d3 ba_plus_dba, c
 }
 // piece 3: the blocks built from Ri^T alone
 __device__ __forceinline__ void imu_piece_blocks(const double* est_i, const double* est_j, const double* pre, double* J) {
+    double qa[4], qb[4];
+    lds_get(est_i + 6, qa); lds_get(est_j + 6, qb);
     const double dT = pre[60];
-    const quat qi = mkq(est_i[6], est_i[7], est_i[8], est_i[9]), qj = mkq(est_j[6], est_j[7], est_j[8], est_j[9]);
+    LDS_READS_DONE();
+    const quat qi = mkq(qa[0], qa[1], qa[2], qa[3]), qj = mkq(qb[0], qb[1], qb[2], qb[3]);
     const m33 RiTm = tr(qmat(qi));
     imu_put(J, 0, 0, eye3(), -1); imu_put(J, 0, 3, RiTm, -dT); imu_put(J, 3, 3, RiTm, -1); imu_put(J, 3, 12, RiTm, 1);
     imu_put(J, 0, 9, mul(RiTm, qmat(qj)), 1);
@@ -1062,7 +1089,9 @@ __device__ __forceinline__ void imu_piece_blocks(const double* est_i, const doub
 // 256 threads, one wave per SIMD, <= 200 registers per lane. Measured at 256 streams beside the extraction stream: 512 threads finish
 // one solve 9 % sooner but hold twice the register file while they run, and the step gets 8 % slower (90.6 k vs 98.3 k frames/s):
 // what this kernel costs the other stream is registers x time, so it stays small.
+#ifndef POSE_THREADS
 #define POSE_THREADS 256
+#endif
 #define POSE_WAVES (POSE_THREADS / 64)
 __global__ __launch_bounds__(POSE_THREADS, 2) void k_pose_opt_vi(PoseOptArgs A) {
     __shared__ PoseOptShared S;
@@ -1091,7 +1120,9 @@ __global__ __launch_bounds__(POSE_THREADS, 2) void k_pose_opt_vi(PoseOptArgs A) 
     // Observations stay in global memory (L2): an LDS copy (24 B per edge as float) made one solve 4 % faster alone and the whole
     // step 9 % slower, because 50 KB more LDS per workgroup keep the extraction stream's workgroups off the CU while this kernel runs.
     auto load_obs = [&](const double* ob, int i) {
-        obs_t o; o.X = ld3(ob + 6 * i); o.u = ob[6 * i + 3]; o.v = ob[6 * i + 4]; o.is2 = ob[6 * i + 5];
+        const double2* p = reinterpret_cast<const double2*>(ob) + 3 * i;      // 48-byte records of a 256-byte aligned array
+        const double2 q0 = p[0], q1 = p[1], q2 = p[2];
+        obs_t o; o.X = mk3(q0.x, q0.y, q1.x); o.u = q1.y; o.v = q2.x; o.is2 = q2.y;
         return o;
     };
     // information of the IMU factor: cov^-1 + diag(1e2,1,1e2) (x) I3, by Gauss-Jordan over all threads
@@ -1168,8 +1199,21 @@ __global__ __launch_bounds__(POSE_THREADS, 2) void k_pose_opt_vi(PoseOptArgs A) 
             const int pR = (variant && R >= 12) ? R - 12 : 15, pC = (!isb && variant && Cc >= 12) ? Cc - 12 : 15;
             S.tab[q][0] = (uint32_t)R | ((uint32_t)Cc << 5) | ((uint32_t)isb << 10) | ((uint32_t)redk << 11) | ((uint32_t)sideR << 16) | ((uint32_t)mR << 17) |
                           ((uint32_t)mC << 22) | ((uint32_t)bsign << 27) | ((uint32_t)(bR < 0 ? 0 : bR) << 29);
-            S.tab[q][1] = (uint32_t)pR | ((uint32_t)pC << 4);
+            const int c6t = isb ? 0 : six(Cc);
+            S.tab[q][1] = (uint32_t)pR | ((uint32_t)pC << 4) | ((uint32_t)(r6 < 0 ? 0 : r6) << 8) | ((uint32_t)(c6t < 0 ? 0 : c6t) << 11);
         }
+    }
+    if (t == 128) {                                                       // T = [Rcb, -hat(Rcb Pbc) Rcb; 0, Rcb] (static indexing only)
+        const m33 HR = mul(hat3(K.RcbPbc), K.Rcb);
+        const double Rm[9] = {K.Rcb.a00, K.Rcb.a01, K.Rcb.a02, K.Rcb.a10, K.Rcb.a11, K.Rcb.a12, K.Rcb.a20, K.Rcb.a21, K.Rcb.a22};
+        const double Hm[9] = {HR.a00, HR.a01, HR.a02, HR.a10, HR.a11, HR.a12, HR.a20, HR.a21, HR.a22};
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                S.T6[r * 6 + c] = Rm[r * 3 + c]; S.T6[r * 6 + 3 + c] = -Hm[r * 3 + c];
+                S.T6[(r + 3) * 6 + c] = 0; S.T6[(r + 3) * 6 + 3 + c] = Rm[r * 3 + c];
+            }
     }
     if (t == 0) imu_constants(S.pre, S.dbg, S.cpv, S.corrT);
     else if (t == 64 && variant) {
@@ -1195,66 +1239,132 @@ __global__ __launch_bounds__(POSE_THREADS, 2) void k_pose_opt_vi(PoseOptArgs A) 
     // the 6x6 (P, Phi) normal-equation blocks of both frames. Followed by the two dense factors (IMU on
     // wave 0, prior on wave 1) and the bias factor. Leaves H, b (when lin) and the total robust chi2 in S.sc[0].
     auto evaluate = [&](bool lin, double* Hm, double* bv) -> double {
-        // dense factors: residuals (+ Jacobians) by one lane of two different waves
         PT_START();
-        if (lane == 0) {
-            if (wave == 0) imu_piece_pv(S.est[1], S.est[0], S.cpv, S.bias[1], S.pre, S.gw, S.e1, lin ? S.J1 : nullptr);
-            else if (wave == 1) {
+        // Reprojection edges go in chunks of 64 (one edge per lane); chunk j of a frame belongs to wave j % POSE_WAVES, and a wave takes its
+        // chunks two at a time (accumulate2 below). Pair q of a wave: q < np0 on the current frame, the rest on the last frame. The first
+        // pair's loads are issued here, under the dense factors, and every later pair's (across the change of frame too) under the
+        // arithmetic of the pair before it: a wave only has two or three trips per evaluation, so an exposed L2 round trip per frame was a
+        // third of the loop.
+        const int nch0 = (ncur + 63) >> 6, nch1 = (nlast + 63) >> 6;
+        const int cnt0 = nch0 > wave ? (nch0 - wave + POSE_WAVES - 1) / POSE_WAVES : 0, cnt1 = nch1 > wave ? (nch1 - wave + POSE_WAVES - 1) / POSE_WAVES : 0;
+        const int np0 = (cnt0 + 1) >> 1, npairs = np0 + ((cnt1 + 1) >> 1);
+        auto fetch_pair = [&](int q, obs_t (&o)[2], int (&f)[2]) {
+            const int sd = q >= np0 && q < npairs, pq = q >= npairs ? 0 : (sd ? q - np0 : q);   // beyond the last pair: any valid address
+            const double* ob = sd ? obs_l : obs_c; const uint8_t* ol = sd ? out_l : out_c; const int ne = sd ? nlast : ncur;
+            const int last = max(ne - 1, 0);
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+                const int i = (wave + POSE_WAVES * (2 * pq + e)) * 64 + lane, c = min(i, last);
+#if defined(POSE_EXP) && POSE_EXP == 2        /* timing experiment: no loads */
+                f[e] = 0; o[e].X = mk3(0.1 * lane, 0.2, 4.0 + c); o[e].u = 300; o[e].v = 200; o[e].is2 = 1;
+#else
+                f[e] = ol[c]; o[e] = load_obs(ob, c);
+#endif
+                if (i >= ne || q >= npairs) f[e] = 1;
+            }
+        };
+        obs_t oc[2]; int fc[2];
+        fetch_pair(0, oc, fc);
+        int qpos = 0;
+        // dense factors: residuals (+ Jacobians) by one lane each of the last four waves
+        const int dw = wave - (POSE_WAVES - 4);
+        if (lane == 0 && dw >= 0) {
+            if (dw == 0) imu_piece_pv(S.est[1], S.est[0], S.cpv, S.bias[1], S.pre, S.gw, S.e1, lin ? S.J1 : nullptr);
+            else if (dw == 1) {
                 if (variant) prior_piece(S.est[1], ld3(S.base_ba[1]) + ld3(S.bias[1]), S.pri, S.e2, lin ? S.J2 : nullptr);
             }
-            else if (wave == 2) imu_piece_rot(S.est[1], S.est[0], S.corrT, S.e1, lin ? S.J1 : nullptr);
+            else if (dw == 2) imu_piece_rot(S.est[1], S.est[0], S.corrT, S.e1, lin ? S.J1 : nullptr);
             else if (lin) imu_piece_blocks(S.est[1], S.est[0], S.pre, S.J1);
         }
         PT_LAP(0);
         for (int side = 0; side < (variant ? 2 : 1); side++) {
             const pvr s = sh_pvr(S.est[side]);
-            const m33 RT = tr(qmat(s.q));
-            const double* ob = side ? obs_l : obs_c; const uint8_t* ol = side ? out_l : out_c; const int ne = side ? nlast : ncur;
+            const m33 Rcw = mul(K.Rcb, tr(qmat(s.q)));                     // Rcb * Rwb^T
+            // The edge Jacobian over (dP, dPhi) factors as J = Jc * T with Jc = Jproj * [I | -hat(Pc)] (the classic 2 x 6 camera-frame
+            // Jacobian, two structural zeros) and T = [Rcb, -hat(Rcb Pbc) Rcb; 0, Rcb], the same 6 x 6 matrix for every edge of every
+            // solve (camera extrinsics only). The lanes therefore accumulate G = sum w Jc^T Jc (20 entries, not 21: G[0][1] has no
+            // term) and -sum w Jc^T e — about 95 f64 instructions per edge instead of about 200 — and T^T G T, T^T g are formed once
+            // per evaluation after the reduction (assembly, step 1). a[0..20]: upper triangle of G row by row, a[21..26]: -g, a[27]: chi2.
             double a[28];
 #pragma unroll
             for (int k = 0; k < 28; k++) a[k] = 0;
             const double dsq_mono = d_mono * d_mono;
-            auto accumulate = [&](const obs_t& o) {
-                double ea0, ea1, ja0[6], ja1[6];
-                proj_edge_lin(K, RT, s.P, o.X, o.u, o.v, ea0, ea1, ja0, ja1);
-                const double chi0 = o.is2 * fma(ea0, ea0, ea1 * ea1);
-                double ra0 = chi0, ra1 = 1;
-                if (kernel_on && chi0 > dsq_mono) { const double sq0 = sqrt(chi0); ra0 = 2 * sq0 * d_mono - dsq_mono; ra1 = d_mono / sq0; }
-                a[27] += ra0;
+            // Two edges per trip, written stage by stage for both: a single edge is a dependent chain of ~26 f64 operations (point ->
+            // 1/z -> error -> chi2 -> Huber weight -> weighted rows) and a dependent v_fma_f64 issues every ~10 cycles against ~5 for
+            // independent ones (tools/ubench/f64_latency.hip); with one wave per SIMD nothing else fills those slots. A flagged
+            // (outlier / out-of-range) edge runs with weight 0 instead of a branch.
+            auto accumulate2 = [&](const obs_t (&o)[2], const int (&flag)[2]) {
+#if defined(POSE_EXP) && POSE_EXP == 1        /* timing experiment: loads only */
+                a[27] += o[0].X.x + o[0].X.y + o[0].X.z + o[0].u + o[0].v + o[0].is2 + o[1].X.x + o[1].X.y + o[1].X.z + o[1].u + o[1].v + o[1].is2; return;
+#endif
+                double pcx[2], pcy[2], pcz[2], iz[2], xz[2], yz[2], ea0[2], ea1[2], chi0[2], ra0[2], ra1[2];
+#pragma unroll
+                for (int e = 0; e < 2; e++) {
+                    const d3 dd = o[e].X - s.P;
+                    pcx[e] = fma(Rcw.a02, dd.z, fma(Rcw.a01, dd.y, fma(Rcw.a00, dd.x, -K.RcbPbc.x)));
+                    pcy[e] = fma(Rcw.a12, dd.z, fma(Rcw.a11, dd.y, fma(Rcw.a10, dd.x, -K.RcbPbc.y)));
+                    pcz[e] = fma(Rcw.a22, dd.z, fma(Rcw.a21, dd.y, fma(Rcw.a20, dd.x, -K.RcbPbc.z)));
+                }
+#pragma unroll
+                for (int e = 0; e < 2; e++) {                              // 1 / z: hardware estimate + two Newton steps
+                    iz[e] = __builtin_amdgcn_rcp(pcz[e]);
+                    iz[e] = fma(fma(-pcz[e], iz[e], 1.0), iz[e], iz[e]);
+                    iz[e] = fma(fma(-pcz[e], iz[e], 1.0), iz[e], iz[e]);
+                }
+#pragma unroll
+                for (int e = 0; e < 2; e++) {
+                    xz[e] = pcx[e] * iz[e]; yz[e] = pcy[e] * iz[e];
+                    ea0[e] = o[e].u - fma(xz[e], K.fx, K.cx); ea1[e] = o[e].v - fma(yz[e], K.fy, K.cy);
+                    chi0[e] = o[e].is2 * fma(ea0[e], ea0[e], ea1[e] * ea1[e]);
+                    ra0[e] = chi0[e]; ra1[e] = 1.0;
+                }
+                // Huber (robust_kernel_impl.cpp:78-91): rho = 2 sqrt(chi) d - d^2, rho' = d / sqrt(chi) beyond d^2; skipped by the
+                // whole wave when no lane is beyond it (always, once the kernel is dropped after round 2)
+                const bool h0 = kernel_on && chi0[0] > dsq_mono, h1 = kernel_on && chi0[1] > dsq_mono;
+                if (__builtin_amdgcn_ballot_w64(h0 || h1) != 0) {
+#pragma unroll
+                    for (int e = 0; e < 2; e++) {
+                        const double rs = rsqrt_nr(fmax(chi0[e], 1e-300));
+                        const bool hub = e ? h1 : h0;
+                        ra0[e] = hub ? fma(2.0 * d_mono, chi0[e] * rs, -dsq_mono) : chi0[e]; ra1[e] = hub ? d_mono * rs : 1.0;
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 2; e++) a[27] += flag[e] ? 0.0 : ra0[e];
                 if (lin) {
-                    const double w0 = ra1 * o.is2;
-                    double wa0[6], wa1[6];
 #pragma unroll
-                    for (int r = 0; r < 6; r++) { wa0[r] = w0 * ja0[r]; wa1[r] = w0 * ja1[r]; }
-                    int k = 0;
+                    for (int e = 0; e < 2; e++) {
+                        const double w0 = flag[e] ? 0.0 : ra1[e] * o[e].is2;
+                        const double A = K.fx * iz[e], B = K.fy * iz[e], fxp = K.fx * xz[e], fyq = K.fy * yz[e];
+                        // Jc row 0 = [A, 0, -A xz, -fx xz yz, fx (1 + xz^2), -fx yz], row 1 = [0, B, -B yz, -fy (1 + yz^2), fy xz yz, fy xz]
+                        const double r0[6] = {A, 0.0, -(A * xz[e]), -(fxp * yz[e]), fma(fxp, xz[e], K.fx), -(K.fx * yz[e])};
+                        const double r1[6] = {0.0, B, -(B * yz[e]), -fma(fyq, yz[e], K.fy), fyq * xz[e], K.fy * xz[e]};
+                        double w0r[6], w1r[6];
 #pragma unroll
-                    for (int r = 0; r < 6; r++)
+                        for (int r = 0; r < 6; r++) { w0r[r] = w0 * r0[r]; w1r[r] = w0 * r1[r]; }
+                        int k = 0;
 #pragma unroll
-                        for (int c = r; c < 6; c++, k++) a[k] = fma(wa1[r], ja1[c], fma(wa0[r], ja0[c], a[k]));
+                        for (int r = 0; r < 6; r++)
 #pragma unroll
-                    for (int r = 0; r < 6; r++) a[21 + r] = fma(-wa1[r], ea1, fma(-wa0[r], ea0, a[21 + r]));
+                            for (int c = r; c < 6; c++, k++) {
+                                if (r != 1 && c != 1) a[k] = fma(w0r[r], r0[c], a[k]);          // row 0 has no entry 1
+                                if (r != 0 && c != 0) a[k] = fma(w1r[r], r1[c], a[k]);          // row 1 has no entry 0
+                            }
+#pragma unroll
+                        for (int r = 0; r < 6; r++) {
+                            if (r != 1) a[21 + r] = fma(-w0r[r], ea0[e], a[21 + r]);
+                            if (r != 0) a[21 + r] = fma(-w1r[r], ea1[e], a[21 + r]);
+                        }
+                    }
                 }
             };
-            // software pipeline, two register sets in turn: the next trip's outlier flag and observation are requested before this
-            // trip's arithmetic (an L2 round trip is as long as the arithmetic of one edge, and one wave per SIMD has nothing else to run)
-            // (the loads are unconditional, from a clamped index: behind a branch the compiler can no longer count how many newer loads
-            // are outstanding and waits for all of them before the arithmetic)
-            int i0 = t;
-            if (ne > 0) {
-                const int last = ne - 1;
-                int fA = ol[min(i0, last)]; obs_t oA = load_obs(ob, min(i0, last));
-                if (i0 >= ne) fA = 1;
-                while (i0 < ne) {
-                    const int iB = i0 + POSE_THREADS, cB = min(iB, last);
-                    int fB = ol[cB]; const obs_t oB = load_obs(ob, cB);
-                    if (!fA) accumulate(oA);
-                    const int iA = iB + POSE_THREADS, cA = min(iA, last);
-                    fA = ol[cA]; oA = load_obs(ob, cA);
-                    if (iB >= ne) fB = 1;
-                    if (!fB) accumulate(oB);
-                    if (iA >= ne) fA = 1;
-                    i0 = iA;
-                }
+            const int qend = side ? npairs : np0;
+            while (qpos < qend) {
+                obs_t on[2]; int fn[2];
+                fetch_pair(qpos + 1, on, fn);                              // unconditional (clamped indices; beyond the last pair: flagged)
+                accumulate2(oc, fc);
+                oc[0] = on[0]; oc[1] = on[1]; fc[0] = fn[0]; fc[1] = fn[1];
+                qpos++;
             }
             PT_LAP(6);
             if (lin) {
@@ -1292,8 +1402,16 @@ __global__ __launch_bounds__(POSE_THREADS, 2) void k_pose_opt_vi(PoseOptArgs A) 
         // ---- assembly. Step 1 (parallel): quadratic forms q[r] = e_r (Omega e)_r of the dense factors, Omega*J of both, and the
         // bias random-walk factor's weight; step 2: every thread derives the two Huber weights itself and builds complete H / b
         // entries from all their sources (reprojection partials, IMU factor, prior factor, bias factor) — one pass, no zeroing.
-        if (t < 9) { double sq = 0; for (int c = 0; c < 9; c++) sq += S.info_pvr[t * 9 + c] * S.e1[c]; S.q[t] = S.e1[t] * sq; }
-        else if (t >= 64 && t < 76 && variant) { const int r = t - 64; double sq = 0; for (int c = 0; c < 12; c++) sq += S.info_prior[r * 12 + c] * S.e2[c]; S.q[12 + r] = S.e2[r] * sq; }
+        if (t < 9) { double iv[9], ev[9]; lds_get(S.info_pvr + t * 9, iv); lds_get(S.e1, ev); const double et = S.e1[t]; LDS_READS_DONE();
+                     double sq = 0;
+#pragma unroll
+                     for (int c = 0; c < 9; c++) sq = fma(iv[c], ev[c], sq);
+                     S.q[t] = et * sq; }
+        else if (t >= 64 && t < 76 && variant) { const int r = t - 64; double iv[12], ev[12]; lds_get(S.info_prior + r * 12, iv); lds_get(S.e2, ev); const double et = S.e2[r]; LDS_READS_DONE();
+                     double sq = 0;
+#pragma unroll
+                     for (int c = 0; c < 12; c++) sq = fma(iv[c], ev[c], sq);
+                     S.q[12 + r] = et * sq; }
         else if (t == 128) {
             const d3 eb = (ld3(S.base_ba[0]) + ld3(S.bias[0])) - (ld3(S.base_ba[1]) + ld3(S.bias[1]));
             double r0, r1; huber(bias_info * dot3(eb, eb), d_bias, &r0, &r1);
@@ -1301,15 +1419,83 @@ __global__ __launch_bounds__(POSE_THREADS, 2) void k_pose_opt_vi(PoseOptArgs A) 
         }
         if (lin) {
             for (int i = t; i < 189 + (variant ? 144 : 0); i += blockDim.x) {
-                if (i < 189) { const int r = i / 21, c = i % 21; double sq = 0; for (int kk = 0; kk < 9; kk++) sq += S.info_pvr[r * 9 + kk] * S.J1[kk * 21 + c]; S.OJ1[i] = sq; }
-                else { const int ii = i - 189, r = ii / 12, c = ii % 12; double sq = 0; for (int kk = 0; kk < 12; kk++) sq += S.info_prior[r * 12 + kk] * S.J2[kk * 12 + c]; S.OJ2[ii] = sq; }
+                // one code path for both factors (row of the information matrix x column of the Jacobian, 9 or 12 terms)
+                const bool f1 = i < 189; const int ii = f1 ? i : i - 189, nc = f1 ? 21 : 12, r = ii / nc, c = ii - r * nc, nk = f1 ? 9 : 12;
+                const double* ip = f1 ? S.info_pvr + r * 9 : S.info_prior + r * 12; const double* jp = (f1 ? S.J1 : S.J2) + c;
+                double iv[12], jvv[12];
+#pragma unroll
+                for (int kk = 0; kk < 12; kk++) { const int k2 = kk < nk ? kk : 0; iv[kk] = ip[k2]; jvv[kk] = jp[k2 * nc]; }
+                LDS_READS_DONE();
+                double sq = 0;
+#pragma unroll
+                for (int kk = 0; kk < 12; kk++) sq = kk < nk ? fma(iv[kk], jvv[kk], sq) : sq;
+                (f1 ? S.OJ1 : S.OJ2)[ii] = sq;
+            }
+        }
+        if (lin && t >= POSE_THREADS - 84) {
+            // reprojection blocks back in (dP, dPhi) coordinates: GT = G T (36 entries per frame), b6 = T^T (-g) (6 per frame)
+            const int i = t - (POSE_THREADS - 84), side = i >= 42, j = i - 42 * side;
+            if (side == 0 || variant) {
+                if (j < 36) {
+                    const int r = j / 6, c = j % 6;
+                    double gv[6][POSE_WAVES], tv[6];
+#pragma unroll
+                    for (int k = 0; k < 6; k++) {
+                        const int lo = min(r, k), hi = max(r, k), gi = lo * 6 - lo * (lo - 1) / 2 + (hi - lo);
+#pragma unroll
+                        for (int w = 0; w < POSE_WAVES; w++) gv[k][w] = S.red[w][side][gi];
+                        tv[k] = S.T6[k * 6 + c];
+                    }
+                    LDS_READS_DONE();
+                    double v = 0;
+#pragma unroll
+                    for (int k = 0; k < 6; k++) {
+                        double g = 0;
+#pragma unroll
+                        for (int w = 0; w < POSE_WAVES; w++) g += gv[k][w];
+                        v = fma(g, tv[k], v);
+                    }
+                    S.GT[side][j] = v;
+                } else {
+                    const int c = j - 36;
+                    double gv[6][POSE_WAVES], tv[6];
+#pragma unroll
+                    for (int k = 0; k < 6; k++) {
+#pragma unroll
+                        for (int w = 0; w < POSE_WAVES; w++) gv[k][w] = S.red[w][side][21 + k];
+                        tv[k] = S.T6[k * 6 + c];
+                    }
+                    LDS_READS_DONE();
+                    double v = 0;
+#pragma unroll
+                    for (int k = 0; k < 6; k++) {
+                        double g = 0;
+#pragma unroll
+                        for (int w = 0; w < POSE_WAVES; w++) g += gv[k][w];
+                        v = fma(tv[k], g, v);
+                    }
+                    S.b6[side][c] = v;
+                }
             }
         }
         __syncthreads();
         PT_LAP(7);
         double w1, w2 = 0, rob1, rob2 = 0;
-        { double chi = 0; for (int i = 0; i < 9; i++) chi += S.q[i]; huber(chi, d_pvr, &rob1, &w1); }
-        if (variant) { double chi = 0; for (int i = 0; i < 12; i++) chi += S.q[12 + i]; huber(chi, d_prior, &rob2, &w2); }
+        {
+            double qv[24];
+            lds_get(S.q, qv);
+            LDS_READS_DONE();
+            double chi = 0;
+#pragma unroll
+            for (int i = 0; i < 9; i++) chi += qv[i];
+            huber(chi, d_pvr, &rob1, &w1);
+            if (variant) {
+                double chi2 = 0;
+#pragma unroll
+                for (int i = 0; i < 12; i++) chi2 += qv[12 + i];
+                huber(chi2, d_prior, &rob2, &w2);
+            }
+        }
         if (t == 0) {
             double tot = 0;
             for (int w = 0; w < POSE_WAVES; w++) { tot += S.red[w][0][27]; if (variant) tot += S.red[w][1][27]; }
@@ -1317,6 +1503,7 @@ __global__ __launch_bounds__(POSE_THREADS, 2) void k_pose_opt_vi(PoseOptArgs A) 
             if (variant) tot += rob2;
             S.sc[0] = tot;
         }
+        PT_LAP(10);
         if (lin) {
             const double wb = S.sc[3];
             const int nitems = n * (n + 1) / 2 + n;
@@ -1325,21 +1512,45 @@ __global__ __launch_bounds__(POSE_THREADS, 2) void k_pose_opt_vi(PoseOptArgs A) 
                 const int R = d0 & 31, Cc = (d0 >> 5) & 31, redk = (d0 >> 11) & 31, sideR = (d0 >> 16) & 1, mR = (d0 >> 17) & 31, mC = (d0 >> 22) & 31;
                 const int bsign = (d0 >> 27) & 3, bR = d0 >> 29, pR = d1 & 15, pC = (d1 >> 4) & 15;
                 const bool isb = (d0 >> 10) & 1;
-                double v = 0;
-                if (redk != 31) { for (int w = 0; w < POSE_WAVES; w++) v += S.red[w][sideR][redk]; }      // reprojection partials
+                // branch-free: every source is read from a clamped index and masked afterwards, so that all LDS reads of an item are in
+                // flight together (one wait) instead of one dependent round trip per taken branch
+                double v = 0, s1 = 0, s2 = 0, scb;
+                {
+                    // reprojection term: H entry (r6, c6) = sum_k T[k][r6] GT[k][c6]; b entry r6 = b6[r6]
+                    const int r6 = (d1 >> 8) & 7, c6 = (d1 >> 11) & 7;
+                    const int mRc = mR == 31 ? 0 : mR, mCc = mC == 31 ? 0 : mC, pRc = pR == 15 ? 0 : pR, pCc = pC == 15 ? 0 : pC;
+                    const double* a1 = (isb ? S.OJ1 : S.J1) + mRc; const double* b1 = isb ? S.e1 : S.OJ1 + mCc; const int sb1 = isb ? 1 : 21;
+                    const double* a2 = (isb ? S.OJ2 : S.J2) + pRc; const double* b2 = isb ? S.e2 : S.OJ2 + pCc; const int sb2 = isb ? 1 : 12;
+                    double A1[9], B1[9], A2[12], B2[12], Tt[6], Gt[6];
+                    lds_get(a1, A1, 21); lds_get(b1, B1, sb1); lds_get(a2, A2, 12); lds_get(b2, B2, sb2);
+                    lds_get(S.T6 + r6, Tt, 6); lds_get(S.GT[sideR] + c6, Gt, 6);
+                    const double bb6 = S.b6[sideR][r6]; scb = S.sc[4 + bR];
+                    LDS_READS_DONE();
+                    double sr = 0;
+#pragma unroll
+                    for (int k = 0; k < 6; k++) sr = fma(Tt[k], Gt[k], sr);
+                    if (isb) sr = bb6;
+                    v = redk != 31 ? sr : 0.0;
+#pragma unroll
+                    for (int kk = 0; kk < 9; kk++) s1 = fma(A1[kk], B1[kk], s1);
+#pragma unroll
+                    for (int kk = 0; kk < 12; kk++) s2 = fma(A2[kk], B2[kk], s2);
+                }
+                const bool has1 = mR != 31 && (isb || mC != 31), has2 = pR != 15 && (isb || pC != 15);
                 if (isb) {
-                    if (mR != 31) { double sq = 0; for (int kk = 0; kk < 9; kk++) sq += S.OJ1[kk * 21 + mR] * S.e1[kk]; v -= w1 * sq; }
-                    if (pR != 15) { double sq = 0; for (int kk = 0; kk < 12; kk++) sq += S.OJ2[kk * 12 + pR] * S.e2[kk]; v -= w2 * sq; }
-                    if (bsign) v += (bsign == 2 ? -wb : wb) * S.sc[4 + bR];
+                    if (has1) v -= w1 * s1;
+                    if (has2) v -= w2 * s2;
+                    if (bsign) v += (bsign == 2 ? -wb : wb) * scb;
                     bv[R] = v;
                 } else {
-                    if (mR != 31 && mC != 31) { double sq = 0; for (int kk = 0; kk < 9; kk++) sq += S.J1[kk * 21 + mR] * S.OJ1[kk * 21 + mC]; v += w1 * sq; }
-                    if (pR != 15 && pC != 15) { double sq = 0; for (int kk = 0; kk < 12; kk++) sq += S.J2[kk * 12 + pR] * S.OJ2[kk * 12 + pC]; v += w2 * sq; }
+                    if (has1) v += w1 * s1;
+                    if (has2) v += w2 * s2;
                     if (bsign) v += bsign == 1 ? wb : -wb;
                     Hm[R * n + Cc] = v; Hm[Cc * n + R] = v;          // both triangles: the marginal at the end reads the full matrix
                 }
             }
         }
+        PT_LAP(11);
         __syncthreads();
         PT_LAP(3); PT_COUNT();
         return S.sc[0];
@@ -1391,9 +1602,11 @@ __global__ __launch_bounds__(POSE_THREADS, 2) void k_pose_opt_vi(PoseOptArgs A) 
                 const int ok2 = S.flag[0];
                 // NavState::IncSmallPVR + the bias increment, one frame per wave pair: the rotation (Exp, two normalisations) on one lane,
                 // position / velocity / bias on another; both read the pre-update state from the backup copy made above
-                if (lane == 0 && ((wave & 1) == 0 || variant)) {
+                if (lane == 0 && wave < 4 && ((wave & 1) == 0 || variant)) {
                     const int side = wave & 1;
-                    const double* u = S.x + 12 * side; const double* old = S.bak[side];
+                    double u[12], old[10];
+                    lds_get(S.x + 12 * side, u); lds_get(S.bak[side], old);
+                    LDS_READS_DONE();
                     const quat q0 = mkq(old[6], old[7], old[8], old[9]);
                     if (wave < 2) {
                         const quat r = so3_mul(q0, so3_exp(mk3(u[6], u[7], u[8])));
@@ -1401,7 +1614,8 @@ __global__ __launch_bounds__(POSE_THREADS, 2) void k_pose_opt_vi(PoseOptArgs A) 
                     } else {
                         st3(S.est[side], ld3(old) + mulv(qmat(q0), mk3(u[0], u[1], u[2])));
                         st3(S.est[side] + 3, ld3(old + 3) + mk3(u[3], u[4], u[5]));
-                        for (int k = 0; k < 3; k++) S.bias[side][k] += u[9 + k];
+                        const d3 bo = ld3(S.bias[side]);
+                        st3(S.bias[side], bo + mk3(u[9], u[10], u[11]));
                     }
                 }
                 __syncthreads();
@@ -1414,6 +1628,7 @@ __global__ __launch_bounds__(POSE_THREADS, 2) void k_pose_opt_vi(PoseOptArgs A) 
                     double xs[24], bs[24];
 #pragma unroll
                     for (int j = 0; j < 24; j++) { xs[j] = S.x[j < n ? j : 0]; bs[j] = bc[j < n ? j : 0]; }
+                    LDS_READS_DONE();
 #pragma unroll
                     for (int j = 0; j < 24; j++) if (j < n) scale += xs[j] * (lambda * xs[j] + bs[j]);
                 }
@@ -1477,6 +1692,7 @@ __global__ __launch_bounds__(POSE_THREADS, 2) void k_pose_opt_vi(PoseOptArgs A) 
     if (b == 0 && lane == 0)
         printf("pose_opt wave=%d total=%llu evals=%d dense=%llu edges=%llu wait=%llu asm=%llu solve=%llu classify=%llu loop=%llu setup=%llu asm1=%llu update=%llu post=%llu\n", wave,
                __builtin_amdgcn_s_memtime() - pt_begin, pt_n, pt_acc[0], pt_acc[1], pt_acc[2], pt_acc[3], pt_acc[4], pt_acc[5], pt_acc[6], pt_setup, pt_acc[7], pt_acc[8], pt_acc[9]);
+    if (b == 0 && lane == 0) printf("pose_opt2 wave=%d asm_w=%llu asm_items=%llu\n", wave, pt_acc[10], pt_acc[11]);
 #endif
     // ---- outputs
     if (t == 0) {

@@ -15,6 +15,15 @@ def descriptor_distance(a, b):
     return lib().viorb_descriptor_distance(ptr(np.ascontiguousarray(a, np.uint8)), ptr(np.ascontiguousarray(b, np.uint8)))
 
 
+def match_bruteforce(q_desc, c_desc):
+    """Brute-force Hamming matcher (viorb_match_bruteforce): (best, second, idx) per query over ALL candidates, strict '<'
+    (the reference's bestDist1 / bestDist2 / bestIdx scan, src/ORBmatcher.cc:204-222, with DescriptorDistance :1648-1664)."""
+    q = np.ascontiguousarray(q_desc, np.uint8).reshape(-1, 32); c = np.ascontiguousarray(c_desc, np.uint8).reshape(-1, 32)
+    best, second, idx = (np.zeros(max(len(q), 1), np.int32) for _ in range(3))
+    check(lib().viorb_match_bruteforce(ptr(q), len(q), ptr(c), len(c), ptr(best), ptr(second), ptr(idx)))
+    return best[:len(q)], second[:len(q)], idx[:len(q)]
+
+
 class ORBmatcher:
     """Mirror of ORB_SLAM2::ORBmatcher for the frame-side searches (reference include/ORBmatcher.h:37-102)."""
     TH_LOW, TH_HIGH, HISTO_LENGTH = 50, 100, 30
