@@ -101,13 +101,31 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 // Kernels
 // ---------------------------------------------------------------------------------------------
 
+// XCD-aware placement. Workgroups are dealt round-robin over the 8 XCDs (block b and block b + 8 share one) and every XCD has its
+// own 4 MB L2, so with the plain (tile, image) grid neighbouring tiles of an image sat on different L2s and every 128-byte line
+// that two tiles share (a 70-byte blur row, the 6-px overlap of FAST cells, a keypoint's windows) was fetched from HBM once per XCD:
+// FETCH_SIZE read 2.1x (blur), 1.9x (orientation + descriptors) and 1.45x (FAST) the bytes the kernel needs. With a 1-D grid of
+// nper * 8 * ceil(batch / 8) blocks, block L works on item (L / 8) % nper of image ((L / 8) / nper) * 8 + L % 8: all work of image b
+// runs on XCD b % 8, in consecutive blocks, and an image's 1.1 MB level set stays in that L2 while its tiles are in flight.
+// A speed measure only (the mapping of blocks to XCDs is not a contract); batch < 8 uses the plain order.
+struct XcdPlace { int nper, batch, xcd; };
+__device__ __forceinline__ bool xcd_place(const XcdPlace P, int& img, int& item) {
+    const int L = blockIdx.x;
+    if (P.xcd) { const int i = L >> 3, g = i / P.nper; item = i - g * P.nper; img = g * 8 + (L & 7); }
+    else { img = L / P.nper; item = L - img * P.nper; }
+    return img < P.batch;
+}
+static inline XcdPlace make_place(int nper, int batch) { XcdPlace P; P.nper = nper; P.batch = batch; P.xcd = batch >= 8; return P; }
+static inline unsigned place_blocks(const XcdPlace& P) { return (unsigned)P.nper * (unsigned)(P.xcd ? 8 * ((P.batch + 7) / 8) : P.batch); }
+
 // Level 0 = the input image re-pitched into the plane buffer.
 __global__ void k_copy_level0(const uint8_t* __restrict__ src, int w, int h, int sstride, size_t spitch,
-                              uint8_t* __restrict__ planes, size_t frame_bytes, int dstride, int* __restrict__ status) {
-    const int b = blockIdx.z;
-    const int y = blockIdx.y;
-    if (blockIdx.x == 0 && y == 0 && threadIdx.x == 0) status[b] = 0;      // per-image status word of this extraction (one launch less than a memset)
-    const int x = (blockIdx.x * blockDim.x + threadIdx.x) * 16;
+                              uint8_t* __restrict__ planes, size_t frame_bytes, int dstride, int* __restrict__ status, XcdPlace PL, int gx) {
+    int b, item;
+    if (!xcd_place(PL, b, item)) return;
+    const int y = item / gx, bx = item - y * gx;
+    if (item == 0 && threadIdx.x == 0) status[b] = 0;      // per-image status word of this extraction (one launch less than a memset)
+    const int x = (bx * blockDim.x + threadIdx.x) * 16;
     if (x >= dstride) return;
     const uint8_t* s = src + (size_t)b * spitch + (size_t)y * sstride;
     uint8_t* d = planes + (size_t)b * frame_bytes + (size_t)y * dstride;
@@ -141,14 +159,17 @@ __global__ __launch_bounds__(256) void k_resize(uint8_t* __restrict__ planes, si
                                                 const LevelDev* __restrict__ lv, int level,
                                                 const int2* __restrict__ xtab_all,
                                                 const int2* __restrict__ ytab_all, int lds_pitch_dw,
-                                                int lds_rows) {
+                                                int lds_rows, XcdPlace PL, int gx) {
     extern __shared__ uint32_t s_tile[];
+    int b, item;
+    if (!xcd_place(PL, b, item)) return;
+    const int tby = item / gx, tbx = item - tby * gx;
     const LevelDev L = lv[level], P = lv[level - 1];
     const int2* xtab = xtab_all + L.xtab_off;
     const int2* ytab = ytab_all + L.ytab_off;
-    const uint8_t* src = planes + (size_t)blockIdx.z * frame_bytes + P.plane_off;
-    uint8_t* dst = planes + (size_t)blockIdx.z * frame_bytes + L.plane_off;
-    const int tx0 = blockIdx.x * RS_TW, ty0 = blockIdx.y * RS_TH;
+    const uint8_t* src = planes + (size_t)b * frame_bytes + P.plane_off;
+    uint8_t* dst = planes + (size_t)b * frame_bytes + L.plane_off;
+    const int tx0 = tbx * RS_TW, ty0 = tby * RS_TH;
     const int tx1 = min(tx0 + RS_TW, L.w) - 1, ty1 = min(ty0 + RS_TH, L.h) - 1;
     const int ys0 = ytab[ty0].x & 0xffff, ys1 = ytab[ty1].x >> 16;
     const int xs0 = (xtab[tx0].x & 0xffff) & ~3, xs1 = xtab[tx1].x >> 16;
@@ -273,8 +294,10 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t* __restrict__ p
                                                    const CellDesc* __restrict__ cells, int ini_th, int min_th,
                                                    uint32_t* __restrict__ slots, int slot_cap,
                                                    int* __restrict__ cell_cnt, int ncells_total,
-                                                   int tile_pitch, int tile_rows, int score_bytes, int list_cap) {
+                                                   int tile_pitch, int tile_rows, int score_bytes, int list_cap, XcdPlace PL) {
     extern __shared__ uint32_t s_mem[];
+    int img_b, item;
+    if (!xcd_place(PL, img_b, item)) return;
     uint8_t* tile = reinterpret_cast<uint8_t*>(s_mem);
     uint8_t* sc = tile + tile_pitch * tile_rows;
     uint16_t* surv = reinterpret_cast<uint16_t*>(sc + score_bytes);     // [list_cap] (r << 8 | q) of pass-1 survivors
@@ -283,10 +306,10 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t* __restrict__ p
     const int pitch_dw = tile_pitch >> 2;
     // A wave takes FAST_CELLS_PER_WAVE consecutive cells. The tile of the next cell is requested (into registers) as soon as the current
     // one has been handed to LDS, so its L2 round trip runs under the current cell's three passes instead of in front of them.
-    const int cell0 = blockIdx.x * FAST_CELLS_PER_WAVE;
+    const int cell0 = item * FAST_CELLS_PER_WAVE;
     const int ncell = min((int)FAST_CELLS_PER_WAVE, ncells_total - cell0);
     uint32_t v[FAST_FETCH_TRIPS]; int at[FAST_FETCH_TRIPS];
-    const uint8_t* img = planes + (size_t)blockIdx.y * frame_bytes;
+    const uint8_t* img = planes + (size_t)img_b * frame_bytes;
     auto request_tile = [&](const CellDesc& cd) {
         const int x0a_ = cd.x0 & ~3, ndw_ = ((cd.x0 + cd.cw - 1 - x0a_) >> 2) + 1;
         const int st_r = 64 / pitch_dw, st_q = 64 - st_r * pitch_dw;      // one division per wave instead of one per dword
@@ -327,7 +350,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t* __restrict__ p
     for (int i = lane; i < (score_bytes >> 2); i += 64) reinterpret_cast<uint32_t*>(sc)[i] = 0;
     __syncthreads();
     if (has_next) request_tile(cn);
-    uint32_t* my_slots = slots + ((size_t)blockIdx.y * ncells_total + cell) * slot_cap;
+    uint32_t* my_slots = slots + ((size_t)img_b * ncells_total + cell) * slot_cap;
     int total = 0;
     if (dw > 0 && dh > 0) {
         const int npx = dw * dh;
@@ -447,7 +470,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t* __restrict__ p
             __syncthreads();
         }
     }
-    if (lane == 0) cell_cnt[(size_t)blockIdx.y * ncells_total + cell] = min(total, slot_cap);
+    if (lane == 0) cell_cnt[(size_t)img_b * ncells_total + cell] = min(total, slot_cap);
     __syncthreads();                                  // every LDS read of this cell is done before the next tile is written
     c = cn;
     }
@@ -830,11 +853,16 @@ __global__ __launch_bounds__(64) void k_octree(const LevelDev* __restrict__ lv, 
 }
 
 // cv::GaussianBlur(7x7, sigma 2, BORDER_REFLECT_101) on 8U, OpenCV 2.4 integer path:
-// taps {18,34,49,55,49,34,18} (x256, sum 257) in both directions, (sum + 2^15) >> 16, saturated.
-// Block = 64x64 output tile, 256 threads. The input rectangle (70 rows x 72 bytes, 4-byte left apron) is
-// staged in LDS as dwords; the horizontal pass takes 4 outputs per work item with v_alignbyte + v_dot4
-// (7 byte taps = two 4-byte dot products) into a u16 buffer (max 255*257 = 65535); the vertical pass
-// computes 4 columns x 4 rows per thread and stores one dword per row.
+// taps {18,34,49,55,49,34,18} (x256, sum 257) in both directions, (sum + 2^15) >> 16, saturated. Everything is exact integer
+// arithmetic, so the order of the two separable passes does not change a bit of the result; the kernel runs the VERTICAL pass first,
+// because a column sum of seven byte x tap products is at most 255 * 257 = 65535 and therefore fits the 16-bit lanes of
+// v_pk_mad_u16 (two pixels per instruction), and the horizontal pass second on the 16-bit column sums with v_dot2_u32_u16 (two taps
+// per instruction, 32-bit accumulator): about 15 vector instructions per pixel where the byte-at-a-time vertical pass of round 1
+// needed 37 — the kernel is bound by vector issue, not by HBM (its 2 P of traffic would take 0.1 ms).
+// Block = 64x64 output tile, 256 threads. The input rectangle (70 rows x 72 bytes, 4-byte left apron) is staged in LDS as dwords.
+// Pass V: a thread takes one dword column (4 px) and 8 output rows: 14 input dwords, each split into its even and odd bytes as
+// 16-bit pairs, 7 taps x 8 rows x 2 v_pk_mad_u16; the sums go back to LDS as (V[4c], V[4c+2]) and (V[4c+1], V[4c+3]).
+// Pass H: a thread takes 4 adjacent outputs of a row: the six 16-bit pair registers of dword columns c-1, c, c+1 and 18 v_dot2.
 #define BL_TW 64
 #define BL_TH 64
 #define BL_IPD 18                         // input pitch in dwords: bytes x0-4 .. x0+67
@@ -844,15 +872,24 @@ __device__ __forceinline__ int reflect101(int p, int len) {
     while (p < 0 || p >= len) p = p < 0 ? -p : 2 * (len - 1) - p;
     return p;
 }
+typedef unsigned short ushort2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_mad_u16(uint32_t a, uint32_t k, uint32_t c) {
+    return __builtin_bit_cast(uint32_t, (ushort2v)(__builtin_bit_cast(ushort2v, a) * __builtin_bit_cast(ushort2v, k) + __builtin_bit_cast(ushort2v, c)));
+}
+__device__ __forceinline__ uint32_t dot2_u16(uint32_t a, uint32_t k, uint32_t c) {
+    return __builtin_amdgcn_udot2(__builtin_bit_cast(ushort2v, a), __builtin_bit_cast(ushort2v, k), c, false);
+}
 __global__ __launch_bounds__(256) void k_blur(const uint8_t* __restrict__ planes, uint8_t* __restrict__ blur,
                                               size_t frame_bytes, const LevelDev* __restrict__ lv,
-                                              const int4* __restrict__ tiles) {
+                                              const int4* __restrict__ tiles, XcdPlace PL) {
     __shared__ uint32_t s_in[(BL_TH + 6) * BL_IPD];
-    __shared__ uint32_t s_h[(BL_TH + 6) * (BL_TW / 2)];      // u16 pairs
-    const int4 t = tiles[blockIdx.x];                 // level, tile x0, tile y0
+    __shared__ uint32_t s_v[BL_TH * BL_IPD * 2];             // per (row, dword column): even-pixel pair, odd-pixel pair of column sums
+    int b, item;
+    if (!xcd_place(PL, b, item)) return;
+    const int4 t = tiles[item];                       // level, tile x0, tile y0
     const LevelDev L = lv[t.x];
-    const uint8_t* src = planes + (size_t)blockIdx.y * frame_bytes + L.plane_off;
-    uint8_t* dst = blur + (size_t)blockIdx.y * frame_bytes + L.plane_off;
+    const uint8_t* src = planes + (size_t)b * frame_bytes + L.plane_off;
+    uint8_t* dst = blur + (size_t)b * frame_bytes + L.plane_off;
     const int x0 = t.y, y0 = t.z;
     {
         // every thread's five input dwords are requested before the first is used (a plain loop made them five dependent round
@@ -881,50 +918,55 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t* __restrict__ planes
         }
     }
     __syncthreads();
-    const uint32_t T0 = (uint32_t)c_gauss[0] | ((uint32_t)c_gauss[1] << 8) | ((uint32_t)c_gauss[2] << 16) | ((uint32_t)c_gauss[3] << 24);
-    const uint32_t T1 = (uint32_t)c_gauss[4] | ((uint32_t)c_gauss[5] << 8) | ((uint32_t)c_gauss[6] << 16);
-    for (int i = threadIdx.x; i < (BL_TH + 6) * (BL_TW / 4); i += 256) {
-        const int r = i / (BL_TW / 4), g = i - r * (BL_TW / 4);          // outputs x0 + 4g .. 4g+3 of row r
-        const uint32_t D0 = s_in[r * BL_IPD + g], D1 = s_in[r * BL_IPD + g + 1], D2 = s_in[r * BL_IPD + g + 2];
-        // output j: bytes (4g+1+j .. 4g+4+j) and (4g+5+j .. 4g+8+j) of the row's byte stream
-        const uint32_t h0 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(D1, D0, 1), T0, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(D2, D1, 1), T1, 0u, false), false);
-        const uint32_t h1 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(D1, D0, 2), T0, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(D2, D1, 2), T1, 0u, false), false);
-        const uint32_t h2 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(D1, D0, 3), T0, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(D2, D1, 3), T1, 0u, false), false);
-        const uint32_t h3 = __builtin_amdgcn_udot4(D1, T0, __builtin_amdgcn_udot4(D2, T1, 0u, false), false);
-        s_h[r * (BL_TW / 2) + 2 * g] = h0 | (h1 << 16);
-        s_h[r * (BL_TW / 2) + 2 * g + 1] = h2 | (h3 << 16);
+    const uint32_t k0 = (uint32_t)c_gauss[0], k1 = (uint32_t)c_gauss[1], k2 = (uint32_t)c_gauss[2], k3 = (uint32_t)c_gauss[3];
+    // ---- pass V: column sums of 8 output rows x 4 px per thread (144 of the 256 threads)
+    if (threadIdx.x < BL_IPD * (BL_TH / 8)) {
+        const int c = threadIdx.x % BL_IPD, rg = threadIdx.x / BL_IPD;
+        uint32_t in[14];
+#pragma unroll
+        for (int r = 0; r < 14; r++) in[r] = s_in[(8 * rg + r) * BL_IPD + c];
+        const uint32_t kk[4] = {k0 * 0x00010001u, k1 * 0x00010001u, k2 * 0x00010001u, k3 * 0x00010001u};
+        uint32_t ae[8], ao[8];
+#pragma unroll
+        for (int o = 0; o < 8; o++) { ae[o] = 0; ao[o] = 0; }
+#pragma unroll
+        for (int r = 0; r < 14; r++) {
+            const uint32_t e = in[r] & 0x00ff00ffu, od = (in[r] >> 8) & 0x00ff00ffu;
+#pragma unroll
+            for (int o = 0; o < 8; o++) {
+                const int j = r - o;
+                if (j < 0 || j > 6) continue;
+                const uint32_t kj = kk[j < 4 ? j : 6 - j];
+                ae[o] = pk_mad_u16(e, kj, ae[o]); ao[o] = pk_mad_u16(od, kj, ao[o]);
+            }
+        }
+#pragma unroll
+        for (int o = 0; o < 8; o++)
+            *reinterpret_cast<uint2*>(&s_v[((8 * rg + o) * BL_IPD + c) * 2]) = make_uint2(ae[o], ao[o]);
     }
     __syncthreads();
-    // vertical: thread -> 4 columns (tx) x 4 rows (ty)
-    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-    const int k0 = c_gauss[0], k1 = c_gauss[1], k2 = c_gauss[2], k3 = c_gauss[3];
-    int acc[4][4];
+    // ---- pass H: 4 outputs per item, 64 rows x 16 dword columns = 1024 items, 4 per thread
+    const uint32_t K02 = k0 | (k2 << 16), K01h = k1 << 16, K35 = k3 | (k1 << 16) /* (k3, k5 = k1) */, K46 = k2 | (k0 << 16) /* (k4 = k2, k6 = k0) */;
+    const uint32_t K00h = k0 << 16, K24 = k2 | (k2 << 16), K60 = k0 /* (k6 = k0, 0) */, K13 = k1 | (k3 << 16), K50 = k1 /* (k5 = k1, 0) */;
 #pragma unroll
-    for (int a = 0; a < 4; a++)
-#pragma unroll
-        for (int c = 0; c < 4; c++) acc[a][c] = 1 << 15;
-#pragma unroll
-    for (int rr = 0; rr < 10; rr++) {
-        const uint32_t p0 = s_h[(4 * ty + rr) * (BL_TW / 2) + 2 * tx], p1 = s_h[(4 * ty + rr) * (BL_TW / 2) + 2 * tx + 1];
-        const int v[4] = {(int)(p0 & 0xffff), (int)(p0 >> 16), (int)(p1 & 0xffff), (int)(p1 >> 16)};
-#pragma unroll
-        for (int a = 0; a < 4; a++) {
-            const int j = rr - a;                      // tap index for output row a
-            if (j < 0 || j > 6) continue;
-            const int kj = (j == 0 || j == 6) ? k0 : (j == 1 || j == 5) ? k1 : (j == 2 || j == 4) ? k2 : k3;
-#pragma unroll
-            for (int c = 0; c < 4; c++) acc[a][c] += kj * v[c];
-        }
-    }
-#pragma unroll
-    for (int a = 0; a < 4; a++) {
-        const int y = y0 + 4 * ty + a;
-        if (y >= L.h) continue;
-        uint32_t w = 0;
-#pragma unroll
-        for (int c = 0; c < 4; c++) { int v = acc[a][c] >> 16; v = v > 255 ? 255 : v; w |= (uint32_t)v << (8 * c); }
-        const int xw = x0 + 4 * tx;
-        if (xw < L.stride) *reinterpret_cast<uint32_t*>(dst + (size_t)y * L.stride + xw) = w;
+    for (int it = 0; it < 4; it++) {
+        const int i = threadIdx.x + 256 * it, r = i >> 4, g = i & 15, c = g + 1;
+        const uint2* vp = reinterpret_cast<const uint2*>(&s_v[(r * BL_IPD + c) * 2]);
+        const uint2 vm = vp[-1], v0 = vp[0], vq = vp[1];
+        const uint32_t Em = vm.x, Om = vm.y, E0 = v0.x, O0 = v0.y, Ep = vq.x, Op = vq.y;
+        // with V[n] the column sum n pixels right of pixel 4c: Em = (V-4, V-2), Om = (V-3, V-1), E0 = (V0, V2), O0 = (V1, V3), Ep = (V4, V6), Op = (V5, V7)
+        uint32_t a0 = 1u << 15, a1 = 1u << 15, a2 = 1u << 15, a3 = 1u << 15;
+        a0 = dot2_u16(Om, K02, a0); a0 = dot2_u16(Em, K01h, a0); a0 = dot2_u16(E0, K35, a0); a0 = dot2_u16(O0, K46, a0);          // V-3 .. V3
+        a1 = dot2_u16(Em, K00h, a1); a1 = dot2_u16(Om, K01h, a1); a1 = dot2_u16(E0, K24, a1); a1 = dot2_u16(O0, K35, a1); a1 = dot2_u16(Ep, K60, a1);   // V-2 .. V4
+        a2 = dot2_u16(Om, K00h, a2); a2 = dot2_u16(E0, K13, a2); a2 = dot2_u16(O0, K24, a2); a2 = dot2_u16(Ep, K50, a2); a2 = dot2_u16(Op, K60, a2);    // V-1 .. V5
+        a3 = dot2_u16(E0, K02, a3); a3 = dot2_u16(O0, K13, a3); a3 = dot2_u16(Ep, K46, a3); a3 = dot2_u16(Op, K50, a3);           // V0 .. V6
+        // (sum + 2^15) >> 16, saturated to 255: clamp below 256 << 16 and take byte 2 of each
+        a0 = min(a0, 0x00ffffffu); a1 = min(a1, 0x00ffffffu); a2 = min(a2, 0x00ffffffu); a3 = min(a3, 0x00ffffffu);
+        const uint32_t lo = __builtin_amdgcn_perm(a1, a0, 0x0c0c0602u);      // byte 2 of a0, byte 2 of a1 (selector bytes 4-7 = first operand)
+        const uint32_t hi = __builtin_amdgcn_perm(a3, a2, 0x0c0c0602u);
+        const uint32_t w = lo | (hi << 16);
+        const int y = y0 + r, xw = x0 + 4 * g;
+        if (y < L.h && xw < L.stride) *reinterpret_cast<uint32_t*>(dst + (size_t)y * L.stride + xw) = w;
     }
 }
 
@@ -946,10 +988,11 @@ __global__ __launch_bounds__(256) void k_orient_describe(const uint8_t* __restri
                                                          const int* __restrict__ lvl_cnt,
                                                          viorb_keypoint* __restrict__ out_kp,
                                                          uint8_t* __restrict__ out_desc, int out_cap,
-                                                         int* __restrict__ out_cnt) {
+                                                         int* __restrict__ out_cnt, XcdPlace PL) {
     const int lane = threadIdx.x & 63;
-    const int k = blockIdx.x * 4 + (threadIdx.x >> 6);       // keypoint slot inside the image
-    const int b = blockIdx.y;
+    int b, item;
+    if (!xcd_place(PL, b, item)) return;
+    const int k = item * 4 + (threadIdx.x >> 6);             // keypoint slot inside the image
     const int* cnt = lvl_cnt + b * nlevels;
     int level = -1, local = 0, total = 0;
     for (int l = 0; l < nlevels; l++) {
@@ -1447,24 +1490,27 @@ static int launch_all(viorb_extractor* h, const uint8_t* d_images, int batch, in
     const int ncells = (int)h->cells.size();
     const LevelDev& L0 = h->lv[0];
     {
-        dim3 grid((L0.stride / 16 + 63) / 64, L0.h, batch);
+        const int gx = (L0.stride / 16 + 63) / 64;
+        const XcdPlace PL = make_place(gx * L0.h, batch);
         ProfScope ps("k_copy_level0", st);
-        hipLaunchKernelGGL(k_copy_level0, grid, dim3(64), 0, st, d_images, L0.w, L0.h, stride, pitch, h->d_planes, h->frame_bytes, L0.stride, h->d_status);
+        hipLaunchKernelGGL(k_copy_level0, dim3(place_blocks(PL)), dim3(64), 0, st, d_images, L0.w, L0.h, stride, pitch, h->d_planes, h->frame_bytes, L0.stride, h->d_status, PL, gx);
     }
     for (int l = 1; l < nl; l++) {
         const LevelDev& L = h->lv[l];
-        dim3 grid((L.w + RS_TW - 1) / RS_TW, (L.h + RS_TH - 1) / RS_TH, batch);
+        const int gx = (L.w + RS_TW - 1) / RS_TW, gy = (L.h + RS_TH - 1) / RS_TH;
+        const XcdPlace PL = make_place(gx * gy, batch);
         const size_t lds = (size_t)h->rs_pitch_dw[l] * h->rs_rows[l] * 4;
         ProfScope ps("k_resize", st);
-        hipLaunchKernelGGL(k_resize, grid, dim3(256), lds, st, h->d_planes, h->frame_bytes, h->d_lv, l, h->d_xtab, h->d_ytab,
-                           h->rs_pitch_dw[l], h->rs_rows[l]);
+        hipLaunchKernelGGL(k_resize, dim3(place_blocks(PL)), dim3(256), lds, st, h->d_planes, h->frame_bytes, h->d_lv, l, h->d_xtab, h->d_ytab,
+                           h->rs_pitch_dw[l], h->rs_rows[l], PL, gx);
     }
     {
         const size_t lds = (size_t)h->fast_tile_pitch * h->fast_tile_rows + h->fast_score_bytes + (size_t)h->fast_list_cap * 4;
         ProfScope ps("k_fast_cells", st);
-        hipLaunchKernelGGL(k_fast_cells, dim3((ncells + FAST_CELLS_PER_WAVE - 1) / FAST_CELLS_PER_WAVE, batch), dim3(64), lds, st, h->d_planes, h->frame_bytes, h->d_lv, h->d_cells,
+        const XcdPlace PL = make_place((ncells + FAST_CELLS_PER_WAVE - 1) / FAST_CELLS_PER_WAVE, batch);
+        hipLaunchKernelGGL(k_fast_cells, dim3(place_blocks(PL)), dim3(64), lds, st, h->d_planes, h->frame_bytes, h->d_lv, h->d_cells,
                            h->p.ini_th_fast, h->p.min_th_fast, h->d_slots, h->slot_cap, h->d_cell_cnt, ncells,
-                           h->fast_tile_pitch, h->fast_tile_rows, h->fast_score_bytes, h->fast_list_cap);
+                           h->fast_tile_pitch, h->fast_tile_rows, h->fast_score_bytes, h->fast_list_cap, PL);
     }
     {
         // common case first: <= OCT_NCAP_SMALL candidates per level fit a ~35 KB footprint (4 single-wave workgroups per CU);
@@ -1487,13 +1533,15 @@ static int launch_all(viorb_extractor* h, const uint8_t* d_images, int batch, in
     {
         // (running the blur on a second stream beside FAST + quadtree was measured: no gain, the kernels contend for the same CUs)
         ProfScope ps("k_blur", st);
-        hipLaunchKernelGGL(k_blur, dim3((unsigned)h->blur_tiles.size(), batch), dim3(256), 0, st, h->d_planes, h->d_blur, h->frame_bytes,
-                           h->d_lv, h->d_blur_tiles);
+        const XcdPlace PL = make_place((int)h->blur_tiles.size(), batch);
+        hipLaunchKernelGGL(k_blur, dim3(place_blocks(PL)), dim3(256), 0, st, h->d_planes, h->d_blur, h->frame_bytes,
+                           h->d_lv, h->d_blur_tiles, PL);
     }
     {
         ProfScope ps("k_orient_describe", st);
-        hipLaunchKernelGGL(k_orient_describe, dim3((h->out_cap + 3) / 4, batch), dim3(256), 0, st, h->d_planes, h->d_blur, h->frame_bytes,
-                           h->d_lv, nl, h->d_lvl_kp, h->kp_pitch, h->d_lvl_cnt, h->d_kps, h->d_desc, h->out_cap, h->d_count);
+        const XcdPlace PL = make_place((h->out_cap + 3) / 4, batch);
+        hipLaunchKernelGGL(k_orient_describe, dim3(place_blocks(PL)), dim3(256), 0, st, h->d_planes, h->d_blur, h->frame_bytes,
+                           h->d_lv, nl, h->d_lvl_kp, h->kp_pitch, h->d_lvl_cnt, h->d_kps, h->d_desc, h->out_cap, h->d_count, PL);
     }
     VIORB_HIP_TRY(hipGetLastError());
     h->last_stream = st; h->last_batch = batch;
