@@ -1,16 +1,19 @@
 #!/usr/bin/env python3
-"""bench.py — frames/s of the per-frame visual-inertial front-end (ORB extract + SearchByProjection +
-IMU pre-integration + PoseOptimization) on MI355X, BASELINE.json's metric.
+"""bench.py — BASELINE.json's metric on MI355X: frames/s of the per-frame visual-inertial front-end (ORB extract + match +
+PoseOptimization), plus the other BASELINE configs behind --config.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config euroc|synth720p|kitti_stereo|local_ba]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (N > 1)
 
-A "step" is one pass of the hot path over one batch of synthetic frames: one new 752x480 frame for each of
-the S independent mono-inertial streams a GPU owns (weak scaling: every rank owns S streams; no data-path
-collective, the only RCCL traffic is the frames/time reduction at the end). Inputs (images, IMU samples)
-are resident in HBM before the timed region. Rank 0 prints ONE JSON line; `roofline` is measured with HIP
-events around the dominant kernel inside the timed region, `cpu_baseline` times the CPU oracle (a port of
-the reference's path; the reference itself cannot be built here) on a bounded sample of the same streams.
+--config euroc (default, BASELINE configs[1]): a "step" is one new 752x480 frame for each of the S independent mono-inertial streams a
+GPU owns, through the C++ batched tracker (viorb_tracker_step: TrackWithIMU + TrackLocalMapWithIMU with the reference's thresholds and
+revert decisions per stream on the device). --config synth720p (configs[4]): the same sequence at 1280x720 / 1500 features, 8 streams
+per GPU. --config kitti_stereo (configs[2]): a step is P 1241x376 stereo pairs: extraction of both images (2000 features each) +
+Frame::ComputeStereoMatches. --config local_ba (configs[3]): a step is one batch of W = 20 LocalBundleAdjustmentNavState windows.
+Weak scaling: every rank owns the same amount of work; the path shards by stream / pair / window with no data-path collective, the
+only RCCL traffic is the (units, time) reduction at the end. Inputs are resident in HBM before the timed region (local_ba: host
+buffers, as its caller is the LocalMapping thread). Rank 0 prints ONE JSON line. `roofline` / `roofline_pose` are measured live with
+HIP events on the launching stream; `cpu_baseline` times the CPU oracle (a port: the reference cannot be built here) on the host.
 """
 import argparse
 import json
@@ -24,94 +27,429 @@ if ROOT not in sys.path:
 
 import numpy as np
 
-W_IMG, H_IMG, NFEAT, NLEVELS = 752, 480, 1000, 8
 N_FRAMES = 8                                  # frames per (periodic) synthetic stream
-P_PIXELS = 1117367                            # sum of level pixels, SURVEY.md §8 table (config E)
 HBM_PEAK_GBS = 8000.0                         # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-ROOFLINE_KERNEL = "k_fast_cells"
-# algorithmic bytes per frame of each extractor kernel (B_ext = 4 P + K (709 + 961 + 60))
-ALGO_BYTES = {
-    "k_fast_cells": P_PIXELS,                                  # 1 P read by FAST
-    "k_blur": 2 * P_PIXELS,                                    # 1 P read + 1 P written
-    "k_resize": P_PIXELS - W_IMG * H_IMG,                      # levels 1..7 written (reads served from cache)
-    "k_copy_level0": W_IMG * H_IMG,                            # level-0 copy
-    "k_orient_describe": NFEAT * (709 + 961 + 60),             # patch + window + outputs per keypoint
+FP64_VECTOR_PEAK_TFLOPS = 78.6                # MI355X FP64 vector spec (AMD data sheet: 256 CUs x 128 FLOP/clk x 2.4 GHz; the guide has no FP64 row)
+CONFIGS = {
+    # name: width, height, features, default units per GPU, BASELINE.json configs index
+    "euroc": dict(w=752, h=480, nfeat=1000, streams=256, baseline_config=1),
+    "synth720p": dict(w=1280, h=720, nfeat=1500, streams=8, baseline_config=4),
+    "kitti_stereo": dict(w=1241, h=376, nfeat=2000, streams=64, baseline_config=2),
+    "local_ba": dict(w=752, h=480, nfeat=1000, streams=64, baseline_config=3),
 }
+EXTRACT_KERNELS = ("k_copy_level0", "k_resize", "k_fast_cells", "k_octree", "k_octree_large", "k_blur", "k_orient_describe")
 
 
-def _gen_stream(seed):
+def level_pixels(w, h, nlevels=8, sf=1.2):
+    """Sum of level pixels P: level l = cvRound(w / sf^l) x cvRound(h / sf^l), float scale table as the reference."""
+    scale, tot, sizes = np.float32(1.0), 0, []
+    for l in range(nlevels):
+        inv = np.float32(1.0) / scale
+        lw, lh = int(np.rint(np.float32(w) * inv)), int(np.rint(np.float32(h) * inv))
+        sizes.append((lw, lh)); tot += lw * lh
+        scale = np.float32(scale * np.float32(sf))
+    return tot, sizes
+
+
+def algo_bytes(w, h, nfeat):
+    """Algorithmic bytes per image of each extractor kernel (B_ext = 4 P + K (709 + 961 + 60))."""
+    P, _ = level_pixels(w, h)
+    return {"k_fast_cells": P, "k_blur": 2 * P, "k_resize": P - w * h, "k_copy_level0": w * h, "k_orient_describe": nfeat * (709 + 961 + 60)}, P
+
+
+def load_traffic_table():
+    """HBM bytes per launch of the extractor / solver kernels from the PMC counters (rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE in
+    separate passes, 2 x FETCH_SIZE + WRITE_SIZE as calibrated by tools/ubench/fetch_calib.hip), recorded per round under profiles/."""
+    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+    try:
+        return json.load(open(path))
+    except Exception:
+        return None
+
+
+def _gen_stream(args):
+    seed, w, h = args
     from viorb_amd.synth import make_periodic_stream
-    s = make_periodic_stream(seed, N_FRAMES, W_IMG, H_IMG)
-    return dict(frames=s["frames"], imu=s["imu"], t=s["t"], ns_true=s["ns_true"], pose_true=s["pose_true"], period=s["period"],
-                cam=s["cam"], gw=s["gw"])
+    s = make_periodic_stream(seed, N_FRAMES, w, h)
+    return dict(frames=s["frames"], imu=s["imu"], t=s["t"], ns_true=s["ns_true"], pose_true=s["pose_true"], period=s["period"], cam=s["cam"], gw=s["gw"])
 
 
-def generate_streams(seeds):
+def generate_streams(seeds, w=752, h=480):
     """CPU-side synthetic data (before anything touches the GPU)."""
     import multiprocessing as mp
     nproc = max(1, min(len(seeds), (os.cpu_count() or 2) // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1"))), 16))
+    jobs = [(s, w, h) for s in seeds]
     if nproc == 1:
-        return [_gen_stream(s) for s in seeds]
+        return [_gen_stream(j) for j in jobs]
     with mp.get_context("fork").Pool(nproc) as pool:
-        return pool.map(_gen_stream, seeds)
+        return pool.map(_gen_stream, jobs)
 
 
-def cpu_baseline(streams, budget_s=12.0, max_frames=150, track_local_map=True):
-    """The oracle (CPU port of the reference path) on one host core, same streams, same per-frame sequence."""
-    from oracle.harness import OracleTracker           # checker only; never on the product path
-    done, t_total = 0, 0.0
-    for s in streams:
-        tr = OracleTracker(s["cam"], s["gw"], W_IMG, H_IMG, NFEAT, track_local_map=track_local_map)
-        tr.bootstrap(s["frames"][0], s["pose_true"][0], s["t"][0], s["ns_true"][0], np.eye(12) * 1e3)
-        k = 1
-        while t_total < budget_s and done < max_frames:
-            j = k % N_FRAMES
-            t0 = time.perf_counter()
-            if j:
-                tr.step(s["frames"][j], s["imu"][j], s["t"][j], s["pose_true"][j])
-            else:      # the loop closes: key-frame boundary, as in the timed GPU sequence
-                tr.step(s["frames"][0], s["imu"][0], s["period"], s["pose_true"][0], t_next_last=0.0, reset_ns=s["ns_true"][0], reset_marg=np.eye(12) * 1e3)
-            t_total += time.perf_counter() - t0
-            done += 1; k += 1
-            if k > 3 * N_FRAMES:
-                break
-        if t_total >= budget_s or done >= max_frames:
-            break
-    return done / t_total, done, t_total
+# ------------------------------------------------------------------------------------------------------------------------------
+# cpu_baseline legs (the oracle is the checker / baseline only; never on the product path)
+# ------------------------------------------------------------------------------------------------------------------------------
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
+def _oracle_track_frames(args):
+    """One oracle stream: per-frame wall times of `n` frames after `warm` warm-up frames (the example mains' convention,
+    reference Examples/Stereo/stereo_kitti.cc:80-124)."""
+    s, w, h, nfeat, warm, n = args
+    from oracle.harness import OracleTracker
+    tr = OracleTracker(s["cam"], s["gw"], w, h, nfeat, track_local_map=True)
+    mci = np.eye(12) * 1e3
+    tr.bootstrap(s["frames"][0], s["pose_true"][0], s["t"][0], s["ns_true"][0], mci)
+    times = []
+    for k in range(1, warm + n + 1):
+        j = k % N_FRAMES
+        t0 = time.perf_counter()
+        if j:
+            tr.step(s["frames"][j], s["imu"][j], s["t"][j], s["pose_true"][j], map_updated=(j == 1 and k > 1))
+        else:
+            tr.step(s["frames"][0], s["imu"][0], s["period"], s["pose_true"][0], t_next_last=0.0, reset_ns=s["ns_true"][0], reset_marg=mci)
+        dt = time.perf_counter() - t0
+        if k > warm:
+            times.append(dt)
+    return times
+
+
+def cpu_baseline_tracking(streams, w, h, nfeat, frames_1core, warm):
+    import multiprocessing as mp
+    hw = os.cpu_count() or 1
+    t1 = _oracle_track_frames((streams[0], w, h, nfeat, warm, frames_1core))
+    one = dict(value=round(len(t1) / sum(t1), 3), median_ms=round(float(np.median(t1)) * 1e3, 3), mean_ms=round(float(np.mean(t1)) * 1e3, 3), frames=len(t1))
+    # all cores: one oracle stream per hardware thread (the batched counterpart), each frames_1core / 4 frames after the warm-up
+    per = max(10, frames_1core // 4)
+    nproc = min(hw, len(streams))
+    t0 = time.perf_counter()
+    with mp.get_context("fork").Pool(nproc) as pool:
+        res = pool.map(_oracle_track_frames, [(streams[i], w, h, nfeat, min(warm, 4), per) for i in range(nproc)])
+    wall = time.perf_counter() - t0
+    busy = sum(sum(r) for r in res)
+    allc = dict(value=round(nproc * per / (busy / nproc), 3), cores=nproc, frames=nproc * per, wall_s=round(wall, 2),
+                note="sum of timed frames / mean per-process busy time (process start and warm-up frames excluded)")
+    return {"value": one["value"], "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": "%d frames after %d warm-up frames of one synthetic stream, same per-frame sequence (oracle, C++ -O3, 1 host thread): "
+                      "median %.2f ms, mean %.2f ms per frame" % (one["frames"], warm, one["median_ms"], one["mean_ms"]),
+            "median_ms_per_frame": one["median_ms"], "mean_ms_per_frame": one["mean_ms"], "all_cores": allc,
+            "hardware_concurrency": hw, "cpu_model": cpu_model()}
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# tracking configs (euroc, synth720p)
+# ------------------------------------------------------------------------------------------------------------------------------
+def run_tracking(args, cfg, rank, dev_index, dev, world):
+    import ctypes as C
+    import torch
+    import torch.distributed as dist
+    import viorb_amd
+    from viorb_amd.distributed import stream_seeds
+    from viorb_amd.tracker import NativeTracker
+    W_IMG, H_IMG, NFEAT, S = cfg["w"], cfg["h"], cfg["nfeat"], args.streams
+    TLM = not args.no_track_local_map
+    # at most 64 distinct synthetic streams are generated per rank (CPU time); beyond that the streams repeat (independent state each)
+    distinct = min(S, 64 if (W_IMG, H_IMG) == (752, 480) and S > 256 else S)
+    base = generate_streams(stream_seeds(rank, distinct), W_IMG, H_IMG)
+    streams = [base[i % distinct] for i in range(S)]
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    frames = up(np.stack([s["frames"] for s in streams], 1))                   # [F, S, h, w] u8
+    imu = up(np.stack([s["imu"] for s in streams], 1))                         # [F, S, n, 7] f64
+    t_frames = up(np.stack([s["t"] for s in streams], 1))                      # [F, S]
+    t_period = up(np.array([s["period"] for s in streams]))                    # [S]
+    pose_true = up(np.stack([s["pose_true"] for s in streams], 1))             # [F, S, 12] f64
+    ns_true = up(np.stack([s["ns_true"] for s in streams], 1))                 # [F, S, 22]
+    zeros_t = torch.zeros(S, dtype=torch.float64, device=dev)
+    mci0 = up(np.stack([np.eye(12).ravel() * 1e3] * S))
+    ones_u8 = torch.ones(S, dtype=torch.uint8, device=dev)
+    cam, gw = streams[0]["cam"], streams[0]["gw"]
+    tr = NativeTracker(cam, gw, S, W_IMG, H_IMG, NFEAT, th=15.0, device=dev_index, compute_marg=True, track_local_map=TLM)
+    tr.bootstrap(frames[0], pose_true[0], t_frames[0], ns_true[0], mci0)
+
+    def run_step(k):
+        j = k % N_FRAMES
+        if j == 0:
+            # closing the loop: frame F == frame 0, its stamp is the period; next "last" stamp is 0. It is also the harness's key-frame
+            # boundary: the frame is tracked in full, the next one starts from the key frame's state with a fresh prior (an endless
+            # frame-to-frame prior chain is not what the reference runs: every key frame / map update restarts it, Tracking.cc:241-287)
+            tr.step(frames[0], imu[0], t_period, pose_true[0], t_next_last=zeros_t, reset_ns=ns_true[0], reset_marg=mci0)
+        elif j == 1 and k > 1:
+            # the frame after the boundary sees mbMapUpdated: PoseOptimization(Frame, KeyFrame) in both stages (Tracking.cc:243, :454)
+            tr.step(frames[1], imu[1], t_frames[1], pose_true[1], map_updated=ones_u8)
+        else:
+            tr.step(frames[j], imu[j], t_frames[j], pose_true[j])
+
+    k = 1
+    for _ in range(args.warmup):
+        run_step(k); k += 1
+    tr.sync(); torch.cuda.synchronize()
+    L = viorb_amd.lib()
+    timed = None if args.all_kernel_events else b"k_fast_cells,k_pose_opt_vi"
+    L.viorb_profile_select(timed)
+    L.viorb_profile_reset(); L.viorb_profile_enable(0 if args.no_kernel_events else 1)
+    tr.host_stats(reset=True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run_step(k); k += 1
+    t_calls = time.perf_counter() - t0                 # host time inside the step calls (enqueue + the in-flight throttle)
+    tr.sync(); torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    L.viorb_profile_enable(0)
+    hs = tr.host_stats()
+
+    # ---- sanity of the timed work (outside the timed region)
+    res = tr.results(["state", "status", "nmatches", "n_loc", "info", "info2", "inliers"])
+    info = res["info2"] if TLM else res["info"]
+    names = C.create_string_buffer(4096); ms = (C.c_double * 64)(); calls = (C.c_int * 64)(); n = C.c_int()
+    L.viorb_profile_read(names, 4096, ms, calls, 64, C.byref(n))
+    prof = {nm_: (ms[i], calls[i]) for i, nm_ in enumerate(names.value.decode().split("\n")[:n.value])}
+
+    out = dict(units=S * args.steps, elapsed=elapsed)
+    if rank == 0:
+        AB, P = algo_bytes(W_IMG, H_IMG, NFEAT)
+        traffic = load_traffic_table()
+        roof = roof_pose = None
+        if "k_fast_cells" in prof and prof["k_fast_cells"][1]:
+            tot_ms, ncalls = prof["k_fast_cells"]
+            avg_s = tot_ms / ncalls * 1e-3
+            bpl = AB["k_fast_cells"] * S * args.steps / ncalls
+            tr_b = None
+            if traffic and traffic.get("config") == args.config and "k_fast_cells" in traffic.get("bytes_per_launch", {}):
+                tr_b = int(traffic["bytes_per_launch"]["k_fast_cells"] * S / traffic["units_per_launch"])
+            roof = {"bound": "hbm", "kernel": "k_fast_cells", "achieved": round(bpl / avg_s / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(bpl / avg_s / 1e9 / HBM_PEAK_GBS, 5), "traffic": tr_b, "avg_launch_us": round(avg_s * 1e6, 2),
+                    "algorithmic_bytes_per_launch": int(bpl),
+                    "traffic_source": (traffic or {}).get("source") if tr_b else None,
+                    "note": "dominant kernel of the HBM-bound extractor family; it is bound by integer vector issue, not by HBM (DESIGN.md §4)"}
+            if args.all_kernel_events:
+                ext_ms = sum(v[0] for kname, v in prof.items() if kname in EXTRACT_KERNELS)
+                ext_bytes = (4 * P + NFEAT * (709 + 961 + 60)) * S * args.steps
+                roof["extractor_all_kernels_GBps"] = round(ext_bytes / (ext_ms * 1e-3) / 1e9, 2)
+                roof["extractor_all_kernels_frac"] = round(ext_bytes / (ext_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
+            roof["kernel_ms_per_step"] = {kname: round(v[0] / args.steps, 4) for kname, v in sorted(prof.items())}
+        if "k_pose_opt_vi" in prof and prof["k_pose_opt_vi"][1]:
+            # FLOP model of one solve (counted from the kernel source, DESIGN.md §4): every evaluation of the objective costs
+            # 190 FLOP per reprojection edge (projection, Huber weight, 2 x 6 camera-frame Jacobian, 20 + 6 accumulations) plus
+            # 27 500 for the dense factors, their 24 x 24 assembly and the Cholesky solve of the trial; evaluations = LM iterations
+            # + one initial evaluation per round (4 rounds). Edges and iterations are the measured ones of the last step.
+            tot_ms, ncalls = prof["k_pose_opt_vi"]
+            avg_s = tot_ms / ncalls * 1e-3
+            its1, its2 = float(res["info"][:, 2].mean()), float(res["info2"][:, 2].mean()) if TLM else 0.0
+            r2 = tr.results(["n_obs", "n_obs2", "last_count"])
+            e1 = float(r2["n_obs"].mean() + r2["last_count"].mean()); e2 = float(r2["n_obs2"].mean() + r2["last_count"].mean())
+            fl1 = (its1 + 4) * (e1 * 190 + 27500); fl2 = (its2 + 4) * (e2 * 190 + 27500) if TLM else 0.0
+            flops_per_launch = (fl1 + fl2) / (2 if TLM else 1) * S
+            ach = flops_per_launch / avg_s / 1e12
+            roof_pose = {"bound": "fp64_vector", "kernel": "k_pose_opt_vi", "achieved": round(ach, 3), "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(ach / FP64_VECTOR_PEAK_TFLOPS, 5), "traffic": None, "avg_launch_us": round(avg_s * 1e6, 2),
+                         "flop_per_launch": int(flops_per_launch), "mean_lm_iterations": [round(its1, 2), round(its2, 2)],
+                         "mean_edges": [round(e1, 1), round(e2, 1)], "problems_per_launch": S,
+                         "note": "the kernel with the largest share of GPU time (profiles/*_kernel_stats.csv); one 256-thread workgroup per "
+                                 "problem, latency / issue bound: the FP64 fraction is small by construction (DESIGN.md §4)"}
+        out["roofline"], out["roofline_pose"] = roof, roof_pose
+        tracked = int((res["state"] == 0).sum())
+        out["config"] = {
+            "workload": "%s-shaped synthetic mono-inertial streams %dx%d, 8 levels, %d features, per frame: extract + IMU pre-integration (10 samples) + "
+                        "SearchByProjection(th=15, 2*th retry) + PoseOptimization + discard outliers%s; thresholds / reverts of the reference per stream "
+                        "on the device; C++ tracker (viorb_tracker_step)" %
+                        ("EuRoC" if args.config == "euroc" else "1280x720", W_IMG, H_IMG, NFEAT,
+                         " + SearchLocalPoints(~2000 local points) + PoseOptimization(marg)  [TrackWithIMU + TrackLocalMapWithIMU]" if TLM else " [TrackWithIMU only]"),
+            "baseline_config": cfg["baseline_config"], "keyframe_boundary_every_frames": N_FRAMES,
+            "keyframe_variant": "PoseOptimization(Frame, KeyFrame) on the frame after every boundary (mbMapUpdated), (Frame, Frame) otherwise",
+            "track_local_map": TLM, "streams_per_gpu": S, "frames_per_step": S * world, "solver_dtype": "f64",
+            "host_enqueue_ms_per_step": round(hs["enqueue_s"] / max(hs["steps"], 1) * 1e3, 4),
+            "host_throttle_wait_ms_per_step": round(hs["throttle_s"] / max(hs["steps"], 1) * 1e3, 4),
+            "host_step_call_ms_per_step": round(t_calls / args.steps * 1e3, 4),
+            "tracked_streams_last_step": tracked, "state_histogram_last_step": np.bincount(res["state"], minlength=5).tolist(),
+            "mean_matches_last_step": round(float(res["nmatches"].mean()), 1), "mean_local_matches_last_step": round(float(res["n_loc"].mean()), 1),
+            "mean_inliers_last_step": round(float(info[:, 0].mean()), 1), "status_ok": bool((res["status"] == 0).all())}
+        if not (res["status"] == 0).all():
+            raise SystemExit("a stream reported a capacity / status error: %s" % res["status"])
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline_tracking(base, W_IMG, H_IMG, NFEAT, 200 if args.config == "euroc" else 60, 20 if args.config == "euroc" else 8)
+    out["metric"] = "frames/sec ORB extract+match+pose-opt, EuRoC 752x480, 1/2/4/8 GPUs" if args.config == "euroc" else \
+        "frames/sec ORB extract+match+pose-opt, synthetic 1280x720 / 1500 features, batched streams"
+    out["unit"] = "frames/s"; out["dtype"] = "u8"
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# kitti_stereo: extraction of both images + Frame::ComputeStereoMatches (reference src/Frame.cc:241-262, :646-820)
+# ------------------------------------------------------------------------------------------------------------------------------
+def run_stereo(args, cfg, rank, dev_index, dev, world):
+    import ctypes as C
+    import torch
+    import torch.distributed as dist
+    import viorb_amd
+    from viorb_amd.capi import lib, check, ptr
+    from viorb_amd.synth import make_stereo_pair, KITTI_K
+    Pn, W_IMG, H_IMG, NFEAT = args.streams, cfg["w"], cfg["h"], cfg["nfeat"]
+    distinct = min(Pn, 8)
+    pairs = [make_stereo_pair(100 + rank * 64 + s, W_IMG, H_IMG)[:2] for s in range(distinct)]
+    imgs = torch.from_numpy(np.stack([pairs[i % distinct][0] for i in range(Pn)] + [pairs[i % distinct][1] for i in range(Pn)])).to(dev)
+    ex = viorb_amd.ORBextractor(NFEAT, 1.2, 8, 20, 7, max_batch=2 * Pn, device=dev_index)
+    u = torch.zeros((Pn, ex.cap), dtype=torch.float32, device=dev); d = torch.zeros_like(u); n = torch.zeros(Pn, dtype=torch.int32, device=dev)
+    st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+    def step():
+        ex.extract_batch_device(imgs)
+        check(lib().viorb_stereo_match_device(ex.h, 0, ex.h, Pn, Pn, KITTI_K["bf"], KITTI_K["fx"], ptr(u), ptr(d), ptr(n), st))
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    L = lib()
+    L.viorb_profile_select(None if args.all_kernel_events else b"k_fast_cells,k_stereo_match")
+    L.viorb_profile_reset(); L.viorb_profile_enable(0 if args.no_kernel_events else 1)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    L.viorb_profile_enable(0)
+    names = C.create_string_buffer(4096); ms = (C.c_double * 64)(); calls = (C.c_int * 64)(); k = C.c_int()
+    L.viorb_profile_read(names, 4096, ms, calls, 64, C.byref(k))
+    prof = {nm_: (ms[i], calls[i]) for i, nm_ in enumerate(names.value.decode().split("\n")[:k.value])}
+    out = dict(units=Pn * args.steps, elapsed=elapsed, metric="stereo pairs/sec: ORB extraction of both images + ComputeStereoMatches, KITTI 1241x376, 2000 features",
+               unit="pairs/s", dtype="u8")
+    if rank == 0:
+        AB, P = algo_bytes(W_IMG, H_IMG, NFEAT)
+        roof = None
+        if "k_fast_cells" in prof and prof["k_fast_cells"][1]:
+            tot_ms, ncalls = prof["k_fast_cells"]; avg_s = tot_ms / ncalls * 1e-3
+            bpl = AB["k_fast_cells"] * 2 * Pn
+            roof = {"bound": "hbm", "kernel": "k_fast_cells", "achieved": round(bpl / avg_s / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(bpl / avg_s / 1e9 / HBM_PEAK_GBS, 5), "traffic": None, "avg_launch_us": round(avg_s * 1e6, 2),
+                    "algorithmic_bytes_per_launch": int(bpl), "kernel_ms_per_step": {kn: round(v[0] / args.steps, 4) for kn, v in sorted(prof.items())}}
+        out["roofline"] = roof
+        out["config"] = {"workload": "KITTI-shaped synthetic stereo pairs 1241x376, 8 levels, 2000 features per image: extraction of left and right image "
+                                     "(one batched handle) + Frame::ComputeStereoMatches (row buckets, Hamming, 11x11 SAD, sub-pixel, median rejection)",
+                         "baseline_config": cfg["baseline_config"], "pairs_per_gpu_per_step": Pn, "pairs_per_step": Pn * world,
+                         "mean_stereo_matches_per_pair": round(float(n.float().mean().item()), 1), "keypoint_capacity": ex.cap}
+        if not args.no_cpu_baseline:
+            from oracle import binding as ora
+            exo = [ora.Extractor(NFEAT, 1.2, 8, 20, 7), ora.Extractor(NFEAT, 1.2, 8, 20, 7)]
+            times = []
+            for i in range(3 + 24):
+                a, b_ = pairs[i % distinct]
+                t1 = time.perf_counter()
+                kl, dl = exo[0](a); kr, dr = exo[1](b_)
+                ora.stereo_match(exo[0], exo[1], kl, dl, kr, dr, KITTI_K["bf"], KITTI_K["fx"])
+                if i >= 3:
+                    times.append(time.perf_counter() - t1)
+            out["cpu_baseline"] = {"value": round(len(times) / sum(times), 3), "unit": "pairs/s", "cores": 1, "kind": "port",
+                                   "sample": "%d pairs after 3 warm-up pairs, oracle (C++ -O3) on 1 host thread (the reference extracts left and right "
+                                             "on two threads, src/Frame.cc:258-261): median %.1f ms, mean %.1f ms per pair"
+                                             % (len(times), np.median(times) * 1e3, np.mean(times) * 1e3),
+                                   "median_ms_per_pair": round(float(np.median(times)) * 1e3, 2), "mean_ms_per_pair": round(float(np.mean(times)) * 1e3, 2),
+                                   "hardware_concurrency": os.cpu_count(), "cpu_model": cpu_model()}
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# local_ba: Optimizer::LocalBundleAdjustmentNavState, 20-key-frame window (reference src/Optimizer.cc:1690-2241)
+# ------------------------------------------------------------------------------------------------------------------------------
+def run_local_ba(args, cfg, rank, dev_index, dev, world):
+    import torch
+    import torch.distributed as dist
+    from oracle import binding as ora                      # pre-integration of the synthetic problem's IMU blocks (input preparation) + baseline
+    from viorb_amd.synth import make_local_ba_problem
+    from viorb_amd import LocalBundleAdjustmentNavStateBatch
+    nwin = args.streams
+    probs = []
+    for s in range(min(nwin, 4)):
+        p = make_local_ba_problem(3 + rank * 16 + s, W=20, n_points=2000)
+        pre = []
+        for i, (imu, t0, t1) in enumerate(p["imu"]):
+            j = i - 1 if i > 0 else p["prev_kf"]
+            pre.append(ora.preintegrate(imu, p["kfs"][j][10:13], p["kfs"][j][13:16], t0, t1))
+        probs.append(dict(kfs=p["kfs"], n_local=p["n_local"], prev_kf=p["prev_kf"], preint=np.stack(pre), points=p["points"], edge_idx=p["edge_idx"],
+                          edge_obs=p["edge_obs"], gw=p["gw"], cam=p["cam"]))
+    batch = [probs[i % len(probs)] for i in range(nwin)]
+    fl = args.in_flight
+    for _ in range(max(1, args.warmup)):
+        LocalBundleAdjustmentNavStateBatch(batch[:max(fl, 2)], max_in_flight=fl)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = LocalBundleAdjustmentNavStateBatch(batch, max_in_flight=fl)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    out = dict(units=nwin * args.steps, elapsed=elapsed, metric="windows/sec LocalBundleAdjustmentNavState, 20-key-frame window, 2000 points", unit="windows/s", dtype="f64")
+    if rank == 0:
+        ne = int(np.mean([len(p["edge_idx"]) for p in probs]))
+        out["roofline"] = None
+        out["config"] = {"workload": "synthetic EuRoC-shaped local window: W = 20 key frames (12 unknowns each) + 3 fixed, 2000 points, ~%d mono edges, IMU + bias "
+                                     "factors; LocalBundleAdjustmentNavState = optimize(5), chi2 gate, optimize(10); viorb_local_ba_navstate_batch, host buffers in "
+                                     "and out (its caller is the LocalMapping thread)" % ne,
+                         "baseline_config": cfg["baseline_config"], "windows_per_gpu_per_step": nwin, "windows_in_flight": fl,
+                         "lm_iterations_first_second": [res[0]["its_first"], res[0]["its_second"]], "final_chi2": round(float(res[0]["chi2_final"]), 3)}
+        if not args.no_cpu_baseline:
+            q = probs[0]; a = (q["kfs"], q["n_local"], q["prev_kf"], q["preint"], q["points"], q["edge_idx"], q["edge_obs"], q["gw"], q["cam"])
+            ora.local_ba(*a)
+            times = []
+            while sum(times) < 10.0 and len(times) < 200:
+                t1 = time.perf_counter(); ora.local_ba(*a); times.append(time.perf_counter() - t1)
+            out["cpu_baseline"] = {"value": round(len(times) / sum(times), 3), "unit": "windows/s", "cores": 1, "kind": "port",
+                                   "sample": "%d solves of one window after 1 warm-up, oracle (C++ -O3, dense Cholesky of the reduced system) on 1 host thread: "
+                                             "median %.1f ms" % (len(times), np.median(times) * 1e3),
+                                   "median_ms_per_window": round(float(np.median(times)) * 1e3, 2), "hardware_concurrency": os.cpu_count(), "cpu_model": cpu_model()}
+    return out
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    # 200 steps = 25 loops of the 8-frame streams, ~0.4 s: the step time is stationary over hundreds of steps (tools/step_times.py)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=16)
-    ap.add_argument("--streams", type=int, default=256, help="independent camera streams per GPU")
-    ap.add_argument("--groups", type=int, default=1, help="split the streams of a GPU into this many independently enqueued groups "
-                    "(each with its own HIP streams) so that latency-bound kernels of one group overlap chip-filling kernels of another")
-    ap.add_argument("--no-track-local-map", action="store_true", help="stop after TrackWithIMU's pose solve (skip the SearchLocalPoints + "
-                    "second PoseOptimization stage of TrackLocalMapWithIMU)")
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default: 200 for euroc, fewer for the heavier configs)")
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="euroc", help="BASELINE.json config: euroc = configs[1] (default), kitti_stereo = configs[2], "
+                    "local_ba = configs[3], synth720p = configs[4]")
+    ap.add_argument("--streams", type=int, default=None, help="independent units per GPU per step: camera streams (euroc 256, synth720p 8), stereo pairs "
+                    "(kitti_stereo 64), windows (local_ba 64)")
+    ap.add_argument("--in-flight", type=int, default=16, help="local_ba: windows kept in flight by the batch driver")
+    ap.add_argument("--no-track-local-map", action="store_true", help="stop after TrackWithIMU's pose solve")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-kernel-events", action="store_true", help="skip the per-kernel HIP events (roofline becomes null); dev aid "
-                    "to measure what the events themselves cost")
-    ap.add_argument("--all-kernel-events", action="store_true", help="time every kernel of the step, not only the roofline kernel: fills "
-                    "roofline.kernel_ms_per_step for all of them and costs ~5 %% of the step (an event pair is ~8 us of stream time)")
+    ap.add_argument("--no-kernel-events", action="store_true", help="skip the per-kernel HIP events (rooflines become null); dev aid")
+    ap.add_argument("--all-kernel-events", action="store_true", help="time every kernel of the step, not only the roofline kernels (costs ~5 %% of the step)")
     args = ap.parse_args()
+    cfg = CONFIGS[args.config]
+    if args.streams is None:
+        args.streams = cfg["streams"]
+    if args.steps is None:
+        args.steps = {"euroc": 200, "synth720p": 200, "kitti_stereo": 50, "local_ba": 4}[args.config]
+    if args.warmup is None:
+        args.warmup = {"euroc": 16, "synth720p": 16, "kitti_stereo": 5, "local_ba": 1}[args.config]
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
-    S = args.streams
-
-    # ---- synthetic inputs on the CPU, then the GPU runtime --------------------------------------------
-    from viorb_amd.distributed import stream_seeds, reduce_throughput, init as dist_init
-    streams = generate_streams(stream_seeds(rank, S))
+    from viorb_amd.distributed import reduce_throughput, init as dist_init
     import torch
     import torch.distributed as dist
     import viorb_amd
-    from viorb_amd.tracker import BatchedTracker
     if viorb_amd.lib().viorb_device_count() < 1:
         raise SystemExit("bench.py needs a HIP device (viorb_amd has no CPU fallback)")
     # VIORB_BENCH_REHEARSAL=1: run the N > 1 code path on a box with fewer GPUs than ranks (ranks share devices, gloo instead of
@@ -122,122 +460,16 @@ def main():
     dev = torch.device("cuda", dev_index)
     if world > 1:
         dist_init("gloo" if rehearsal else "nccl", None if rehearsal else dev)       # "nccl" is RCCL on ROCm
-    up = lambda a, dt=None: torch.from_numpy(np.ascontiguousarray(a)).to(dev) if dt is None else torch.from_numpy(np.ascontiguousarray(a)).to(dev, dt)
-    frames = up(np.stack([s["frames"] for s in streams], 1))                   # [F, S, h, w] u8
-    imu = up(np.stack([s["imu"] for s in streams], 1))                         # [F, S, n, 7] f64
-    t_frames = up(np.stack([s["t"] for s in streams], 1))                      # [F, S]
-    t_period = up(np.array([s["period"] for s in streams]))                    # [S]
-    pose_true = up(np.stack([s["pose_true"] for s in streams], 1))             # [F, S, 12] f64
-    ns_true = up(np.stack([s["ns_true"] for s in streams], 1))                 # [F, S, 22]
-    zeros_t = torch.zeros(S, dtype=torch.float64, device=dev)
-    mci0 = up(np.stack([np.eye(12).ravel() * 1e3] * S))
-    cam, gw = streams[0]["cam"], streams[0]["gw"]
-
-    G = max(1, args.groups)
-    if S % G:
-        raise SystemExit("--streams must be a multiple of --groups")
-    Sg = S // G
-    sl = [slice(g * Sg, (g + 1) * Sg) for g in range(G)]
-    cut = lambda t, g: t[:, sl[g]].contiguous()
-    fr_g = [cut(frames, g) for g in range(G)]; imu_g = [cut(imu, g) for g in range(G)]; tf_g = [cut(t_frames, g) for g in range(G)]
-    pt_g = [cut(pose_true, g) for g in range(G)]; ns_g = [cut(ns_true, g) for g in range(G)]; tp_g = [t_period[sl[g]].contiguous() for g in range(G)]
-    zeros_g = zeros_t[:Sg].contiguous()
-    mci_g = [mci0[sl[g]].contiguous() for g in range(G)]
-    TLM = not args.no_track_local_map
-    trs = [BatchedTracker(cam, gw, Sg, W_IMG, H_IMG, NFEAT, th=15.0, device=dev_index, compute_marg=True, track_local_map=TLM) for _ in range(G)]
-    for g, tr in enumerate(trs):
-        tr.skip_input_wait = bool(os.environ.get('SKIPWAIT'))
-        tr.bootstrap(fr_g[g][0], pt_g[g][0], tf_g[g][0], ns_g[g][0], mci0[sl[g]].contiguous())
-
-    def run_step(k):
-        j = k % N_FRAMES
-        for g, tr in enumerate(trs):
-            if j == 0:      # closing the loop: frame F == frame 0, its stamp is the period; next "last" stamp is 0. It is also the
-                # harness's key-frame boundary: the frame is tracked in full, the next one starts from the key frame's state with a
-                # fresh prior (an endless frame-to-frame prior chain is not what the reference runs, and it degrades: after ~50 chained
-                # frames of this synthetic world the inlier count falls and the LM steps start to be rejected)
-                tr.step(fr_g[g][0], imu_g[g][0], tp_g[g], pt_g[g][0], t_next_last=zeros_g, chain_estimate=False, true_ns=ns_g[g][0],
-                        marg_reset=mci_g[g])
-            else:
-                tr.step(fr_g[g][j], imu_g[g][j], tf_g[g][j], pt_g[g][j])
-
-    k = 1
-    for _ in range(args.warmup):
-        run_step(k); k += 1
-    torch.cuda.synchronize()
-    L = viorb_amd.lib()
-    # the dominant extractor kernel (profiles/*_kernel_stats.csv) is the one the roofline object is about; only its launches carry events
-    L.viorb_profile_select(None if args.all_kernel_events else ROOFLINE_KERNEL.encode())
-    L.viorb_profile_reset(); L.viorb_profile_enable(0 if args.no_kernel_events else 1)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        run_step(k); k += 1
-    t_enq = time.perf_counter() - t0                   # host time to enqueue all steps (the device may still be working)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    L.viorb_profile_enable(0)
-
-    # ---- sanity of the timed work (outside the timed region): every stream tracked its frame ------------
-    info = np.concatenate([(tr.info2 if TLM else tr.info).cpu().numpy() for tr in trs])
-    n_loc = np.concatenate([tr.n_loc.cpu().numpy() for tr in trs]) if TLM else np.zeros(1)
-    nm = np.concatenate([tr.nmatches.cpu().numpy() for tr in trs])
-    status_ok = bool(all((tr.status.cpu().numpy() == 0).all() for tr in trs))
-    tracked = int((info[:, 0] >= 20).sum())
-
-    # ---- per-kernel HIP-event times ------------------------------------------------------------------------
-    import ctypes as C
-    names = C.create_string_buffer(4096); ms = (C.c_double * 64)(); calls = (C.c_int * 64)(); n = C.c_int()
-    L.viorb_profile_read(names, 4096, ms, calls, 64, C.byref(n))
-    prof = {nm_: (ms[i], calls[i]) for i, nm_ in enumerate(names.value.decode().split("\n")[:n.value])}
-    ext = {kname: v for kname, v in prof.items() if kname in ALGO_BYTES}
-    dom = ROOFLINE_KERNEL if ROOFLINE_KERNEL in ext else None
-
-    # ---- reduce over ranks: total frames, max time ----------------------------------------------------------
-    frames_done, elapsed = reduce_throughput(S * args.steps, elapsed, None if rehearsal else dev)
-
+    runner = {"euroc": run_tracking, "synth720p": run_tracking, "kitti_stereo": run_stereo, "local_ba": run_local_ba}[args.config]
+    r = runner(args, cfg, rank, dev_index, dev, world)
+    units, elapsed = reduce_throughput(r["units"], r["elapsed"], None if rehearsal else dev)
     if rank == 0:
-        roof = None
-        if dom:
-            tot_ms, ncalls = ext[dom]
-            launches_per_step = ncalls / args.steps
-            avg_s = tot_ms / ncalls * 1e-3
-            bytes_per_launch = ALGO_BYTES[dom] * S / launches_per_step
-            achieved = bytes_per_launch / avg_s / 1e9
-            ext_ms = sum(v[0] for v in ext.values())
-            ext_bytes = (4 * P_PIXELS + NFEAT * (709 + 961 + 60)) * S * args.steps
-            roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-                    "avg_launch_us": round(avg_s * 1e6, 2), "algorithmic_bytes_per_launch": int(bytes_per_launch),
-                    "extractor_all_kernels_GBps": round(ext_bytes / (ext_ms * 1e-3) / 1e9, 2) if args.all_kernel_events else None,
-                    "kernel_ms_per_step": {kname: round(v[0] / args.steps, 4) for kname, v in sorted(prof.items())}}
-        cpu = None
-        if not args.no_cpu_baseline:
-            fps, nfr, tsec = cpu_baseline(streams[:8], track_local_map=TLM)
-            cpu = {"value": round(fps, 3), "unit": "frames/s", "cores": 1, "kind": "port",
-                   "sample": "%d frames of the same synthetic streams, same per-frame sequence, oracle (C++ -O3) on 1 host thread, %.1f s"
-                             % (nfr, tsec)}
-        out = {
-            "metric": "frames/sec ORB extract+match+pose-opt, EuRoC 752x480, 1/2/4/8 GPUs",
-            "value": round(frames_done / elapsed, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "EuRoC-shaped synthetic mono-inertial streams 752x480, 8 levels, 1000 features, per frame: extract + IMU "
-                                   "pre-integration (10 samples) + SearchByProjection(th=15) + PoseOptimization(Frame,Frame)" +
-                                   (" + SearchLocalPoints(~2000 local points, th=1) + PoseOptimization(Frame,Frame,marg)  [TrackWithIMU + TrackLocalMapWithIMU]"
-                                    if TLM else " with marginal  [TrackWithIMU only]"),
-                       "keyframe_boundary_every_frames": N_FRAMES,
-                       "track_local_map": TLM, "mean_local_matches_last_step": round(float(n_loc.mean()), 1),
-                       "streams_per_gpu": S, "stream_groups_per_gpu": G, "frames_per_step": S * world, "solver_dtype": "f64",
-                       "host_enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 3), "tracked_streams_last_step": tracked, "mean_matches_last_step": round(float(nm.mean()), 1),
-                       "mean_inliers_last_step": round(float(info[:, 0].mean()), 1), "status_ok": status_ok},
-            "roofline": roof, "cpu_baseline": cpu,
-        }
+        out = {"metric": r["metric"], "value": round(units / elapsed, 2), "unit": r["unit"], "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": r["dtype"], "data": "synthetic", "config": r.get("config"), "roofline": r.get("roofline")}
+        if r.get("roofline_pose") is not None:
+            out["roofline_pose"] = r["roofline_pose"]
+        out["cpu_baseline"] = r.get("cpu_baseline")
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -281,6 +281,86 @@ int viorb_synth_plane_points_device(viorb_frontend* h, const viorb_keypoint* kps
                                     const double* pose12, double z0, int batch, float* Pw, uint8_t* flags,
                                     int32_t* self_index /* [b][cap]: i for i < count[b], else -1; may be NULL */, void* stream);
 
+/* The per-stream variant of viorb_frontend_pose_opt_device: variant[b] = 0 selects the (Frame, KeyFrame) overload for stream b
+ * (Tracking's "if(mpLocalMapper->GetFirstVINSInited() || bMapUpdated)", reference src/Tracking.cc:454, :243), 1 the (Frame, Frame)
+ * overload (NULL: all 1); streams with skip[b] != 0 (may be NULL) return at once with out_ns = cur_ns and info = 0, as
+ * "if(nInitialCorrespondences<3) return 0" does. All the Frame-overload arrays must be given. obs arrays must be 16-byte aligned. */
+int viorb_frontend_pose_opt_select_device(viorb_frontend* h, const uint8_t* variant, const uint8_t* skip, int compute_marg,
+                                          const double* cur_ns, const double* last_ns, const double* prior_ns, const double* marg_cov_inv,
+                                          const double* preint, const double* obs_cur, const int32_t* n_cur, const double* obs_last,
+                                          const int32_t* n_last, int batch, double* out_ns, double* out_last_ns, uint8_t* outlier_cur,
+                                          uint8_t* outlier_last, double* marg_out, double* info, void* stream);
+/* self_index[b][i] = i where keypoint i of the last frame holds a map point (flags bit 0) and i < count[b], else -1: the `match`
+ * input that makes viorb_frontend_build_observations_device build the LAST frame's own edges (reference src/Optimizer.cc:549-589). */
+int viorb_frontend_self_index_device(viorb_frontend* h, const uint8_t* flags, const int32_t* count, int batch, int32_t* self_index,
+                                     void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Batched tracking sequence: what Tracking::TrackWithIMU followed by Tracking::TrackLocalMapWithIMU do for one
+ * frame (reference src/Tracking.cc:412-534, :229-346) for `batch` independent mono-inertial streams, thresholds 20 / 10 / 15 / 30 and
+ * the backup / revert decisions included, enqueued by ONE host call on two HIP streams of the tracker (extraction of frame k+1
+ * overlaps the matching and pose solves of frame k). No host synchronisation inside a step. Per-stream outcome in state[b]:
+ * ---------------------------------------------------------------------------------------------- */
+#define VIORB_TRACK_OK           0   /* both stages returned true */
+#define VIORB_TRACK_FEW_MATCHES  1   /* TrackWithIMU: nmatches < 20 after the 2*th retry: "return false" before any optimisation (:446-447) */
+#define VIORB_TRACK_REVERT_1     2   /* TrackWithIMU: nmatchesMap < 10: frames reverted to the backup (IMU prediction), false (:518-533) */
+#define VIORB_TRACK_REVERT_2     3   /* TrackLocalMapWithIMU: mnMatchesInliers < 15: reverted to the state it started from, false (:333-342) */
+#define VIORB_TRACK_RELOC_FEW    4   /* TrackLocalMapWithIMU: relocalised recently and mnMatchesInliers < 30: false, no revert (:330-331) */
+
+typedef struct viorb_tracker viorb_tracker;   /* opaque */
+typedef struct viorb_tracker_config {
+    viorb_extractor_params extractor;
+    viorb_frontend_config  frontend;      /* bounds, scale tables and nlevels are filled from width / height / the extractor */
+    int32_t width, height, batch, device;
+    float   th_projection;                /* SearchByProjection window: 15 mono, 7 stereo (src/Tracking.cc:427-431) */
+    int32_t track_local_map;              /* 0: TrackWithIMU only */
+    int32_t local_frames;                 /* local map = the points of this many frames before the last one (1..8) */
+    int32_t compute_marg;                 /* bComputeMarg of the last solve of a frame */
+    int32_t max_steps_ahead;              /* host runs at most this many steps in front of the device (<= 0: 8) */
+    double  synth_plane_z0;               /* plane of the synthetic world (workload support; used with d_synth_pose12) */
+} viorb_tracker_config;
+typedef struct viorb_tracker_inputs {     /* device pointers; row b belongs to stream b */
+    const uint8_t* d_images; int32_t image_stride; size_t image_pitch_bytes;   /* batch images, as viorb_extract_batch_device */
+    const double*  d_imu; int32_t n_imu;  /* [b][n_imu][7] gyro3 acc3 t since the last frame */
+    const double*  d_t_cur;               /* [b] frame stamps */
+    const uint8_t* d_map_updated;         /* [b] != 0: mbMapUpdated -> PoseOptimization(Frame, KeyFrame) with the last frame as the
+                                             key frame it was just promoted to; NULL: never */
+    const uint8_t* d_recent_reloc;        /* [b] != 0: mCurrentFrame.mnId < mnLastRelocFrameId + mMaxFrames; NULL: never */
+    const double*  d_t_next_last;         /* [b] stamp the frame carries as "last frame" (NULL: d_t_cur; periodic synthetic streams) */
+    const double*  d_reset_ns;            /* [b][22] harness key-frame boundary: the next frame starts from this state (NULL: chained) */
+    const double*  d_reset_marg;          /* [b][144] ... and this prior information (NULL: chained) */
+    const double*  d_synth_pose12;        /* [b][12] double Rcw tcw: map points of the new last frame from the synthetic plane world
+                                             (NULL: the caller supplies them with viorb_tracker_set_last_points_device before the next step) */
+} viorb_tracker_inputs;
+typedef struct viorb_tracker_results {    /* device pointers into the tracker, valid after viorb_tracker_sync until the next step */
+    int32_t cap;
+    const int32_t *state, *status, *nmatches, *n_map, *n_loc, *inliers, *n_obs, *n_obs2, *cur_match, *loc_match, *last_count;
+    const double *info, *info2, *pred_ns, *ns_stage1, *ns_stage2, *final_ns, *final_marg, *last_ns;
+    const uint8_t *outlier_cur, *outlier_cur2, *last_flags;
+    const float *last_Pw, *last_pts_f;
+    const viorb_extractor* extractor;     /* the handle that holds the frame's keypoints / descriptors / pyramid */
+} viorb_tracker_results;
+int viorb_tracker_create(const viorb_tracker_config* cfg, viorb_tracker** out);
+int viorb_tracker_destroy(viorb_tracker* h);
+int viorb_tracker_capacity(const viorb_tracker* h, int* cap);
+/* First frame of every stream: extract and adopt as last frame with the given state / prior information. Synchronises. */
+int viorb_tracker_bootstrap(viorb_tracker* h, const uint8_t* d_images, int stride, size_t image_pitch_bytes, const double* d_ns0,
+                            const double* d_t0, const double* d_marg_cov_inv, const double* d_synth_pose12, void* caller_stream);
+/* Map points of the current last frame from the caller's map: Pw[b][cap][3], flags[b][cap] (bit0 point, bit1 outlier, bit2 has
+ * observations), pts_f[b][cap][8] (isInFrustum fields; NULL without the local-map stage). */
+int viorb_tracker_set_last_points_device(viorb_tracker* h, const float* d_Pw, const uint8_t* d_flags, const float* d_pts_f, void* caller_stream);
+/* One frame for every stream. The inputs must stay valid until the step has completed (viorb_tracker_sync, or max_steps_ahead
+ * later calls): they are read on the tracker's own streams. */
+int viorb_tracker_step(viorb_tracker* h, const viorb_tracker_inputs* in, void* caller_stream);
+int viorb_tracker_sync(viorb_tracker* h);
+int viorb_tracker_results_device(const viorb_tracker* h, viorb_tracker_results* out);
+/* Host cost of the steps since the last reset: seconds spent enqueueing (launch calls only) and seconds blocked in the
+ * max_steps_ahead throttle. */
+int viorb_tracker_host_stats(viorb_tracker* h, double* enqueue_s, double* throttle_s, long long* steps, int reset);
+/* Blocking host <-> device copies for callers that hold raw device addresses. */
+int viorb_memcpy_dtoh(void* dst_host, const void* src_device, size_t bytes);
+int viorb_memcpy_htod(void* dst_device, const void* src_host, size_t bytes);
+
 /* hipMemcpyAsync(device -> device) on `stream`, for callers that hold raw device addresses. */
 int viorb_memcpy_dtod_async(void* dst, const void* src, size_t bytes, void* stream);
 
@@ -289,7 +369,7 @@ int viorb_memcpy_dtod_async(void* dst, const void* src, size_t bytes, void* stre
  * total_ms[i] / calls[i] the summed duration and launch count of name i since the last reset. */
 int viorb_profile_enable(int on);
 int viorb_profile_reset(void);
-/* Restrict the timing to one kernel name (NULL or "" = every kernel). An event pair around a kernel costs about 8 us of stream
+/* Restrict the timing to one kernel name or a comma-separated list of names (NULL or "" = every kernel). An event pair around a kernel costs about 8 us of stream
  * time, so timing all ~30 launches of a tracking step slows the step by ~5 %; bench.py times only its roofline kernel. */
 int viorb_profile_select(const char* kernel_name);
 int viorb_profile_read(char* names_buf, int names_cap, double* total_ms, int* calls, int cap, int* n);
@@ -328,8 +408,10 @@ int viorb_pose_opt_se3(const float pose12[12], const float intr5[5], const doubl
  * key frame i, points [np][3], edge_idx [ne][2] = (point, key frame) sorted by point, edge_obs [ne][3] = u v invSigma2.
  * stop: the reference's pbStopFlag (polled between LM trials; may be NULL). Outputs: kfs_out [n_local][22],
  * points_out [np][3], erase [ne], info = chi2 after optimize(5), final chi2, iterations of both runs, 0, 0.
- * Host buffers in and out (the caller is the LocalMapping thread); all arithmetic runs on the GPU in FP64, on HIP device 0 of the
- * calling process (select the GPU with HIP_VISIBLE_DEVICES). Re-entrant: concurrent callers get their own stream and device arena. */
+ * Host buffers in and out (the caller is the LocalMapping thread); all arithmetic runs on the GPU in FP64, on the device
+ * chosen with viorb_local_ba_set_device (default: the calling thread's current HIP device). Re-entrant: concurrent callers get their own stream and device arena. */
+/* Device of all window solves of this process: >= 0 fixes it, < 0 (default) = the calling thread's current HIP device. */
+int viorb_local_ba_set_device(int device);
 int viorb_local_ba_navstate(const double* kfs, int nk, int n_local, int prev_kf, const double* preint,
                             const double* points, int np, const int32_t* edge_idx, const double* edge_obs, int ne,
                             const double gw[3], const double cam[16], const volatile int* stop, double* kfs_out,
@@ -337,7 +419,7 @@ int viorb_local_ba_navstate(const double* kfs, int nk, int n_local, int prev_kf,
 
 /* Several windows at once (one per camera stream in a multi-stream deployment; the reference runs one LocalMapping thread per system):
  * each entry carries the arguments of one viorb_local_ba_navstate call and receives its return code in `status`. Up to max_in_flight
- * windows (<= 0: 16) are kept going concurrently, each on its own HIP stream of device 0, by ONE host thread that resumes a window's
+ * windows (<= 0: 16) are kept going concurrently, each on its own HIP stream of that device, by ONE host thread that resumes a window's
  * LM driver whenever its stream has drained — a single window is a chain of small latency-bound launches that leaves most of the GPU
  * idle, and several host threads calling the single-window entry point slow each other down inside the HIP runtime. Results are those
  * of the individual calls (to rounding: the Schur accumulation uses LDS atomics, whose order is not fixed from run to run). */

@@ -35,7 +35,13 @@ class OracleTracker:
         self.marg_cov_inv = np.asarray(marg_cov_inv, np.float64).reshape(12, 12).copy()
         self._adopt(k, d, pose_true, np.asarray(ns0, np.float64), t0)
 
-    def step(self, image, imu, t_cur, pose_true, t_next_last=None, reset_ns=None, reset_marg=None):
+    def step(self, image, imu, t_cur, pose_true, t_next_last=None, reset_ns=None, reset_marg=None, map_updated=False, recent_reloc=False,
+             last_points=None):
+        """One frame. Returns a dict with the intermediate results and `state`: 0 ok, 1 nmatches < 20 (TrackWithIMU returns false before
+        optimising, Tracking.cc:446-447), 2 nmatchesMap < 10 (revert, :518-533), 3 mnMatchesInliers < 15 (revert, :333-342), 4 recent
+        relocalisation and mnMatchesInliers < 30 (false without revert, :330-331). map_updated selects PoseOptimization(Frame, KeyFrame)
+        with the last frame as the key frame it was just promoted to (:454, :243). last_points = (Pw, flags, pts_f) overrides the synthetic
+        map points the NEW last frame gets (tests of the failure paths)."""
         kps, desc = self.ex(image)
         last = self.last_ns
         pre = ora.preintegrate(imu, last[10:13], last[13:16], self.t_last, t_cur)
@@ -52,23 +58,41 @@ class OracleTracker:
                                   np.stack([kps["x"][sel], kps["y"][sel]], 1).astype(np.float64),
                                   inv_s2[kps["octave"][sel]].astype(np.float64)[:, None]], 1).reshape(-1, 6)
         lk = self.last_kps
-        obs_last = np.concatenate([self.last_Pw.astype(np.float64), np.stack([lk["x"], lk["y"]], 1).astype(np.float64),
-                                   inv_s2[lk["octave"]].astype(np.float64)[:, None]], 1).reshape(-1, 6)
+        has = (self.last_flags & 1) != 0                  # the last frame's own edges: keypoints that hold a map point
+        obs_last = np.concatenate([self.last_Pw[has].astype(np.float64), np.stack([lk["x"][has], lk["y"][has]], 1).astype(np.float64),
+                                   inv_s2[lk["octave"][has]].astype(np.float64)[:, None]], 1).reshape(-1, 6)
         tlm = self.track_local_map
-        r = ora.pose_opt_vi_frame(cur_ns, last, self.prior_ns, self.marg_cov_inv, pre, self.gw, self.cam, obs_cur, obs_last,
-                                  marg=self.compute_marg and not tlm)
-        out = dict(n_kps=len(kps), nmatches=nm, match=match, n_inliers=r["n_inliers"], final_chi2=r["final_chi2"], ns=r["ns"],
-                   pred_ns=cur_ns, outlier_cur=r["outlier_cur"], kps=kps, desc=desc)
-        if tlm:
-            # discard outliers (Tracking.cc:489-507), then SearchLocalPoints + the second pose solve (:228-346)
+
+        def solve(ns0, obs, marg):
+            if map_updated:
+                return ora.pose_opt_vi_kf(ns0, last, pre, self.gw, self.cam, obs, marg=marg)
+            return ora.pose_opt_vi_frame(ns0, last, self.prior_ns, self.marg_cov_inv, pre, self.gw, self.cam, obs, obs_last, marg=marg)
+
+        out = dict(n_kps=len(kps), nmatches=nm, match=match, pred_ns=cur_ns, kps=kps, desc=desc, state=0)
+        state, final_ns, r = 0, cur_ns, None
+        if nm < 20:
+            state = 1
+        else:
+            r = solve(cur_ns, obs_cur, self.compute_marg and not tlm)
+            out.update(n_inliers=r["n_inliers"], final_chi2=r["final_chi2"], ns=r["ns"], outlier_cur=r["outlier_cur"], lm_iterations=r["lm_iterations"])
+            # discard outliers (Tracking.cc:489-507)
             match2 = match.copy()
             match2[sel[r["outlier_cur"][:len(sel)] != 0]] = -1
             owner = ((match2 >= 0) & ((self.last_flags[np.maximum(match2, 0)] & 4) != 0)).astype(np.uint8)
+            n_map = int(owner.sum())
+            out.update(n_map=n_map, match_after_discard=match2)
+            if n_map < 10:
+                state = 2                                   # revert: the frame keeps the IMU prediction
+            else:
+                final_ns = r["ns"]
+        if state == 0 and tlm:
+            # SearchLocalPoints + the second pose solve (:228-346)
+            ns1 = final_ns
             pts_f = np.concatenate([l[0] for l in self.local]) if self.local else np.zeros((0, 8), np.float32)
             pflags = np.concatenate([l[1] for l in self.local]) if self.local else np.zeros(0, np.uint8)
             pdesc = np.concatenate([l[2] for l in self.local]) if self.local else np.zeros((0, 32), np.uint8)
             offs = np.cumsum([0] + [len(l[0]) for l in self.local])
-            pose12_b = ora.pose_from_navstate(r["ns"], self.cam)
+            pose12_b = ora.pose_from_navstate(ns1, self.cam)
             log_sf = np.float32(np.log(np.float64(self.tab["scale"][1])))
             if len(pts_f):
                 n_loc, loc_match, _ = ora.search_local_points(kps, desc, self.bounds, pose12_b, self.cam[:4], self.tab["scale"], log_sf, pts_f, pflags,
@@ -81,16 +105,31 @@ class OracleTracker:
             X = np.where(use_a[sel2, None], self.last_Pw[np.maximum(match2[sel2], 0)], pts_f[np.maximum(loc_match[sel2], 0), :3] if len(pts_f) else 0.0)
             obs_cur2 = np.concatenate([X.astype(np.float64), np.stack([kps["x"][sel2], kps["y"][sel2]], 1).astype(np.float64),
                                        inv_s2[kps["octave"][sel2]].astype(np.float64)[:, None]], 1).reshape(-1, 6)
-            r2 = ora.pose_opt_vi_frame(r["ns"], last, self.prior_ns, self.marg_cov_inv, pre, self.gw, self.cam, obs_cur2, obs_last, marg=self.compute_marg)
-            out.update(n_map=int(owner.sum()), match_after_discard=match2, n_loc=n_loc, loc_match=loc_match, loc_offsets=offs, n_inliers2=r2["n_inliers"],
-                       final_chi2_2=r2["final_chi2"], ns2=r2["ns"], n_obs2=len(sel2))
-            r = r2
-        if self.compute_marg:
+            r2 = solve(ns1, obs_cur2, self.compute_marg)
+            # mnMatchesInliers (:307-325): inlier edges whose map point has observations
+            pf = np.where(use_a[sel2], self.last_flags[np.maximum(match2[sel2], 0)], pflags[np.maximum(loc_match[sel2], 0)] if len(pflags) else 0)
+            inl = int(((r2["outlier_cur"][:len(sel2)] == 0) & ((pf & 4) != 0)).sum())
+            out.update(n_loc=n_loc, loc_match=loc_match, loc_offsets=offs, n_inliers2=r2["n_inliers"], final_chi2_2=r2["final_chi2"], ns2=r2["ns"],
+                       n_obs2=len(sel2), inliers=inl, lm_iterations2=r2["lm_iterations"])
+            if recent_reloc and inl < 30:
+                state, final_ns, r = 4, r2["ns"], r2
+            elif inl < 15:
+                state = 3                                   # revert to the state this stage started from
+            else:
+                final_ns, r = r2["ns"], r2
+        out["state"] = state
+        out["final_ns"] = final_ns
+        if self.compute_marg and state in (0, 4) and r is not None:
             self.marg_cov_inv = r["marg_cov_inv"].copy()
+        t_adopt = t_cur if t_next_last is None else t_next_last
         if reset_ns is not None:                       # key-frame boundary of the harness: the next frame starts from the given state / prior
             if reset_marg is not None:
                 self.marg_cov_inv = np.asarray(reset_marg, np.float64).reshape(12, 12).copy()
-            self._adopt(kps, desc, pose_true, np.asarray(reset_ns, np.float64), t_cur if t_next_last is None else t_next_last)
-            return out
-        self._adopt(kps, desc, pose_true, r["ns"], t_cur if t_next_last is None else t_next_last)
+            self._adopt(kps, desc, pose_true, np.asarray(reset_ns, np.float64), t_adopt)
+        else:
+            self._adopt(kps, desc, pose_true, final_ns, t_adopt)
+        if last_points is not None:
+            self.last_Pw, self.last_flags = np.asarray(last_points[0], np.float32).copy(), np.asarray(last_points[1], np.uint8).copy()
+            if self.track_local_map and last_points[2] is not None:
+                self.last_pts_f = np.asarray(last_points[2], np.float32).copy()
         return out

@@ -1,0 +1,114 @@
+"""The C++ batched tracking sequence (viorb_tracker_*) against the oracle twin, stream by stream and frame by frame,
+including the reference's failure paths: nmatches < 20 (Tracking.cc:446-447), the nmatchesMap < 10 revert (:518-533), the
+mnMatchesInliers < 15 revert and the recent-relocalisation gate (:330-342), and the mbMapUpdated -> PoseOptimization(Frame, KeyFrame)
+variant (:243, :454). Streams are built to fail: a frame from another scene, corrupted map points, a nearly empty map."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(width, height, nfeat, nframes, plan):
+    """plan(stream, frame, twin) -> dict(image=..., map_updated=bool, recent_reloc=bool, last_points=fn or None)."""
+    import torch
+    from viorb_amd.synth import make_periodic_stream
+    from viorb_amd.tracker import NativeTracker
+    from oracle.harness import OracleTracker
+    B = plan["B"]
+    streams = [make_periodic_stream(200 + (b % plan.get("distinct", B)), nframes, width, height) for b in range(B)]
+    dev = torch.device("cuda", 0)
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    cam, gw = streams[0]["cam"], streams[0]["gw"]
+    tr = NativeTracker(cam, gw, B, width, height, nfeat, track_local_map=True)
+    twins = [OracleTracker(cam, gw, width, height, nfeat, track_local_map=True) for _ in range(B)]
+    mci = np.eye(12) * 1e3
+    fr = lambda j: np.stack([plan["image"](b, j, streams) for b in range(B)])
+    tr.bootstrap(up(fr(0)), up(np.stack([s["pose_true"][0] for s in streams])), up(np.array([s["t"][0] for s in streams])),
+                 up(np.stack([s["ns_true"][0] for s in streams])), up(np.stack([mci.ravel()] * B)))
+    for b, tw in enumerate(twins):
+        tw.bootstrap(plan["image"](b, 0, streams), streams[b]["pose_true"][0], streams[b]["t"][0], streams[b]["ns_true"][0], mci)
+    seen = set()
+    for j in range(1, nframes):
+        mu = np.array([plan["map_updated"](b, j) for b in range(B)], np.uint8)
+        rr = np.array([plan["recent_reloc"](b, j) for b in range(B)], np.uint8)
+        tr.step(up(fr(j)), up(np.stack([s["imu"][j] for s in streams])), up(np.array([s["t"][j] for s in streams])),
+                up(np.stack([s["pose_true"][j] for s in streams])), map_updated=up(mu), recent_reloc=up(rr))
+        g = tr.results()
+        # overrides of the new last frame's map points (the same arrays go to both sides)
+        ov = [plan["last_points"](b, j) for b in range(B)]
+        lp = [None] * B
+        if any(o is not None for o in ov):
+            Pw, fl, pf = g["last_Pw"].copy(), g["last_flags"].copy(), g["last_pts_f"].copy()
+            for b, o in enumerate(ov):
+                if o is None:
+                    continue
+                n = int(g["last_count"][b])
+                Pw[b, :n], fl[b, :n], pf[b, :n] = o(Pw[b, :n].copy(), fl[b, :n].copy(), pf[b, :n].copy())
+                lp[b] = (Pw[b, :n].copy(), fl[b, :n].copy(), pf[b, :n].copy())
+            tr.set_last_points(up(Pw), up(fl), up(pf))
+        for b, tw in enumerate(twins):
+            r = tw.step(plan["image"](b, j, streams), streams[b]["imu"][j], streams[b]["t"][j], streams[b]["pose_true"][j],
+                        map_updated=bool(mu[b]), recent_reloc=bool(rr[b]), last_points=lp[b])
+            tag = "stream %d frame %d state %d" % (b, j, r["state"])
+            seen.add(r["state"])
+            assert int(g["status"][b]) == 0, tag
+            assert int(g["state"][b]) == r["state"], (tag, int(g["state"][b]))
+            assert int(g["nmatches"][b]) == r["nmatches"], tag
+            assert np.array_equal(g["cur_match"][b, :r["n_kps"]], r["match"] if r["state"] == 1 else r["match_after_discard"]), tag
+            assert np.allclose(g["pred_ns"][b], r["pred_ns"], rtol=0, atol=1e-9), tag
+            if r["state"] != 1:
+                assert int(g["n_map"][b]) == r["n_map"], tag
+                assert int(g["info"][b, 0]) == r["n_inliers"] and int(g["info"][b, 2]) == r["lm_iterations"], tag
+                assert abs(g["info"][b, 1] - r["final_chi2"]) <= 1e-5 * abs(r["final_chi2"]), tag
+            if "n_inliers2" in r:
+                assert int(g["n_loc"][b]) == r["n_loc"] and int(g["inliers"][b]) == r["inliers"], tag
+                assert int(g["info2"][b, 0]) == r["n_inliers2"] and int(g["info2"][b, 2]) == r["lm_iterations2"], tag
+                assert abs(g["info2"][b, 1] - r["final_chi2_2"]) <= 1e-5 * abs(r["final_chi2_2"]), tag
+            assert np.allclose(g["final_ns"][b], r["final_ns"], rtol=0, atol=1e-7), tag
+            assert np.allclose(g["last_ns"][b], tw.last_ns, rtol=0, atol=1e-7), tag
+    return seen
+
+
+def test_native_tracker_failure_paths_equal_oracle_twin():
+    rng = np.random.default_rng(5)
+    noise = rng.normal(0, 1, (4000, 3)).astype(np.float32)
+
+    def image(b, j, streams):
+        if b == 1 and j == 3:
+            return streams[0]["frames"][(j + 3) % len(streams[0]["frames"])][::-1, ::-1].copy()     # another scene: nothing to match
+        return streams[b]["frames"][j]
+
+    def last_points(b, j):
+        if b == 2 and j == 2:                        # every map point of the new last frame moved sideways: matches become outliers
+            def f(Pw, fl, pf):
+                Pw = Pw + 0.12 * noise[:len(Pw)] * np.array([1, 1, 0], np.float32)
+                pf[:, :3] = Pw
+                return Pw, fl, pf
+            return f
+        if b in (3, 4) and j in (1, 2):              # an (almost) empty map behind the frame: few matches on the next frames
+            return lambda Pw, fl, pf: (Pw, np.zeros_like(fl), pf)
+        if b in (3, 4) and j == 3:                   # 26 map points, half of them wrong, empty local map: stage 2 ends below 15 inliers
+            def f(Pw, fl, pf):
+                keep = np.zeros(len(fl), bool); keep[::max(1, len(fl) // 26)][:26] = True
+                fl = np.where(keep, fl, 0).astype(np.uint8)
+                idx = np.nonzero(keep)[0][::2]
+                Pw[idx] += 0.5 * noise[:len(idx)] * np.array([1, 1, 0], np.float32)
+                pf[:, :3] = Pw
+                return Pw, fl, pf
+            return f
+        return None
+
+    plan = dict(B=5, distinct=4, image=image, last_points=last_points,
+                map_updated=lambda b, j: (b == 0 and j in (2, 5)) or (b == 2 and j == 4),
+                recent_reloc=lambda b, j: b == 4 or (b == 0 and j == 3))
+    seen = _run(752, 480, 1000, 6, plan)
+    assert {0, 1}.issubset(seen), seen
+    assert seen & {2, 3, 4}, seen                    # at least one revert / relocalisation gate was taken
+
+
+def test_native_tracker_1280x720_1500_features_equals_twin():
+    """BASELINE config 5's shape (1280x720, 1500 features) through the whole two-stage sequence (closes configs_untested)."""
+    plan = dict(B=2, image=lambda b, j, streams: streams[b]["frames"][j], last_points=lambda b, j: None,
+                map_updated=lambda b, j: b == 1 and j == 2, recent_reloc=lambda b, j: False)
+    seen = _run(1280, 720, 1500, 4, plan)
+    assert seen == {0}, seen

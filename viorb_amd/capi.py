@@ -48,6 +48,28 @@ class ExtractorParams(C.Structure):
                 ("ini_th_fast", C.c_int32), ("min_th_fast", C.c_int32)]
 
 
+class TrackerConfig(C.Structure):
+    """viorb_tracker_config (include/viorb.h)."""
+    _fields_ = [("extractor", ExtractorParams), ("frontend", FrontendConfig), ("width", C.c_int32), ("height", C.c_int32), ("batch", C.c_int32),
+                ("device", C.c_int32), ("th_projection", C.c_float), ("track_local_map", C.c_int32), ("local_frames", C.c_int32),
+                ("compute_marg", C.c_int32), ("max_steps_ahead", C.c_int32), ("synth_plane_z0", C.c_double)]
+
+
+class TrackerInputs(C.Structure):
+    """viorb_tracker_inputs (include/viorb.h)."""
+    _fields_ = [("d_images", C.c_void_p), ("image_stride", C.c_int32), ("image_pitch_bytes", C.c_size_t), ("d_imu", C.c_void_p), ("n_imu", C.c_int32),
+                ("d_t_cur", C.c_void_p), ("d_map_updated", C.c_void_p), ("d_recent_reloc", C.c_void_p), ("d_t_next_last", C.c_void_p),
+                ("d_reset_ns", C.c_void_p), ("d_reset_marg", C.c_void_p), ("d_synth_pose12", C.c_void_p)]
+
+
+class TrackerResults(C.Structure):
+    """viorb_tracker_results (include/viorb.h)."""
+    _fields_ = [("cap", C.c_int32)] + [(n, C.c_void_p) for n in (
+        "state", "status", "nmatches", "n_map", "n_loc", "inliers", "n_obs", "n_obs2", "cur_match", "loc_match", "last_count",
+        "info", "info2", "pred_ns", "ns_stage1", "ns_stage2", "final_ns", "final_marg", "last_ns",
+        "outlier_cur", "outlier_cur2", "last_flags", "last_Pw", "last_pts_f", "extractor")]
+
+
 vp, i32, f32, sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 PP = C.POINTER
 # name -> (restype, argtypes); mirrors include/viorb.h
@@ -81,6 +103,7 @@ SIGNATURES = {
     "viorb_pose_opt_se3": (i32, [vp, vp, vp, i32, vp, vp, vp]),
     "viorb_local_ba_navstate": (i32, [vp, i32, i32, i32, vp, vp, i32, vp, vp, i32] + [vp] * 7),
     "viorb_local_ba_navstate_batch": (i32, [vp, i32, i32]),
+    "viorb_local_ba_set_device": (i32, [i32]),
     "viorb_local_ba_se3_batch": (i32, [vp, i32, i32]),
     "viorb_local_ba_se3": (i32, [vp, i32, i32, vp, i32, vp, vp, i32] + [vp] * 6),
     "viorb_vocabulary_create": (i32, [i32, i32, vp, vp, vp, vp, vp, PP(vp)]),
@@ -102,6 +125,19 @@ SIGNATURES = {
     "viorb_synth_plane_points_device": (i32, [vp, vp, vp, vp, C.c_double, i32, vp, vp, vp, vp]),
     "viorb_frontend_roll_device": (i32, [vp] * 12 + [i32, i32] + [vp] * 7 + [i32, vp]),
     "viorb_memcpy_dtod_async": (i32, [vp, vp, sz, vp]),
+    "viorb_memcpy_dtoh": (i32, [vp, vp, sz]),
+    "viorb_memcpy_htod": (i32, [vp, vp, sz]),
+    "viorb_frontend_pose_opt_select_device": (i32, [vp, vp, vp, i32] + [vp] * 9 + [i32] + [vp] * 7),
+    "viorb_frontend_self_index_device": (i32, [vp, vp, vp, i32, vp, vp]),
+    "viorb_tracker_create": (i32, [PP(TrackerConfig), PP(vp)]),
+    "viorb_tracker_destroy": (i32, [vp]),
+    "viorb_tracker_capacity": (i32, [vp, PP(i32)]),
+    "viorb_tracker_bootstrap": (i32, [vp, vp, i32, sz, vp, vp, vp, vp, vp]),
+    "viorb_tracker_set_last_points_device": (i32, [vp, vp, vp, vp, vp]),
+    "viorb_tracker_step": (i32, [vp, PP(TrackerInputs), vp]),
+    "viorb_tracker_sync": (i32, [vp]),
+    "viorb_tracker_results_device": (i32, [vp, PP(TrackerResults)]),
+    "viorb_tracker_host_stats": (i32, [vp, PP(C.c_double), PP(C.c_double), PP(C.c_longlong), i32]),
     "viorb_profile_enable": (i32, [i32]),
     "viorb_profile_reset": (i32, []),
     "viorb_profile_select": (i32, [C.c_char_p]),

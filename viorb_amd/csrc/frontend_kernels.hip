@@ -794,6 +794,12 @@ __global__ __launch_bounds__(256) void k_roll(RollArgs A) {
 // Workload support (not a reference function): map points for the keypoints of a frame of the
 // synthetic plane world of viorb_amd/synth.py — intersects the pixel ray with the plane z = z0 using
 // the given camera pose (Rcw, tcw) in double, writes float world points and flags = 1|4.
+__global__ void k_self_index(const uint8_t* __restrict__ flags, const int* __restrict__ count, int cap, int* __restrict__ self_index) {
+    const int b = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cap) return;
+    self_index[(size_t)b * cap + i] = (i < count[b] && (flags[(size_t)b * cap + i] & 1)) ? i : -1;
+}
+
 __global__ void k_synth_plane_points(const viorb_keypoint* __restrict__ kps, const int* __restrict__ count, int cap,
                                      const double* __restrict__ pose12, double fx, double fy, double cx, double cy, double z0,
                                      float* __restrict__ Pw, uint8_t* __restrict__ flags, int* __restrict__ self_index) {
@@ -826,6 +832,8 @@ struct PoseOptArgs {
     double *out_ns, *out_last_ns, *marg_out, *info;
     uint8_t *outlier_cur, *outlier_last;
     double acc_bias_rw2;
+    const uint8_t* variant_arr;  // optional per-problem variant (overrides `variant`)
+    const uint8_t* skip;         // optional: problems with skip[b] != 0 return at once like "fewer than 3 correspondences"
 };
 
 struct PoseOptShared {
@@ -1099,8 +1107,10 @@ __global__ __launch_bounds__(POSE_THREADS, 2) void k_pose_opt_vi(PoseOptArgs A) 
     const unsigned long long pt_begin = __builtin_amdgcn_s_memtime();
 #endif
     const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6, cap = A.cap;
-    const int variant = A.variant, n = variant ? 24 : 12;
-    const int ncur = min(A.n_cur[b], cap), nlast = variant ? min(A.n_last[b], cap) : 0;
+    const int variant = A.variant_arr ? (A.variant_arr[b] ? 1 : 0) : A.variant, n = variant ? 24 : 12;
+    const bool skipped = A.skip && A.skip[b];
+    const int ncur_all = min(A.n_cur[b], cap);                            // a skipped problem still clears its outlier flags
+    const int ncur = skipped ? 0 : ncur_all, nlast = variant ? min(A.n_last[b], cap) : 0;
     const double* obs_c = A.obs_cur + (size_t)b * cap * 6;
     const double* obs_l = A.obs_last ? A.obs_last + (size_t)b * cap * 6 : nullptr;
     uint8_t* out_c = A.outlier_cur + (size_t)b * cap;
@@ -1114,7 +1124,7 @@ __global__ __launch_bounds__(POSE_THREADS, 2) void k_pose_opt_vi(PoseOptArgs A) 
                  d_prior = (double)(float)sqrt(30.5779);
     const double bias_info = 1.0 / A.acc_bias_rw2 / pre[141];
     // ---- setup
-    for (int i = t; i < ncur; i += blockDim.x) out_c[i] = 0;
+    for (int i = t; i < ncur_all; i += blockDim.x) out_c[i] = 0;
     for (int i = t; i < nlast; i += blockDim.x) out_l[i] = 0;
     struct obs_t { d3 X; double u, v, is2; };
     // Observations stay in global memory (L2): an LDS copy (24 B per edge as float) made one solve 4 % faster alone and the whole
@@ -2184,8 +2194,39 @@ int viorb_frontend_pose_opt_device(viorb_frontend* h, int variant, int compute_m
     A.gw = h->d_gw; A.cam = h->d_cam; A.obs_cur = obs_cur; A.obs_last = variant ? obs_last : nullptr; A.n_cur = n_cur; A.n_last = n_last;
     A.out_ns = out_ns; A.out_last_ns = out_last_ns; A.marg_out = marg_out; A.info = info;
     A.outlier_cur = outlier_cur; A.outlier_last = variant ? outlier_last : nullptr; A.acc_bias_rw2 = h->cfg.acc_bias_rw2;
+    A.variant_arr = nullptr; A.skip = nullptr;
     ProfScope ps("k_pose_opt_vi", (hipStream_t)stream);
     hipLaunchKernelGGL(k_pose_opt_vi, dim3(batch), dim3(POSE_THREADS), 0, (hipStream_t)stream, A);
+    VIORB_HIP_TRY(hipGetLastError());
+    return VIORB_OK;
+}
+
+int viorb_frontend_pose_opt_select_device(viorb_frontend* h, const uint8_t* variant, const uint8_t* skip, int compute_marg,
+                                          const double* cur_ns, const double* last_ns, const double* prior_ns, const double* marg_cov_inv,
+                                          const double* preint, const double* obs_cur, const int32_t* n_cur, const double* obs_last,
+                                          const int32_t* n_last, int batch, double* out_ns, double* out_last_ns, uint8_t* outlier_cur,
+                                          uint8_t* outlier_last, double* marg_out, double* info, void* stream) {
+    FE_CHECK_BATCH(h, batch);
+    VIORB_REQUIRE(cur_ns && last_ns && preint && obs_cur && n_cur && out_ns && outlier_cur && info, "null array");
+    VIORB_REQUIRE(prior_ns && marg_cov_inv && obs_last && n_last && outlier_last, "the Frame variant needs prior and last-frame arrays");
+    VIORB_REQUIRE(!compute_marg || marg_out, "marg_out is NULL");
+    PoseOptArgs A;
+    A.variant = 1; A.compute_marg = compute_marg; A.cap = h->cap;
+    A.cur_ns = cur_ns; A.last_ns = last_ns; A.prior_ns = prior_ns; A.marg_cov_inv = marg_cov_inv; A.preint = preint;
+    A.gw = h->d_gw; A.cam = h->d_cam; A.obs_cur = obs_cur; A.obs_last = obs_last; A.n_cur = n_cur; A.n_last = n_last;
+    A.out_ns = out_ns; A.out_last_ns = out_last_ns; A.marg_out = marg_out; A.info = info;
+    A.outlier_cur = outlier_cur; A.outlier_last = outlier_last; A.acc_bias_rw2 = h->cfg.acc_bias_rw2;
+    A.variant_arr = variant; A.skip = skip;
+    ProfScope ps("k_pose_opt_vi", (hipStream_t)stream);
+    hipLaunchKernelGGL(k_pose_opt_vi, dim3(batch), dim3(POSE_THREADS), 0, (hipStream_t)stream, A);
+    VIORB_HIP_TRY(hipGetLastError());
+    return VIORB_OK;
+}
+
+int viorb_frontend_self_index_device(viorb_frontend* h, const uint8_t* flags, const int32_t* count, int batch, int32_t* self_index, void* stream) {
+    FE_CHECK_BATCH(h, batch);
+    VIORB_REQUIRE(flags && count && self_index, "null array");
+    hipLaunchKernelGGL(k_self_index, dim3((h->cap + 255) / 256, batch), dim3(256), 0, (hipStream_t)stream, flags, count, h->cap, self_index);
     VIORB_HIP_TRY(hipGetLastError());
     return VIORB_OK;
 }

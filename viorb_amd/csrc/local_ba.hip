@@ -603,19 +603,32 @@ using namespace viorb;
 namespace {
 // A solve borrows a context (a HIP stream + a device arena) from a small pool, so that concurrent callers (the LocalMapping threads
 // of several SLAM instances) run on different streams and no call pays hipMalloc / hipFree, which synchronise the whole device.
-struct BaCtx { hipStream_t st = nullptr; void* arena = nullptr; size_t bytes = 0; double* pinned = nullptr; /* 16 doubles of page-locked host memory for the LM scalars */ };
+struct BaCtx { hipStream_t st = nullptr; void* arena = nullptr; size_t bytes = 0; double* pinned = nullptr; /* 16 doubles of page-locked host memory for the LM scalars */ int device = 0; };
 std::mutex g_ctx_mu;
 std::vector<BaCtx*> g_ctx_free;
+std::atomic<int> g_lba_device{-1};
+// The device the window solves run on: viorb_local_ba_set_device(), else the calling thread's current HIP device (what
+// torch.cuda.set_device(LOCAL_RANK) / hipSetDevice selected), so that under torchrun every rank's windows land on its own GPU.
+static int lba_device() {
+    int d = g_lba_device.load();
+    if (d < 0 && hipGetDevice(&d) != hipSuccess) d = 0;
+    return d;
+}
 struct BaCtxLease {
     BaCtx* c = nullptr;
-    BaCtxLease() {
-        std::lock_guard<std::mutex> lk(g_ctx_mu);
-        if (!g_ctx_free.empty()) { c = g_ctx_free.back(); g_ctx_free.pop_back(); }
-    }
+    BaCtxLease() {}
     ~BaCtxLease() { if (c) { std::lock_guard<std::mutex> lk(g_ctx_mu); g_ctx_free.push_back(c); } }
-    bool ready() {
+    bool ready() {                     // the calling thread has selected the device (hipSetDevice(lba_device()))
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return false;
+        if (!c) {
+            std::lock_guard<std::mutex> lk(g_ctx_mu);
+            for (size_t i = 0; i < g_ctx_free.size(); i++)
+                if (g_ctx_free[i]->device == dev) { c = g_ctx_free[i]; g_ctx_free.erase(g_ctx_free.begin() + i); break; }
+        }
         if (!c) {
             c = new BaCtx();
+            c->device = dev;
             if (hipStreamCreateWithFlags(&c->st, hipStreamNonBlocking) != hipSuccess || hipHostMalloc(reinterpret_cast<void**>(&c->pinned), 16 * sizeof(double)) != hipSuccess) {
                 delete c; c = nullptr; return false;
             }
@@ -849,7 +862,7 @@ static int ba_prepare_navstate(BaSolve& S, const double* kfs, int nk, int n_loca
     std::vector<double> info_pvr((size_t)n_local * 81);
     for (int i = 0; i < n_local; i++) if (!host_inverse9(preint + (size_t)i * 142 + 60, &info_pvr[(size_t)i * 81])) { set_error("singular IMU covariance"); return VIORB_ERR_INVALID_ARG; }
 
-    VIORB_HIP_TRY(hipSetDevice(0));
+    VIORB_HIP_TRY(hipSetDevice(lba_device()));
     BaCtxLease& lease = S.lease;
     if (!lease.ready()) { set_error("could not create a HIP stream"); return VIORB_ERR_HIP; }
     BaBuf B; BaDev& D = S.D;
@@ -875,6 +888,13 @@ static int ba_prepare_navstate(BaSolve& S, const double* kfs, int nk, int n_loca
     return VIORB_OK;
 }
 
+extern "C" int viorb_local_ba_set_device(int device) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || device >= n) { set_error("no such HIP device: %d", device); return VIORB_ERR_INVALID_ARG; }
+    g_lba_device.store(device < 0 ? -1 : device);
+    return VIORB_OK;
+}
+
 extern "C" int viorb_local_ba_navstate(const double* kfs, int nk, int n_local, int prev_kf, const double* preint, const double* points, int npts,
                                        const int32_t* edge_idx, const double* edge_obs, int ne, const double gw[3], const double cam[16],
                                        const volatile int* stop, double* kfs_out, double* points_out, uint8_t* erase, double info[6]) {
@@ -889,7 +909,7 @@ template <class Prepare, class SetStatus>
 static int ba_run_batch(int n, int max_in_flight, Prepare prepare, SetStatus set_status) {
     if (viorb_device_count() < 1) { set_error("no HIP device: libviorb_hip has no CPU fallback"); return VIORB_ERR_NO_DEVICE; }
     if (max_in_flight <= 0) max_in_flight = 16;
-    VIORB_HIP_TRY(hipSetDevice(0));
+    VIORB_HIP_TRY(hipSetDevice(lba_device()));
     std::vector<std::unique_ptr<BaSolve>> live(std::min(max_in_flight, std::max(n, 1)));
     std::vector<int> which(live.size(), -1);
     int next = 0, finished = 0, first_error = VIORB_OK;
@@ -965,7 +985,7 @@ static int ba_prepare_se3(BaSolve& S, const double* kfs, int nk, int n_local, co
     for (int i = 0; i < n_local; i++) kf_start[i + 1] += kf_start[i];
     kf_list.resize(kf_start[n_local]);
     { std::vector<int> pos(kf_start.begin(), kf_start.end() - 1); for (int k = 0; k < ne; k++) if (e_kf[k] < n_local) kf_list[pos[e_kf[k]]++] = k; }
-    VIORB_HIP_TRY(hipSetDevice(0));
+    VIORB_HIP_TRY(hipSetDevice(lba_device()));
     BaCtxLease& lease = S.lease;
     if (!lease.ready()) { set_error("could not create a HIP stream"); return VIORB_ERR_HIP; }
     BaBuf B; BaDev& D = S.D;

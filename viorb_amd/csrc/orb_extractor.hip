@@ -38,7 +38,7 @@ namespace {
 struct ProfRec { hipEvent_t a, b; int slot; };
 struct Profiler {
     bool enabled = false;
-    std::string only;                 // when not empty: only this kernel is timed (an event pair costs ~8 us of stream time)
+    std::string only;                 // when not empty: only these kernels (comma-separated) are timed (an event pair costs ~8 us of stream time)
     std::vector<std::string> names;
     std::vector<ProfRec> recs;
     size_t used = 0;
@@ -46,7 +46,10 @@ struct Profiler {
 }
 ProfScope::ProfScope(const char* name, hipStream_t s) : idx(-1), st(s) {
     if (!g_prof.enabled) return;
-    if (!g_prof.only.empty() && g_prof.only != name) return;
+    if (!g_prof.only.empty()) {                  // comma-separated list of kernel names
+        const std::string key = "," + g_prof.only + ",", me = std::string(",") + name + ",";
+        if (key.find(me) == std::string::npos) return;
+    }
     if (g_prof.used >= g_prof.recs.size()) {
         if (g_prof.recs.size() >= 16384) return;
         ProfRec r; r.slot = -1;

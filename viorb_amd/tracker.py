@@ -19,6 +19,7 @@ torch tensors only carry device memory and the stream."""
 import ctypes as C
 import numpy as np
 from .capi import lib, check, ptr, KP_DTYPE
+from . import capi as capi_mod
 from .extractor import ORBextractor
 from .frontend import Frontend
 from . import synth
@@ -226,3 +227,109 @@ def _hip_memcpy_dtod_async(dst, src, nbytes, stream):
     """Device-to-device copy of raw device addresses on `stream`, through libviorb_hip's own HIP runtime binding
     (dlopen-ing libamdhip64 by name from Python could load a second runtime next to torch's)."""
     return lib().viorb_memcpy_dtod_async(C.c_void_p(dst), C.c_void_p(src), nbytes, stream)
+
+
+class NativeTracker:
+    """The C++ batched tracking sequence (viorb_tracker_*, viorb_amd/csrc/tracker.hip): one host call per frame enqueues
+    TrackWithIMU + TrackLocalMapWithIMU for B streams with the reference's thresholds and backup / revert decisions taken per stream
+    on the device (reference src/Tracking.cc:229-346, 412-534). This class only marshals torch tensors into the C structs and keeps the
+    inputs of the steps still in flight alive (they are read on the tracker's own HIP streams: a caller that drops a tensor right after
+    step() would otherwise hand its memory back to torch's caching allocator while the GPU still reads it)."""
+    STATE_NAMES = ("ok", "few_matches", "revert_1", "revert_2", "reloc_few")
+
+    def __init__(self, cam, gw, batch, width=752, height=480, nfeatures=1000, th=15.0, device=0, compute_marg=True, track_local_map=True,
+                 local_frames=2, max_steps_ahead=8, scale_factor=1.2, nlevels=8, ini_th=20, min_th=7):
+        import torch
+        self.torch = torch
+        self.B, self.w, self.h = batch, width, height
+        self.dev = torch.device("cuda", device)
+        cfg = capi_mod.TrackerConfig()
+        cfg.extractor.nfeatures, cfg.extractor.scale_factor, cfg.extractor.nlevels = nfeatures, scale_factor, nlevels
+        cfg.extractor.ini_th_fast, cfg.extractor.min_th_fast = ini_th, min_th
+        fe = cfg.frontend
+        fe.fx, fe.fy, fe.cx, fe.cy = [float(np.float32(v)) for v in cam[:4]]
+        for i in range(16):
+            fe.cam[i] = float(cam[i])
+        for i in range(3):
+            fe.gravity[i] = float(gw[i])
+        fe.check_orientation = 1
+        cfg.width, cfg.height, cfg.batch, cfg.device = width, height, batch, device
+        cfg.th_projection = float(th); cfg.track_local_map = int(track_local_map); cfg.local_frames = int(local_frames)
+        cfg.compute_marg = int(compute_marg); cfg.max_steps_ahead = int(max_steps_ahead); cfg.synth_plane_z0 = float(synth.PLANE_Z0)
+        h = C.c_void_p()
+        check(lib().viorb_tracker_create(C.byref(cfg), C.byref(h)))
+        self.hnd = h
+        cap = C.c_int()
+        check(lib().viorb_tracker_capacity(h, C.byref(cap)))
+        self.cap = cap.value
+        self.track_local_map = bool(track_local_map)
+        self._keep = []
+        self.max_steps_ahead = max_steps_ahead
+
+    def close(self):
+        if getattr(self, "hnd", None):
+            lib().viorb_tracker_destroy(self.hnd); self.hnd = None
+
+    __del__ = close
+
+    def _stream(self):
+        return C.c_void_p(self.torch.cuda.current_stream(self.dev).cuda_stream)
+
+    def bootstrap(self, images, true_pose12, t0, ns0, marg_cov_inv):
+        assert images.is_cuda and images.dim() == 3 and images.stride(2) == 1
+        check(lib().viorb_tracker_bootstrap(self.hnd, ptr(images), images.stride(1), images.stride(0), ptr(ns0), ptr(t0), ptr(marg_cov_inv),
+                                            ptr(true_pose12), self._stream()))
+        self._keep = []
+
+    def step(self, images, imu, t_cur, true_pose12=None, map_updated=None, recent_reloc=None, t_next_last=None, reset_ns=None, reset_marg=None):
+        """images [B,h,w] u8, imu [B,n,7] f64, t_cur [B] f64 — CUDA tensors. true_pose12 [B,12] f64: map points of the new last frame from
+        the synthetic plane world (None: call set_last_points before the next step). map_updated / recent_reloc: [B] u8 flags."""
+        inp = capi_mod.TrackerInputs()
+        inp.d_images = images.data_ptr(); inp.image_stride = images.stride(1); inp.image_pitch_bytes = images.stride(0)
+        inp.d_imu = imu.data_ptr(); inp.n_imu = imu.shape[1]; inp.d_t_cur = t_cur.data_ptr()
+        opt = lambda t: t.data_ptr() if t is not None else None
+        inp.d_map_updated = opt(map_updated); inp.d_recent_reloc = opt(recent_reloc); inp.d_t_next_last = opt(t_next_last)
+        inp.d_reset_ns = opt(reset_ns); inp.d_reset_marg = opt(reset_marg); inp.d_synth_pose12 = opt(true_pose12)
+        check(lib().viorb_tracker_step(self.hnd, C.byref(inp), self._stream()))
+        self._keep.append((images, imu, t_cur, true_pose12, map_updated, recent_reloc, t_next_last, reset_ns, reset_marg))
+        if len(self._keep) > self.max_steps_ahead + 1:          # the C++ throttle has waited for everything older
+            self._keep.pop(0)
+
+    def set_last_points(self, Pw, flags, pts_f=None):
+        check(lib().viorb_tracker_set_last_points_device(self.hnd, ptr(Pw), ptr(flags), ptr(pts_f) if pts_f is not None else None, self._stream()))
+        self._keep.append((Pw, flags, pts_f))
+
+    def sync(self):
+        check(lib().viorb_tracker_sync(self.hnd))
+        self._keep = []
+
+    def host_stats(self, reset=False):
+        a, b, n = C.c_double(), C.c_double(), C.c_longlong()
+        check(lib().viorb_tracker_host_stats(self.hnd, C.byref(a), C.byref(b), C.byref(n), int(reset)))
+        return dict(enqueue_s=a.value, throttle_s=b.value, steps=n.value)
+
+    def results(self, names=None):
+        """Synchronise and copy results of the last step to the host: dict of numpy arrays."""
+        self.sync()
+        r = capi_mod.TrackerResults()
+        check(lib().viorb_tracker_results_device(self.hnd, C.byref(r)))
+        B, cap = self.B, self.cap
+        shapes = dict(state=((B,), np.int32), status=((B,), np.int32), nmatches=((B,), np.int32), n_map=((B,), np.int32), n_loc=((B,), np.int32),
+                      inliers=((B,), np.int32), n_obs=((B,), np.int32), n_obs2=((B,), np.int32), cur_match=((B, cap), np.int32),
+                      loc_match=((B, cap), np.int32), last_count=((B,), np.int32), info=((B, 4), np.float64), info2=((B, 4), np.float64),
+                      pred_ns=((B, 22), np.float64), ns_stage1=((B, 22), np.float64), ns_stage2=((B, 22), np.float64),
+                      final_ns=((B, 22), np.float64), final_marg=((B, 144), np.float64), last_ns=((B, 22), np.float64),
+                      outlier_cur=((B, cap), np.uint8), outlier_cur2=((B, cap), np.uint8), last_flags=((B, cap), np.uint8),
+                      last_Pw=((B, cap, 3), np.float32), last_pts_f=((B, cap, 8), np.float32))
+        out = {}
+        for k in (names or shapes.keys()):
+            shp, dt = shapes[k]
+            a = np.zeros(shp, dt)
+            check(lib().viorb_memcpy_dtoh(ptr(a), C.c_void_p(getattr(r, k)), a.nbytes))
+            out[k] = a
+        return out
+
+    def device_ptrs(self):
+        r = capi_mod.TrackerResults()
+        check(lib().viorb_tracker_results_device(self.hnd, C.byref(r)))
+        return r
