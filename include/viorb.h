@@ -198,6 +198,18 @@ int viorb_frontend_search_projection_retry_device(viorb_frontend* h, const viorb
                                             float th, int retry_below, int batch, int32_t* cur_match, int32_t* nmatches, int32_t* status,
                                             void* stream);
 
+/* The stereo / RGB-D branch of the same search (bMono == false; reference src/ORBmatcher.cc:1346-1349, 1385-1410): cur_uright[b][cap] =
+ * CurrentFrame.mvuRight (<= 0: no right match), last_pose12[b] = LastFrame.mTcw, bf = mbf, mb = mb. When the camera has moved forward
+ * (backward) along the last frame's optical axis by more than the baseline, the candidates come from the octaves >= (<=) the point's
+ * octave instead of octave +- 1, and a candidate with a right coordinate must agree with the projected one within the window radius. */
+int viorb_frontend_search_projection_stereo_device(viorb_frontend* h, const viorb_keypoint* cur_kps, const uint8_t* cur_desc,
+                                                   const int32_t* cur_count, const float* cur_uright, const int32_t* cell_start,
+                                                   const int32_t* cell_idx, const float* pose12, const float* last_pose12,
+                                                   const viorb_keypoint* last_kps, const int32_t* last_count, const uint8_t* last_flags,
+                                                   const float* last_Pw, const uint8_t* last_desc, float th, float bf, float mb,
+                                                   int retry_below, int batch, int32_t* cur_match, int32_t* nmatches, int32_t* status,
+                                                   void* stream);
+
 /* Tracking::SearchLocalPoints (reference src/Tracking.cc:1904-1958): Frame::isInFrustum(pMP, 0.5) for every local map
  * point that is valid and not yet matched in this frame, then ORBmatcher::SearchByProjection(F, vpMapPoints, th)
  * (src/ORBmatcher.cc:45-129, ORBmatcher(nnratio)). pts_f[b][pcap][8] = Pw3 normal3 mfMinDistance mfMaxDistance,
@@ -384,6 +396,22 @@ int viorb_search_by_projection_frame(const viorb_keypoint* cur_kps, const uint8_
                                      const float pose12[12], const float intr4[4], const float* scale_factors, int nlevels,
                                      const viorb_keypoint* last_kps, int nlast, const uint8_t* last_flags, const float* last_Pw,
                                      const uint8_t* last_desc, float th, int check_orientation, int32_t* cur_match, int* nmatches);
+/* Tracking::SearchLocalPoints' matcher call (reference src/Tracking.cc:1904-1958): Frame::isInFrustum(pMP, 0.5) for every local map point
+ * (src/Frame.cc:449-505) followed by ORBmatcher(nnratio).SearchByProjection(F, vpMapPoints, th) (src/ORBmatcher.cc:45-129), host arrays.
+ * Layouts as viorb_frontend_search_local_points_device: pts_f[p][8] = Pw3 normal3 mfMinDistance mfMaxDistance, pts_flags bit0 !isBad,
+ * bit1 mnLastFrameSeen == frame id, bit2 Observations() > 0, cur_owner_obs[i] != 0 where keypoint i already holds a map point with
+ * observations. match[i] = local point given to keypoint i or -1; frustum5 (may be NULL) [p][5] = mbTrackInView mTrackProjX mTrackProjY
+ * mTrackViewCos mnTrackScaleLevel. */
+int viorb_search_by_projection_points(const viorb_keypoint* cur_kps, const uint8_t* cur_desc, int ncur, const float bounds4[4],
+                                      const float pose12[12], const float intr4[4], const float* scale_factors, int nlevels,
+                                      const float* pts_f, const uint8_t* pts_flags, const uint8_t* pts_desc, int npts, float th,
+                                      float nnratio, const uint8_t* cur_owner_obs, int32_t* match, int* nmatches, float* frustum5);
+/* ... and with bMono = false (stereo / RGB-D, Tracking.cc:432 with mSensor != MONOCULAR): see viorb_frontend_search_projection_stereo_device. */
+int viorb_search_by_projection_frame_stereo(const viorb_keypoint* cur_kps, const uint8_t* cur_desc, const float* cur_uright, int ncur,
+                                            const float bounds4[4], const float pose12[12], const float last_pose12[12], const float intr4[4],
+                                            float bf, float mb, const float* scale_factors, int nlevels, const viorb_keypoint* last_kps, int nlast,
+                                            const uint8_t* last_flags, const float* last_Pw, const uint8_t* last_desc, float th,
+                                            int check_orientation, int32_t* cur_match, int* nmatches);
 int viorb_preintegrate(const double* imu, int n_imu, const double bg[3], const double ba[3], double t_last,
                        double t_cur, double* preint142);
 int viorb_pose_opt_vi(int variant, int compute_marg, const double cur_ns[22], const double last_ns[22],
@@ -458,6 +486,25 @@ typedef struct viorb_vocabulary viorb_vocabulary;   /* opaque */
 int viorb_vocabulary_create(int n_nodes, int L, const int32_t* child_start, const int32_t* child_ids, const uint8_t* desc,
                             const int32_t* word_id, const double* weight, viorb_vocabulary** out);
 int viorb_vocabulary_destroy(viorb_vocabulary* v);
+/* The two file formats of the reference's vocabulary: text = TemplatedVocabulary::loadFromTextFile /
+ * saveToTextFile (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1351-1460: "k L scoring weighting", then "parent isLeaf d0..d31 weight"
+ * per node), binary = loadFromBinaryFile / saveToBinaryFile (:1462-1533, the file tools/bin_vocabulary.cc writes: u32 nb_nodes,
+ * u32 size_node, i32 k, L, scoring, weighting, then { i32 parent; u8 desc[32]; f32 weight; u8 is_leaf } per node). Node ids are file
+ * order, children keep file order, word ids count the leaves in file order. viorb_vocabulary_read_file parses into malloc'ed flat
+ * arrays (the layout of viorb_vocabulary_create; no GPU needed; release with viorb_vocabulary_flat_free); the load functions parse and
+ * create the device vocabulary; the save functions write a flat tree whose ids are in file order. */
+typedef struct viorb_vocabulary_flat {
+    int32_t n_nodes, k, L, n_words;
+    int32_t *child_start, *child_ids, *word_id; uint8_t* desc; double* weight;
+} viorb_vocabulary_flat;
+int viorb_vocabulary_read_file(const char* path, int binary, viorb_vocabulary_flat* out);
+void viorb_vocabulary_flat_free(viorb_vocabulary_flat* f);
+int viorb_vocabulary_load_text(const char* path, viorb_vocabulary** out);
+int viorb_vocabulary_load_binary(const char* path, viorb_vocabulary** out);
+int viorb_vocabulary_save_text(const char* path, int n_nodes, int k, int L, const int32_t* child_start, const int32_t* child_ids,
+                               const uint8_t* desc, const double* weight);
+int viorb_vocabulary_save_binary(const char* path, int n_nodes, int k, int L, const int32_t* child_start, const int32_t* child_ids,
+                                 const uint8_t* desc, const double* weight);
 
 /* TemplatedVocabulary::transform(feature, word_id, weight, nid, levelsup) (TemplatedVocabulary.h:1231-1272) for every
  * descriptor: word[i], weight[i] of the leaf reached and node[i] = the ancestor at level L - levelsup (0 = root when

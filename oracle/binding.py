@@ -319,6 +319,7 @@ def _match():
         L.ora_frame_grid.argtypes = [vp, i, f, f, f, f, vp, vp]
         L.ora_features_in_area.argtypes = [vp, i, f, f, f, f, f, f, f, i, i, vp, i]
         L.ora_search_by_projection_frame.argtypes = [vp, vp, i, vp, vp, vp, vp, i, vp, vp, vp, vp, vp, f, i, vp]
+        L.ora_search_by_projection_frame_stereo.argtypes = [vp, vp, vp, i, vp, vp, vp, vp, f, f, vp, i, vp, vp, vp, vp, vp, f, i, vp]
         L.ora_search_local_points.argtypes = [vp, vp, i, vp, vp, vp, vp, i, f, i, vp, vp, vp, f, f, vp, vp, vp]
         _match_ready = True
     return L
@@ -363,6 +364,21 @@ def search_by_projection_frame(cur_kps, cur_desc, bounds, pose12, intr4, scale_f
     nm = _match().ora_search_by_projection_frame(
         _p(cur_kps), _p(np.ascontiguousarray(cur_desc, np.uint8)), n, _p(f32(bounds)), _p(f32(pose12)), _p(f32(intr4)),
         _p(f32(scale_factors)), len(last_flags), _p(np.ascontiguousarray(last_flags, np.uint8)), _p(f32(last_Pw)),
+        _p(np.ascontiguousarray(last_mp_desc, np.uint8)), _p(np.ascontiguousarray(last_octave, np.int32)), _p(f32(last_angle)),
+        float(th), int(check_ori), _p(m))
+    return nm, m[:n]
+
+
+def search_by_projection_frame_stereo(cur_kps, cur_desc, cur_uright, bounds, pose12, last_pose12, intr4, bf, mb, scale_factors, last_flags, last_Pw,
+                                      last_mp_desc, last_octave, last_angle, th, check_ori=True):
+    """ORBmatcher::SearchByProjection(Cur, Last, th, bMono=false): stereo / RGB-D branch. Returns (nmatches, cur_match[Ncur])."""
+    cur_kps = np.ascontiguousarray(cur_kps, KP_DTYPE)
+    n = len(cur_kps)
+    m = np.full(max(n, 1), -1, np.int32)
+    f32 = lambda a: np.ascontiguousarray(a, np.float32)
+    nm = _match().ora_search_by_projection_frame_stereo(
+        _p(cur_kps), _p(np.ascontiguousarray(cur_desc, np.uint8)), _p(f32(cur_uright)), n, _p(f32(bounds)), _p(f32(pose12)), _p(f32(last_pose12)),
+        _p(f32(intr4)), float(bf), float(mb), _p(f32(scale_factors)), len(last_flags), _p(np.ascontiguousarray(last_flags, np.uint8)), _p(f32(last_Pw)),
         _p(np.ascontiguousarray(last_mp_desc, np.uint8)), _p(np.ascontiguousarray(last_octave, np.int32)), _p(f32(last_angle)),
         float(th), int(check_ori), _p(m))
     return nm, m[:n]

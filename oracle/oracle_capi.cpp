@@ -271,6 +271,28 @@ int ora_search_by_projection_frame(const KeyPoint* cur_kps, const uint8_t* cur_d
     for (int i = 0; i < ncur; i++) cur_match[i] = m[i];
     return n;
 }
+// bMono == false: + CurrentFrame.mvuRight, LastFrame.mTcw, mbf, mb
+int ora_search_by_projection_frame_stereo(const KeyPoint* cur_kps, const uint8_t* cur_desc, const float* cur_uright, int ncur, const float* bounds4,
+                                          const float* pose12, const float* last_pose12, const float* intr4, float bf, float mb,
+                                          const float* scale_factors, int nlast, const uint8_t* last_flags, const float* last_Pw,
+                                          const uint8_t* last_mp_desc, const int* last_octave, const float* last_angle, float th, int check_ori,
+                                          int* cur_match) {
+    FrameGrid g; g.build(cur_kps, cur_desc, ncur, bounds4[0], bounds4[1], bounds4[2], bounds4[3]);
+    PoseF T; for (int i = 0; i < 9; i++) T.Rcw[i] = pose12[i]; for (int i = 0; i < 3; i++) T.tcw[i] = pose12[9 + i];
+    T.fx = intr4[0]; T.fy = intr4[1]; T.cx = intr4[2]; T.cy = intr4[3];
+    StereoSearch st; st.mb = mb; st.bf = bf; st.uright = cur_uright; st.last = T;
+    for (int i = 0; i < 9; i++) st.last.Rcw[i] = last_pose12[i]; for (int i = 0; i < 3; i++) st.last.tcw[i] = last_pose12[9 + i];
+    std::vector<LastFramePoint> last(nlast);
+    for (int i = 0; i < nlast; i++) {
+        last[i].has_point = last_flags[i] & 1; last[i].outlier = (last_flags[i] >> 1) & 1; last[i].has_observations = (last_flags[i] >> 2) & 1;
+        for (int k = 0; k < 3; k++) last[i].Pw[k] = last_Pw[3 * i + k];
+        last[i].desc = last_mp_desc + (size_t)32 * i; last[i].octave = last_octave[i]; last[i].angle = last_angle[i];
+    }
+    std::vector<int> m(cur_match, cur_match + ncur);
+    int n = search_by_projection_frame(g, T, scale_factors, last, th, check_ori != 0, m, &st);
+    for (int i = 0; i < ncur; i++) cur_match[i] = m[i];
+    return n;
+}
 } // extern "C"
 
 extern "C" {

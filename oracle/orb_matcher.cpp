@@ -79,11 +79,23 @@ void compute_three_maxima(const std::vector<int>* histo, int L, int& ind1, int& 
     else if (max3 < 0.1f * (float)max1) { ind3 = -1; }
 }
 
-// ORBmatcher.cc:1328-1471, monocular case (bForward = bBackward = false, mvuRight < 0 everywhere).
+void camera_centre(const PoseF& T, float* Ow);
+// ORBmatcher.cc:1328-1471. stereo == nullptr: the monocular case (bForward = bBackward = false, mvuRight < 0 everywhere).
 int search_by_projection_frame(const FrameGrid& cur, const PoseF& T, const float* sf,
                                const std::vector<LastFramePoint>& last, float th, bool check_ori,
-                               std::vector<int>& cur_match) {
+                               std::vector<int>& cur_match, const StereoSearch* stereo) {
     int nmatches = 0;
+    bool bForward = false, bBackward = false;
+    if (stereo) {
+        // twc = -Rcw.t()*tcw ; tlc = Rlw*twc+tlw (:1339-1346), 3-term float sums as OpenCV's small-matrix gemm forms them
+        float twc[3], tlc[3];
+        camera_centre(T, twc);
+        for (int r = 0; r < 3; r++) {
+            const float t = stereo->last.Rcw[3 * r] * twc[0] + stereo->last.Rcw[3 * r + 1] * twc[1] + stereo->last.Rcw[3 * r + 2] * twc[2];
+            tlc[r] = t + stereo->last.tcw[r];
+        }
+        bForward = tlc[2] > stereo->mb; bBackward = -tlc[2] > stereo->mb;
+    }
     std::vector<int> rotHist[HISTO_LENGTH];
     const float factor = 1.0f / HISTO_LENGTH;
     std::vector<uint8_t> owner_has_obs(cur.N, 0);     // Observations() > 0 of the point currently assigned
@@ -101,11 +113,18 @@ int search_by_projection_frame(const FrameGrid& cur, const PoseF& T, const float
         if (v < cur.minY || v > cur.maxY) continue;
         const int nLastOctave = lp.octave;
         const float radius = th * sf[nLastOctave];
-        const std::vector<int> cand = cur.features_in_area(u, v, radius, nLastOctave - 1, nLastOctave + 1);
+        const std::vector<int> cand = bForward ? cur.features_in_area(u, v, radius, nLastOctave, -1)
+                                    : (bBackward ? cur.features_in_area(u, v, radius, 0, nLastOctave)
+                                                 : cur.features_in_area(u, v, radius, nLastOctave - 1, nLastOctave + 1));
         if (cand.empty()) continue;
         int bestDist = 256, bestIdx2 = -1;
         for (int i2 : cand) {
             if (cur_match[i2] >= 0 && owner_has_obs[i2]) continue;
+            if (stereo && stereo->uright[i2] > 0) {
+                const float ur = u - stereo->bf * invzc;
+                const float er = std::fabs(ur - stereo->uright[i2]);
+                if (er > radius) continue;
+            }
             const int dist = descriptor_distance(lp.desc, cur.desc + (size_t)32 * i2);
             if (dist < bestDist) { bestDist = dist; bestIdx2 = i2; }
         }

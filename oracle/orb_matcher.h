@@ -41,9 +41,11 @@ struct LastFramePoint {                    // one entry of LastFrame.mvpMapPoint
 // ORBmatcher::SearchByProjection(Frame& Cur, const Frame& Last, th, bMono=true), reference
 // src/ORBmatcher.cc:1328-1471. cur_match[i2] = index i of the last-frame point assigned to current
 // keypoint i2, or -1 (caller passes it filled with -1, as Tracking fills mvpMapPoints with NULL).
+// bMono == false (:1346-1349, 1385-1410): the last frame's pose, the baseline mb, mbf and the current frame's mvuRight.
+struct StereoSearch { PoseF last; float mb, bf; const float* uright; };
 int search_by_projection_frame(const FrameGrid& cur, const PoseF& Tcur, const float* scale_factors,
                                const std::vector<LastFramePoint>& last, float th, bool check_orientation,
-                               std::vector<int>& cur_match);
+                               std::vector<int>& cur_match, const StereoSearch* stereo = nullptr);
 
 // One local map point as Tracking::SearchLocalPoints sees it (reference src/Tracking.cc:1904-1958).
 struct LocalPoint {

@@ -280,6 +280,26 @@ def test_host_dropin_search_by_projection(torch_cuda, oracle, streams):
     assert nm == 0 and len(match) == 0
 
 
+@pytest.mark.parametrize("motion", [0.0, 0.5, -0.5])
+def test_host_dropin_search_by_projection_stereo_branch(torch_cuda, oracle, motion):
+    """SearchByProjection(CurrentFrame, LastFrame, th, bMono=false): forward / backward octave windows and the mvuRight gate
+    (reference src/ORBmatcher.cc:1346-1349, 1385-1410), device vs oracle."""
+    from test_oracle_matcher import stereo_scenario
+    from viorb_amd.synth import make_vi_stream
+    s = make_vi_stream(1, 2)
+    ex = oracle.Extractor()
+    k0, d0 = ex(s["frames"][0]); k1, d1 = ex(s["frames"][1])
+    pair = (s, ex.tables()["scale"], k0, d0, k1, d1)
+    pose, last_pose, intr, flags, Pw, mpd, loct, lang, ur, bf, mb = stereo_scenario(pair, motion)
+    m = viorb_amd.ORBmatcher(0.9, True)
+    for th in (7.0, 14.0):
+        nm, match = m.SearchByProjection(k1, d1, BOUNDS, pose, intr, pair[1], k0, flags, Pw, mpd, th, bMono=False, cur_uright=ur, last_pose12=last_pose,
+                                         bf=bf, mb=mb)
+        onm, om = oracle.search_by_projection_frame_stereo(k1, d1, ur, BOUNDS, pose, last_pose, intr, bf, mb, pair[1], flags, Pw, mpd, loct, lang, th)
+        assert nm == onm and nm > 50
+        np.testing.assert_array_equal(match, om)
+
+
 @pytest.mark.parametrize("th,nnratio", [(1.0, 0.8), (5.0, 0.8)])
 def test_search_local_points_matches_oracle(torch_cuda, oracle, th, nnratio):
     """a12: isInFrustum + SearchByProjection(Frame, local map points), two streams in one launch."""
@@ -329,6 +349,14 @@ def test_search_local_points_matches_oracle(torch_cuda, oracle, th, nnratio):
         np.testing.assert_array_equal(fr[b, :len(ofr)].cpu().numpy(), ofr)
         assert nm[b].item() == onm and onm > 100
         np.testing.assert_array_equal(match[b, :len(om)].cpu().numpy(), om)
+        # the host-buffer drop-in for Tracking.cc:1955 (viorb_search_by_projection_points) gives the same answer
+        hn, hm, hfr = viorb_amd.SearchLocalPoints(c["k2"], c["d2"], BOUNDS, c["pose"], c["s"]["cam"][:4], sf, c["pts_f"], c["flags"], c["pts_desc"], th, nnratio,
+                                                  c["owner"], want_frustum=True)
+        assert hn == onm
+        np.testing.assert_array_equal(hm, om); np.testing.assert_array_equal(hfr, ofr)
+    n0, m0 = viorb_amd.SearchLocalPoints(scenes[0]["k2"][:0], scenes[0]["d2"][:0], BOUNDS, scenes[0]["pose"], scenes[0]["s"]["cam"][:4], sf,
+                                         scenes[0]["pts_f"], scenes[0]["flags"], scenes[0]["pts_desc"])
+    assert n0 == 0 and len(m0) == 0
 
 
 @pytest.mark.parametrize("stereo_frac", [0.0, 0.6, 1.0])

@@ -135,6 +135,88 @@ def test_search_by_projection_equals_literal_restatement(oracle, pair, th, pertu
     assert ((m >= 0).sum() == nm) or True               # duplicates may be double counted, as in the reference
 
 
+def stereo_scenario(pair, motion):
+    """The mono scenario with the stereo additions: right coordinates for most current keypoints (some inconsistent with the
+    depth of the point they would match), a last-frame pose `motion` metres behind / ahead of the current one along the optical axis."""
+    s, sf, k0, d0, k1, d1 = pair
+    pose, intr, flags, Pw, mpd, loct, lang = scenario(pair)
+    rng = np.random.default_rng(21)
+    bf, mb = np.float32(40.0), np.float32(0.11)
+    R, t = pose[:9].reshape(3, 3).astype(np.float64), pose[9:].astype(np.float64)
+    # depth of the plane world at each current keypoint: use the projections of the last frame's points to seed nearby right coordinates
+    ur = np.full(len(k1), -1.0, np.float32)
+    pc = (R @ Pw.T.astype(np.float64)).T + t
+    u = intr[0] * pc[:, 0] / pc[:, 2] + intr[2]; v = intr[1] * pc[:, 1] / pc[:, 2] + intr[3]
+    for i in range(len(Pw)):
+        d = np.abs(k1["x"] - u[i]) + np.abs(k1["y"] - v[i])
+        j = int(np.argmin(d))
+        if d[j] < 6:
+            ur[j] = np.float32(k1["x"][j] - bf / pc[i, 2])
+    bad = rng.random(len(k1)) < 0.15
+    ur[bad & (ur > 0)] += np.float32(60.0)                # right coordinate far from the projected one: gated out
+    ur[rng.random(len(k1)) < 0.2] = -1.0                   # monocular keypoints
+    last_pose = pose.copy(); last_pose[11] += np.float32(motion)      # tlc.z = motion
+    return pose, last_pose, intr, flags, Pw, mpd, loct, lang, ur, bf, mb
+
+
+@pytest.mark.parametrize("motion", [0.0, 0.5, -0.5])
+def test_search_by_projection_stereo_branch_equals_literal_restatement(oracle, pair, motion):
+    """bMono == false (ORBmatcher.cc:1346-1349, 1385-1410): forward / backward octave windows and the mvuRight gate."""
+    s, sf, k0, d0, k1, d1 = pair
+    pose, last_pose, intr, flags, Pw, mpd, loct, lang, ur, bf, mb = stereo_scenario(pair, motion)
+    th = 7
+    nm, m = oracle.search_by_projection_frame_stereo(k1, d1, ur, BOUNDS, pose, last_pose, intr, bf, mb, sf, flags, Pw, mpd, loct, lang, th)
+    # literal restatement
+    f = np.float32
+    R, t = pose[:9].reshape(3, 3), pose[9:]
+    fwd, bwd = motion > mb, -motion > mb
+    match = np.full(len(k1), -1, np.int32); wn = 0; hist = [[] for _ in range(30)]
+    for i in range(len(flags)):
+        if not (flags[i] & 1) or (flags[i] & 2):
+            continue
+        pc = [f(f(f(R[r, 0] * Pw[i, 0]) + f(R[r, 1] * Pw[i, 1])) + f(R[r, 2] * Pw[i, 2])) + t[r] for r in range(3)]
+        invz = f(1.0 / np.float64(pc[2]))
+        if invz < 0:
+            continue
+        u = f(f(f(intr[0] * pc[0]) * invz) + intr[2]); v = f(f(f(intr[1] * pc[1]) * invz) + intr[3])
+        if u < 0 or u > 752 or v < 0 or v > 480:
+            continue
+        radius = f(f(th) * sf[loct[i]])
+        lo, hi = (loct[i], -1) if fwd else ((0, loct[i]) if bwd else (loct[i] - 1, loct[i] + 1))
+        best, bidx = 256, -1
+        for i2 in oracle.features_in_area(k1, BOUNDS, u, v, radius, lo, hi):
+            if match[i2] >= 0 and (flags[match[i2]] & 4):
+                continue
+            if ur[i2] > 0 and abs(f(f(u - f(bf * invz)) - ur[i2])) > radius:
+                continue
+            dist = oracle.descriptor_distance(mpd[i], d1[i2])
+            if dist < best:
+                best, bidx = dist, i2
+        if best <= 100:
+            match[bidx] = i; wn += 1
+            rot = f(lang[i] - k1["angle"][bidx])
+            if rot < 0:
+                rot = f(rot + f(360))
+            b = int(np.floor(f(rot * f(1.0 / 30)) + f(0.5)))
+            hist[0 if b == 30 else b].append(bidx)
+    sizes = [len(h) for h in hist]
+    order = sorted(range(30), key=lambda i: (-sizes[i], i))
+    keep = [order[0]]
+    if sizes[order[1]] >= 0.1 * sizes[order[0]]:
+        keep.append(order[1])
+        if sizes[order[2]] >= 0.1 * sizes[order[0]]:
+            keep.append(order[2])
+    for i in range(30):
+        if i not in keep:
+            for idx in hist[i]:
+                match[idx] = -1; wn -= 1
+    assert nm == wn and nm > 50
+    np.testing.assert_array_equal(m, match)
+    # the stereo rules change the result: not the monocular answer
+    nm0, m0 = oracle.search_by_projection_frame(k1, d1, BOUNDS, pose, intr, sf, flags, Pw, mpd, loct, lang, th)
+    assert not np.array_equal(m0, m)
+
+
 def test_search_edge_cases(oracle, pair):
     s, sf, k0, d0, k1, d1 = pair
     pose, intr, flags, Pw, mpd, loct, lang = scenario(pair)

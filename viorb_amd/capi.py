@@ -48,6 +48,12 @@ class ExtractorParams(C.Structure):
                 ("ini_th_fast", C.c_int32), ("min_th_fast", C.c_int32)]
 
 
+class VocabularyFlat(C.Structure):
+    """viorb_vocabulary_flat (include/viorb.h)."""
+    _fields_ = [("n_nodes", C.c_int32), ("k", C.c_int32), ("L", C.c_int32), ("n_words", C.c_int32), ("child_start", C.c_void_p),
+                ("child_ids", C.c_void_p), ("word_id", C.c_void_p), ("desc", C.c_void_p), ("weight", C.c_void_p)]
+
+
 class TrackerConfig(C.Structure):
     """viorb_tracker_config (include/viorb.h)."""
     _fields_ = [("extractor", ExtractorParams), ("frontend", FrontendConfig), ("width", C.c_int32), ("height", C.c_int32), ("batch", C.c_int32),
@@ -108,6 +114,12 @@ SIGNATURES = {
     "viorb_local_ba_se3": (i32, [vp, i32, i32, vp, i32, vp, vp, i32] + [vp] * 6),
     "viorb_vocabulary_create": (i32, [i32, i32, vp, vp, vp, vp, vp, PP(vp)]),
     "viorb_vocabulary_destroy": (i32, [vp]),
+    "viorb_vocabulary_read_file": (i32, [C.c_char_p, i32, PP(VocabularyFlat)]),
+    "viorb_vocabulary_flat_free": (None, [PP(VocabularyFlat)]),
+    "viorb_vocabulary_load_text": (i32, [C.c_char_p, PP(vp)]),
+    "viorb_vocabulary_load_binary": (i32, [C.c_char_p, PP(vp)]),
+    "viorb_vocabulary_save_text": (i32, [C.c_char_p, i32, i32, i32, vp, vp, vp, vp]),
+    "viorb_vocabulary_save_binary": (i32, [C.c_char_p, i32, i32, i32, vp, vp, vp, vp]),
     "viorb_bow_transform_device": (i32, [vp, vp, vp, i32, i32, i32, vp, vp, vp, vp]),
     "viorb_bow_transform": (i32, [vp, vp, i32, i32, vp, vp, vp]),
     "viorb_search_by_bow_device": (i32, [vp] * 9 + [i32, i32, f32, i32, vp, vp, vp]),
@@ -144,6 +156,9 @@ SIGNATURES = {
     "viorb_profile_read": (i32, [C.c_char_p, i32, vp, vp, i32, PP(i32)]),
     "viorb_descriptor_distance": (i32, [vp, vp]),
     "viorb_search_by_projection_frame": (i32, [vp, vp, i32, vp, vp, vp, vp, i32, vp, i32, vp, vp, vp, f32, i32, vp, PP(i32)]),
+    "viorb_search_by_projection_frame_stereo": (i32, [vp, vp, vp, i32, vp, vp, vp, vp, f32, f32, vp, i32, vp, i32, vp, vp, vp, f32, i32, vp, PP(i32)]),
+    "viorb_frontend_search_projection_stereo_device": (i32, [vp] * 14 + [f32, f32, f32, i32, i32, vp, vp, vp, vp]),
+    "viorb_search_by_projection_points": (i32, [vp, vp, i32, vp, vp, vp, vp, i32, vp, vp, vp, i32, f32, f32, vp, vp, PP(i32), vp]),
     "viorb_preintegrate": (i32, [vp, i32, vp, vp, C.c_double, C.c_double, vp]),
     "viorb_pose_opt_vi": (i32, [i32, i32] + [vp] * 8 + [i32, vp, i32] + [vp] * 6),
     "viorb_debug_pvr_edge": (None, [vp] * 7),

@@ -91,6 +91,10 @@ struct SearchArgs {
     float scale[16];
     int check_ori;
     int skip_if_at_least;     // > 0: leave streams whose nmatches[b] is already >= this untouched (TrackWithIMU's retry with 2*th)
+    // stereo / RGB-D branch (bMono == false, reference src/ORBmatcher.cc:1346-1349, 1385-1410); all NULL / 0 for the monocular call
+    const float* cur_uright;  // [B][cap] CurrentFrame.mvuRight (<= 0: monocular keypoint)
+    const float* last_pose12; // [B][12] LastFrame.mTcw as Rlw(9) tlw(3)
+    float bf, mb;             // CurrentFrame.mbf, CurrentFrame.mb
 };
 
 // LDS plan (dynamic, per workgroup): the current frame's grid (u16 CSR), keypoint x/y/octave/angle, the first
@@ -140,6 +144,17 @@ __global__ __launch_bounds__(SEARCH_THREADS) void k_search_projection(SearchArgs
     if (t == 0) { s_overflow = 0; s_nm = 0; }
     for (int i = t; i < HISTO_LENGTH; i += blockDim.x) { s_hist[i] = 0; s_keep[i] = 0; }
     __syncthreads();
+    // stereo: does the camera move forward / backward by more than the baseline? (tlc = Rlw * twc + tlw, twc = -Rcw^T tcw; :1339-1349)
+    int motion = 0;
+    const float* cur_ur = A.cur_uright ? A.cur_uright + (size_t)b * cap : nullptr;
+    if (A.last_pose12) {
+        const float* Lp = A.last_pose12 + (size_t)b * 12;
+        float twc[3];
+#pragma unroll
+        for (int r = 0; r < 3; r++) twc[r] = -(P[r] * P[9] + P[3 + r] * P[10] + P[6 + r] * P[11]);
+        const float tz = (Lp[6] * twc[0] + Lp[7] * twc[1] + Lp[8] * twc[2]) + Lp[11];
+        motion = tz > A.mb ? 1 : (-tz > A.mb ? 2 : 0);
+    }
     // ---- phase A
     for (int i = t; i < nlast; i += blockDim.x) {
         int nc = 0;
@@ -154,7 +169,8 @@ __global__ __launch_bounds__(SEARCH_THREADS) void k_search_projection(SearchArgs
             if (!(invz < 0) && !(u < A.minX || u > A.maxX) && !(v < A.minY || v > A.maxY)) {
                 const int oct = lk[i].octave;
                 const float radius = A.th * A.scale[oct];
-                const int minL = oct - 1, maxL = oct + 1;
+                // bForward: levels >= octave; bBackward: levels <= octave; else octave +- 1 (:1385-1390)
+                const int minL = motion == 1 ? oct : (motion == 2 ? 0 : oct - 1), maxL = motion == 1 ? -1 : (motion == 2 ? oct : oct + 1);
                 const int x0 = max(0, (int)floorf((u - A.minX - radius) * A.wInv));
                 const int x1 = min((int)GRID_COLS - 1, (int)ceilf((u - A.minX + radius) * A.wInv));
                 const int y0 = max(0, (int)floorf((v - A.minY - radius) * A.hInv));
@@ -172,6 +188,10 @@ __global__ __launch_bounds__(SEARCH_THREADS) void k_search_projection(SearchArgs
                             if (check_levels) { if (o2 < minL) continue; if (maxL >= 0 && o2 > maxL) continue; }
                             const float2 q = cxy[i2];
                             if (!(fabsf(q.x - u) < radius && fabsf(q.y - v) < radius)) continue;
+                            if (cur_ur) {                                  // "if(CurrentFrame.mvuRight[i2]>0)" (:1404-1410)
+                                const float r2 = cur_ur[i2];
+                                if (r2 > 0) { const float ur = u - A.bf * invz; if (fabsf(ur - r2) > radius) continue; }
+                            }
                             const uint4* dc = reinterpret_cast<const uint4*>(A.cur_desc + ((size_t)b * cap + i2) * 32);
                             const uint4 ea = dc[0], eb = dc[1];
                             const int dist = __popc(da.x ^ ea.x) + __popc(da.y ^ ea.y) + __popc(da.z ^ ea.z) + __popc(da.w ^ ea.w) +
@@ -2004,6 +2024,10 @@ int viorb_frontend_imu_predict_device(viorb_frontend* h, const double* imu, int 
     return VIORB_OK;
 }
 
+// the stereo arguments of the call in progress on this thread (set by viorb_frontend_search_projection_stereo_device only)
+struct StereoSearchArgs { const float* cur_uright = nullptr; const float* last_pose12 = nullptr; float bf = 0, mb = 0; };
+static thread_local StereoSearchArgs g_stereo_args;
+
 int viorb_frontend_search_projection_retry_device(viorb_frontend* h, const viorb_keypoint* cur_kps, const uint8_t* cur_desc,
                                                   const int32_t* cur_count, const int32_t* cell_start, const int32_t* cell_idx,
                                                   const float* pose12, const viorb_keypoint* last_kps, const int32_t* last_count,
@@ -2023,6 +2047,7 @@ int viorb_frontend_search_projection_retry_device(viorb_frontend* h, const viorb
     for (int i = 0; i < 16; i++) A.scale[i] = h->cfg.scale_factors[i];
     A.check_ori = h->cfg.check_orientation;
     A.skip_if_at_least = retry_below > 0 ? retry_below : 0;
+    A.cur_uright = g_stereo_args.cur_uright; A.last_pose12 = g_stereo_args.last_pose12; A.bf = g_stereo_args.bf; A.mb = g_stereo_args.mb;
     ProfScope ps("k_search_projection", (hipStream_t)stream);
     hipLaunchKernelGGL(k_search_projection, dim3(batch), dim3(SEARCH_THREADS), search_lds_bytes(h->cap), (hipStream_t)stream, A);
     VIORB_HIP_TRY(hipGetLastError());
@@ -2036,6 +2061,21 @@ int viorb_frontend_search_projection_device(viorb_frontend* h, const viorb_keypo
                                             int batch, int32_t* cur_match, int32_t* nmatches, int32_t* status, void* stream) {
     return viorb_frontend_search_projection_retry_device(h, cur_kps, cur_desc, cur_count, cell_start, cell_idx, pose12, last_kps, last_count, last_flags,
                                                          last_Pw, last_desc, th, 0, batch, cur_match, nmatches, status, stream);
+}
+
+int viorb_frontend_search_projection_stereo_device(viorb_frontend* h, const viorb_keypoint* cur_kps, const uint8_t* cur_desc,
+                                                   const int32_t* cur_count, const float* cur_uright, const int32_t* cell_start,
+                                                   const int32_t* cell_idx, const float* pose12, const float* last_pose12,
+                                                   const viorb_keypoint* last_kps, const int32_t* last_count, const uint8_t* last_flags,
+                                                   const float* last_Pw, const uint8_t* last_desc, float th, float bf, float mb,
+                                                   int retry_below, int batch, int32_t* cur_match, int32_t* nmatches, int32_t* status,
+                                                   void* stream) {
+    VIORB_REQUIRE(cur_uright && last_pose12, "null stereo array");
+    g_stereo_args.cur_uright = cur_uright; g_stereo_args.last_pose12 = last_pose12; g_stereo_args.bf = bf; g_stereo_args.mb = mb;
+    const int rc = viorb_frontend_search_projection_retry_device(h, cur_kps, cur_desc, cur_count, cell_start, cell_idx, pose12, last_kps, last_count,
+                                                                 last_flags, last_Pw, last_desc, th, retry_below, batch, cur_match, nmatches, status, stream);
+    g_stereo_args = StereoSearchArgs();
+    return rc;
 }
 
 int viorb_frontend_search_local_points_device(viorb_frontend* h, const viorb_keypoint* cur_kps, const uint8_t* cur_desc, const int32_t* cur_count,
@@ -2289,16 +2329,18 @@ viorb_frontend_config default_cfg() {
 
 extern "C" {
 
-int viorb_search_by_projection_frame(const viorb_keypoint* cur_kps, const uint8_t* cur_desc, int ncur, const float bounds4[4],
-                                     const float pose12[12], const float intr4[4], const float* scale_factors, int nlevels,
-                                     const viorb_keypoint* last_kps, int nlast, const uint8_t* last_flags, const float* last_Pw,
-                                     const uint8_t* last_desc, float th, int check_orientation, int32_t* cur_match, int* nmatches) {
+static int search_by_projection_frame_host(const viorb_keypoint* cur_kps, const uint8_t* cur_desc, const float* cur_uright, int ncur,
+                                           const float bounds4[4], const float pose12[12], const float* last_pose12, const float intr4[4],
+                                           float bf, float mb, const float* scale_factors, int nlevels, const viorb_keypoint* last_kps, int nlast,
+                                           const uint8_t* last_flags, const float* last_Pw, const uint8_t* last_desc, float th,
+                                           int check_orientation, int32_t* cur_match, int* nmatches) {
     VIORB_REQUIRE(bounds4 && pose12 && intr4 && scale_factors && nmatches && ncur >= 0 && nlast >= 0, "null array");
     VIORB_REQUIRE(nlevels >= 1 && nlevels <= 16, "nlevels must be 1..16");
+    VIORB_REQUIRE(ncur == 0 || cur_match, "cur_match is NULL");
     *nmatches = 0;
     for (int i = 0; i < ncur; i++) cur_match[i] = -1;
     if (ncur == 0 || nlast == 0) return VIORB_OK;
-    VIORB_REQUIRE(cur_kps && cur_desc && last_kps && last_flags && last_Pw && last_desc && cur_match, "null array");
+    VIORB_REQUIRE(cur_kps && cur_desc && last_kps && last_flags && last_Pw && last_desc, "null array");
     viorb_frontend_config c = default_cfg();
     c.min_x = bounds4[0]; c.max_x = bounds4[1]; c.min_y = bounds4[2]; c.max_y = bounds4[3];
     c.fx = intr4[0]; c.fy = intr4[1]; c.cx = intr4[2]; c.cy = intr4[3];
@@ -2322,7 +2364,15 @@ int viorb_search_by_projection_frame(const viorb_keypoint* cur_kps, const uint8_
     VIORB_HIP_TRY(hipMemcpy(d_lf, last_flags, (size_t)nlast, hipMemcpyHostToDevice));
     VIORB_HIP_TRY(hipMemcpy(d_lp, last_Pw, sizeof(float) * 3 * nlast, hipMemcpyHostToDevice));
     FE_TRY(viorb_frontend_grid_device(h, d_ck, d_cc, 1, d_cs, d_ci, nullptr));
-    FE_TRY(viorb_frontend_search_projection_device(h, d_ck, d_cd, d_cc, d_cs, d_ci, d_pose, d_lk, d_lc, d_lf, d_lp, d_ld, th, 1, d_m, d_nm, d_st, nullptr));
+    if (cur_uright) {
+        float *d_ur, *d_lpose;
+        FE_TRY(B.up(&d_ur, (const float*)nullptr, (size_t)cap)); FE_TRY(B.up(&d_lpose, last_pose12, 12));
+        VIORB_HIP_TRY(hipMemcpy(d_ur, cur_uright, sizeof(float) * ncur, hipMemcpyHostToDevice));
+        FE_TRY(viorb_frontend_search_projection_stereo_device(h, d_ck, d_cd, d_cc, d_ur, d_cs, d_ci, d_pose, d_lpose, d_lk, d_lc, d_lf, d_lp, d_ld, th, bf, mb,
+                                                              0, 1, d_m, d_nm, d_st, nullptr));
+    } else {
+        FE_TRY(viorb_frontend_search_projection_device(h, d_ck, d_cd, d_cc, d_cs, d_ci, d_pose, d_lk, d_lc, d_lf, d_lp, d_ld, th, 1, d_m, d_nm, d_st, nullptr));
+    }
     VIORB_HIP_TRY(hipDeviceSynchronize());
     int st = 0;
     VIORB_HIP_TRY(hipMemcpy(cur_match, d_m, sizeof(int) * ncur, hipMemcpyDeviceToHost));
@@ -2330,6 +2380,24 @@ int viorb_search_by_projection_frame(const viorb_keypoint* cur_kps, const uint8_
     VIORB_HIP_TRY(hipMemcpy(&st, d_st, sizeof(int), hipMemcpyDeviceToHost));
     if (st != VIORB_OK) { set_error("more than %d grid candidates for one point", (int)CAND_CAP); return st; }
     return VIORB_OK;
+}
+
+int viorb_search_by_projection_frame(const viorb_keypoint* cur_kps, const uint8_t* cur_desc, int ncur, const float bounds4[4],
+                                     const float pose12[12], const float intr4[4], const float* scale_factors, int nlevels,
+                                     const viorb_keypoint* last_kps, int nlast, const uint8_t* last_flags, const float* last_Pw,
+                                     const uint8_t* last_desc, float th, int check_orientation, int32_t* cur_match, int* nmatches) {
+    return search_by_projection_frame_host(cur_kps, cur_desc, nullptr, ncur, bounds4, pose12, nullptr, intr4, 0.f, 0.f, scale_factors, nlevels, last_kps,
+                                           nlast, last_flags, last_Pw, last_desc, th, check_orientation, cur_match, nmatches);
+}
+
+int viorb_search_by_projection_frame_stereo(const viorb_keypoint* cur_kps, const uint8_t* cur_desc, const float* cur_uright, int ncur,
+                                            const float bounds4[4], const float pose12[12], const float last_pose12[12], const float intr4[4],
+                                            float bf, float mb, const float* scale_factors, int nlevels, const viorb_keypoint* last_kps, int nlast,
+                                            const uint8_t* last_flags, const float* last_Pw, const uint8_t* last_desc, float th,
+                                            int check_orientation, int32_t* cur_match, int* nmatches) {
+    VIORB_REQUIRE(last_pose12 && (ncur == 0 || cur_uright), "null stereo array");
+    return search_by_projection_frame_host(cur_kps, cur_desc, cur_uright, ncur, bounds4, pose12, last_pose12, intr4, bf, mb, scale_factors, nlevels,
+                                           last_kps, nlast, last_flags, last_Pw, last_desc, th, check_orientation, cur_match, nmatches);
 }
 
 int viorb_fuse(const viorb_keypoint* kps, const uint8_t* desc, const float* uright, int n, const float bounds4[4], const float pose12[12],
@@ -2359,6 +2427,45 @@ int viorb_fuse(const viorb_keypoint* kps, const uint8_t* desc, const float* urig
     VIORB_HIP_TRY(hipDeviceSynchronize());
     VIORB_HIP_TRY(hipMemcpy(best_idx, d_bi, sizeof(int) * npts, hipMemcpyDeviceToHost));
     VIORB_HIP_TRY(hipMemcpy(nfused, d_nf, sizeof(int), hipMemcpyDeviceToHost));
+    return VIORB_OK;
+}
+
+int viorb_search_by_projection_points(const viorb_keypoint* cur_kps, const uint8_t* cur_desc, int ncur, const float bounds4[4], const float pose12[12],
+                                      const float intr4[4], const float* scale_factors, int nlevels, const float* pts_f, const uint8_t* pts_flags,
+                                      const uint8_t* pts_desc, int npts, float th, float nnratio, const uint8_t* cur_owner_obs, int32_t* match,
+                                      int* nmatches, float* frustum5) {
+    VIORB_REQUIRE(bounds4 && pose12 && intr4 && scale_factors && nmatches && ncur >= 0 && npts >= 0, "null array");
+    VIORB_REQUIRE(nlevels >= 1 && nlevels <= 16, "nlevels must be 1..16");
+    VIORB_REQUIRE(ncur == 0 || match, "match is NULL");
+    *nmatches = 0;
+    for (int i = 0; i < ncur; i++) match[i] = -1;
+    if (frustum5) memset(frustum5, 0, sizeof(float) * 5 * (size_t)npts);
+    if (ncur == 0 || npts == 0) return VIORB_OK;
+    VIORB_REQUIRE(cur_kps && cur_desc && pts_f && pts_flags && pts_desc && cur_owner_obs, "null array");
+    viorb_frontend_config c = default_cfg();
+    c.min_x = bounds4[0]; c.max_x = bounds4[1]; c.min_y = bounds4[2]; c.max_y = bounds4[3];
+    c.fx = intr4[0]; c.fy = intr4[1]; c.cx = intr4[2]; c.cy = intr4[3];
+    c.nlevels = nlevels;
+    for (int i = 0; i < 16; i++) c.scale_factors[i] = scale_factors[i < nlevels ? i : nlevels - 1];
+    viorb_frontend* h = nullptr;
+    FE_TRY(viorb_frontend_create(&c, 1, ncur, 0, &h));
+    struct Guard { viorb_frontend* h; ~Guard() { viorb_frontend_destroy(h); } } g{h};
+    DevBuf B; viorb_keypoint* d_k; uint8_t *d_d, *d_pfl, *d_pd, *d_own; float *d_pose, *d_pf, *d_fr = nullptr; int *d_c, *d_cs, *d_ci, *d_pc, *d_m, *d_nm, *d_st;
+    FE_TRY(B.up(&d_k, cur_kps, (size_t)ncur)); FE_TRY(B.up(&d_d, cur_desc, (size_t)ncur * 32)); FE_TRY(B.up(&d_own, cur_owner_obs, (size_t)ncur));
+    FE_TRY(B.up(&d_pose, pose12, 12)); FE_TRY(B.up(&d_c, &ncur, 1)); FE_TRY(B.up(&d_cs, (const int*)nullptr, GRID_CELLS + 1)); FE_TRY(B.up(&d_ci, (const int*)nullptr, (size_t)ncur));
+    FE_TRY(B.up(&d_pf, pts_f, (size_t)npts * 8)); FE_TRY(B.up(&d_pfl, pts_flags, (size_t)npts)); FE_TRY(B.up(&d_pd, pts_desc, (size_t)npts * 32));
+    FE_TRY(B.up(&d_pc, &npts, 1)); FE_TRY(B.up(&d_m, (const int*)nullptr, (size_t)ncur)); FE_TRY(B.up(&d_nm, (const int*)nullptr, 1)); FE_TRY(B.up(&d_st, (const int*)nullptr, 1));
+    if (frustum5) FE_TRY(B.up(&d_fr, (const float*)nullptr, (size_t)npts * 5));
+    FE_TRY(viorb_frontend_grid_device(h, d_k, d_c, 1, d_cs, d_ci, nullptr));
+    FE_TRY(viorb_frontend_search_local_points_device(h, d_k, d_d, d_c, d_cs, d_ci, d_pose, d_pf, d_pfl, d_pd, d_pc, npts, th, nnratio, d_own, 1, d_m, d_nm, d_fr, d_st,
+                                                     nullptr));
+    VIORB_HIP_TRY(hipDeviceSynchronize());
+    int st = 0;
+    VIORB_HIP_TRY(hipMemcpy(match, d_m, sizeof(int) * ncur, hipMemcpyDeviceToHost));
+    VIORB_HIP_TRY(hipMemcpy(nmatches, d_nm, sizeof(int), hipMemcpyDeviceToHost));
+    VIORB_HIP_TRY(hipMemcpy(&st, d_st, sizeof(int), hipMemcpyDeviceToHost));
+    if (frustum5) VIORB_HIP_TRY(hipMemcpy(frustum5, d_fr, sizeof(float) * 5 * (size_t)npts, hipMemcpyDeviceToHost));
+    if (st != VIORB_OK) { set_error("more grid candidates for one local point than the scratch list holds"); return st; }
     return VIORB_OK;
 }
 

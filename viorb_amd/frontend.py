@@ -34,21 +34,47 @@ class ORBmatcher:
     DescriptorDistance = staticmethod(descriptor_distance)
 
     def SearchByProjection(self, cur_kps, cur_desc, bounds, pose12, intr4, scale_factors, last_kps, last_flags, last_Pw,
-                           last_mp_desc, th, bMono=True):
-        """SearchByProjection(CurrentFrame, LastFrame, th, bMono) on SoA host arrays.
+                           last_mp_desc, th, bMono=True, cur_uright=None, last_pose12=None, bf=0.0, mb=0.0):
+        """SearchByProjection(CurrentFrame, LastFrame, th, bMono) on SoA host arrays. bMono=False (stereo / RGB-D) also needs
+        CurrentFrame.mvuRight, LastFrame.mTcw (Rlw, tlw), mbf and mb (reference src/ORBmatcher.cc:1346-1349, 1385-1410).
         Returns (nmatches, cur_match[Ncur]) with cur_match[i2] = last-frame index or -1."""
-        assert bMono, "stereo gating (mvuRight) is not part of this drop-in yet"
         f32 = lambda a: np.ascontiguousarray(a, np.float32)
         ck = np.ascontiguousarray(cur_kps, capi.KP_DTYPE); lk = np.ascontiguousarray(last_kps, capi.KP_DTYPE)
         match = np.full(max(len(ck), 1), -1, np.int32)
         nm = C.c_int()
         sf = f32(scale_factors)
+        if not bMono:
+            assert cur_uright is not None and last_pose12 is not None
+            check(lib().viorb_search_by_projection_frame_stereo(ptr(ck), ptr(np.ascontiguousarray(cur_desc, np.uint8)), ptr(f32(cur_uright)), len(ck),
+                                                                ptr(f32(bounds)), ptr(f32(pose12)), ptr(f32(last_pose12)), ptr(f32(intr4)), float(bf),
+                                                                float(mb), ptr(sf), len(sf), ptr(lk), len(lk),
+                                                                ptr(np.ascontiguousarray(last_flags, np.uint8)), ptr(f32(last_Pw)),
+                                                                ptr(np.ascontiguousarray(last_mp_desc, np.uint8)), float(th),
+                                                                int(self.mbCheckOrientation), ptr(match), C.byref(nm)))
+            return nm.value, match[:len(ck)]
         check(lib().viorb_search_by_projection_frame(ptr(ck), ptr(np.ascontiguousarray(cur_desc, np.uint8)), len(ck), ptr(f32(bounds)),
                                                      ptr(f32(pose12)), ptr(f32(intr4)), ptr(sf), len(sf), ptr(lk), len(lk),
                                                      ptr(np.ascontiguousarray(last_flags, np.uint8)), ptr(f32(last_Pw)),
                                                      ptr(np.ascontiguousarray(last_mp_desc, np.uint8)), float(th),
                                                      int(self.mbCheckOrientation), ptr(match), C.byref(nm)))
         return nm.value, match[:len(ck)]
+
+
+def SearchLocalPoints(cur_kps, cur_desc, bounds, pose12, intr4, scale_factors, pts_f, pts_flags, pts_desc, th=1.0, nnratio=0.8, cur_owner_obs=None,
+                      want_frustum=False):
+    """Tracking::SearchLocalPoints' matcher call: Frame::isInFrustum + ORBmatcher(nnratio).SearchByProjection(F, vpMapPoints, th)
+    (reference src/Tracking.cc:1904-1958, src/ORBmatcher.cc:45-129), host arrays. Returns (nmatches, match[N]) (+ frustum[npts,5])."""
+    f32 = lambda a: np.ascontiguousarray(a, np.float32)
+    ck = np.ascontiguousarray(cur_kps, capi.KP_DTYPE)
+    pf = f32(pts_f).reshape(-1, 8); sf = f32(scale_factors)
+    own = np.zeros(max(len(ck), 1), np.uint8) if cur_owner_obs is None else np.ascontiguousarray(cur_owner_obs, np.uint8)
+    match = np.full(max(len(ck), 1), -1, np.int32); nm = C.c_int()
+    fr = np.zeros((max(len(pf), 1), 5), np.float32) if want_frustum else None
+    check(lib().viorb_search_by_projection_points(ptr(ck), ptr(np.ascontiguousarray(cur_desc, np.uint8)), len(ck), ptr(f32(bounds)), ptr(f32(pose12)),
+                                                  ptr(f32(intr4)), ptr(sf), len(sf), ptr(pf), ptr(np.ascontiguousarray(pts_flags, np.uint8)),
+                                                  ptr(np.ascontiguousarray(pts_desc, np.uint8)), len(pf), float(th), float(nnratio), ptr(own), ptr(match),
+                                                  C.byref(nm), ptr(fr) if fr is not None else None))
+    return (nm.value, match[:len(ck)], fr[:len(pf)]) if want_frustum else (nm.value, match[:len(ck)])
 
 
 def preintegrate(imu, bg, ba, t_last, t_cur):
@@ -175,6 +201,13 @@ class ORBVocabulary:
                                             ptr(a("word_id", np.int32)), ptr(a("weight", np.float64)), C.byref(h)))
         self.h = h
 
+    @classmethod
+    def load(cls, path, binary=None):
+        """ORBVocabulary::loadFromTextFile / loadFromBinaryFile (reference Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1351-1508)."""
+        binary = path.endswith(".bin") if binary is None else binary
+        flat = read_vocabulary_file(path, binary)
+        return cls(flat)
+
     def close(self):
         if getattr(self, "h", None):
             lib().viorb_vocabulary_destroy(self.h); self.h = None
@@ -202,6 +235,28 @@ class ORBVocabulary:
             norm += abs(bow[k])
         vals = np.array([bow[k] / norm if norm > 0 else bow[k] for k in ids])
         return np.array(ids, np.int32), vals, np.where(weight > 0, node, -1).astype(np.int32)
+
+
+def read_vocabulary_file(path, binary):
+    """Parse a vocabulary file (text or binary format of the reference) into the flat-tree dict ORBVocabulary takes. Host only."""
+    f = capi.VocabularyFlat()
+    check(lib().viorb_vocabulary_read_file(path.encode(), int(binary), C.byref(f)))
+    try:
+        n = f.n_nodes
+        arr = lambda p, dt, cnt: np.ctypeslib.as_array(C.cast(p, C.POINTER(dt)), shape=(cnt,)).copy()
+        cs = arr(f.child_start, C.c_int32, n + 1)
+        return dict(k=f.k, L=f.L, n_words=f.n_words, child_start=cs, child_ids=arr(f.child_ids, C.c_int32, int(cs[n])) if cs[n] else np.zeros(0, np.int32),
+                    word_id=arr(f.word_id, C.c_int32, n), desc=arr(f.desc, C.c_uint8, 32 * n).reshape(n, 32), weight=arr(f.weight, C.c_double, n))
+    finally:
+        lib().viorb_vocabulary_flat_free(C.byref(f))
+
+
+def write_vocabulary_file(path, voc, binary):
+    """saveToTextFile / saveToBinaryFile (reference TemplatedVocabulary.h:1437-1460, :1511-1533) of a flat tree whose ids are in file order."""
+    a = lambda k, dt: np.ascontiguousarray(voc[k], dt)
+    fn = lib().viorb_vocabulary_save_binary if binary else lib().viorb_vocabulary_save_text
+    check(fn(path.encode(), len(voc["word_id"]), int(voc.get("k", 10)), int(voc["L"]), ptr(a("child_start", np.int32)), ptr(a("child_ids", np.int32)),
+             ptr(a("desc", np.uint8)), ptr(a("weight", np.float64))))
 
 
 def SearchByBoW(kf_kps, kf_desc, kf_node, kf_has_point, f_kps, f_desc, f_node, nnratio=0.7, check_orientation=True):
