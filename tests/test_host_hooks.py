@@ -18,6 +18,27 @@ def declared_functions():
     return sorted(set(re.findall(r"\b(viorb_[a-z0-9_]+)\s*\(", txt)))
 
 
+def declared_arg_counts():
+    """name -> number of parameters of every prototype in include/viorb.h (void = 0)."""
+    txt = open(os.path.join(ROOT, "include", "viorb.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    out = {}
+    for m in re.finditer(r"\b(viorb_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", txt, flags=re.S):
+        args = m.group(2).strip()
+        out[m.group(1)] = 0 if args in ("", "void") else args.count(",") + 1
+    return out
+
+
+def test_ctypes_signatures_have_the_declared_argument_counts():
+    counts = declared_arg_counts()
+    assert len(counts) >= 60
+    for name, n in counts.items():
+        assert name in capi.SIGNATURES, name
+        assert len(capi.SIGNATURES[name][1]) == n, "%s: header declares %d parameters, capi.py %d" % (name, n, len(capi.SIGNATURES[name][1]))
+    for name in capi.SIGNATURES:
+        assert name in counts, "capi.py declares %s, include/viorb.h does not" % name
+
+
 def test_library_exports_every_declared_symbol():
     L = viorb_amd.lib()
     names = declared_functions()

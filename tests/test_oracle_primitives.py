@@ -129,3 +129,42 @@ def test_fast_atan2_accuracy_and_quadrants(oracle):
 def test_cv_round_half_even(oracle):
     L = oracle.lib()
     assert [L.ora_cv_round(v) for v in (0.5, 1.5, 2.5, -0.5, -1.5, 2.4999, 2.5001)] == [0, 2, 2, 0, -2, 2, 3]
+
+
+def _cv_round(x):
+    """cvRound: round half to even (SSE2 cvtsd2si)."""
+    return np.rint(x).astype(np.int64)
+
+
+def _resize_linear_8u_integer(src, dw, dh):
+    """cv::resize(INTER_LINEAR) on CV_8UC1 as OpenCV 2.4 computes it, written out independently in numpy integers: float source
+    coordinate (dx + 0.5) * scale - 0.5 (double product, cast to float), cvFloor, clamped end taps, 11-bit coefficients
+    saturate_cast<short>(c * 2048) (cvRound of the float product), horizontal pass S[sx] * a0 + S[sx + 1] * a1 in int, vertical pass
+    (((b0 * (H0 >> 4)) >> 16) + ((b1 * (H1 >> 4)) >> 16) + 2) >> 2 (VResizeLinear<uchar, int, short, FixedPtCast<int, uchar, 22>>)."""
+    sh, sw = src.shape
+
+    def taps(dn, sn):
+        scale = np.float64(sn) / np.float64(dn)
+        f = ((np.arange(dn, dtype=np.float64) + 0.5) * scale - 0.5).astype(np.float32)
+        s0 = np.floor(f).astype(np.int64)
+        f = (f - s0.astype(np.float32)).astype(np.float32)
+        lo = s0 < 0
+        f[lo] = 0; s0[lo] = 0
+        hi = s0 >= sn - 1
+        f[hi] = 0; s0[hi] = sn - 1
+        a1 = _cv_round((f * np.float32(2048)).astype(np.float64))
+        a0 = _cv_round(((np.float32(1) - f) * np.float32(2048)).astype(np.float64))
+        return s0, np.minimum(s0 + 1, sn - 1), a0, a1
+    x0, x1, a0, a1 = taps(dw, sw)
+    y0, y1, b0, b1 = taps(dh, sh)
+    s = src.astype(np.int64)
+    Hh = s[:, x0] * a0[None, :] + s[:, x1] * a1[None, :]                       # [sh, dw] int
+    out = (((b0[:, None] * (Hh[y0] >> 4)) >> 16) + ((b1[:, None] * (Hh[y1] >> 4)) >> 16) + 2) >> 2
+    return np.clip(out, 0, 255).astype(np.uint8)
+
+
+@pytest.mark.parametrize("sw,sh,dw,dh", [(752, 480, 627, 400), (627, 400, 522, 333), (252, 161, 210, 134), (1241, 376, 1034, 313), (97, 61, 81, 51)])
+def test_resize_equals_the_integer_restatement_bit_for_bit(oracle, sw, sh, dw, dh):
+    """Pins the >>4 / >>16 / +2 >>2 rounding sequence and the 11-bit coefficient tables, not just closeness to float bilinear."""
+    src = make_image(31 + sw, sw, sh, n_shapes=80)
+    np.testing.assert_array_equal(oracle.resize_linear(src, dw, dh), _resize_linear_8u_integer(src, dw, dh))

@@ -255,3 +255,53 @@ def test_pose_opt_se3_degenerate(oracle):
     r = oracle.pose_opt_se3(p["pose0"], p["intr5"], p["obs7"][:2])
     assert r["n_inliers"] == 0
     np.testing.assert_array_equal(r["pose12"], p["pose0"])
+
+
+def test_marginal_information_equals_the_dense_double_inverse(oracle):
+    """mMargCovInv (reference src/Optimizer.cc:741-768): computeMarginals gives the (cur PVR, cur bias) blocks of H^-1 and the
+    reference inverts that 12 x 12 matrix again. The oracle forms the Schur complement of the last-frame block instead; here the
+    24 x 24 normal matrix is assembled in numpy from the edge Jacobians (themselves checked against central differences above) with
+    the Huber weights of the dense factors, inverted densely, the block taken and inverted again. g2o linearises at the estimate
+    before its last accepted step, so the two agree to the size of that step, not to rounding."""
+    worst = 0.0
+    for seed in range(4):
+        p = make_vio_problem(seed)
+        last = p["ns_last"]
+        pre = oracle.preintegrate(p["imu"], last[10:13], last[13:16], p["t_last"], p["t_cur"])
+        cur0 = oracle.update_ns(last, pre, p["gw"])
+        r = oracle.pose_opt_vi_frame(cur0, last, p["prior"], p["marg_cov_inv"], pre, p["gw"], p["cam"], p["obs_cur"], p["obs_last"], marg=True)
+        cur, lst = r["ns"], r["ns_last"]
+        H = np.zeros((24, 24))
+        C, CB, L, LB = slice(0, 9), slice(9, 12), slice(12, 21), slice(21, 24)
+
+        def huber_w(chi2, delta):
+            return 1.0 if chi2 <= delta * delta else delta / np.sqrt(chi2)
+        for obs, flags, ns, sl in ((p["obs_cur"], r["outlier_cur"], cur, C), (p["obs_last"], r["outlier_last"], lst, L)):
+            for o, bad in zip(obs, flags):
+                if bad:
+                    continue
+                _, J = oracle.edge_proj(ns, p["cam"], o)
+                H[sl, sl] += o[5] * J.T @ J                       # round 4: no kernel on the reprojection edges
+        e, Ji, Jj, Jb = oracle.edge_pvr(lst, cur, lst, pre, p["gw"])
+        info = np.linalg.inv(pre[60:141].reshape(9, 9)) + np.diag([1e2] * 3 + [1.0] * 3 + [1e2] * 3)
+        w = huber_w(e @ info @ e, float(np.float32(np.sqrt(21.666))))
+        J = np.zeros((9, 24)); J[:, L] = Ji; J[:, C] = Jj; J[:, LB] = Jb
+        H += w * J.T @ info @ J
+        e, Jp, Jbb = oracle.edge_prior(lst, lst, p["prior"])
+        infop = p["marg_cov_inv"].reshape(12, 12) + np.diag([1e2] * 3 + [1.0] * 3 + [1e2] * 3 + [0.0] * 3)
+        w = huber_w(e @ infop @ e, float(np.float32(np.sqrt(30.5779))))
+        J = np.zeros((12, 24)); J[:, L] = Jp; J[:, LB] = Jbb
+        H += w * J.T @ infop @ J
+        eb = (cur[13:16] + cur[19:22]) - (lst[13:16] + lst[19:22])
+        ib = 1.0 / (5e-3 ** 2) / pre[141]
+        w = huber_w(ib * eb @ eb, float(np.float32(np.sqrt(16.812))))
+        J = np.zeros((3, 24)); J[:, CB] = np.eye(3); J[:, LB] = -np.eye(3)
+        H += w * ib * J.T @ J
+        want = np.linalg.inv(np.linalg.inv(H)[:12, :12])
+        got = r["marg_cov_inv"]
+        rel = np.abs(got - want).max() / np.abs(want).max()
+        worst = max(worst, rel)
+        # and the identity the oracle relies on: double inverse == Schur complement of the last-frame block
+        schur = H[:12, :12] - H[:12, 12:] @ np.linalg.solve(H[12:, 12:], H[12:, :12])
+        assert np.abs(schur - want).max() / np.abs(want).max() < 1e-9
+    assert worst < 2e-3, worst

@@ -1,5 +1,5 @@
-"""ctypes declarations of include/viorb.h (kept 1:1 with the header; tests/test_capi_symbols.py checks
-that every declared entry point is exported)."""
+"""ctypes declarations of include/viorb.h (kept 1:1 with the header; tests/test_host_hooks.py checks that every
+declared entry point is exported, has a signature here and that the argument counts agree)."""
 import ctypes as C
 import os
 import numpy as np

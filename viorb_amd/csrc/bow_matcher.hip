@@ -370,7 +370,7 @@ int viorb_search_by_bow_device(const viorb_keypoint* kf_kps, const uint8_t* kf_d
     VIORB_REQUIRE(cap >= 1 && cap <= 65535 && batch >= 1, "1 <= cap <= 65535");
     const size_t lds = bow_search_lds_bytes(cap);
     if (lds > 160 * 1024) { set_error("cap %d needs %zu B of LDS for SearchByBoW", cap, lds); return VIORB_ERR_UNSUPPORTED; }
-    if (lds > 64 * 1024) VIORB_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_search_by_bow), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (lds > 64 * 1024) VIORB_HIP_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(k_search_by_bow), lds));
     BowSearchArgs A;
     A.kf_kps = kf_kps; A.kf_desc = kf_desc; A.kf_node = kf_node; A.kf_has_point = kf_has_point; A.kf_count = kf_count;
     A.f_kps = f_kps; A.f_desc = f_desc; A.f_node = f_node; A.f_count = f_count; A.match = match; A.nmatches = nmatches;
@@ -440,7 +440,7 @@ int viorb_search_for_triangulation_device(const viorb_keypoint* k1, const uint8_
     int sn = 1; while (sn < cap) sn <<= 1;
     const size_t lds = tri_lds_bytes(cap, sn);
     if (lds > 160 * 1024) { set_error("cap %d needs %zu B of LDS for SearchForTriangulation", cap, lds); return VIORB_ERR_UNSUPPORTED; }
-    if (lds > 64 * 1024) VIORB_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_search_triangulation), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (lds > 64 * 1024) VIORB_HIP_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(k_search_triangulation), lds));
     TriArgs A;
     A.k1 = k1; A.k2 = k2; A.d1 = d1; A.d2 = d2; A.hp1 = has_point1; A.hp2 = has_point2; A.ur1 = uright1; A.ur2 = uright2; A.node1 = node1; A.node2 = node2;
     A.n1 = n1; A.n2 = n2; A.F12 = F12; A.Cw1 = Cw1; A.pose2 = pose12_2; A.match12 = match12; A.nmatches = nmatches;

@@ -1969,7 +1969,7 @@ int viorb_frontend_create(const viorb_frontend_config* cfg, int max_batch, int c
     h->sort_n = s;
     if (search_lds_bytes(cap) > 160 * 1024) { delete h; set_error("cap %d needs %zu B of LDS for the projection search", cap, search_lds_bytes(cap)); return VIORB_ERR_UNSUPPORTED; }
     if (search_lds_bytes(cap) > 64 * 1024)
-        VIORB_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_search_projection), hipFuncAttributeMaxDynamicSharedMemorySize, (int)search_lds_bytes(cap)));
+        VIORB_HIP_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(k_search_projection), search_lds_bytes(cap)));
     VIORB_HIP_TRY(hipMalloc(&h->d_cand, (size_t)max_batch * cap * CAND_CAP * sizeof(uint32_t)));
     VIORB_HIP_TRY(hipMalloc(&h->d_cand_n, (size_t)max_batch * cap * sizeof(int)));
     VIORB_HIP_TRY(hipMalloc(&h->d_cam, 16 * sizeof(double)));
@@ -2097,7 +2097,7 @@ int viorb_frontend_search_local_points_device(viorb_frontend* h, const viorb_key
         VIORB_HIP_TRY(hipMalloc(&h->d_lcand_n, (size_t)h->max_batch * pcap * sizeof(int)));
         h->lcand_pcap = pcap;
         if (lds > 64 * 1024)
-            VIORB_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_search_local_points), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            VIORB_HIP_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(k_search_local_points), lds));
     }
     LocalSearchArgs A;
     A.cur_kps = cur_kps; A.cur_desc = cur_desc; A.cur_count = cur_count; A.cell_start = cell_start; A.cell_idx = cell_idx; A.pose12 = pose12;
@@ -2319,6 +2319,8 @@ struct DevBuf {                      // RAII scratch for the host wrappers
     }
 };
 #define FE_TRY(x) do { int _rc = (x); if (_rc != VIORB_OK) return _rc; } while (0)
+// the host-buffer drop-ins run on the calling thread's current HIP device (hipSetDevice / torch.cuda.set_device), not on device 0
+int current_device() { int d = 0; if (hipGetDevice(&d) != hipSuccess) d = 0; return d; }
 viorb_frontend_config default_cfg() {
     viorb_frontend_config c; memset(&c, 0, sizeof(c));
     c.min_x = 0; c.max_x = 752; c.min_y = 0; c.max_y = 480; c.nlevels = 8; c.check_orientation = 1;
@@ -2348,7 +2350,7 @@ static int search_by_projection_frame_host(const viorb_keypoint* cur_kps, const 
     for (int i = 0; i < 16; i++) c.scale_factors[i] = scale_factors[i < nlevels ? i : nlevels - 1];
     const int cap = std::max(ncur, nlast);
     viorb_frontend* h = nullptr;
-    FE_TRY(viorb_frontend_create(&c, 1, cap, 0, &h));
+    FE_TRY(viorb_frontend_create(&c, 1, cap, current_device(), &h));
     struct Guard { viorb_frontend* h; ~Guard() { viorb_frontend_destroy(h); } } g{h};
     DevBuf B; viorb_keypoint *d_ck, *d_lk; uint8_t *d_cd, *d_ld, *d_lf; float *d_lp, *d_pose; int *d_cc, *d_lc, *d_cs, *d_ci, *d_m, *d_nm, *d_st;
     FE_TRY(B.up(&d_ck, (const viorb_keypoint*)nullptr, (size_t)cap)); FE_TRY(B.up(&d_lk, (const viorb_keypoint*)nullptr, (size_t)cap));
@@ -2405,6 +2407,7 @@ int viorb_fuse(const viorb_keypoint* kps, const uint8_t* desc, const float* urig
                const uint8_t* pts_valid, const uint8_t* pts_desc, int npts, float th, int32_t* best_idx, int* nfused) {
     VIORB_REQUIRE(bounds4 && pose12 && intr5 && scale_factors && inv_level_sigma2 && nfused && n >= 0 && npts >= 0, "null array");
     VIORB_REQUIRE(nlevels >= 1 && nlevels <= 16, "nlevels must be 1..16");
+    VIORB_REQUIRE(npts == 0 || best_idx, "best_idx is NULL");
     *nfused = 0;
     for (int i = 0; i < npts; i++) best_idx[i] = -1;
     if (n == 0 || npts == 0) return VIORB_OK;
@@ -2415,7 +2418,7 @@ int viorb_fuse(const viorb_keypoint* kps, const uint8_t* desc, const float* urig
     c.nlevels = nlevels;
     for (int i = 0; i < 16; i++) { c.scale_factors[i] = scale_factors[i < nlevels ? i : nlevels - 1]; c.inv_level_sigma2[i] = inv_level_sigma2[i < nlevels ? i : nlevels - 1]; }
     viorb_frontend* h = nullptr;
-    FE_TRY(viorb_frontend_create(&c, 1, n, 0, &h));
+    FE_TRY(viorb_frontend_create(&c, 1, n, current_device(), &h));
     struct Guard { viorb_frontend* h; ~Guard() { viorb_frontend_destroy(h); } } g{h};
     DevBuf B; viorb_keypoint* d_k; uint8_t *d_d, *d_pv, *d_pd; float *d_ur, *d_pose, *d_pf; int *d_c, *d_cs, *d_ci, *d_pc, *d_bi, *d_nf;
     FE_TRY(B.up(&d_k, kps, (size_t)n)); FE_TRY(B.up(&d_d, desc, (size_t)n * 32)); FE_TRY(B.up(&d_ur, uright, (size_t)n));
@@ -2448,7 +2451,7 @@ int viorb_search_by_projection_points(const viorb_keypoint* cur_kps, const uint8
     c.nlevels = nlevels;
     for (int i = 0; i < 16; i++) c.scale_factors[i] = scale_factors[i < nlevels ? i : nlevels - 1];
     viorb_frontend* h = nullptr;
-    FE_TRY(viorb_frontend_create(&c, 1, ncur, 0, &h));
+    FE_TRY(viorb_frontend_create(&c, 1, ncur, current_device(), &h));
     struct Guard { viorb_frontend* h; ~Guard() { viorb_frontend_destroy(h); } } g{h};
     DevBuf B; viorb_keypoint* d_k; uint8_t *d_d, *d_pfl, *d_pd, *d_own; float *d_pose, *d_pf, *d_fr = nullptr; int *d_c, *d_cs, *d_ci, *d_pc, *d_m, *d_nm, *d_st;
     FE_TRY(B.up(&d_k, cur_kps, (size_t)ncur)); FE_TRY(B.up(&d_d, cur_desc, (size_t)ncur * 32)); FE_TRY(B.up(&d_own, cur_owner_obs, (size_t)ncur));
@@ -2474,7 +2477,7 @@ int viorb_preintegrate(const double* imu, int n_imu, const double bg[3], const d
     viorb_frontend_config c = default_cfg();
     for (int i = 0; i < 9; i += 4) c.cam[4 + i] = 1;
     viorb_frontend* h = nullptr;
-    FE_TRY(viorb_frontend_create(&c, 1, 64, 0, &h));
+    FE_TRY(viorb_frontend_create(&c, 1, 64, current_device(), &h));
     struct Guard { viorb_frontend* h; ~Guard() { viorb_frontend_destroy(h); } } g{h};
     double ns[22]; memset(ns, 0, sizeof(ns)); ns[9] = 1; for (int k = 0; k < 3; k++) { ns[10 + k] = bg[k]; ns[13 + k] = ba[k]; }
     DevBuf B; double *d_imu, *d_tl, *d_tc, *d_ns, *d_pre, *d_cur; float* d_pose;
@@ -2493,12 +2496,14 @@ int viorb_pose_opt_vi(int variant, int compute_marg, const double cur_ns[22], co
                       uint8_t* outlier_cur, uint8_t* outlier_last, double* marg_out144, double info[4]) {
     VIORB_REQUIRE(cur_ns && last_ns && preint && gw && cam && out_ns && info && n_cur >= 0 && n_last >= 0, "null array");
     VIORB_REQUIRE(n_cur == 0 || (obs_cur && outlier_cur), "obs_cur/outlier_cur NULL");
+    VIORB_REQUIRE(variant == 0 || (prior_ns && marg_cov_inv144), "the Frame overload needs the prior NavState and its information");
+    VIORB_REQUIRE(variant == 0 || n_last == 0 || (obs_last && outlier_last), "the Frame overload with n_last > 0 needs obs_last / outlier_last");
     viorb_frontend_config c = default_cfg();
     for (int i = 0; i < 16; i++) c.cam[i] = cam[i];
     for (int i = 0; i < 3; i++) c.gravity[i] = gw[i];
     const int cap = std::max(std::max(n_cur, n_last), 1);
     viorb_frontend* h = nullptr;
-    FE_TRY(viorb_frontend_create(&c, 1, cap, 0, &h));
+    FE_TRY(viorb_frontend_create(&c, 1, cap, current_device(), &h));
     struct Guard { viorb_frontend* h; ~Guard() { viorb_frontend_destroy(h); } } g{h};
     DevBuf B; double *d_cur, *d_last, *d_prior, *d_mci, *d_pre, *d_oc, *d_ol, *d_out, *d_outl, *d_marg, *d_info; int *d_nc, *d_nl; uint8_t *d_fc, *d_fl;
     double zero22[22] = {0}, zero144[144] = {0};
@@ -2528,7 +2533,7 @@ int viorb_pose_opt_se3(const float pose12[12], const float intr5[5], const doubl
     c.fx = intr5[0]; c.fy = intr5[1]; c.cx = intr5[2]; c.cy = intr5[3];
     const int cap = std::max(n, 1);
     viorb_frontend* h = nullptr;
-    FE_TRY(viorb_frontend_create(&c, 1, cap, 0, &h));
+    FE_TRY(viorb_frontend_create(&c, 1, cap, current_device(), &h));
     struct Guard { viorb_frontend* h; ~Guard() { viorb_frontend_destroy(h); } } g{h};
     DevBuf B; float *d_p, *d_o; double *d_obs, *d_info; int* d_n; uint8_t* d_f;
     FE_TRY(B.up(&d_p, pose12, 12)); FE_TRY(B.up(&d_o, (const float*)nullptr, 12)); FE_TRY(B.up(&d_obs, obs7, (size_t)n * 7));

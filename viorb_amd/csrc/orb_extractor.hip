@@ -20,6 +20,7 @@
 #include <math.h>
 #include <vector>
 #include <string>
+#include <mutex>
 #include <algorithm>
 #include "viorb_common.h"
 #include "orb_math.h"
@@ -64,6 +65,22 @@ ProfScope::ProfScope(const char* name, hipStream_t s) : idx(-1), st(s) {
     (void)hipEventRecord(g_prof.recs[idx].a, st);
 }
 ProfScope::~ProfScope() { if (idx >= 0) (void)hipEventRecord(g_prof.recs[idx].b, st); }
+
+hipError_t raise_dynamic_lds(const void* kernel, size_t bytes) {
+    static std::mutex mu;
+    static std::vector<std::pair<const void*, size_t>> seen;
+    std::lock_guard<std::mutex> lk(mu);
+    for (auto& e : seen)
+        if (e.first == kernel) {
+            if (bytes <= e.second) return hipSuccess;
+            const hipError_t rc = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+            if (rc == hipSuccess) e.second = bytes;
+            return rc;
+        }
+    const hipError_t rc = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (rc == hipSuccess) seen.push_back({kernel, bytes});
+    return rc;
+}
 
 static const int8_t kPatternHost[1024] = {
 #include "orb_pattern.inc"
@@ -1422,7 +1439,7 @@ static int configure(viorb_extractor* h, int w, int hgt) {
     size_t oct_lds = (size_t)h->oct_ncap * 8 + (size_t)h->oct_nodecap * sizeof(OctNode) + (size_t)sc * 4;
     if (oct_lds > 160 * 1024 || h->oct_nodecap > 65535) { set_error("nfeatures too large for the LDS quadtree (%zu B)", oct_lds); return VIORB_ERR_UNSUPPORTED; }
     if (oct_lds > 64 * 1024 &&
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_octree), hipFuncAttributeMaxDynamicSharedMemorySize, (int)oct_lds) != hipSuccess) {
+        raise_dynamic_lds(reinterpret_cast<const void*>(k_octree), oct_lds) != hipSuccess) {
         (void)hipGetLastError();
         h->oct_ncap = 4096;                              // stay inside the default 64 KiB dynamic-LDS window
         oct_lds = (size_t)h->oct_ncap * 8 + (size_t)h->oct_nodecap * sizeof(OctNode) + (size_t)sc * 4;
@@ -1773,7 +1790,7 @@ int viorb_stereo_match_device(const viorb_extractor* L, int left_index, const vi
     A.uright = d_uright; A.depth = d_depth; A.nmatched = d_nmatched;
     const size_t lds = stereo_lds_bytes(cap, sn);
     if (lds > 160 * 1024) { set_error("stereo matcher needs %zu B of LDS", lds); return VIORB_ERR_UNSUPPORTED; }
-    if (lds > 64 * 1024) VIORB_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_stereo_match), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (lds > 64 * 1024) VIORB_HIP_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(k_stereo_match), lds));
     ProfScope ps("k_stereo_match", (hipStream_t)stream);
     hipLaunchKernelGGL(k_stereo_match, dim3(pairs), dim3(1024), lds, (hipStream_t)stream, A);
     VIORB_HIP_TRY(hipGetLastError());

@@ -20,6 +20,10 @@ struct ProfScope {
     ~ProfScope();
 };
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a process-wide, per-kernel setting: every handle asks for its own size, so the limit is
+// only ever raised (a later, smaller handle must not lower it under a long-lived one's launches).
+hipError_t raise_dynamic_lds(const void* kernel, size_t bytes);
+
 } // namespace viorb
 
 #define VIORB_HIP_TRY(expr)                                                                   \

@@ -218,9 +218,26 @@ class BatchedTracker:
         self.k += 1
         # keep the host at most MAX_STEPS_AHEAD steps in front of the device: a live system never queues more (frames arrive one at a
         # time), and an unbounded backlog only holds events and command-queue slots (no measurable effect on the step time either way)
-        self._in_flight.append(ev)
+        # the inputs are read on s_ex / s_tr, not on the caller's stream: a caller that drops a tensor right after step() would hand its
+        # memory back to torch's caching allocator while the GPU still reads it, so the step's inputs stay referenced until its event
+        self._in_flight.append((ev, (images, imu, t_cur, true_pose12, true_ns, t_next_last, marg_reset)))
         if len(self._in_flight) > self.MAX_STEPS_AHEAD:
-            self._in_flight.pop(0).synchronize()
+            self._in_flight.pop(0)[0].synchronize()
+
+    def status_all(self):
+        """Per-stream status of the last step folded over the extractor and both searches (0 = ok, VIORB_ERR_CAPACITY when a level's
+        quadtree input or a search candidate list was truncated): assert on it — a truncated stream no longer equals the reference."""
+        torch = self.torch
+        _, _, _, ex_status, _ = self._cur_ptrs()
+        st = torch.zeros(self.B, dtype=torch.int32, device=self.dev)
+        check(_hip_memcpy_dtod_async(st.data_ptr(), ex_status, 4 * self.B, C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)))
+        torch.cuda.synchronize()
+        out = st.cpu().numpy()
+        for other in (self.status, getattr(self, "status2", None)):
+            if other is not None:
+                o = other.cpu().numpy()
+                out = np.where(out == 0, o, out)
+        return out
 
 
 def _hip_memcpy_dtod_async(dst, src, nbytes, stream):
