@@ -463,64 +463,79 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t* __restrict__ p
             // ---- pass 1
             int nsurv = 0;
             {
-                // A lane takes one aligned dword = 4 horizontally adjacent pixels of a row (lanes run over (row, dword) in row-major
-                // order, so lane order x byte order is cv::FAST's keypoint order): five dword LDS reads (centre, left, right, three rows
-                // up, three rows down) instead of twenty byte reads, and the address / stepping / compaction overhead is paid once per
-                // four pixels. The kernel is VALU-issue bound, so instructions per pixel is the lever.
+                // A lane takes a PAIR of adjacent aligned dwords = 8 horizontally adjacent pixels of a row (lanes run over (row, pair) in
+                // row-major order, so lane order x byte order is cv::FAST's keypoint order): eight dword LDS reads (two centres, left,
+                // right, two three rows up, two three rows down) instead of forty byte reads, and the address / stepping / prefix-sum /
+                // store overhead is paid once per eight pixels (it was ~45 % of a four-pixel trip). The kernel is VALU-issue bound, so
+                // instructions per pixel is the lever.
                 const int g0 = (xoff + 3) >> 2;                                  // tile dword holding the first interior pixel
                 const int G = ((xoff + 3 + dw - 1) >> 2) - g0 + 1;               // dwords per interior row
-                const int step_r = 64 / G, step_g = 64 - step_r * G;
-                int r = lane / G, g = lane - r * G;
-                const int ntrip = (dh * G + 63) >> 6;
+                const int G2 = (G + 1) >> 1;                                     // dword pairs per interior row
+                const int step_r = 64 / G2, step_g = 64 - step_r * G2;
+                int r = lane / G2, gp = lane - r * G2;
+                const int ntrip = (dh * G2 + 63) >> 6;
+                const uint32_t M = 0x00ff00ffu, Hb = 0x80008000u;
+                const uint32_t K1 = Hb + (uint32_t)th * 0x00010001u, K2 = Hb - (uint32_t)(th + 1) * 0x00010001u;
                 for (int trip = 0; trip < ntrip; trip++) {
                     const int rc = min(r, dh - 1);                                // lanes past the last row read a valid address and are masked
-                    const uint32_t* pc = reinterpret_cast<const uint32_t*>(tile + (rc + 3) * tile_pitch) + g0 + g;
-                    const uint32_t C = pc[0], Lf = pc[-1], Rt = pc[1];
-                    const uint32_t U = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(pc) - 3 * tile_pitch);
-                    const uint32_t D = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(pc) + 3 * tile_pitch);
-                    const uint32_t W = __builtin_amdgcn_alignbyte(C, Lf, 1);     // pixels 3 to the left of C's four
-                    const uint32_t E = __builtin_amdgcn_alignbyte(Rt, C, 3);     // pixels 3 to the right
-                    const int q0 = 4 * (g0 + g) - (xoff + 3);                    // interior column of byte 0 (may be < 0 in the first dword)
-                    // Four pixels at once, bytes widened to 16-bit fields (even bytes in one register, odd bytes in another): with
+                    const int ga = 2 * gp, gb = min(ga + 1, G - 1);               // second dword of the last (odd) pair: clamped, masked below
+                    const uint32_t* row = reinterpret_cast<const uint32_t*>(tile + (rc + 3) * tile_pitch) + g0;
+                    const uint32_t* rowU = reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(row) - 3 * tile_pitch);
+                    const uint32_t* rowD = reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(row) + 3 * tile_pitch);
+                    const uint32_t Lf = row[ga - 1], C0 = row[ga], C1 = row[gb], Rt = row[gb + 1];
+                    const uint32_t U0 = rowU[ga], U1 = rowU[gb], D0 = rowD[ga], D1 = rowD[gb];
+                    // pixels 3 to the left / right of each dword's four (the second dword's left neighbour is the first, unless it was clamped)
+                    const uint32_t Cl1 = gb == ga ? Lf : C0;
+                    const uint32_t W0 = __builtin_amdgcn_alignbyte(C0, Lf, 1), E0 = __builtin_amdgcn_alignbyte(gb == ga ? Rt : C1, C0, 3);
+                    const uint32_t W1 = __builtin_amdgcn_alignbyte(C1, Cl1, 1), E1 = __builtin_amdgcn_alignbyte(Rt, C1, 3);
+                    const int q0 = 4 * (g0 + ga) - (xoff + 3);                   // interior column of byte 0 (may be < 0 in the first dword)
+                    // Four pixels at once per dword, bytes widened to 16-bit fields (even bytes in one register, odd bytes in another): with
                     // c1 = 0x8000 + t - v and c2 = 0x8000 - t - 1 - v per field, bit 15 of (p + c1) says "p is NOT darker than v - t" and
                     // bit 15 of (p + c2) says "p is brighter than v + t"; no field can carry into its neighbour. Some adjacent pair of the four
                     // compass pixels (0, 4, 8, 12) is dark-dark iff (dark0 | dark8) & (dark4 | dark12), same for bright: plain and/or/add
                     // at full rate instead of four extract + sixteen min/max per pixel.
-                    const uint32_t M = 0x00ff00ffu, Hb = 0x80008000u;
-                    const uint32_t K1 = Hb + (uint32_t)th * 0x00010001u, K2 = Hb - (uint32_t)(th + 1) * 0x00010001u;
-                    uint32_t cand[2];
+                    uint32_t bits = 0;
     #pragma unroll
-                    for (int half = 0; half < 2; half++) {
-                        // even bytes: one and; odd bytes: one v_perm_b32 (bytes 1 and 3 into the low byte of each 16-bit field)
-                        auto field = [&](uint32_t x) { return half ? __builtin_amdgcn_perm(x, x, 0x0c030c01u) : (x & M); };
-                        const uint32_t v2 = field(C), c1 = K1 - v2, c2 = K2 - v2;
-                        const uint32_t p0 = field(D), p4 = field(E), p8 = field(U), p12 = field(W);
-                        const uint32_t nd = ((p0 + c1) & (p8 + c1)) | ((p4 + c1) & (p12 + c1));      // bit 15: no adjacent dark pair
-                        const uint32_t br = ((p0 + c2) | (p8 + c2)) & ((p4 + c2) | (p12 + c2));      // bit 15: an adjacent bright pair
-                        cand[half] = (~nd | br) & Hb;
+                    for (int dwi = 0; dwi < 2; dwi++) {
+                        const uint32_t C = dwi ? C1 : C0, U = dwi ? U1 : U0, D = dwi ? D1 : D0, W = dwi ? W1 : W0, E = dwi ? E1 : E0;
+                        uint32_t cand[2];
+    #pragma unroll
+                        for (int half = 0; half < 2; half++) {
+                            // even bytes: one and; odd bytes: one v_perm_b32 (bytes 1 and 3 into the low byte of each 16-bit field)
+                            auto field = [&](uint32_t x) { return half ? __builtin_amdgcn_perm(x, x, 0x0c030c01u) : (x & M); };
+                            const uint32_t v2 = field(C), c1 = K1 - v2, c2 = K2 - v2;
+                            const uint32_t p0 = field(D), p4 = field(E), p8 = field(U), p12 = field(W);
+                            const uint32_t nd = ((p0 + c1) & (p8 + c1)) | ((p4 + c1) & (p12 + c1));      // bit 15: no adjacent dark pair
+                            const uint32_t br = ((p0 + c2) | (p8 + c2)) & ((p4 + c2) | (p12 + c2));      // bit 15: an adjacent bright pair
+                            cand[half] = (~nd | br) & Hb;
+                        }
+                        // pixel k of the dword: k = 0, 2 in cand[0] bits 15, 31; k = 1, 3 in cand[1] bits 15, 31
+                        const uint32_t b4 = ((cand[0] >> 15) & 1u) | ((cand[1] >> 14) & 2u) | ((cand[0] >> 29) & 4u) | ((cand[1] >> 28) & 8u);
+                        bits |= b4 << (4 * dwi);
                     }
-                    // pixel k of the dword: k = 0, 2 in cand[0] bits 15, 31; k = 1, 3 in cand[1] bits 15, 31
-                    uint32_t bits = ((cand[0] >> 15) & 1u) | ((cand[1] >> 14) & 2u) | ((cand[0] >> 29) & 4u) | ((cand[1] >> 28) & 8u);
-                    {   // columns outside the interior
-                        const int lo = max(0, -q0), hi = min(4, dw - q0);                            // valid k in [lo, hi)
+                    {   // columns outside the interior (and the clamped second dword of an odd row end)
+                        const int lo = max(0, -q0), hi = min(gb == ga ? 4 : 8, dw - q0);              // valid k in [lo, hi)
                         const uint32_t rng = hi > lo ? (((1u << hi) - 1u) & ~((1u << lo) - 1u)) : 0u;
                         bits &= rng;
                     }
                     if (r >= dh) bits = 0;
                     // ordered compaction: position = survivors in lower lanes + survivors in lower bytes of this lane, from a DPP prefix sum
-                    // of the per-lane counts (ten instructions where four ballots with their mbcnt / bcnt pairs took twenty-five)
+                    // of the per-lane counts
                     const int cnt = __popc(bits), incl = wave_inclusive_scan(cnt);
                     const int trip_total = __builtin_amdgcn_readlane(incl, 63);
                     if (trip_total) {                                            // wave-uniform: nothing to store on a flat stretch
                         int pos = nsurv + incl - cnt;
                         const uint32_t rq0 = ((uint32_t)r << 8) + (uint32_t)q0;
-    #pragma unroll
-                        for (int k = 0; k < 4; k++)
-                            if (bits & (1u << k)) { surv[pos] = (uint16_t)(rq0 + k); pos++; }
+                        uint32_t bb = bits;
+                        while (bb) {                                             // survivors are sparse: one or two trips for the whole wave
+                            const int k = __builtin_ctz(bb);
+                            surv[pos++] = (uint16_t)(rq0 + k);
+                            bb &= bb - 1;
+                        }
                         nsurv += trip_total;
                     }
-                    r += step_r; g += step_g;
-                    if (g >= G) { g -= G; r++; }
+                    r += step_r; gp += step_g;
+                    if (gp >= G2) { gp -= G2; r++; }
                 }
             }
             __syncthreads();

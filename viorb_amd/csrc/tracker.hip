@@ -27,6 +27,7 @@
 // the synthetic plane world of viorb_amd/synth.py (workload support for bench.py / tests).
 #include <hip/hip_runtime.h>
 #include <chrono>
+#include <cstdlib>
 #include <deque>
 #include <vector>
 #include "viorb_common.h"
@@ -193,8 +194,14 @@ int viorb_tracker_create(const viorb_tracker_config* cfg, viorb_tracker** out) {
     fc.nlevels = h->nlevels;
     fc.min_x = 0; fc.max_x = (float)cfg->width; fc.min_y = 0; fc.max_y = (float)cfg->height;
     TR_TRY(viorb_frontend_create(&fc, cfg->batch, h->cap, cfg->device, &h->fe));
-    VIORB_HIP_TRY(hipStreamCreateWithFlags(&h->s_ex, hipStreamNonBlocking));
-    VIORB_HIP_TRY(hipStreamCreateWithFlags(&h->s_tr, hipStreamNonBlocking));
+    {
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);                  // hi = numerically lowest = highest priority
+        const char* pr = getenv("VIORB_TRACK_PRIORITY");                  // experiment switch: 1 = tracking stream above extraction, 2 = below
+        const int p_tr = pr && pr[0] == '1' ? hi : (pr && pr[0] == '2' ? lo : 0), p_ex = pr && pr[0] == '1' ? lo : (pr && pr[0] == '2' ? hi : 0);
+        VIORB_HIP_TRY(hipStreamCreateWithPriority(&h->s_ex, hipStreamNonBlocking, p_ex));
+        VIORB_HIP_TRY(hipStreamCreateWithPriority(&h->s_tr, hipStreamNonBlocking, p_tr));
+    }
     VIORB_HIP_TRY(hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming));
     for (int i = 0; i < 2; i++) { VIORB_HIP_TRY(hipEventCreateWithFlags(&h->ev_ex[i], hipEventDisableTiming)); VIORB_HIP_TRY(hipEventCreateWithFlags(&h->ev_tr[i], hipEventDisableTiming)); }
     const size_t B = (size_t)h->B, cap = (size_t)h->cap, R = (size_t)(cfg->track_local_map ? cfg->local_frames : 1);
