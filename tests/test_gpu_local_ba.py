@@ -56,6 +56,38 @@ def test_local_ba_batch_equals_single_calls(oracle):
             assert abs(g["chi2_final"] - r["chi2_final"]) <= 1e-9 * r["chi2_final"]
 
 
+def test_local_ba_batch_stop_flag_set_before_the_call(oracle):
+    """A window whose pbStopFlag is already set comes back untouched from the lock-step batch while its neighbours are solved."""
+    import ctypes as C
+    from viorb_amd import capi, LocalBundleAdjustmentNavState
+    from viorb_amd.capi import lib, check
+    probs = []
+    for seed in (21, 22, 23):
+        p = make_local_ba_problem(seed, W=5, n_points=200, n_fixed_extra=2)
+        probs.append(_args(p, _preints(oracle, p)))
+    single = [LocalBundleAdjustmentNavState(*a) for a in probs]
+    W = (capi.LbaWindow * 3)()
+    keep, stop = [], np.ones(1, np.int32)
+    for i, a in enumerate(probs):
+        kfs = np.ascontiguousarray(a[0], np.float64); pre = np.ascontiguousarray(a[3], np.float64); pts = np.ascontiguousarray(a[4], np.float64)
+        ei = np.ascontiguousarray(a[5], np.int32); eo = np.ascontiguousarray(a[6], np.float64); gw = np.ascontiguousarray(a[7], np.float64); cam = np.ascontiguousarray(a[8], np.float64)
+        ko, po, er, info = np.zeros((a[1], 22)), np.zeros_like(pts), np.zeros(len(ei), np.uint8), np.zeros(6)
+        keep.append((kfs, pre, pts, ei, eo, gw, cam, ko, po, er, info))
+        w = W[i]
+        w.kfs = kfs.ctypes.data; w.nk = len(kfs); w.n_local = a[1]; w.prev_kf = a[2]; w.preint = pre.ctypes.data; w.points = pts.ctypes.data; w.np = len(pts)
+        w.edge_idx = ei.ctypes.data; w.edge_obs = eo.ctypes.data; w.ne = len(ei); w.gw = gw.ctypes.data; w.cam = cam.ctypes.data
+        w.stop = stop.ctypes.data if i == 1 else None
+        w.kfs_out = ko.ctypes.data; w.points_out = po.ctypes.data; w.erase = er.ctypes.data; w.info = info.ctypes.data
+    check(lib().viorb_local_ba_navstate_batch(C.cast(W, C.c_void_p), 3, 0))
+    assert [W[i].status for i in range(3)] == [0, 0, 0]
+    np.testing.assert_array_equal(keep[1][7], keep[1][0][:probs[1][1]])            # stopped window: key frames unchanged
+    np.testing.assert_array_equal(keep[1][8], keep[1][2]); assert keep[1][9].sum() == 0 and keep[1][10][2] == 0
+    for i in (0, 2):
+        assert (int(keep[i][10][2]), int(keep[i][10][3])) == (single[i]["its_first"], single[i]["its_second"])
+        np.testing.assert_allclose(keep[i][7], single[i]["kfs"], rtol=0, atol=1e-9)
+        np.testing.assert_array_equal(keep[i][9], single[i]["erase"])
+
+
 def test_local_ba_without_prev_keyframe(oracle):
     """prev_kf = -1: the first local key frame has no IMU / bias factor (map start)."""
     from viorb_amd import LocalBundleAdjustmentNavState

@@ -20,6 +20,7 @@
 #include <vector>
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <limits>
 #include <mutex>
 #include "viorb_common.h"
@@ -43,9 +44,19 @@ struct BaDev {
     const double *preint, *info_pvr; // [W][142], [W][81]
     double *e_pvr, *e_b;            // [W][9], [W][3]
     double *scal;                   // [8]: 0 chi2, 1 scale, 2 ok, 3 max diag
+    double *ctl;                    // device-side LM control (BA_CTL_*), used when use_ctl != 0: kernels return at once while ctl[HALT] != 0
+    int use_ctl;                    // and take lambda from ctl[LAMBDA] instead of their argument
     double cam[16], gw[3];
     double acc_bias_rw2;
 };
+
+// Device-side Levenberg control (g2o optimization_algorithm_levenberg.cpp:61-164) for the common case of an LM iteration whose first
+// trial is accepted: the host enqueues several iterations back to back, k_ba_decide takes the accept / stop decisions on the device, and
+// after a REJECTED trial every later kernel of the chunk returns at once (ctl[HALT] = 1) so that the host finds the system, the trial
+// state and the trial's scalars untouched and continues with its own trial loop (lambda *= ni, restore, retry).
+enum { BA_CTL_LAMBDA = 0, BA_CTL_NI, BA_CTL_CHI, BA_CTL_INICHI, BA_CTL_NBAD, BA_CTL_HALT, BA_CTL_ITS, BA_CTL_IT, BA_CTL_RHO, BA_CTL_N = 32 };
+__device__ __forceinline__ bool ba_skip(const BaDev& D) { return D.use_ctl && D.ctl[BA_CTL_HALT] != 0.0; }
+__device__ __forceinline__ double ba_lambda(const BaDev& D, double arg) { return D.use_ctl ? D.ctl[BA_CTL_LAMBDA] : arg; }
 
 __device__ __forceinline__ void ba_edge_geom(const BaDev& D, int k, const double* kfv, const double* ptv, d3& Pc, m33& RwbT, d3& Paux, cam_t& K) {
     K = ld_cam(D.cam);
@@ -60,7 +71,8 @@ __device__ __forceinline__ int ba_pred(const BaDev& D, int i) { return i == 0 ? 
 __device__ __forceinline__ int ba_loc(const BaDev& D, int r) { return D.pose_dim == 12 ? (r < 3 ? r : r + 3) : r; }
 
 // residuals of the active edges + robust chi2 (mono kernel optional) + IMU / bias factors
-__global__ void k_ba_errors(BaDev D, int mono_kernel) {
+__device__ __forceinline__ void k_ba_errors_body(const BaDev& D, int mono_kernel) {
+    if (ba_skip(D)) return;
     __shared__ double s_red[8];
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     double c = 0;
@@ -97,7 +109,8 @@ __global__ void k_ba_errors(BaDev D, int mono_kernel) {
 }
 
 // one thread per point: Jacobians + weights of its active edges (stored per edge), Hll and bl of the point
-__global__ void k_ba_lin_points(BaDev D, int mono_kernel) {
+__device__ __forceinline__ void k_ba_lin_points_body(const BaDev& D, int mono_kernel) {
+    if (ba_skip(D)) return;
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= D.NP) return;
     double H[6] = {0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};
@@ -134,7 +147,8 @@ __global__ void k_ba_lin_points(BaDev D, int mono_kernel) {
 }
 
 // one workgroup per local key frame: sum of Jk^T w Jk / Jk^T w e over its active edges -> the 6x6 reprojection block of Hpp, bp
-__global__ __launch_bounds__(256) void k_ba_hpp(BaDev D) {
+__device__ __forceinline__ void k_ba_hpp_body(const BaDev& D) {
+    if (ba_skip(D)) return;
     __shared__ double s_red[4][27];
     const int i = blockIdx.x, t = threadIdx.x, rows = D.rows;
     double a[27];
@@ -176,7 +190,8 @@ __global__ __launch_bounds__(256) void k_ba_hpp(BaDev D) {
 }
 
 // one workgroup per local key frame i: IMU factor (pred(i) -> i) and bias factor
-__global__ __launch_bounds__(256) void k_ba_imu(BaDev D) {
+__device__ __forceinline__ void k_ba_imu_body(const BaDev& D) {
+    if (ba_skip(D)) return;
     __shared__ double J[9 * 21], OJ[9 * 21], e[9];
     __shared__ int map[21];
     __shared__ double s_w;
@@ -212,7 +227,9 @@ __global__ __launch_bounds__(256) void k_ba_imu(BaDev D) {
 }
 
 // S = Hpp + lambda I, bs = bp, written with the padded leading dimension ld (a multiple of 16: identity on the padding)
-__global__ void k_ba_init_reduced(BaDev D, double lambda) {
+__device__ __forceinline__ void k_ba_init_reduced_body(const BaDev& D, double lambda_arg) {
+    if (ba_skip(D)) return;
+    const double lambda = ba_lambda(D, lambda_arg);
     const int q = blockIdx.x * blockDim.x + threadIdx.x, n = D.np, ld = D.ld;
     if (q < ld * ld) {
         const int i = q / ld, j = q - i * ld;
@@ -220,7 +237,8 @@ __global__ void k_ba_init_reduced(BaDev D, double lambda) {
     }
     if (q < ld) D.bs[q] = q < n ? D.bp[q] : 0.0;
 }
-__global__ void k_ba_max_diag(BaDev D) {
+__device__ __forceinline__ void k_ba_max_diag_body(const BaDev& D) {
+    if (ba_skip(D)) return;
     __shared__ double s_red[4];
     double m = 0;
     for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < D.np + 3 * D.NP; q += gridDim.x * blockDim.x)
@@ -237,7 +255,9 @@ __global__ void k_ba_max_diag(BaDev D) {
 }
 
 // one thread per point: Dinv = (Hll + lambda I)^-1 and Dinv * bl
-__global__ void k_ba_dinv(BaDev D, double lambda) {
+__device__ __forceinline__ void k_ba_dinv_body(const BaDev& D, double lambda_arg) {
+    if (ba_skip(D)) return;
+    const double lambda = ba_lambda(D, lambda_arg);
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= D.NP) return;
     const double* H = D.Hll + (size_t)p * 9;
@@ -253,7 +273,8 @@ __global__ void k_ba_dinv(BaDev D, double lambda) {
 // [a][0..a] of -sum_p W_pa Dinv_p W_pb^T (6 x 12(a+1) values; the Cholesky never reads above the diagonal) and -W_pa Dinv_p bl_p in
 // LDS with ds_add_f64, walking a's observations and, for each, the other observations of that point; the row is then added to S
 // and bs without global atomics (rows of key frame a belong to this workgroup alone).
-__global__ __launch_bounds__(256) void k_ba_schur(BaDev D) {
+__device__ __forceinline__ void k_ba_schur_body(const BaDev& D) {
+    if (ba_skip(D)) return;
     __shared__ double s_row[6][240], s_b[6];
     const int ka = blockIdx.x, t = threadIdx.x, ld = D.ld, rows = D.rows, pd = D.pose_dim, ncol = pd * (ka + 1);
     for (int q = t; q < 6 * 240; q += blockDim.x) (&s_row[0][0])[q] = 0.0;
@@ -321,7 +342,8 @@ __device__ __forceinline__ double ba_rsqrt(double d) {
     y = fma(0.5 * y, fma(-(d * y), y, 1.0), y);
     return y;
 }
-__global__ __launch_bounds__(1024) void k_ba_chol_solve(BaDev D) {
+__device__ __forceinline__ void k_ba_chol_solve_body(const BaDev& D) {
+    if (ba_skip(D)) return;
     __shared__ double s_L[16][17], s_P[256][17], s_y[256], s_rd[16];
     __shared__ int s_ok;
     const int n = D.np, ld = D.ld, nb = ld >> 4, t = threadIdx.x, lane = t & 63, wv = t >> 6;
@@ -444,7 +466,9 @@ __global__ __launch_bounds__(1024) void k_ba_chol_solve(BaDev D) {
 }
 
 // xl = Dinv (bl - W^T xp) per point, and the LM scale term sum x (lambda x + b)
-__global__ void k_ba_backsub(BaDev D, double lambda) {
+__device__ __forceinline__ void k_ba_backsub_body(const BaDev& D, double lambda_arg) {
+    if (ba_skip(D)) return;
+    const double lambda = ba_lambda(D, lambda_arg);
     __shared__ double s_red[4];
     const int p = blockIdx.x * blockDim.x + threadIdx.x, rows = D.rows;
     double sc = 0;
@@ -474,7 +498,8 @@ __global__ void k_ba_backsub(BaDev D, double lambda) {
     if (threadIdx.x == 0) atomicAdd(&D.scal[1], s_red[0] + s_red[1] + s_red[2] + s_red[3]);
 }
 
-__global__ void k_ba_update(BaDev D) {
+__device__ __forceinline__ void k_ba_update_body(const BaDev& D) {
+    if (ba_skip(D)) return;
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q < D.W) {
         double* k = D.kf + (size_t)q * 22;
@@ -486,14 +511,14 @@ __global__ void k_ba_update(BaDev D) {
     if (q < D.NP) for (int c = 0; c < 3; c++) { D.pt_bak[3 * q + c] = D.pt[3 * q + c]; D.pt[3 * q + c] += D.xl[3 * q + c]; }
 }
 // a rejected trial: local key frames and points back to what k_ba_update / k_ba_se3_update saved
-__global__ void k_ba_restore(BaDev D) {
+__device__ __forceinline__ void k_ba_restore_body(const BaDev& D) {
     const int q = blockIdx.x * blockDim.x + threadIdx.x, stride = D.kf_stride;
     if (q < D.W) for (int c = 0; c < stride; c++) D.kf[(size_t)q * stride + c] = D.kf_bak[(size_t)q * stride + c];
     if (q < D.NP) for (int c = 0; c < 3; c++) D.pt[3 * q + c] = D.pt_bak[3 * q + c];
 }
 
 // chi2 / depth gate on every edge (stale error on excluded edges, fresh depth), Optimizer.cc:2037-2051 and :2105-2118
-__global__ void k_ba_gate(BaDev D, uint8_t* out, int set_level) {
+__device__ __forceinline__ void k_ba_gate_body(const BaDev& D, uint8_t* out, int set_level) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= D.NE) return;
     d3 Pc, Paux; m33 RT; cam_t K;
@@ -503,11 +528,183 @@ __global__ void k_ba_gate(BaDev D, uint8_t* out, int set_level) {
     if (set_level) { if (bad) D.level[k] = 1; } else out[k] = (uint8_t)bad;
 }
 
+// zero Hpp / bp (and the max-diagonal accumulator) for the linearisation of an iteration; first = 1 on the first iteration of a phase
+__device__ __forceinline__ void k_ba_clear_body(const BaDev& D, int first) {
+    if (ba_skip(D)) return;
+    const size_t n2 = (size_t)D.np * D.np;
+    for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < n2; q += (size_t)gridDim.x * blockDim.x) D.Hpp[q] = 0.0;
+    if (blockIdx.x == 0) {
+        for (int q = threadIdx.x; q < D.np; q += blockDim.x) D.bp[q] = 0.0;
+        if (threadIdx.x == 0) {
+            if (first) { D.scal[3] = 0.0; D.ctl[BA_CTL_CHI] = D.scal[0]; D.ctl[BA_CTL_NBAD] = 0.0; }   // chi2 of the phase's first computeActiveErrors
+            D.ctl[BA_CTL_INICHI] = D.ctl[BA_CTL_CHI];
+        }
+    }
+}
+// lambda_0 = 1e-5 * max diagonal (:166-180), after k_ba_max_diag on the first iteration of a phase
+__device__ __forceinline__ void k_ba_lambda0_body(const BaDev& D) {
+    if (ba_skip(D)) return;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { D.ctl[BA_CTL_LAMBDA] = 1e-5 * D.scal[3]; D.ctl[BA_CTL_NI] = 2.0; }
+}
+// after the trial's k_ba_*_errors: rho = (chi - chi_trial) / (sum x (lambda x + b) + 1e-3) (:129-132); accepted -> lambda update, stop
+// tests; rejected -> HALT = 1 and nothing else changes (the host takes over from ST_AFTER_TRIAL with the scalars as they are)
+__global__ void k_ba_decide(BaDev D, int last_of_phase) {
+    if (ba_skip(D)) return;
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    double* c = D.ctl;
+    double tempChi = D.scal[0];
+    const bool ok2 = D.scal[2] > 0.5;
+    if (!ok2) tempChi = 1.7976931348623157e308;
+    const double scale = (ok2 ? D.scal[1] : 0.0) + 1e-3;
+    const double rho = (c[BA_CTL_CHI] - tempChi) / scale;
+    c[BA_CTL_RHO] = rho;
+    if (!(rho > 0 && isfinite(tempChi))) { c[BA_CTL_HALT] = 1.0; return; }
+    const double t = 2 * rho - 1;
+    double alpha = 1. - t * t * t;
+    alpha = fmin(alpha, 2. / 3.);
+    c[BA_CTL_LAMBDA] *= fmax(1. / 3., alpha); c[BA_CTL_NI] = 2.0;
+    const double iniChi = c[BA_CTL_INICHI];
+    c[BA_CTL_CHI] = tempChi;
+    c[BA_CTL_ITS] += 1.0; c[BA_CTL_IT] += 1.0;
+    // "if ((iniChi - currentChi) * 1e3 < iniChi) nBad++ else nBad = 0; if (nBad >= 3) stop" (:154-161)
+    double nBad = c[BA_CTL_NBAD];
+    if ((iniChi - tempChi) * 1e3 < iniChi) nBad += 1.0; else nBad = 0.0;
+    c[BA_CTL_NBAD] = nBad;
+    if (nBad >= 3.0 || last_of_phase) c[BA_CTL_HALT] = 2.0;      // this optimize() call is over
+}
+
+
+// ---- by-value kernels of the single-window driver ---------------------------------------------------------------------------------
+__global__ void k_ba_errors(BaDev D, int mono_kernel) { k_ba_errors_body(D, mono_kernel); }
+__global__ void k_ba_lin_points(BaDev D, int mono_kernel) { k_ba_lin_points_body(D, mono_kernel); }
+__global__ __launch_bounds__(256) void k_ba_hpp(BaDev D) { k_ba_hpp_body(D); }
+__global__ __launch_bounds__(256) void k_ba_imu(BaDev D) { k_ba_imu_body(D); }
+__global__ void k_ba_init_reduced(BaDev D, double lambda_arg) { k_ba_init_reduced_body(D, lambda_arg); }
+__global__ void k_ba_max_diag(BaDev D) { k_ba_max_diag_body(D); }
+__global__ void k_ba_dinv(BaDev D, double lambda_arg) { k_ba_dinv_body(D, lambda_arg); }
+__global__ __launch_bounds__(256) void k_ba_schur(BaDev D) { k_ba_schur_body(D); }
+__global__ __launch_bounds__(1024) void k_ba_chol_solve(BaDev D) { k_ba_chol_solve_body(D); }
+__global__ void k_ba_backsub(BaDev D, double lambda_arg) { k_ba_backsub_body(D, lambda_arg); }
+__global__ void k_ba_update(BaDev D) { k_ba_update_body(D); }
+__global__ void k_ba_restore(BaDev D) { k_ba_restore_body(D); }
+__global__ void k_ba_gate(BaDev D, uint8_t* out, int set_level) { k_ba_gate_body(D, out, set_level); }
+__global__ void k_ba_clear(BaDev D, int first) { k_ba_clear_body(D, first); }
+__global__ void k_ba_lambda0(BaDev D) { k_ba_lambda0_body(D); }
+
+// ---- lock-step batch: one launch covers every window of a batch (blockIdx.y = window) ------------------------------------------------
+// viorb_local_ba_navstate_batch used to give every window its own stream and host-driven LM loop; the streams share four hardware queues,
+// so at most four windows' kernel chains really overlapped (436 windows/s for 64 W = 20 windows). Here all windows advance through the
+// same ROUND of launches — [chi2 of a new phase] [linearise if the last trial was accepted] [lambda_0 on a phase's first iteration]
+// [one LM trial] [decide] [restore a rejected trial] [phase gate] — and the per-window state machine of g2o's Levenberg loop
+// (optimization_algorithm_levenberg.cpp:61-164) plus LocalBundleAdjustmentNavState's two optimize() calls (src/Optimizer.cc:2026-2099)
+// lives in the window's control block on the device. A round is 20 launches for the whole batch; the host only counts finished windows
+// every few rounds.
+enum { BA_B_DONE = 16, BA_B_NEED_CHI, BA_B_NEED_LIN, BA_B_FIRST, BA_B_PHASE, BA_B_MONO, BA_B_QMAX, BA_B_GATE, BA_B_RESTORE, BA_B_ITERS,
+       BA_B_ITS0, BA_B_ITS1, BA_B_CHI0, BA_B_CHI1, BA_B_ABORT, BA_B_N = 32 };
+#define BA_B_WINDOW() const BaDev& D = Dv[blockIdx.y]; const double* c = D.ctl; if (c[BA_B_DONE] != 0.0 || c[BA_B_ABORT] != 0.0) return
+__global__ void k_bab_round_begin(const BaDev* __restrict__ Dv, int nwin) {
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= nwin) return;
+    const BaDev& D = Dv[w]; double* c = D.ctl;
+    if (c[BA_B_DONE] != 0.0 || c[BA_B_ABORT] != 0.0) return;
+    if (c[BA_B_NEED_CHI] != 0.0) D.scal[0] = 0.0;                        // accumulator of the phase's first computeActiveErrors
+    if (c[BA_B_NEED_LIN] != 0.0 && c[BA_B_FIRST] != 0.0) D.scal[3] = 0.0;  // accumulator of k_ba_max_diag
+}
+__global__ void k_bab_errors_chi(const BaDev* __restrict__ Dv) { BA_B_WINDOW(); if (c[BA_B_NEED_CHI] == 0.0) return; k_ba_errors_body(D, c[BA_B_MONO] != 0.0); }
+__global__ void k_bab_take_chi(const BaDev* __restrict__ Dv, int nwin) {
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= nwin) return;
+    const BaDev& D = Dv[w]; double* c = D.ctl;
+    if (c[BA_B_DONE] != 0.0 || c[BA_B_ABORT] != 0.0 || c[BA_B_NEED_CHI] == 0.0) return;
+    c[BA_CTL_CHI] = D.scal[0]; c[BA_B_NEED_CHI] = 0.0;
+}
+__global__ void k_bab_clear(const BaDev* __restrict__ Dv) { BA_B_WINDOW(); if (c[BA_B_NEED_LIN] == 0.0) return; k_ba_clear_body(D, 0); }
+__global__ void k_bab_lin_points(const BaDev* __restrict__ Dv) { BA_B_WINDOW(); if (c[BA_B_NEED_LIN] == 0.0) return; k_ba_lin_points_body(D, c[BA_B_MONO] != 0.0); }
+__global__ __launch_bounds__(256) void k_bab_hpp(const BaDev* __restrict__ Dv) { BA_B_WINDOW(); if (c[BA_B_NEED_LIN] == 0.0 || (int)blockIdx.x >= D.W) return; k_ba_hpp_body(D); }
+__global__ __launch_bounds__(256) void k_bab_imu(const BaDev* __restrict__ Dv) { BA_B_WINDOW(); if (c[BA_B_NEED_LIN] == 0.0 || (int)blockIdx.x >= D.W) return; k_ba_imu_body(D); }
+__global__ void k_bab_max_diag(const BaDev* __restrict__ Dv) { BA_B_WINDOW(); if (c[BA_B_NEED_LIN] == 0.0 || c[BA_B_FIRST] == 0.0) return; k_ba_max_diag_body(D); }
+__global__ void k_bab_lambda0(const BaDev* __restrict__ Dv, int nwin) {
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= nwin) return;
+    const BaDev& D = Dv[w]; double* c = D.ctl;
+    if (c[BA_B_DONE] != 0.0 || c[BA_B_ABORT] != 0.0 || c[BA_B_NEED_LIN] == 0.0) return;
+    if (c[BA_B_FIRST] != 0.0) { c[BA_CTL_LAMBDA] = 1e-5 * D.scal[3]; c[BA_CTL_NI] = 2.0; c[BA_CTL_NBAD] = 0.0; c[BA_B_FIRST] = 0.0; }
+    c[BA_B_NEED_LIN] = 0.0;
+}
+__global__ void k_bab_init_reduced(const BaDev* __restrict__ Dv) { BA_B_WINDOW(); k_ba_init_reduced_body(D, 0.0); }
+__global__ void k_bab_dinv(const BaDev* __restrict__ Dv) { BA_B_WINDOW(); k_ba_dinv_body(D, 0.0); }
+__global__ __launch_bounds__(256) void k_bab_schur(const BaDev* __restrict__ Dv) { BA_B_WINDOW(); if ((int)blockIdx.x >= D.W) return; k_ba_schur_body(D); }
+__global__ __launch_bounds__(1024) void k_bab_chol_solve(const BaDev* __restrict__ Dv) { BA_B_WINDOW(); k_ba_chol_solve_body(D); }
+__global__ void k_bab_backsub(const BaDev* __restrict__ Dv) { BA_B_WINDOW(); k_ba_backsub_body(D, 0.0); }
+__global__ void k_bab_update(const BaDev* __restrict__ Dv) { BA_B_WINDOW(); k_ba_update_body(D); }
+__global__ void k_bab_errors(const BaDev* __restrict__ Dv) { BA_B_WINDOW(); k_ba_errors_body(D, c[BA_B_MONO] != 0.0); }
+// the Levenberg decisions of one trial, per window (:129-161), and the end of an optimize() call
+__global__ void k_bab_decide(const BaDev* __restrict__ Dv, int nwin) {
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= nwin) return;
+    const BaDev& D = Dv[w]; double* c = D.ctl;
+    if (c[BA_B_DONE] != 0.0) return;
+    if (c[BA_B_ABORT] != 0.0) { c[BA_B_GATE] = 2.0; return; }            // the caller's stop flag: final gate and outputs of the state as it is
+    double tempChi = D.scal[0];
+    const bool ok2 = D.scal[2] > 0.5;
+    if (!ok2) tempChi = 1.7976931348623157e308;
+    const double scale = (ok2 ? D.scal[1] : 0.0) + 1e-3;
+    const double rho = (c[BA_CTL_CHI] - tempChi) / scale;
+    c[BA_CTL_RHO] = rho;
+    int qmax = (int)c[BA_B_QMAX];
+    if (rho > 0 && isfinite(tempChi)) {
+        const double t = 2 * rho - 1;
+        double alpha = 1. - t * t * t;
+        alpha = fmin(alpha, 2. / 3.);
+        c[BA_CTL_LAMBDA] *= fmax(1. / 3., alpha); c[BA_CTL_NI] = 2.0; c[BA_CTL_CHI] = tempChi;
+    } else {
+        c[BA_CTL_LAMBDA] *= c[BA_CTL_NI]; c[BA_CTL_NI] *= 2.0;
+        c[BA_B_RESTORE] = 1.0;
+    }
+    qmax++;
+    if (rho < 0 && qmax < 10) { c[BA_B_QMAX] = qmax; return; }           // another trial of the same iteration (no re-linearisation)
+    // the iteration is over
+    const int phase = (int)c[BA_B_PHASE];
+    c[BA_B_ITS0 + phase] += 1.0; c[BA_B_CHI0 + phase] = c[BA_CTL_CHI];
+    bool stop_opt = (qmax == 10 || rho == 0);
+    if (!stop_opt) {
+        double nBad = c[BA_CTL_NBAD];
+        if ((c[BA_CTL_INICHI] - c[BA_CTL_CHI]) * 1e3 < c[BA_CTL_INICHI]) nBad += 1.0; else nBad = 0.0;
+        c[BA_CTL_NBAD] = nBad;
+        if (nBad >= 3.0) stop_opt = true;
+    }
+    c[BA_CTL_IT] += 1.0; c[BA_B_QMAX] = 0.0;
+    if (stop_opt || c[BA_CTL_IT] >= c[BA_B_ITERS]) c[BA_B_GATE] = phase == 0 ? 1.0 : 2.0;
+    else c[BA_B_NEED_LIN] = 1.0;
+}
+__global__ void k_bab_restore(const BaDev* __restrict__ Dv) { BA_B_WINDOW(); if (c[BA_B_RESTORE] == 0.0) return; k_ba_restore_body(D); }
+__global__ void k_bab_gate(const BaDev* __restrict__ Dv, uint8_t* const* __restrict__ erase) {
+    const BaDev& D = Dv[blockIdx.y]; const double* c = D.ctl;
+    if (c[BA_B_DONE] != 0.0 || c[BA_B_GATE] == 0.0) return;
+    k_ba_gate_body(D, erase[blockIdx.y], c[BA_B_GATE] == 1.0 ? 1 : 0);
+}
+// after the gate: phase 0 -> second optimize() without the mono kernel (src/Optimizer.cc:2037-2099), phase 1 -> the window is finished
+__global__ void k_bab_phase(const BaDev* __restrict__ Dv, int nwin, int* __restrict__ n_done) {
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= nwin) return;
+    const BaDev& D = Dv[w]; double* c = D.ctl;
+    if (c[BA_B_DONE] != 0.0) return;
+    c[BA_B_RESTORE] = 0.0;
+    if (c[BA_B_GATE] == 1.0) {
+        c[BA_B_PHASE] = 1.0; c[BA_B_MONO] = 0.0; c[BA_B_ITERS] = 10.0; c[BA_CTL_IT] = 0.0; c[BA_B_QMAX] = 0.0;
+        c[BA_B_NEED_CHI] = 1.0; c[BA_B_NEED_LIN] = 1.0; c[BA_B_FIRST] = 1.0; c[BA_B_GATE] = 0.0;
+    } else if (c[BA_B_GATE] == 2.0) {
+        c[BA_B_GATE] = 0.0; c[BA_B_DONE] = 1.0;
+        atomicAdd(n_done, 1);
+    }
+}
+
 // ---- vision-only LocalBundleAdjustment (reference src/Optimizer.cc:3980-4311): SE3 key frames (kf = qx qy qz qw tx ty tz of Tcw),
 // EdgeSE3ProjectXYZ / EdgeStereoSE3ProjectXYZ (Thirdparty/g2o/g2o/types/types_six_dof_expmap.cpp:66-250). e_obs[k] = u v uRight invSigma2
 // (uRight < 0: mono); cam[0..4] = fx fy cx cy bf. Three residual rows per edge (the third is zero for mono edges).
 __device__ __forceinline__ se3q ba_ld_se3(const double* k) { se3q s; s.r = mkq(k[0], k[1], k[2], k[3]); s.t = mk3(k[4], k[5], k[6]); return s; }
 __global__ void k_ba_se3_errors(BaDev D, int kernels) {
+    if (ba_skip(D)) return;
     __shared__ double s_red[8];
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     double c = 0;
@@ -528,6 +725,7 @@ __global__ void k_ba_se3_errors(BaDev D, int kernels) {
     if (threadIdx.x == 0) { double t = 0; for (int w = 0; w < (int)(blockDim.x >> 6); w++) t += s_red[w]; atomicAdd(&D.scal[0], t); }
 }
 __global__ void k_ba_se3_lin_points(BaDev D, int kernels) {
+    if (ba_skip(D)) return;
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= D.NP) return;
     double H[6] = {0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};
@@ -576,6 +774,7 @@ __global__ void k_ba_se3_lin_points(BaDev D, int kernels) {
     for (int a = 0; a < 3; a++) D.bl[(size_t)p * 3 + a] = b[a];
 }
 __global__ void k_ba_se3_update(BaDev D) {
+    if (ba_skip(D)) return;
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q < D.W) {                                                   // VertexSE3Expmap::oplusImpl: T <- exp(update) * T
         double* k = D.kf + (size_t)q * 7;
@@ -603,7 +802,7 @@ using namespace viorb;
 namespace {
 // A solve borrows a context (a HIP stream + a device arena) from a small pool, so that concurrent callers (the LocalMapping threads
 // of several SLAM instances) run on different streams and no call pays hipMalloc / hipFree, which synchronise the whole device.
-struct BaCtx { hipStream_t st = nullptr; void* arena = nullptr; size_t bytes = 0; double* pinned = nullptr; /* 16 doubles of page-locked host memory for the LM scalars */ int device = 0; };
+struct BaCtx { hipStream_t st = nullptr; void* arena = nullptr; size_t bytes = 0; double* pinned = nullptr; /* 64 doubles of page-locked host memory for the LM scalars */ int device = 0; };
 std::mutex g_ctx_mu;
 std::vector<BaCtx*> g_ctx_free;
 std::atomic<int> g_lba_device{-1};
@@ -629,7 +828,7 @@ struct BaCtxLease {
         if (!c) {
             c = new BaCtx();
             c->device = dev;
-            if (hipStreamCreateWithFlags(&c->st, hipStreamNonBlocking) != hipSuccess || hipHostMalloc(reinterpret_cast<void**>(&c->pinned), 16 * sizeof(double)) != hipSuccess) {
+            if (hipStreamCreateWithFlags(&c->st, hipStreamNonBlocking) != hipSuccess || hipHostMalloc(reinterpret_cast<void**>(&c->pinned), 64 * sizeof(double)) != hipSuccess) {
                 delete c; c = nullptr; return false;
             }
         }
@@ -709,11 +908,17 @@ static hipError_t ba_wait(hipStream_t st) {
 enum { BA_WAIT = 0, BA_DONE = 1 };
 struct BaSolve {
     BaCtxLease lease;
-    BaDev D; hipStream_t st = nullptr; double* h = nullptr;       // h: 16 page-locked doubles
+    BaDev D; hipStream_t st = nullptr; double* h = nullptr;       // h: 64 page-locked doubles (0..7 scal, 8..39 ctl)
     int model = 0; const volatile int* stop = nullptr; uint8_t* d_erase = nullptr;
     double* kfs_out = nullptr; double* points_out = nullptr; uint8_t* erase = nullptr; double* info = nullptr;
     // LM state
-    enum State { ST_OPT_BEGIN, ST_ITER_BEGIN, ST_AFTER_CHI, ST_AFTER_DIAG, ST_TRIAL_ENQ, ST_AFTER_TRIAL, ST_FINISH, ST_AFTER_FINAL, ST_DONE } state = ST_OPT_BEGIN;
+    enum State { ST_OPT_BEGIN, ST_ITER_BEGIN, ST_AFTER_CHI, ST_AFTER_DIAG, ST_TRIAL_ENQ, ST_AFTER_TRIAL, ST_FINISH, ST_AFTER_FINAL, ST_DONE,
+                 ST_FAST_CHUNK, ST_FAST_WAIT } state = ST_OPT_BEGIN;
+    // Device-side LM control (k_ba_decide): iterations are enqueued FAST_CHUNK at a time with no host round trip in between; the host
+    // looks at the control block (and at the caller's stop flag, which g2o polls once per iteration) once per chunk and only takes the
+    // per-trial path below after a trial was rejected. VIORB_LBA_HOST_LM=1 forces the per-trial path (tests compare both).
+    enum { FAST_CHUNK = 5 };
+    bool fast_phase = false; int fast_enq = 0;
     int phase = 0, iterations = 5, it = 0, nBad = 0, qmax = 0, mono_kernel = 1;
     int its[2] = {0, 0}; double chi[2] = {0, 0};
     double lambda = 0, ni = 2, currentChi = 0, iniChi = 0, rho = 0;
@@ -731,9 +936,61 @@ struct BaSolve {
         int rc;
         for (;;) {
             switch (state) {
-            case ST_OPT_BEGIN:
-                it = 0; currentChi = 0; nBad = 0; state = ST_ITER_BEGIN;
+            case ST_OPT_BEGIN: {
+                it = 0; currentChi = 0; nBad = 0;
+                static const bool host_lm = getenv("VIORB_LBA_HOST_LM") != nullptr;
+                fast_phase = !host_lm;
+                D.use_ctl = 0;
+                if (!fast_phase) { state = ST_ITER_BEGIN; break; }
+                // chi2 at the phase's starting point (computeActiveErrors of the first iteration) and a clean control block
+                VIORB_HIP_TRY(hipMemsetAsync(D.ctl, 0, BA_CTL_N * sizeof(double), st));
+                if ((rc = enqueue_errors()) != VIORB_OK) return rc;
+                fast_enq = 0; state = ST_FAST_CHUNK;
                 break;
+            }
+            case ST_FAST_CHUNK: {
+                if (terminate() || fast_enq >= iterations) { state = ST_FINISH; break; }
+                D.use_ctl = 1;
+                const int n = std::min((int)FAST_CHUNK, iterations - fast_enq);
+                const unsigned gC = (unsigned)std::min<size_t>((n2 + TB - 1) / TB, 256);
+                for (int i = 0; i < n; i++, fast_enq++) {
+                    const int first = fast_enq == 0;
+                    hipLaunchKernelGGL(k_ba_clear, dim3(gC), dim3(TB), 0, st, D, first);
+                    if (model == 0) hipLaunchKernelGGL(k_ba_lin_points, dim3(gP), dim3(TB), 0, st, D, mono_kernel);
+                    else hipLaunchKernelGGL(k_ba_se3_lin_points, dim3(gP), dim3(TB), 0, st, D, mono_kernel);
+                    hipLaunchKernelGGL(k_ba_hpp, dim3(n_local), dim3(256), 0, st, D);
+                    if (model == 0) hipLaunchKernelGGL(k_ba_imu, dim3(n_local), dim3(256), 0, st, D);
+                    if (first) {
+                        hipLaunchKernelGGL(k_ba_max_diag, dim3(32), dim3(256), 0, st, D);
+                        hipLaunchKernelGGL(k_ba_lambda0, dim3(1), dim3(64), 0, st, D);
+                    }
+                    hipLaunchKernelGGL(k_ba_init_reduced, dim3((unsigned)((nl2 + TB - 1) / TB)), dim3(TB), 0, st, D, 0.0);
+                    hipLaunchKernelGGL(k_ba_dinv, dim3(gP), dim3(TB), 0, st, D, 0.0);
+                    hipLaunchKernelGGL(k_ba_schur, dim3(n_local), dim3(256), 0, st, D);
+                    hipLaunchKernelGGL(k_ba_chol_solve, dim3(1), dim3(1024), 0, st, D);
+                    hipLaunchKernelGGL(k_ba_backsub, dim3(gP), dim3(TB), 0, st, D, 0.0);
+                    if (model == 0) hipLaunchKernelGGL(k_ba_update, dim3(std::max(gP, 1)), dim3(TB), 0, st, D);
+                    else hipLaunchKernelGGL(k_ba_se3_update, dim3(std::max(gP, 1)), dim3(TB), 0, st, D);
+                    if (model == 0) hipLaunchKernelGGL(k_ba_errors, dim3(gE), dim3(TB), 0, st, D, mono_kernel);
+                    else hipLaunchKernelGGL(k_ba_se3_errors, dim3(gE), dim3(TB), 0, st, D, mono_kernel);
+                    hipLaunchKernelGGL(k_ba_decide, dim3(1), dim3(64), 0, st, D, 0);
+                }
+                D.use_ctl = 0;
+                VIORB_HIP_TRY(hipMemcpyAsync(h, D.scal, 8 * sizeof(double), hipMemcpyDeviceToHost, st));
+                VIORB_HIP_TRY(hipMemcpyAsync(h + 8, D.ctl, BA_CTL_N * sizeof(double), hipMemcpyDeviceToHost, st));
+                state = ST_FAST_WAIT;
+                return BA_WAIT;
+            }
+            case ST_FAST_WAIT: {
+                const double* c = h + 8;
+                its[phase] = (int)c[BA_CTL_ITS]; chi[phase] = c[BA_CTL_CHI]; it = (int)c[BA_CTL_IT];
+                currentChi = c[BA_CTL_CHI]; iniChi = c[BA_CTL_INICHI]; lambda = c[BA_CTL_LAMBDA]; ni = c[BA_CTL_NI]; nBad = (int)c[BA_CTL_NBAD];
+                const int halt = (int)c[BA_CTL_HALT];
+                if (halt == 1) { qmax = 0; rho = 0; fast_phase = false; state = ST_AFTER_TRIAL; break; }      // a rejected trial: h[0..2] hold its scalars
+                if (halt == 2 || it >= iterations) { state = ST_FINISH; break; }
+                state = ST_FAST_CHUNK;
+                break;
+            }
             case ST_ITER_BEGIN:
                 if (it >= iterations || terminate()) { state = ST_FINISH; break; }
                 if ((rc = enqueue_errors()) != VIORB_OK) return rc;
@@ -880,7 +1137,7 @@ static int ba_prepare_navstate(BaSolve& S, const double* kfs, int nk, int n_loca
               B.alloc(&D.Hll, (size_t)npts * 9) && B.alloc(&D.bl, (size_t)npts * 3) && B.alloc(&D.Dinv, (size_t)npts * 9) &&
               B.alloc(&D.Hpp, n2) && B.alloc(&D.bp, D.np) && B.alloc(&D.S, nl2 + (size_t)16 * D.ld + (size_t)(D.ld / 16) * 256) && B.alloc(&D.bs, D.ld) && B.alloc(&D.xp, D.ld) && B.alloc(&D.db, (size_t)npts * 3) && B.alloc(&D.xl, (size_t)npts * 3) &&
               B.alloc(&d_pre, (size_t)n_local * 142, preint) && B.alloc(&d_info, info_pvr.size(), info_pvr.data()) &&
-              B.alloc(&D.e_pvr, (size_t)n_local * 9) && B.alloc(&D.e_b, (size_t)n_local * 3) && B.alloc(&D.scal, 8) && B.alloc(&d_erase, ne) && B.commit(lease.c);
+              B.alloc(&D.e_pvr, (size_t)n_local * 9) && B.alloc(&D.e_b, (size_t)n_local * 3) && B.alloc(&D.scal, 8) && B.alloc(&D.ctl, (size_t)BA_CTL_N) && B.alloc(&d_erase, ne) && B.commit(lease.c);
     if (!ok) { set_error("device allocation / upload failed"); return VIORB_ERR_HIP; }
     D.e_pt = d_ept; D.e_kf = d_ekf; D.e_obs = d_obs; D.pt_start = d_pts; D.kf_start = d_kfs; D.kf_list = d_kfl; D.preint = d_pre; D.info_pvr = d_info;
     S.st = lease.c->st; S.h = lease.c->pinned; S.model = 0; S.stop = stop; S.d_erase = d_erase;
@@ -950,8 +1207,113 @@ static int ba_run_batch(int n, int max_in_flight, Prepare prepare, SetStatus set
     return first_error;
 }
 
+// Lock-step batch of NavState windows (kernels k_bab_*): returns the first error; every window's status through set_status.
+static int ba_run_lockstep(viorb_lba_window* w, int n) {
+    if (viorb_device_count() < 1) { set_error("no HIP device: libviorb_hip has no CPU fallback"); return VIORB_ERR_NO_DEVICE; }
+    VIORB_HIP_TRY(hipSetDevice(lba_device()));
+    int first_error = VIORB_OK;
+    const int GROUP = 128, TB = 256, ROUNDS_PER_CHECK = 4, MAX_ROUNDS = 600;
+    for (int g0 = 0; g0 < n; g0 += GROUP) {
+        const int ng = std::min(GROUP, n - g0);
+        std::vector<std::unique_ptr<BaSolve>> S(ng);
+        std::vector<int> act;
+        for (int i = 0; i < ng; i++) {
+            viorb_lba_window& q = w[g0 + i];
+            S[i] = std::make_unique<BaSolve>();
+            const int rc = ba_prepare_navstate(*S[i], q.kfs, q.nk, q.n_local, q.prev_kf, q.preint, q.points, q.np, q.edge_idx, q.edge_obs, q.ne, q.gw, q.cam,
+                                               q.stop, q.kfs_out, q.points_out, q.erase, q.info);
+            q.status = rc;
+            if (rc != VIORB_OK) { if (first_error == VIORB_OK) first_error = rc; continue; }
+            if (S[i]->state == BaSolve::ST_DONE) continue;               // stop flag already set: inputs copied to the outputs
+            act.push_back(i);
+        }
+        const int na = (int)act.size();
+        if (na == 0) continue;
+        hipStream_t st = S[act[0]]->st;
+        std::vector<BaDev> Dh(na); std::vector<uint8_t*> Eh(na);
+        int gE = 1, gP = 1, Wmax = 1; size_t nl2 = 1, n2 = 1;
+        std::vector<double> c0(BA_B_N, 0.0);
+        c0[BA_B_NEED_CHI] = 1; c0[BA_B_NEED_LIN] = 1; c0[BA_B_FIRST] = 1; c0[BA_B_MONO] = 1; c0[BA_B_ITERS] = 5;
+        for (int a = 0; a < na; a++) {
+            BaSolve& B = *S[act[a]];
+            VIORB_HIP_TRY(hipStreamSynchronize(B.st));                   // the window's inputs are uploaded
+            Dh[a] = B.D; Dh[a].use_ctl = 1; Eh[a] = B.d_erase;
+            gE = std::max(gE, (B.D.NE + TB - 1) / TB); gP = std::max(gP, (B.D.NP + TB - 1) / TB); Wmax = std::max(Wmax, B.D.W);
+            nl2 = std::max(nl2, (size_t)B.D.ld * B.D.ld); n2 = std::max(n2, (size_t)B.D.np * B.D.np);
+            VIORB_HIP_TRY(hipMemcpyAsync(B.D.ctl, c0.data(), sizeof(double) * BA_B_N, hipMemcpyHostToDevice, st));
+        }
+        BaDev* Dv = nullptr; uint8_t** Ev = nullptr; int* d_done = nullptr;
+        struct Free { void* p[3]; ~Free() { for (void* q : p) if (q) (void)hipFree(q); } } fr{{nullptr, nullptr, nullptr}};
+        VIORB_HIP_TRY(hipMalloc(&fr.p[0], sizeof(BaDev) * na)); VIORB_HIP_TRY(hipMalloc(&fr.p[1], sizeof(uint8_t*) * na)); VIORB_HIP_TRY(hipMalloc(&fr.p[2], sizeof(int)));
+        Dv = (BaDev*)fr.p[0]; Ev = (uint8_t**)fr.p[1]; d_done = (int*)fr.p[2];
+        VIORB_HIP_TRY(hipMemcpyAsync(Dv, Dh.data(), sizeof(BaDev) * na, hipMemcpyHostToDevice, st));
+        VIORB_HIP_TRY(hipMemcpyAsync(Ev, Eh.data(), sizeof(uint8_t*) * na, hipMemcpyHostToDevice, st));
+        VIORB_HIP_TRY(hipMemsetAsync(d_done, 0, sizeof(int), st));
+        double* pin = S[act[0]]->h;                                      // page-locked scratch of the first window's context
+        int* h_done = reinterpret_cast<int*>(pin + 48);
+        const unsigned gw = (unsigned)((na + 63) / 64), gR = (unsigned)((nl2 + TB - 1) / TB), gC = (unsigned)std::min<size_t>((n2 + TB - 1) / TB, 64);
+        const dim3 Y1(1, na), YE(gE, na), YP(std::max(gP, 1), na), YW(Wmax, na);
+        int rounds = 0, done = 0;
+        std::vector<char> aborted(na, 0);
+        while (done < na && rounds < MAX_ROUNDS) {
+            for (int r = 0; r < ROUNDS_PER_CHECK; r++, rounds++) {
+                hipLaunchKernelGGL(k_bab_round_begin, dim3(gw), dim3(64), 0, st, Dv, na);
+                hipLaunchKernelGGL(k_bab_errors_chi, YE, dim3(TB), 0, st, Dv);
+                hipLaunchKernelGGL(k_bab_take_chi, dim3(gw), dim3(64), 0, st, Dv, na);
+                hipLaunchKernelGGL(k_bab_clear, dim3(gC, na), dim3(TB), 0, st, Dv);
+                hipLaunchKernelGGL(k_bab_lin_points, YP, dim3(TB), 0, st, Dv);
+                hipLaunchKernelGGL(k_bab_hpp, YW, dim3(256), 0, st, Dv);
+                hipLaunchKernelGGL(k_bab_imu, YW, dim3(256), 0, st, Dv);
+                hipLaunchKernelGGL(k_bab_max_diag, dim3(8, na), dim3(256), 0, st, Dv);
+                hipLaunchKernelGGL(k_bab_lambda0, dim3(gw), dim3(64), 0, st, Dv, na);
+                hipLaunchKernelGGL(k_bab_init_reduced, dim3(gR, na), dim3(TB), 0, st, Dv);
+                hipLaunchKernelGGL(k_bab_dinv, YP, dim3(TB), 0, st, Dv);
+                hipLaunchKernelGGL(k_bab_schur, YW, dim3(256), 0, st, Dv);
+                hipLaunchKernelGGL(k_bab_chol_solve, Y1, dim3(1024), 0, st, Dv);
+                hipLaunchKernelGGL(k_bab_backsub, YP, dim3(TB), 0, st, Dv);
+                hipLaunchKernelGGL(k_bab_update, YP, dim3(TB), 0, st, Dv);
+                hipLaunchKernelGGL(k_bab_errors, YE, dim3(TB), 0, st, Dv);
+                hipLaunchKernelGGL(k_bab_decide, dim3(gw), dim3(64), 0, st, Dv, na);
+                hipLaunchKernelGGL(k_bab_restore, YP, dim3(TB), 0, st, Dv);
+                hipLaunchKernelGGL(k_bab_gate, YE, dim3(TB), 0, st, Dv, Ev);
+                hipLaunchKernelGGL(k_bab_phase, dim3(gw), dim3(64), 0, st, Dv, na, d_done);
+            }
+            VIORB_HIP_TRY(hipGetLastError());
+            VIORB_HIP_TRY(hipMemcpyAsync(h_done, d_done, sizeof(int), hipMemcpyDeviceToHost, st));
+            VIORB_HIP_TRY(ba_wait(st));
+            done = *h_done;
+            // the callers' stop flags (g2o polls pbStopFlag once per iteration; here once per ROUNDS_PER_CHECK trials)
+            for (int a = 0; a < na; a++) {
+                BaSolve& B = *S[act[a]];
+                if (!aborted[a] && B.terminate()) {
+                    aborted[a] = 1;
+                    const double one = 1.0;
+                    VIORB_HIP_TRY(hipMemcpyAsync(B.D.ctl + BA_B_ABORT, &one, sizeof(double), hipMemcpyHostToDevice, st));
+                }
+            }
+        }
+        if (done < na) { set_error("window solve did not finish in %d rounds", MAX_ROUNDS); return VIORB_ERR_HIP; }
+        std::vector<double> ch((size_t)na * BA_B_N);
+        for (int a = 0; a < na; a++) {
+            BaSolve& B = *S[act[a]];
+            VIORB_HIP_TRY(hipMemcpyAsync(B.kfs_out, B.D.kf, (size_t)B.D.W * B.D.kf_stride * sizeof(double), hipMemcpyDeviceToHost, st));
+            VIORB_HIP_TRY(hipMemcpyAsync(B.points_out, B.D.pt, (size_t)B.D.NP * 3 * sizeof(double), hipMemcpyDeviceToHost, st));
+            VIORB_HIP_TRY(hipMemcpyAsync(B.erase, B.d_erase, B.D.NE, hipMemcpyDeviceToHost, st));
+            VIORB_HIP_TRY(hipMemcpyAsync(&ch[(size_t)a * BA_B_N], B.D.ctl, sizeof(double) * BA_B_N, hipMemcpyDeviceToHost, st));
+        }
+        VIORB_HIP_TRY(hipStreamSynchronize(st));
+        for (int a = 0; a < na; a++) {
+            double* info = S[act[a]]->info; const double* c = &ch[(size_t)a * BA_B_N];
+            info[0] = c[BA_B_CHI0]; info[1] = c[BA_B_CHI1]; info[2] = c[BA_B_ITS0]; info[3] = c[BA_B_ITS1];
+        }
+    }
+    return first_error;
+}
+
 extern "C" int viorb_local_ba_navstate_batch(viorb_lba_window* w, int n, int max_in_flight) {
     VIORB_REQUIRE(w && n >= 0, "null windows");
+    static const bool per_stream = getenv("VIORB_LBA_STREAMS") != nullptr;      // the round-1 driver: one stream and host LM loop per window
+    if (!per_stream) return ba_run_lockstep(w, n);
     return ba_run_batch(n, max_in_flight,
         [&](int i, BaSolve& S) {
             viorb_lba_window& q = w[i];
@@ -1003,7 +1365,7 @@ static int ba_prepare_se3(BaSolve& S, const double* kfs, int nk, int n_local, co
               B.alloc(&d_pts, npts + 1, pt_start.data()) && B.alloc(&d_kfs, n_local + 1, kf_start.data()) && B.alloc(&d_kfl, kf_list.size(), kf_list.data()) &&
               B.alloc(&D.Hll, (size_t)npts * 9) && B.alloc(&D.bl, (size_t)npts * 3) && B.alloc(&D.Dinv, (size_t)npts * 9) &&
               B.alloc(&D.Hpp, n2) && B.alloc(&D.bp, D.np) && B.alloc(&D.S, nl2 + (size_t)16 * D.ld + (size_t)(D.ld / 16) * 256) && B.alloc(&D.bs, D.ld) && B.alloc(&D.xp, D.ld) &&
-              B.alloc(&D.db, (size_t)npts * 3) && B.alloc(&D.xl, (size_t)npts * 3) && B.alloc(&D.scal, 8) && B.alloc(&d_erase, ne) && B.commit(lease.c);
+              B.alloc(&D.db, (size_t)npts * 3) && B.alloc(&D.xl, (size_t)npts * 3) && B.alloc(&D.scal, 8) && B.alloc(&D.ctl, (size_t)BA_CTL_N) && B.alloc(&d_erase, ne) && B.commit(lease.c);
     if (!ok) { set_error("device allocation / upload failed"); return VIORB_ERR_HIP; }
     D.e_pt = d_ept; D.e_kf = d_ekf; D.e_obs = d_obs; D.pt_start = d_pts; D.kf_start = d_kfs; D.kf_list = d_kfl;
     S.st = lease.c->st; S.h = lease.c->pinned; S.model = 1; S.stop = stop; S.d_erase = d_erase;
