@@ -328,7 +328,9 @@ __device__ __forceinline__ void k_ba_schur_body(const BaDev& D) {
 // per block. The matrix stays in L2; the panel is staged in LDS. scal[2] = 1 on success; a pivot that is not positive and finite
 // fails the solve like the reference's LLT (linear_solver_eigen.h / Eigen info()).
 typedef double v4d __attribute__((ext_vector_type(4)));
-#define BA_MAX_TILES_PER_WAVE 9              // ceil(16 * 17 / 2 / 16) trailing tiles per wave at ld = 256 (+ the rhs block row)
+#define BA_CHOL_THREADS 512                  // 8 waves: 17 register tiles (136 registers) per wave leave room for the panel solve's row
+#define BA_CHOL_WAVES (BA_CHOL_THREADS / 64)
+#define BA_MAX_TILES_PER_WAVE 17             // ceil((15 * 16 / 2 + 15) / 8) register tiles per wave at ld = 240 (the lower block triangle + the rhs block row)
 // lane broadcast of a double and a full-precision reciprocal square root (hardware estimate + two Newton steps) for the factorisation's
 // diagonal blocks
 __device__ __forceinline__ double ba_readlane(double v, int l) {
@@ -346,20 +348,61 @@ __device__ __forceinline__ void k_ba_chol_solve_body(const BaDev& D) {
     if (ba_skip(D)) return;
     __shared__ double s_L[16][17], s_P[256][17], s_y[256], s_rd[16];
     __shared__ int s_ok;
-    const int n = D.np, ld = D.ld, nb = ld >> 4, t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int n = D.np, ld = D.ld, nb = ld >> 4, t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);
     const int rows = ld + 16;                                    // + the block row that carries bs^T in its first row
     double* A = D.S;
     double* inv = A + (size_t)rows * ld;                         // [nb][16][16] inverted diagonal blocks
     if (t == 0) s_ok = 1;
-    for (int q = t; q < 16 * ld; q += blockDim.x) A[(size_t)ld * ld + q] = (q < ld) ? D.bs[q] : 0.0;
+    // The lower block triangle (and the rhs block row) lives in REGISTERS for the whole factorisation: tile idx = wv + 16 u of the
+    // row-major enumeration (I, J <= min(I, nb - 1)), I = nb being the rhs row, belongs to slot u of wave wv, 4 doubles per lane in the
+    // MFMA accumulator layout (row = lane / 16 + 4 reg, col = lane % 16). Per block column kb the owners hand the diagonal tile and the
+    // panel tiles to LDS, one wave factors the diagonal tile, a thread per row solves the panel, and every wave applies the rank-16 update
+    // to the tiles it owns — no global-memory round trip inside the loop (round 1 re-read and re-wrote the trailing matrix in L2 for every
+    // panel: ~35 k cycles per panel where the arithmetic needs ~6 k). L and the solved rhs row are still written to global memory for the
+    // backward substitution.
+    v4d acc[BA_MAX_TILES_PER_WAVE]; int tI[BA_MAX_TILES_PER_WAVE], tJ[BA_MAX_TILES_PER_WAVE];
+    const int ntiles_all = nb * (nb + 1) / 2 + nb;
+#pragma unroll
+    for (int u = 0; u < BA_MAX_TILES_PER_WAVE; u++) {
+        const int idx = wv + BA_CHOL_WAVES * u;
+        tI[u] = -1; tJ[u] = -1;
+        acc[u] = (v4d){0.0, 0.0, 0.0, 0.0};
+        if (idx < ntiles_all) {
+            int I, J;
+            if (idx < nb * (nb + 1) / 2) { I = 0; int rem = idx; while (rem > I) { rem -= I + 1; I++; } J = rem; }
+            else { I = nb; J = idx - nb * (nb + 1) / 2; }
+            tI[u] = I; tJ[u] = J;
+            if (I < nb) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) acc[u][r] = A[(size_t)(I * 16 + (lane >> 4) + 4 * r) * ld + J * 16 + (lane & 15)];
+            } else if ((lane >> 4) == 0) {
+                acc[u][0] = D.bs[J * 16 + (lane & 15)];                   // the rhs block row: bs^T in its first row, zeros below
+            }
+        }
+    }
+    for (int q = t; q < 15 * ld; q += blockDim.x) A[(size_t)ld * ld + ld + q] = 0.0;       // rows 1..15 of the rhs block row (never read back, kept defined)
     __syncthreads();
     for (int kb = 0; kb < nb; kb++) {
         const int k0 = kb << 4;
+        // (0) the owners publish block column kb: the diagonal tile to s_L, the tiles below it to s_P
+#pragma unroll
+        for (int u = 0; u < BA_MAX_TILES_PER_WAVE; u++) {
+            if (tJ[u] != kb) continue;
+            if (tI[u] == kb) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) s_L[(lane >> 4) + 4 * r][lane & 15] = acc[u][r];
+            } else {
+                const int rb = (tI[u] - kb - 1) * 16;
+#pragma unroll
+                for (int r = 0; r < 4; r++) s_P[rb + (lane >> 4) + 4 * r][lane & 15] = acc[u][r];
+            }
+        }
+        __syncthreads();
         if (wv == 0) {                                           // (1) diagonal block: row (lane & 15) of it in registers, pivots and
             const int li = lane & 15;                            //     multipliers by v_readlane, 1/sqrt by rsq + two Newton steps
             double a[16];
 #pragma unroll
-            for (int c = 0; c < 16; c++) a[c] = A[(size_t)(k0 + li) * ld + k0 + c];
+            for (int c = 0; c < 16; c++) a[c] = s_L[li][c];
             bool good = true;
 #pragma unroll
             for (int j = 0; j < 16; j++) {
@@ -388,7 +431,7 @@ __device__ __forceinline__ void k_ba_chol_solve_body(const BaDev& D) {
             const int r = k0 + 16 + t;
             double x[16];
 #pragma unroll
-            for (int c = 0; c < 16; c++) x[c] = A[(size_t)r * ld + k0 + c];
+            for (int c = 0; c < 16; c++) x[c] = s_P[t][c];
 #pragma unroll
             for (int c = 0; c < 16; c++) {
                 double v = x[c];
@@ -398,8 +441,8 @@ __device__ __forceinline__ void k_ba_chol_solve_body(const BaDev& D) {
             }
 #pragma unroll
             for (int c = 0; c < 16; c++) { A[(size_t)r * ld + k0 + c] = x[c]; s_P[t][c] = x[c]; }
-        } else if (t >= 1008) {                                  // 16 idle threads invert the diagonal block: column c of L11^-1
-            const int c = t - 1008;
+        } else if (t >= BA_CHOL_THREADS - 16) {                  // 16 idle threads invert the diagonal block: column c of L11^-1
+            const int c = t - (BA_CHOL_THREADS - 16);
             double x[16];
 #pragma unroll
             for (int i = 0; i < 16; i++) {
@@ -412,33 +455,16 @@ __device__ __forceinline__ void k_ba_chol_solve_body(const BaDev& D) {
             for (int i = 0; i < 16; i++) inv[(size_t)kb * 256 + i * 16 + c] = x[i];
         }
         __syncthreads();
-        // (3) trailing update, lower block triangle; the last block row (rhs) only against the matrix block columns
-        const int m = below >> 4, mm = m - 1, ntiles = mm * (mm + 1) / 2 + mm;
-        v4d acc[BA_MAX_TILES_PER_WAVE]; double* T[BA_MAX_TILES_PER_WAVE];
+        // (3) trailing update of the owned tiles right of block column kb (the rhs row's tiles included), v_mfma_f64_16x16x4
 #pragma unroll
         for (int u = 0; u < BA_MAX_TILES_PER_WAVE; u++) {
-            const int tile = wv + 16 * u;
-            T[u] = nullptr;
-            if (tile < ntiles) {
-                int I, J;
-                if (tile < mm * (mm + 1) / 2) { I = 0; int rem = tile; while (rem > I) { rem -= I + 1; I++; } J = rem; }
-                else { I = mm; J = tile - mm * (mm + 1) / 2; }
-                T[u] = A + (size_t)(k0 + 16 + I * 16) * ld + k0 + 16 + J * 16;
+            if (tJ[u] <= kb) continue;                           // tJ > kb implies tI > kb
+            const int Io = (tI[u] - kb - 1) * 16 + (lane & 15), Jo = (tJ[u] - kb - 1) * 16 + (lane & 15);
 #pragma unroll
-                for (int r = 0; r < 4; r++) acc[u][r] = T[u][(size_t)((lane >> 4) + 4 * r) * ld + (lane & 15)];
-                const int Io = I * 16 + (lane & 15), Jo = J * 16 + (lane & 15);
-#pragma unroll
-                for (int kc = 0; kc < 4; kc++)
-                    acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(-s_P[Io][4 * kc + (lane >> 4)], s_P[Jo][4 * kc + (lane >> 4)], acc[u], 0, 0, 0);
-            }
+            for (int kc = 0; kc < 4; kc++)
+                acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(-s_P[Io][4 * kc + (lane >> 4)], s_P[Jo][4 * kc + (lane >> 4)], acc[u], 0, 0, 0);
         }
-#pragma unroll
-        for (int u = 0; u < BA_MAX_TILES_PER_WAVE; u++)
-            if (T[u]) {
-#pragma unroll
-                for (int r = 0; r < 4; r++) T[u][(size_t)((lane >> 4) + 4 * r) * ld + (lane & 15)] = acc[u][r];
-            }
-        __syncthreads();
+        __syncthreads();                                         // s_P / s_L are rewritten by the next block column
     }
     // y = L^-1 bs now sits in the rhs row; backward substitution L^T x = y, 16 unknowns at a time
     for (int i = t; i < ld; i += blockDim.x) s_y[i] = A[(size_t)ld * ld + i];
@@ -583,7 +609,7 @@ __global__ void k_ba_init_reduced(BaDev D, double lambda_arg) { k_ba_init_reduce
 __global__ void k_ba_max_diag(BaDev D) { k_ba_max_diag_body(D); }
 __global__ void k_ba_dinv(BaDev D, double lambda_arg) { k_ba_dinv_body(D, lambda_arg); }
 __global__ __launch_bounds__(256) void k_ba_schur(BaDev D) { k_ba_schur_body(D); }
-__global__ __launch_bounds__(1024) void k_ba_chol_solve(BaDev D) { k_ba_chol_solve_body(D); }
+__global__ __launch_bounds__(BA_CHOL_THREADS) void k_ba_chol_solve(BaDev D) { k_ba_chol_solve_body(D); }
 __global__ void k_ba_backsub(BaDev D, double lambda_arg) { k_ba_backsub_body(D, lambda_arg); }
 __global__ void k_ba_update(BaDev D) { k_ba_update_body(D); }
 __global__ void k_ba_restore(BaDev D) { k_ba_restore_body(D); }
@@ -634,7 +660,7 @@ __global__ void k_bab_lambda0(const BaDev* __restrict__ Dv, int nwin) {
 __global__ void k_bab_init_reduced(const BaDev* __restrict__ Dv) { BA_B_WINDOW(); k_ba_init_reduced_body(D, 0.0); }
 __global__ void k_bab_dinv(const BaDev* __restrict__ Dv) { BA_B_WINDOW(); k_ba_dinv_body(D, 0.0); }
 __global__ __launch_bounds__(256) void k_bab_schur(const BaDev* __restrict__ Dv) { BA_B_WINDOW(); if ((int)blockIdx.x >= D.W) return; k_ba_schur_body(D); }
-__global__ __launch_bounds__(1024) void k_bab_chol_solve(const BaDev* __restrict__ Dv) { BA_B_WINDOW(); k_ba_chol_solve_body(D); }
+__global__ __launch_bounds__(BA_CHOL_THREADS) void k_bab_chol_solve(const BaDev* __restrict__ Dv) { BA_B_WINDOW(); k_ba_chol_solve_body(D); }
 __global__ void k_bab_backsub(const BaDev* __restrict__ Dv) { BA_B_WINDOW(); k_ba_backsub_body(D, 0.0); }
 __global__ void k_bab_update(const BaDev* __restrict__ Dv) { BA_B_WINDOW(); k_ba_update_body(D); }
 __global__ void k_bab_errors(const BaDev* __restrict__ Dv) { BA_B_WINDOW(); k_ba_errors_body(D, c[BA_B_MONO] != 0.0); }
@@ -967,7 +993,7 @@ struct BaSolve {
                     hipLaunchKernelGGL(k_ba_init_reduced, dim3((unsigned)((nl2 + TB - 1) / TB)), dim3(TB), 0, st, D, 0.0);
                     hipLaunchKernelGGL(k_ba_dinv, dim3(gP), dim3(TB), 0, st, D, 0.0);
                     hipLaunchKernelGGL(k_ba_schur, dim3(n_local), dim3(256), 0, st, D);
-                    hipLaunchKernelGGL(k_ba_chol_solve, dim3(1), dim3(1024), 0, st, D);
+                    hipLaunchKernelGGL(k_ba_chol_solve, dim3(1), dim3(BA_CHOL_THREADS), 0, st, D);
                     hipLaunchKernelGGL(k_ba_backsub, dim3(gP), dim3(TB), 0, st, D, 0.0);
                     if (model == 0) hipLaunchKernelGGL(k_ba_update, dim3(std::max(gP, 1)), dim3(TB), 0, st, D);
                     else hipLaunchKernelGGL(k_ba_se3_update, dim3(std::max(gP, 1)), dim3(TB), 0, st, D);
@@ -1022,7 +1048,7 @@ struct BaSolve {
                 hipLaunchKernelGGL(k_ba_init_reduced, dim3((unsigned)((nl2 + TB - 1) / TB)), dim3(TB), 0, st, D, lambda);
                 hipLaunchKernelGGL(k_ba_dinv, dim3(gP), dim3(TB), 0, st, D, lambda);
                 hipLaunchKernelGGL(k_ba_schur, dim3(n_local), dim3(256), 0, st, D);
-                hipLaunchKernelGGL(k_ba_chol_solve, dim3(1), dim3(1024), 0, st, D);
+                hipLaunchKernelGGL(k_ba_chol_solve, dim3(1), dim3(BA_CHOL_THREADS), 0, st, D);
                 hipLaunchKernelGGL(k_ba_backsub, dim3(gP), dim3(TB), 0, st, D, lambda);
                 if (model == 0) hipLaunchKernelGGL(k_ba_update, dim3(std::max(gP, 1)), dim3(TB), 0, st, D);
                 else hipLaunchKernelGGL(k_ba_se3_update, dim3(std::max(gP, 1)), dim3(TB), 0, st, D);
@@ -1269,7 +1295,7 @@ static int ba_run_lockstep(viorb_lba_window* w, int n) {
                 hipLaunchKernelGGL(k_bab_init_reduced, dim3(gR, na), dim3(TB), 0, st, Dv);
                 hipLaunchKernelGGL(k_bab_dinv, YP, dim3(TB), 0, st, Dv);
                 hipLaunchKernelGGL(k_bab_schur, YW, dim3(256), 0, st, Dv);
-                hipLaunchKernelGGL(k_bab_chol_solve, Y1, dim3(1024), 0, st, Dv);
+                hipLaunchKernelGGL(k_bab_chol_solve, Y1, dim3(BA_CHOL_THREADS), 0, st, Dv);
                 hipLaunchKernelGGL(k_bab_backsub, YP, dim3(TB), 0, st, Dv);
                 hipLaunchKernelGGL(k_bab_update, YP, dim3(TB), 0, st, Dv);
                 hipLaunchKernelGGL(k_bab_errors, YE, dim3(TB), 0, st, Dv);
