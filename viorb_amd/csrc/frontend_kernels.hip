@@ -2306,21 +2306,74 @@ int viorb_descriptor_distance(const uint8_t* a, const uint8_t* b) {
 } // extern "C"
 
 namespace {
-struct DevBuf {                      // RAII scratch for the host wrappers
-    std::vector<void*> ptrs;
-    ~DevBuf() { for (void* p : ptrs) (void)hipFree(p); }
+// Scratch of the host-buffer drop-ins: a thread-local device arena that is bump-allocated per call and kept between calls (a Tracking
+// thread calls these once or twice per frame; hipMalloc / hipFree per buffer cost 0.3-0.5 ms per call and synchronise the whole device).
+struct HostArena {
+    struct Block { void* p; size_t bytes; };
+    std::vector<Block> blocks; size_t used = 0; int device = -1;
+    ~HostArena() { for (auto& b : blocks) (void)hipFree(b.p); }
+    void* take(size_t bytes) {
+        bytes = (bytes + 255) & ~(size_t)255;
+        if (!blocks.empty() && used + bytes <= blocks.back().bytes) { void* r = (char*)blocks.back().p + used; used += bytes; return r; }
+        const size_t want = std::max<size_t>(bytes * 2, blocks.empty() ? (size_t)4 << 20 : blocks.back().bytes * 2);
+        void* p = nullptr;
+        if (hipMalloc(&p, want) != hipSuccess) return nullptr;
+        blocks.push_back({p, want}); used = bytes;
+        return p;
+    }
+    void reset(int dev) {                 // start of a call: keep only the largest block
+        if (dev != device) { for (auto& b : blocks) (void)hipFree(b.p); blocks.clear(); device = dev; }
+        while (blocks.size() > 1) { (void)hipFree(blocks.front().p); blocks.erase(blocks.begin()); }
+        used = 0;
+    }
+};
+static thread_local HostArena g_host_arena;
+int current_device();
+struct DevBuf {                      // per-call view of the arena
+    DevBuf() { g_host_arena.reset(current_device()); }
     template <class T> int up(T** d, const T* hsrc, size_t n) {
-        hipError_t e = hipMalloc((void**)d, std::max<size_t>(n, 1) * sizeof(T));
-        if (e != hipSuccess) { set_error("hipMalloc failed: %s", hipGetErrorString(e)); return VIORB_ERR_HIP; }
-        ptrs.push_back(*d);
-        if (hsrc && n) { e = hipMemcpy(*d, hsrc, n * sizeof(T), hipMemcpyHostToDevice); if (e != hipSuccess) { set_error("H2D failed: %s", hipGetErrorString(e)); return VIORB_ERR_HIP; } }
-        else if (n) { e = hipMemset(*d, 0, n * sizeof(T)); if (e != hipSuccess) { set_error("memset failed"); return VIORB_ERR_HIP; } }
+        const size_t bytes = std::max<size_t>(n, 1) * sizeof(T);
+        *d = (T*)g_host_arena.take(bytes);
+        if (!*d) { set_error("hipMalloc failed for the host drop-in scratch"); return VIORB_ERR_HIP; }
+        hipError_t e = hipSuccess;
+        if (hsrc && n) { e = hipMemcpyAsync(*d, hsrc, n * sizeof(T), hipMemcpyHostToDevice, nullptr); if (e != hipSuccess) { set_error("H2D failed: %s", hipGetErrorString(e)); return VIORB_ERR_HIP; } }
+        else if (n) { e = hipMemsetAsync(*d, 0, n * sizeof(T), nullptr); if (e != hipSuccess) { set_error("memset failed"); return VIORB_ERR_HIP; } }
         return VIORB_OK;
     }
 };
 #define FE_TRY(x) do { int _rc = (x); if (_rc != VIORB_OK) return _rc; } while (0)
 // the host-buffer drop-ins run on the calling thread's current HIP device (hipSetDevice / torch.cuda.set_device), not on device 0
 int current_device() { int d = 0; if (hipGetDevice(&d) != hipSuccess) d = 0; return d; }
+// One front-end handle per calling thread, re-used across host drop-in calls: re-configured in place when only the camera / bounds /
+// tables change, re-created when a call needs more keypoint capacity or runs on another device.
+struct HostFrontend { viorb_frontend* h = nullptr; ~HostFrontend() { if (h) viorb_frontend_destroy(h); } };
+static thread_local HostFrontend g_host_fe;
+static int host_frontend(const viorb_frontend_config& c, int cap, viorb_frontend** out) {
+    const int dev = current_device();
+    viorb_frontend*& h = g_host_fe.h;
+    if (h && (h->cap < cap || h->device != dev)) { viorb_frontend_destroy(h); h = nullptr; }
+    if (!h) {
+        int want = 1024; while (want < cap) want *= 2;
+        want = std::min(want, 32768);
+        const int rc = viorb_frontend_create(&c, 1, std::max(cap, want), dev, &h);
+        if (rc != VIORB_OK) { h = nullptr; return rc; }
+    } else {
+        viorb_frontend_config cc = c;
+        if (cc.gyr_meas_cov <= 0) cc.gyr_meas_cov = 2.0e-3 * 2.0e-3 * 200;
+        if (cc.acc_meas_cov <= 0) cc.acc_meas_cov = 8.0e-3 * 8.0e-3 * 200;
+        if (cc.acc_bias_rw2 <= 0) cc.acc_bias_rw2 = 5e-3 * 5e-3;
+        h->cfg = cc;
+        h->wInv = static_cast<float>(GRID_COLS) / static_cast<float>(cc.max_x - cc.min_x);
+        h->hInv = static_cast<float>(GRID_ROWS) / static_cast<float>(cc.max_y - cc.min_y);
+        VIORB_HIP_TRY(hipSetDevice(dev));
+        VIORB_HIP_TRY(hipMemcpyAsync(h->d_cam, cc.cam, 16 * sizeof(double), hipMemcpyHostToDevice, nullptr));
+        VIORB_HIP_TRY(hipMemcpyAsync(h->d_gw, cc.gravity, 3 * sizeof(double), hipMemcpyHostToDevice, nullptr));
+        VIORB_HIP_TRY(hipMemcpyAsync(h->d_inv_sigma2, cc.inv_level_sigma2, 16 * sizeof(float), hipMemcpyHostToDevice, nullptr));
+        if (h->d_scale) VIORB_HIP_TRY(hipMemcpyAsync(h->d_scale, cc.scale_factors, 16 * sizeof(float), hipMemcpyHostToDevice, nullptr));
+    }
+    *out = h;
+    return VIORB_OK;
+}
 viorb_frontend_config default_cfg() {
     viorb_frontend_config c; memset(&c, 0, sizeof(c));
     c.min_x = 0; c.max_x = 752; c.min_y = 0; c.max_y = 480; c.nlevels = 8; c.check_orientation = 1;
@@ -2350,15 +2403,15 @@ static int search_by_projection_frame_host(const viorb_keypoint* cur_kps, const 
     for (int i = 0; i < 16; i++) c.scale_factors[i] = scale_factors[i < nlevels ? i : nlevels - 1];
     const int cap = std::max(ncur, nlast);
     viorb_frontend* h = nullptr;
-    FE_TRY(viorb_frontend_create(&c, 1, cap, current_device(), &h));
-    struct Guard { viorb_frontend* h; ~Guard() { viorb_frontend_destroy(h); } } g{h};
+    FE_TRY(host_frontend(c, cap, &h));
+    const int hc = h->cap;                                 // staging arrays are pitched by the (cached, possibly larger) handle capacity
     DevBuf B; viorb_keypoint *d_ck, *d_lk; uint8_t *d_cd, *d_ld, *d_lf; float *d_lp, *d_pose; int *d_cc, *d_lc, *d_cs, *d_ci, *d_m, *d_nm, *d_st;
-    FE_TRY(B.up(&d_ck, (const viorb_keypoint*)nullptr, (size_t)cap)); FE_TRY(B.up(&d_lk, (const viorb_keypoint*)nullptr, (size_t)cap));
-    FE_TRY(B.up(&d_cd, (const uint8_t*)nullptr, (size_t)cap * 32)); FE_TRY(B.up(&d_ld, (const uint8_t*)nullptr, (size_t)cap * 32));
-    FE_TRY(B.up(&d_lf, (const uint8_t*)nullptr, (size_t)cap)); FE_TRY(B.up(&d_lp, (const float*)nullptr, (size_t)cap * 3));
+    FE_TRY(B.up(&d_ck, (const viorb_keypoint*)nullptr, (size_t)hc)); FE_TRY(B.up(&d_lk, (const viorb_keypoint*)nullptr, (size_t)hc));
+    FE_TRY(B.up(&d_cd, (const uint8_t*)nullptr, (size_t)hc * 32)); FE_TRY(B.up(&d_ld, (const uint8_t*)nullptr, (size_t)hc * 32));
+    FE_TRY(B.up(&d_lf, (const uint8_t*)nullptr, (size_t)hc)); FE_TRY(B.up(&d_lp, (const float*)nullptr, (size_t)hc * 3));
     FE_TRY(B.up(&d_pose, pose12, 12)); FE_TRY(B.up(&d_cc, &ncur, 1)); FE_TRY(B.up(&d_lc, &nlast, 1));
-    FE_TRY(B.up(&d_cs, (const int*)nullptr, GRID_CELLS + 1)); FE_TRY(B.up(&d_ci, (const int*)nullptr, (size_t)cap));
-    FE_TRY(B.up(&d_m, (const int*)nullptr, (size_t)cap)); FE_TRY(B.up(&d_nm, (const int*)nullptr, 1)); FE_TRY(B.up(&d_st, (const int*)nullptr, 1));
+    FE_TRY(B.up(&d_cs, (const int*)nullptr, GRID_CELLS + 1)); FE_TRY(B.up(&d_ci, (const int*)nullptr, (size_t)hc));
+    FE_TRY(B.up(&d_m, (const int*)nullptr, (size_t)hc)); FE_TRY(B.up(&d_nm, (const int*)nullptr, 1)); FE_TRY(B.up(&d_st, (const int*)nullptr, 1));
     VIORB_HIP_TRY(hipMemcpy(d_ck, cur_kps, sizeof(viorb_keypoint) * ncur, hipMemcpyHostToDevice));
     VIORB_HIP_TRY(hipMemcpy(d_cd, cur_desc, (size_t)32 * ncur, hipMemcpyHostToDevice));
     VIORB_HIP_TRY(hipMemcpy(d_lk, last_kps, sizeof(viorb_keypoint) * nlast, hipMemcpyHostToDevice));
@@ -2368,14 +2421,14 @@ static int search_by_projection_frame_host(const viorb_keypoint* cur_kps, const 
     FE_TRY(viorb_frontend_grid_device(h, d_ck, d_cc, 1, d_cs, d_ci, nullptr));
     if (cur_uright) {
         float *d_ur, *d_lpose;
-        FE_TRY(B.up(&d_ur, (const float*)nullptr, (size_t)cap)); FE_TRY(B.up(&d_lpose, last_pose12, 12));
+        FE_TRY(B.up(&d_ur, (const float*)nullptr, (size_t)hc)); FE_TRY(B.up(&d_lpose, last_pose12, 12));
         VIORB_HIP_TRY(hipMemcpy(d_ur, cur_uright, sizeof(float) * ncur, hipMemcpyHostToDevice));
         FE_TRY(viorb_frontend_search_projection_stereo_device(h, d_ck, d_cd, d_cc, d_ur, d_cs, d_ci, d_pose, d_lpose, d_lk, d_lc, d_lf, d_lp, d_ld, th, bf, mb,
                                                               0, 1, d_m, d_nm, d_st, nullptr));
     } else {
         FE_TRY(viorb_frontend_search_projection_device(h, d_ck, d_cd, d_cc, d_cs, d_ci, d_pose, d_lk, d_lc, d_lf, d_lp, d_ld, th, 1, d_m, d_nm, d_st, nullptr));
     }
-    VIORB_HIP_TRY(hipDeviceSynchronize());
+    VIORB_HIP_TRY(hipStreamSynchronize(nullptr));
     int st = 0;
     VIORB_HIP_TRY(hipMemcpy(cur_match, d_m, sizeof(int) * ncur, hipMemcpyDeviceToHost));
     VIORB_HIP_TRY(hipMemcpy(nmatches, d_nm, sizeof(int), hipMemcpyDeviceToHost));
@@ -2418,16 +2471,18 @@ int viorb_fuse(const viorb_keypoint* kps, const uint8_t* desc, const float* urig
     c.nlevels = nlevels;
     for (int i = 0; i < 16; i++) { c.scale_factors[i] = scale_factors[i < nlevels ? i : nlevels - 1]; c.inv_level_sigma2[i] = inv_level_sigma2[i < nlevels ? i : nlevels - 1]; }
     viorb_frontend* h = nullptr;
-    FE_TRY(viorb_frontend_create(&c, 1, n, current_device(), &h));
-    struct Guard { viorb_frontend* h; ~Guard() { viorb_frontend_destroy(h); } } g{h};
+    FE_TRY(host_frontend(c, n, &h));
+    const size_t hc = (size_t)h->cap;
     DevBuf B; viorb_keypoint* d_k; uint8_t *d_d, *d_pv, *d_pd; float *d_ur, *d_pose, *d_pf; int *d_c, *d_cs, *d_ci, *d_pc, *d_bi, *d_nf;
-    FE_TRY(B.up(&d_k, kps, (size_t)n)); FE_TRY(B.up(&d_d, desc, (size_t)n * 32)); FE_TRY(B.up(&d_ur, uright, (size_t)n));
-    FE_TRY(B.up(&d_pose, pose12, 12)); FE_TRY(B.up(&d_c, &n, 1)); FE_TRY(B.up(&d_cs, (const int*)nullptr, GRID_CELLS + 1)); FE_TRY(B.up(&d_ci, (const int*)nullptr, (size_t)n));
+    FE_TRY(B.up(&d_k, (const viorb_keypoint*)nullptr, hc)); FE_TRY(B.up(&d_d, (const uint8_t*)nullptr, hc * 32)); FE_TRY(B.up(&d_ur, (const float*)nullptr, hc));
+    VIORB_HIP_TRY(hipMemcpyAsync(d_k, kps, sizeof(viorb_keypoint) * n, hipMemcpyHostToDevice, nullptr)); VIORB_HIP_TRY(hipMemcpyAsync(d_d, desc, (size_t)32 * n, hipMemcpyHostToDevice, nullptr));
+    VIORB_HIP_TRY(hipMemcpyAsync(d_ur, uright, sizeof(float) * n, hipMemcpyHostToDevice, nullptr));
+    FE_TRY(B.up(&d_pose, pose12, 12)); FE_TRY(B.up(&d_c, &n, 1)); FE_TRY(B.up(&d_cs, (const int*)nullptr, GRID_CELLS + 1)); FE_TRY(B.up(&d_ci, (const int*)nullptr, hc));
     FE_TRY(B.up(&d_pf, pts_f, (size_t)npts * 8)); FE_TRY(B.up(&d_pv, pts_valid, (size_t)npts)); FE_TRY(B.up(&d_pd, pts_desc, (size_t)npts * 32));
     FE_TRY(B.up(&d_pc, &npts, 1)); FE_TRY(B.up(&d_bi, (const int*)nullptr, (size_t)npts)); FE_TRY(B.up(&d_nf, (const int*)nullptr, 1));
     FE_TRY(viorb_frontend_grid_device(h, d_k, d_c, 1, d_cs, d_ci, nullptr));
     FE_TRY(viorb_frontend_fuse_device(h, d_k, d_d, d_ur, d_c, d_cs, d_ci, d_pose, d_pf, d_pv, d_pd, d_pc, npts, th, intr5[4], 1, d_bi, d_nf, nullptr));
-    VIORB_HIP_TRY(hipDeviceSynchronize());
+    VIORB_HIP_TRY(hipStreamSynchronize(nullptr));
     VIORB_HIP_TRY(hipMemcpy(best_idx, d_bi, sizeof(int) * npts, hipMemcpyDeviceToHost));
     VIORB_HIP_TRY(hipMemcpy(nfused, d_nf, sizeof(int), hipMemcpyDeviceToHost));
     return VIORB_OK;
@@ -2451,18 +2506,20 @@ int viorb_search_by_projection_points(const viorb_keypoint* cur_kps, const uint8
     c.nlevels = nlevels;
     for (int i = 0; i < 16; i++) c.scale_factors[i] = scale_factors[i < nlevels ? i : nlevels - 1];
     viorb_frontend* h = nullptr;
-    FE_TRY(viorb_frontend_create(&c, 1, ncur, current_device(), &h));
-    struct Guard { viorb_frontend* h; ~Guard() { viorb_frontend_destroy(h); } } g{h};
+    FE_TRY(host_frontend(c, ncur, &h));
+    const size_t hc = (size_t)h->cap;
     DevBuf B; viorb_keypoint* d_k; uint8_t *d_d, *d_pfl, *d_pd, *d_own; float *d_pose, *d_pf, *d_fr = nullptr; int *d_c, *d_cs, *d_ci, *d_pc, *d_m, *d_nm, *d_st;
-    FE_TRY(B.up(&d_k, cur_kps, (size_t)ncur)); FE_TRY(B.up(&d_d, cur_desc, (size_t)ncur * 32)); FE_TRY(B.up(&d_own, cur_owner_obs, (size_t)ncur));
-    FE_TRY(B.up(&d_pose, pose12, 12)); FE_TRY(B.up(&d_c, &ncur, 1)); FE_TRY(B.up(&d_cs, (const int*)nullptr, GRID_CELLS + 1)); FE_TRY(B.up(&d_ci, (const int*)nullptr, (size_t)ncur));
+    FE_TRY(B.up(&d_k, (const viorb_keypoint*)nullptr, hc)); FE_TRY(B.up(&d_d, (const uint8_t*)nullptr, hc * 32)); FE_TRY(B.up(&d_own, (const uint8_t*)nullptr, hc));
+    VIORB_HIP_TRY(hipMemcpyAsync(d_k, cur_kps, sizeof(viorb_keypoint) * ncur, hipMemcpyHostToDevice, nullptr)); VIORB_HIP_TRY(hipMemcpyAsync(d_d, cur_desc, (size_t)32 * ncur, hipMemcpyHostToDevice, nullptr));
+    VIORB_HIP_TRY(hipMemcpyAsync(d_own, cur_owner_obs, (size_t)ncur, hipMemcpyHostToDevice, nullptr));
+    FE_TRY(B.up(&d_pose, pose12, 12)); FE_TRY(B.up(&d_c, &ncur, 1)); FE_TRY(B.up(&d_cs, (const int*)nullptr, GRID_CELLS + 1)); FE_TRY(B.up(&d_ci, (const int*)nullptr, hc));
     FE_TRY(B.up(&d_pf, pts_f, (size_t)npts * 8)); FE_TRY(B.up(&d_pfl, pts_flags, (size_t)npts)); FE_TRY(B.up(&d_pd, pts_desc, (size_t)npts * 32));
-    FE_TRY(B.up(&d_pc, &npts, 1)); FE_TRY(B.up(&d_m, (const int*)nullptr, (size_t)ncur)); FE_TRY(B.up(&d_nm, (const int*)nullptr, 1)); FE_TRY(B.up(&d_st, (const int*)nullptr, 1));
+    FE_TRY(B.up(&d_pc, &npts, 1)); FE_TRY(B.up(&d_m, (const int*)nullptr, hc)); FE_TRY(B.up(&d_nm, (const int*)nullptr, 1)); FE_TRY(B.up(&d_st, (const int*)nullptr, 1));
     if (frustum5) FE_TRY(B.up(&d_fr, (const float*)nullptr, (size_t)npts * 5));
     FE_TRY(viorb_frontend_grid_device(h, d_k, d_c, 1, d_cs, d_ci, nullptr));
     FE_TRY(viorb_frontend_search_local_points_device(h, d_k, d_d, d_c, d_cs, d_ci, d_pose, d_pf, d_pfl, d_pd, d_pc, npts, th, nnratio, d_own, 1, d_m, d_nm, d_fr, d_st,
                                                      nullptr));
-    VIORB_HIP_TRY(hipDeviceSynchronize());
+    VIORB_HIP_TRY(hipStreamSynchronize(nullptr));
     int st = 0;
     VIORB_HIP_TRY(hipMemcpy(match, d_m, sizeof(int) * ncur, hipMemcpyDeviceToHost));
     VIORB_HIP_TRY(hipMemcpy(nmatches, d_nm, sizeof(int), hipMemcpyDeviceToHost));
@@ -2477,15 +2534,14 @@ int viorb_preintegrate(const double* imu, int n_imu, const double bg[3], const d
     viorb_frontend_config c = default_cfg();
     for (int i = 0; i < 9; i += 4) c.cam[4 + i] = 1;
     viorb_frontend* h = nullptr;
-    FE_TRY(viorb_frontend_create(&c, 1, 64, current_device(), &h));
-    struct Guard { viorb_frontend* h; ~Guard() { viorb_frontend_destroy(h); } } g{h};
+    FE_TRY(host_frontend(c, 64, &h));
     double ns[22]; memset(ns, 0, sizeof(ns)); ns[9] = 1; for (int k = 0; k < 3; k++) { ns[10 + k] = bg[k]; ns[13 + k] = ba[k]; }
     DevBuf B; double *d_imu, *d_tl, *d_tc, *d_ns, *d_pre, *d_cur; float* d_pose;
     FE_TRY(B.up(&d_imu, imu, (size_t)n_imu * 7)); FE_TRY(B.up(&d_tl, &t_last, 1)); FE_TRY(B.up(&d_tc, &t_cur, 1));
     FE_TRY(B.up(&d_ns, ns, 22)); FE_TRY(B.up(&d_pre, (const double*)nullptr, 142)); FE_TRY(B.up(&d_cur, (const double*)nullptr, 22));
     FE_TRY(B.up(&d_pose, (const float*)nullptr, 12));
     FE_TRY(viorb_frontend_imu_predict_device(h, d_imu, n_imu, d_tl, d_tc, d_ns, 1, d_pre, d_cur, d_pose, nullptr));
-    VIORB_HIP_TRY(hipDeviceSynchronize());
+    VIORB_HIP_TRY(hipStreamSynchronize(nullptr));
     VIORB_HIP_TRY(hipMemcpy(preint142, d_pre, 142 * sizeof(double), hipMemcpyDeviceToHost));
     return VIORB_OK;
 }
@@ -2503,8 +2559,7 @@ int viorb_pose_opt_vi(int variant, int compute_marg, const double cur_ns[22], co
     for (int i = 0; i < 3; i++) c.gravity[i] = gw[i];
     const int cap = std::max(std::max(n_cur, n_last), 1);
     viorb_frontend* h = nullptr;
-    FE_TRY(viorb_frontend_create(&c, 1, cap, current_device(), &h));
-    struct Guard { viorb_frontend* h; ~Guard() { viorb_frontend_destroy(h); } } g{h};
+    FE_TRY(host_frontend(c, cap, &h));
     DevBuf B; double *d_cur, *d_last, *d_prior, *d_mci, *d_pre, *d_oc, *d_ol, *d_out, *d_outl, *d_marg, *d_info; int *d_nc, *d_nl; uint8_t *d_fc, *d_fl;
     double zero22[22] = {0}, zero144[144] = {0};
     FE_TRY(B.up(&d_cur, cur_ns, 22)); FE_TRY(B.up(&d_last, last_ns, 22)); FE_TRY(B.up(&d_prior, prior_ns ? prior_ns : zero22, 22));
@@ -2516,7 +2571,7 @@ int viorb_pose_opt_vi(int variant, int compute_marg, const double cur_ns[22], co
     FE_TRY(B.up(&d_fc, (const uint8_t*)nullptr, cap)); FE_TRY(B.up(&d_fl, (const uint8_t*)nullptr, cap));
     FE_TRY(viorb_frontend_pose_opt_device(h, variant, compute_marg, d_cur, d_last, d_prior, d_mci, d_pre, d_oc, d_nc, d_ol, d_nl, 1,
                                           d_out, d_outl, d_fc, d_fl, d_marg, d_info, nullptr));
-    VIORB_HIP_TRY(hipDeviceSynchronize());
+    VIORB_HIP_TRY(hipStreamSynchronize(nullptr));
     VIORB_HIP_TRY(hipMemcpy(out_ns, d_out, 22 * sizeof(double), hipMemcpyDeviceToHost));
     if (out_last_ns) VIORB_HIP_TRY(hipMemcpy(out_last_ns, d_outl, 22 * sizeof(double), hipMemcpyDeviceToHost));
     if (n_cur) VIORB_HIP_TRY(hipMemcpy(outlier_cur, d_fc, n_cur, hipMemcpyDeviceToHost));
@@ -2533,13 +2588,12 @@ int viorb_pose_opt_se3(const float pose12[12], const float intr5[5], const doubl
     c.fx = intr5[0]; c.fy = intr5[1]; c.cx = intr5[2]; c.cy = intr5[3];
     const int cap = std::max(n, 1);
     viorb_frontend* h = nullptr;
-    FE_TRY(viorb_frontend_create(&c, 1, cap, current_device(), &h));
-    struct Guard { viorb_frontend* h; ~Guard() { viorb_frontend_destroy(h); } } g{h};
+    FE_TRY(host_frontend(c, cap, &h));
     DevBuf B; float *d_p, *d_o; double *d_obs, *d_info; int* d_n; uint8_t* d_f;
     FE_TRY(B.up(&d_p, pose12, 12)); FE_TRY(B.up(&d_o, (const float*)nullptr, 12)); FE_TRY(B.up(&d_obs, obs7, (size_t)n * 7));
     FE_TRY(B.up(&d_info, (const double*)nullptr, 4)); FE_TRY(B.up(&d_n, &n, 1)); FE_TRY(B.up(&d_f, (const uint8_t*)nullptr, (size_t)cap));
     FE_TRY(viorb_frontend_pose_opt_se3_device(h, d_p, d_obs, d_n, (double)intr5[4], 1, d_o, d_f, d_info, nullptr));
-    VIORB_HIP_TRY(hipDeviceSynchronize());
+    VIORB_HIP_TRY(hipStreamSynchronize(nullptr));
     VIORB_HIP_TRY(hipMemcpy(out_pose12, d_o, 12 * sizeof(float), hipMemcpyDeviceToHost));
     if (n) VIORB_HIP_TRY(hipMemcpy(outlier, d_f, n, hipMemcpyDeviceToHost));
     VIORB_HIP_TRY(hipMemcpy(info, d_info, 4 * sizeof(double), hipMemcpyDeviceToHost));
