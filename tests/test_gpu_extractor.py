@@ -68,6 +68,25 @@ def test_stage_parity(gpu, oracle, name):
     np.testing.assert_array_equal(desc, odesc)
 
 
+@pytest.mark.parametrize("w,h", [(200, 97), (201, 130), (202, 257), (203, 96), (129, 100), (257, 131)])
+def test_blur_borders_every_width_class(gpu, oracle, w, h):
+    """The streaming blur patches the right image border by byte permutes that depend on w mod 4, and the strips / bands end at
+    different lanes and rows for every size: all four classes, strip ends next to the border (129 = one pixel into a second
+    32-dword strip, 257 = one pixel into a third), all levels."""
+    img = make_image(77 + w, w, h)
+    ex = viorb_amd.ORBextractor(300, 1.2, 8, 20, 7)
+    ex(img)
+    ox = oracle.Extractor(300, 1.2, 8, 20, 7)
+    ox(img)
+    checked = 0
+    for l in range(8):
+        ob = ox.level(l, blurred=True)
+        if ob is not None:
+            np.testing.assert_array_equal(ex.level(l, blurred=True), ob, err_msg="blur level %d of %dx%d" % (l, w, h))
+            checked += 1
+    assert checked >= 3
+
+
 def test_golden_fixtures(gpu):
     for name in sorted(os.listdir(GOLD)):
         if not name.startswith("extract_"):

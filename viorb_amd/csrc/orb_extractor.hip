@@ -969,119 +969,119 @@ __global__ __launch_bounds__(64) void k_octree(const LevelDev* __restrict__ lv, 
 
 // cv::GaussianBlur(7x7, sigma 2, BORDER_REFLECT_101) on 8U, OpenCV 2.4 integer path:
 // taps {18,34,49,55,49,34,18} (x256, sum 257) in both directions, (sum + 2^15) >> 16, saturated. Everything is exact integer
-// arithmetic, so the order of the two separable passes does not change a bit of the result; the kernel runs the VERTICAL pass first,
-// because a column sum of seven byte x tap products is at most 255 * 257 = 65535 and therefore fits the 16-bit lanes of
-// v_pk_mad_u16 (two pixels per instruction), and the horizontal pass second on the 16-bit column sums with v_dot2_u32_u16 (two taps
-// per instruction, 32-bit accumulator): about 15 vector instructions per pixel where the byte-at-a-time vertical pass of round 1
-// needed 37 — the kernel is bound by vector issue, not by HBM (its 2 P of traffic would take 0.1 ms).
-// Block = 64x64 output tile, 256 threads. The input rectangle (70 rows x 72 bytes, 4-byte left apron) is staged in LDS as dwords.
-// Pass V: a thread takes one dword column (4 px) and 8 output rows: 14 input dwords, each split into its even and odd bytes as
-// 16-bit pairs, 7 taps x 8 rows x 2 v_pk_mad_u16; the sums go back to LDS as (V[4c], V[4c+2]) and (V[4c+1], V[4c+3]).
-// Pass H: a thread takes 4 adjacent outputs of a row: the six 16-bit pair registers of dword columns c-1, c, c+1 and 18 v_dot2.
-#define BL_TW 64
-#define BL_TH 64
-#define BL_IPD 18                         // input pitch in dwords: bytes x0-4 .. x0+67
+// arithmetic, so neither the order of the two separable passes nor the grouping of the products changes a bit of the result.
+// The kernel is bound by vector issue, not by HBM (its 2 P of traffic would take 0.1 ms), so it is built for instructions per pixel:
+// no LDS, no tiles — a half-wavefront (32 lanes) owns a strip of 32 dword columns (128 px) and streams down a band of rows, one
+// coalesced dword load per lane and row (BS_PF rows in flight); the two halves of a wavefront take two bands of the same strip.
+//   H  the row's left / right neighbour dwords come from the adjacent lanes (DPP wave shifts; the two end lanes of a half load
+//      theirs), six v_alignbyte build the byte windows and 8 v_dot4_u32_u8 give the four 7-tap row sums (<= 255 * 257, 16 bits);
+//   V  a row sum is packed with the previous row's into a 16-bit pair (one v_lshl_or per pixel); an output row is
+//      3 v_dot2_u32_u16 over the pairs (o, o+1), (o+2, o+3), (o+4, o+5) + one v_mad_u32_u24 for row o+6: the last six pairs of
+//      every pixel stay in registers (a ring, the row loop is unrolled by six).
+// ~13 vector instructions per pixel (the 64x64 LDS tile form of this kernel, V by v_pk_mad_u16 then H by v_dot2, needed ~30 of
+// which half were staging and index arithmetic). Image borders: rows by reflecting the row index (scalar), columns by byte
+// permutes of the edge lanes' dwords.
+#define BS_LANES 32
+#define BS_PF 6
 __constant__ int c_gauss[7];
-__device__ __forceinline__ int reflect101(int p, int len) {
-    if (len == 1) return 0;
-    while (p < 0 || p >= len) p = p < 0 ? -p : 2 * (len - 1) - p;
-    return p;
-}
 typedef unsigned short ushort2v __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ uint32_t pk_mad_u16(uint32_t a, uint32_t k, uint32_t c) {
-    return __builtin_bit_cast(uint32_t, (ushort2v)(__builtin_bit_cast(ushort2v, a) * __builtin_bit_cast(ushort2v, k) + __builtin_bit_cast(ushort2v, c)));
-}
 __device__ __forceinline__ uint32_t dot2_u16(uint32_t a, uint32_t k, uint32_t c) {
     return __builtin_amdgcn_udot2(__builtin_bit_cast(ushort2v, a), __builtin_bit_cast(ushort2v, k), c, false);
 }
-__global__ __launch_bounds__(256) void k_blur(const uint8_t* __restrict__ planes, uint8_t* __restrict__ blur,
-                                              size_t frame_bytes, const LevelDev* __restrict__ lv,
-                                              const int4* __restrict__ tiles, XcdPlace PL) {
-    __shared__ uint32_t s_in[(BL_TH + 6) * BL_IPD];
-    __shared__ uint32_t s_v[BL_TH * BL_IPD * 2];             // per (row, dword column): even-pixel pair, odd-pixel pair of column sums
+__global__ __launch_bounds__(64) void k_blur(const uint8_t* __restrict__ planes, uint8_t* __restrict__ blur,
+                                             size_t frame_bytes, const LevelDev* __restrict__ lv,
+                                             const int4* __restrict__ items, XcdPlace PL) {
     int b, item;
     if (!xcd_place(PL, b, item)) return;
-    const int4 t = tiles[item];                       // level, tile x0, tile y0
+    const int4 t = items[item];                       // level, first dword column of the strip, first row of band A, rows per band
     const LevelDev L = lv[t.x];
     const uint8_t* src = planes + (size_t)b * frame_bytes + L.plane_off;
     uint8_t* dst = blur + (size_t)b * frame_bytes + L.plane_off;
-    const int x0 = t.y, y0 = t.z;
-    {
-        // every thread's five input dwords are requested before the first is used (a plain loop made them five dependent round
-        // trips); dwords that straddle the image border are patched byte by byte afterwards (BORDER_REFLECT_101)
-        constexpr int NIN = (BL_TH + 6) * BL_IPD, TRIPS = (NIN + 255) / 256;
-        uint32_t v[TRIPS]; int xbs[TRIPS]; const uint8_t* rows[TRIPS];
-#pragma unroll
-        for (int k = 0; k < TRIPS; k++) {
-            const int i = min((int)threadIdx.x + 256 * k, NIN - 1);
-            const int r = i / BL_IPD, c = i - r * BL_IPD;
-            rows[k] = src + (size_t)reflect101(y0 + r - 3, L.h) * L.stride;
-            xbs[k] = x0 - 4 + 4 * c;
-            v[k] = *reinterpret_cast<const uint32_t*>(rows[k] + min(max(xbs[k], 0), L.stride - 4));
-        }
-#pragma unroll
-        for (int k = 0; k < TRIPS; k++) {
-            const int i = (int)threadIdx.x + 256 * k;
-            if (i >= NIN) continue;
-            uint32_t w = v[k];
-            if (!(xbs[k] >= 0 && xbs[k] + 3 < L.w)) {
-                w = 0;
-#pragma unroll
-                for (int j = 0; j < 4; j++) w |= (uint32_t)rows[k][reflect101(xbs[k] + j, L.w)] << (8 * j);
-            }
-            s_in[i] = w;
-        }
-    }
-    __syncthreads();
+    const int lane = threadIdx.x, hl = lane & (BS_LANES - 1);
+    const bool upper = lane >= BS_LANES;
+    const int Rb = t.w, y0A = t.z, y0B = t.z + Rb;
+    const int rows = upper ? min(Rb, L.h - y0B) : min(Rb, L.h - y0A);          // band B may be short or empty
+    const int sdw = L.stride >> 2;
+    const int d = t.y + hl;                                                     // this lane's dword column
+    const int dlast = (L.w - 1) >> 2, m = (L.w - 1) & 3;                        // dword and byte of the last pixel of a row
+    const int dc = min(d, sdw - 1);
+    const bool end_lane = hl == 0 || hl == BS_LANES - 1;
+    const int dn = hl == 0 ? max(dc - 1, 0) : min(dc + 1, sdw - 1);            // neighbour column an end lane loads itself
+    // byte selectors of the right border (BORDER_REFLECT_101: pixel w - 1 + k = pixel w - 1 - k) over the stream [left dword, dword]:
+    // bytes of the last dword beyond byte m, and the dword after it
+    const uint32_t selC = m == 0 ? 0x01020304u : m == 1 ? 0x03040504u : m == 2 ? 0x05060504u : 0x07060504u;
+    const uint32_t selR = m == 0 ? 0x0c0c0c0cu : m == 1 ? 0x0c000102u : m == 2 ? 0x01020304u : 0x03040506u;
+    const bool has_edge = t.y == 0 || t.y + BS_LANES > dlast - 1;                // wave-uniform
+    const bool is_d0 = d == 0, is_dl = d == dlast, is_dl1 = d == dlast - 1;
     const uint32_t k0 = (uint32_t)c_gauss[0], k1 = (uint32_t)c_gauss[1], k2 = (uint32_t)c_gauss[2], k3 = (uint32_t)c_gauss[3];
-    // ---- pass V: column sums of 8 output rows x 4 px per thread (144 of the 256 threads)
-    if (threadIdx.x < BL_IPD * (BL_TH / 8)) {
-        const int c = threadIdx.x % BL_IPD, rg = threadIdx.x / BL_IPD;
-        uint32_t in[14];
+    const uint32_t Ka = k0 | (k1 << 8) | (k2 << 16) | (k3 << 24), Kb = k2 | (k1 << 8) | (k0 << 16);   // taps -3..0, +1..+3
+    const uint32_t K01 = k0 | (k1 << 16), K23 = k2 | (k3 << 16), K45 = k2 | (k1 << 16);
+    const int nrow = Rb + 6;                                                    // input rows per band
+    // Loads are unconditional (row index clamped, every lane also loads a neighbour dword although only the end lanes use it) and the
+    // row loop runs to a multiple of six without an exit: any branch around a load or inside the unrolled body made the compiler copy the
+    // register ring and wait for each load where it was issued.
+    const uint8_t* pc = src + 4u * (uint32_t)dc;
+    const uint8_t* pn = src + 4u * (uint32_t)(end_lane ? dn : dc);
+    uint32_t cb[BS_PF], nb[BS_PF];
+    auto request = [&](int i, uint32_t& c, uint32_t& n) {
+        const int ii = min(i, nrow - 1);
+        int ya = y0A + ii - 3, yb = y0B + ii - 3;                               // both bands' input row, reflected at the image border
+        ya = ya < 0 ? -ya : ya; ya = ya >= L.h ? 2 * L.h - 2 - ya : ya; ya = min(max(ya, 0), L.h - 1);
+        yb = yb < 0 ? -yb : yb; yb = yb >= L.h ? 2 * L.h - 2 - yb : yb; yb = min(max(yb, 0), L.h - 1);
+        const uint32_t offA = __builtin_amdgcn_readfirstlane(ya * L.stride), offB = __builtin_amdgcn_readfirstlane(yb * L.stride);
+        const uint32_t off = upper ? offB : offA;
+        c = *reinterpret_cast<const uint32_t*>(pc + off);
+        n = *reinterpret_cast<const uint32_t*>(pn + off);
+    };
 #pragma unroll
-        for (int r = 0; r < 14; r++) in[r] = s_in[(8 * rg + r) * BL_IPD + c];
-        const uint32_t kk[4] = {k0 * 0x00010001u, k1 * 0x00010001u, k2 * 0x00010001u, k3 * 0x00010001u};
-        uint32_t ae[8], ao[8];
+    for (int u = 0; u < BS_PF; u++) request(u, cb[u], nb[u]);
+    uint32_t P[6][4], hp[4] = {0, 0, 0, 0};
 #pragma unroll
-        for (int o = 0; o < 8; o++) { ae[o] = 0; ao[o] = 0; }
+    for (int u = 0; u < 6; u++) { P[u][0] = P[u][1] = P[u][2] = P[u][3] = 0; }
+    uint8_t* pd = dst + 4u * (uint32_t)min(d, sdw - 1);
+    const bool col_ok = d < sdw;
+    for (int i0 = 0; i0 < nrow; i0 += 6) {
 #pragma unroll
-        for (int r = 0; r < 14; r++) {
-            const uint32_t e = in[r] & 0x00ff00ffu, od = (in[r] >> 8) & 0x00ff00ffu;
+        for (int u = 0; u < 6; u++) {
+            const int i = i0 + u;
+            uint32_t c = cb[u];
+            uint32_t Lr = __builtin_amdgcn_update_dpp(c, c, 0x138, 0xf, 0xf, true);        // wave_shr:1 — lane n reads lane n - 1
+            uint32_t Rr = __builtin_amdgcn_update_dpp(c, c, 0x130, 0xf, 0xf, true);        // wave_shl:1 — lane n reads lane n + 1
+            Lr = hl == 0 ? nb[u] : Lr; Rr = hl == BS_LANES - 1 ? nb[u] : Rr;
+            request(i + BS_PF, cb[u], nb[u]);
+            if (has_edge) {
+                const uint32_t Lf = __builtin_amdgcn_perm(Rr, c, 0x01020304u);               // pixels -4 .. -1 = pixels 4 .. 1
+                const uint32_t Cf = __builtin_amdgcn_perm(c, Lr, selC), Rf = __builtin_amdgcn_perm(c, Lr, selR);
+                const uint32_t Rf1 = __builtin_amdgcn_perm(Rr, c, selC);                     // the dword before the last: its right neighbour is the patched last dword
+                Lr = is_d0 ? Lf : Lr;
+                Rr = is_dl ? Rf : (is_dl1 ? Rf1 : Rr);
+                c = is_dl ? Cf : c;
+            }
+            // H: row sums of the lane's four pixels
+            uint32_t h[4];
+            h[0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(c, Lr, 1), Ka, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(Rr, c, 1), Kb, 0u, false), false);
+            h[1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(c, Lr, 2), Ka, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(Rr, c, 2), Kb, 0u, false), false);
+            h[2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(c, Lr, 3), Ka, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(Rr, c, 3), Kb, 0u, false), false);
+            h[3] = __builtin_amdgcn_udot4(c, Ka, __builtin_amdgcn_udot4(Rr, Kb, 0u, false), false);
+            // V: rows o .. o + 6 = i - 6 .. i; the pair of rows (r - 1, r) lives in P[r % 6]
+            uint32_t a[4];
 #pragma unroll
-            for (int o = 0; o < 8; o++) {
-                const int j = r - o;
-                if (j < 0 || j > 6) continue;
-                const uint32_t kj = kk[j < 4 ? j : 6 - j];
-                ae[o] = pk_mad_u16(e, kj, ae[o]); ao[o] = pk_mad_u16(od, kj, ao[o]);
+            for (int j = 0; j < 4; j++) {
+                a[j] = dot2_u16(P[(u + 1) % 6][j], K01, 1u << 15);
+                a[j] = dot2_u16(P[(u + 3) % 6][j], K23, a[j]);
+                a[j] = dot2_u16(P[(u + 5) % 6][j], K45, a[j]);
+                a[j] = __umul24(h[j], k0) + a[j];
+                a[j] = min(a[j], 0x00ffffffu);                                               // (sum + 2^15) >> 16 saturated to 255 = byte 2
+                P[u][j] = hp[j] | (h[j] << 16);
+                hp[j] = h[j];
+            }
+            const int o = i - 6;
+            const uint32_t yoA = __builtin_amdgcn_readfirstlane((y0A + o) * L.stride), yoB = __builtin_amdgcn_readfirstlane((y0B + o) * L.stride);
+            if (o >= 0 && o < rows && col_ok) {
+                const uint32_t lo = __builtin_amdgcn_perm(a[1], a[0], 0x0c0c0602u), hi = __builtin_amdgcn_perm(a[3], a[2], 0x0c0c0602u);
+                *reinterpret_cast<uint32_t*>(pd + (upper ? yoB : yoA)) = lo | (hi << 16);
             }
         }
-#pragma unroll
-        for (int o = 0; o < 8; o++)
-            *reinterpret_cast<uint2*>(&s_v[((8 * rg + o) * BL_IPD + c) * 2]) = make_uint2(ae[o], ao[o]);
-    }
-    __syncthreads();
-    // ---- pass H: 4 outputs per item, 64 rows x 16 dword columns = 1024 items, 4 per thread
-    const uint32_t K02 = k0 | (k2 << 16), K01h = k1 << 16, K35 = k3 | (k1 << 16) /* (k3, k5 = k1) */, K46 = k2 | (k0 << 16) /* (k4 = k2, k6 = k0) */;
-    const uint32_t K00h = k0 << 16, K24 = k2 | (k2 << 16), K60 = k0 /* (k6 = k0, 0) */, K13 = k1 | (k3 << 16), K50 = k1 /* (k5 = k1, 0) */;
-#pragma unroll
-    for (int it = 0; it < 4; it++) {
-        const int i = threadIdx.x + 256 * it, r = i >> 4, g = i & 15, c = g + 1;
-        const uint2* vp = reinterpret_cast<const uint2*>(&s_v[(r * BL_IPD + c) * 2]);
-        const uint2 vm = vp[-1], v0 = vp[0], vq = vp[1];
-        const uint32_t Em = vm.x, Om = vm.y, E0 = v0.x, O0 = v0.y, Ep = vq.x, Op = vq.y;
-        // with V[n] the column sum n pixels right of pixel 4c: Em = (V-4, V-2), Om = (V-3, V-1), E0 = (V0, V2), O0 = (V1, V3), Ep = (V4, V6), Op = (V5, V7)
-        uint32_t a0 = 1u << 15, a1 = 1u << 15, a2 = 1u << 15, a3 = 1u << 15;
-        a0 = dot2_u16(Om, K02, a0); a0 = dot2_u16(Em, K01h, a0); a0 = dot2_u16(E0, K35, a0); a0 = dot2_u16(O0, K46, a0);          // V-3 .. V3
-        a1 = dot2_u16(Em, K00h, a1); a1 = dot2_u16(Om, K01h, a1); a1 = dot2_u16(E0, K24, a1); a1 = dot2_u16(O0, K35, a1); a1 = dot2_u16(Ep, K60, a1);   // V-2 .. V4
-        a2 = dot2_u16(Om, K00h, a2); a2 = dot2_u16(E0, K13, a2); a2 = dot2_u16(O0, K24, a2); a2 = dot2_u16(Ep, K50, a2); a2 = dot2_u16(Op, K60, a2);    // V-1 .. V5
-        a3 = dot2_u16(E0, K02, a3); a3 = dot2_u16(O0, K13, a3); a3 = dot2_u16(Ep, K46, a3); a3 = dot2_u16(Op, K50, a3);           // V0 .. V6
-        // (sum + 2^15) >> 16, saturated to 255: clamp below 256 << 16 and take byte 2 of each
-        a0 = min(a0, 0x00ffffffu); a1 = min(a1, 0x00ffffffu); a2 = min(a2, 0x00ffffffu); a3 = min(a3, 0x00ffffffu);
-        const uint32_t lo = __builtin_amdgcn_perm(a1, a0, 0x0c0c0602u);      // byte 2 of a0, byte 2 of a1 (selector bytes 4-7 = first operand)
-        const uint32_t hi = __builtin_amdgcn_perm(a3, a2, 0x0c0c0602u);
-        const uint32_t w = lo | (hi << 16);
-        const int y = y0 + r, xw = x0 + 4 * g;
-        if (y < L.h && xw < L.stride) *reinterpret_cast<uint32_t*>(dst + (size_t)y * L.stride + xw) = w;
     }
 }
 
@@ -1540,8 +1540,12 @@ static int configure(viorb_extractor* h, int w, int hgt) {
                 if (l == 1) h->rs2_copy_ok = cover && h->rs2_ok[1];
             }
         }
-        for (int ty = 0; ty < L.h; ty += BL_TH)
-            for (int tx = 0; tx < L.w; tx += BL_TW) h->blur_tiles.push_back(make_int4(l, tx, ty, 0));
+        {   // blur work items: one wavefront = one 32-dword strip x two bands of rows (an even number of bands of <= 64 rows)
+            const int nb = 2 * ((L.h + 127) / 128), rb = (L.h + nb - 1) / nb, ndw = (L.w + 3) / 4;
+            for (int sx = 0; sx < ndw; sx += BS_LANES)
+                for (int k = 0; k < nb; k += 2) h->blur_tiles.push_back(make_int4(l, sx, k * rb, rb));
+            if (L.w < 12 || L.h < 4) { set_error("level %d (%dx%d) too small for the blur", l, L.w, L.h); return VIORB_ERR_UNSUPPORTED; }
+        }
     }
     h->frame_bytes = align_up(off, 256);
     h->kp_pitch = kp_off;
@@ -1702,7 +1706,7 @@ static int launch_all(viorb_extractor* h, const uint8_t* d_images, int batch, in
         // (running the blur on a second stream beside FAST + quadtree was measured: no gain, the kernels contend for the same CUs)
         ProfScope ps("k_blur", st);
         const XcdPlace PL = make_place((int)h->blur_tiles.size(), batch);
-        hipLaunchKernelGGL(k_blur, dim3(place_blocks(PL)), dim3(256), 0, st, h->d_planes, h->d_blur, h->frame_bytes,
+        hipLaunchKernelGGL(k_blur, dim3(place_blocks(PL)), dim3(64), 0, st, h->d_planes, h->d_blur, h->frame_bytes,
                            h->d_lv, h->d_blur_tiles, PL);
     }
     {
