@@ -128,15 +128,17 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 // nper * 8 * ceil(batch / 8) blocks, block L works on item (L / 8) % nper of image ((L / 8) / nper) * 8 + L % 8: all work of image b
 // runs on XCD b % 8, in consecutive blocks, and an image's 1.1 MB level set stays in that L2 while its tiles are in flight.
 // A speed measure only (the mapping of blocks to XCDs is not a contract); batch < 8 uses the plain order.
-struct XcdPlace { int nper, batch, xcd; };
+struct XcdPlace { int nper, batch, xcd, img0; };            // images img0 .. batch - 1 (a launch may take a sub-range of the batch)
 __device__ __forceinline__ bool xcd_place(const XcdPlace P, int& img, int& item) {
     const int L = blockIdx.x;
-    if (P.xcd) { const int i = L >> 3, g = i / P.nper; item = i - g * P.nper; img = g * 8 + (L & 7); }
-    else { img = L / P.nper; item = L - img * P.nper; }
+    if (P.xcd) { const int i = L >> 3, g = i / P.nper; item = i - g * P.nper; img = P.img0 + g * 8 + (L & 7); }
+    else { img = L / P.nper; item = L - img * P.nper; img += P.img0; }
     return img < P.batch;
 }
-static inline XcdPlace make_place(int nper, int batch) { XcdPlace P; P.nper = nper; P.batch = batch; P.xcd = batch >= 8; return P; }
-static inline unsigned place_blocks(const XcdPlace& P) { return (unsigned)P.nper * (unsigned)(P.xcd ? 8 * ((P.batch + 7) / 8) : P.batch); }
+static inline XcdPlace make_place(int nper, int batch, int img0 = 0, int img1 = -1) {
+    XcdPlace P; P.nper = nper; P.batch = img1 < 0 ? batch : std::min(batch, img1); P.xcd = batch >= 8; P.img0 = img0; return P;
+}
+static inline unsigned place_blocks(const XcdPlace& P) { const int n = P.batch - P.img0; return (unsigned)P.nper * (unsigned)(P.xcd ? 8 * ((n + 7) / 8) : n); }
 
 // Level 0 = the input image re-pitched into the plane buffer.
 __global__ void k_copy_level0(const uint8_t* __restrict__ src, int w, int h, int sstride, size_t spitch,
@@ -318,6 +320,119 @@ __global__ __launch_bounds__(256) void k_resize2(Resize2Args A, XcdPlace PL) {
     }
 }
 
+typedef unsigned short ushort2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t dot2_u16(uint32_t a, uint32_t k, uint32_t c) {
+    return __builtin_amdgcn_udot2(__builtin_bit_cast(ushort2v, a), __builtin_bit_cast(ushort2v, k), c, false);
+}
+// Third form of the resize, the default whenever the level's tables allow it (downscaling, every source row is the lower row of at
+// most one output row, the four outputs of a dword take their eight source bytes from an 8-byte window): no LDS, no tiles. The resize
+// is bound by vector issue like the rest of the extractor, so it is built for instructions per pixel:
+//   * a half-wavefront owns 32 output dword columns and streams down the SOURCE rows of a band of output rows (one unaligned 8-byte
+//     load per lane and row, RSS_PF rows in flight); the two halves of a wavefront take two bands of the same strip;
+//   * per source row the horizontal interpolation of the lane's four outputs is one v_perm (the two source bytes into 16-bit fields, the
+//     selector is fixed per column) + one v_dot2_u32_u16 with (a0, a1) each, kept as (sum >> 4) << 9; each source row is interpolated
+//     ONCE (the tile forms did it for both source rows of every output row);
+//   * an output row is emitted at its lower source row from the previous and the current row sums:
+//     ((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) as two v_mul_hi_u32_u24 of pre-shifted operands, + 2, >> 2, packed.
+//     Which output row a source row emits, and its (b0, b1), is a per-level table (etab) each lane loads once for its band and
+//     the row loop reads with v_readlane.
+// ~16 vector instructions per output pixel (tile forms: ~44). Same integer recipe as above, bit for bit.
+#define RSS_LANES 32
+#define RSS_PF 6
+#define RSS_MAX_SRC_ROWS 60               // source rows of one band: one etab entry per lane, and the row loop (a multiple of RSS_PF) must stay below lane 64
+struct ResizeStreamArgs {
+    const uint8_t* planes; size_t frame_bytes;
+    uint32_t src_off, dst_off;
+    int src_stride, src_h, dst_stride, dst_w, dst_h;
+    const int2* xtab; const int2* ytab; const uint2* etab; const int4* items;   // items[i] = {first dword column of the strip, first row of band A, rows per band, 0}
+};
+struct __attribute__((packed, aligned(1))) rss_u8x8 { uint32_t lo, hi; };
+__global__ __launch_bounds__(64) void k_resize_stream(ResizeStreamArgs A, XcdPlace PL) {
+    int b, item;
+    if (!xcd_place(PL, b, item)) return;
+    const int4 t = A.items[item];
+    const uint8_t* src = A.planes + (size_t)b * A.frame_bytes + A.src_off;
+    uint8_t* dst = const_cast<uint8_t*>(A.planes) + (size_t)b * A.frame_bytes + A.dst_off;
+    const int lane = threadIdx.x, hl = lane & (RSS_LANES - 1);
+    const bool upper = lane >= RSS_LANES;
+    const int Rb = t.z, y0A = t.y, y0B = t.y + Rb;
+    const int rowsA = min(Rb, A.dst_h - y0A), rowsB = max(min(Rb, A.dst_h - y0B), 0);
+    // source rows of the two bands: first = upper row of the first output row, last = lower row of the last output row
+    const int rsA = A.ytab[y0A].x & 0xffff, reA = A.ytab[y0A + rowsA - 1].x >> 16;
+    const int rsB = rowsB > 0 ? A.ytab[min(y0B, A.dst_h - 1)].x & 0xffff : 0, reB = rowsB > 0 ? A.ytab[min(y0B + rowsB - 1, A.dst_h - 1)].x >> 16 : -1;
+    const int ns = max(reA - rsA, reB - rsB) + 1;                                // rows the loop walks (<= RSS_MAX_SRC_ROWS, host-checked)
+    // this lane's four output columns: byte selectors inside the 8-byte window that starts at the first column's left source pixel, weights
+    const int d = t.x + hl, sdw = A.dst_stride >> 2;
+    uint32_t sel[4], aw[4]; int sxf = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int2 e = A.xtab[min(4 * d + j, A.dst_w - 1)];
+        if (j == 0) sxf = e.x & 0xffff;
+        sel[j] = (uint32_t)((e.x & 0xffff) - sxf) | ((uint32_t)((e.x >> 16) - sxf) << 16) | 0x0c000c00u;
+        aw[j] = (uint32_t)e.y;
+    }
+    // emit entries of both bands, one source row per lane, packed as band-relative row (7 bits, 127 = none) | b0 << 7 | b1 << 19 | same-row flag << 31
+    auto pack_entry = [&](int r0, int r1, int yb0, int nrows) {
+        const int r = r0 + lane;
+        const uint2 e = A.etab[min(r, A.src_h - 1)];
+        const int y = (int)(e.x & 0x7fff) - yb0;
+        const bool ok = r <= r1 && (e.x & 0x7fff) != 0x7fff && y >= 0 && y < nrows;
+        return ok ? ((uint32_t)y | ((e.y & 0xfffu) << 7) | (((e.y >> 16) & 0xfffu) << 19) | ((e.x >> 15) << 31)) : 127u;
+    };
+    const uint32_t EA = pack_entry(rsA, reA, y0A, rowsA), EB = pack_entry(rsB, reB, y0B, rowsB);
+    const uint8_t* pc = src + sxf;
+    uint8_t* pd = dst + 4u * (uint32_t)min(d, sdw - 1);
+    const bool col_ok = d < sdw;
+    // loads are unconditional (row index clamped) and the loop runs to a multiple of RSS_PF: see k_blur
+    uint32_t lo[RSS_PF], hi[RSS_PF];
+    auto request = [&](int i, uint32_t& l, uint32_t& h) {
+        const uint32_t offA = __builtin_amdgcn_readfirstlane(min(rsA + i, A.src_h - 1) * A.src_stride), offB = __builtin_amdgcn_readfirstlane(min(rsB + i, A.src_h - 1) * A.src_stride);
+        const rss_u8x8 v = *reinterpret_cast<const rss_u8x8*>(pc + (upper ? offB : offA));
+        l = v.lo; h = v.hi;
+    };
+#pragma unroll
+    for (int u = 0; u < RSS_PF; u++) request(u, lo[u], hi[u]);
+    uint32_t hp[4] = {0, 0, 0, 0};
+    for (int i0 = 0; i0 < ns; i0 += RSS_PF) {
+#pragma unroll
+        for (int u = 0; u < RSS_PF; u++) {
+            const int i = i0 + u;
+            uint32_t hc[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint32_t two = __builtin_amdgcn_perm(hi[u], lo[u], sel[j]);             // (left source byte, right source byte) as 16-bit fields
+                hc[j] = (dot2_u16(two, aw[j], 0u) & 0x7fff0u) << 5;                         // ((S[sx0] * a0 + S[sx1] * a1) >> 4) << 9
+            }
+            request(i + RSS_PF, lo[u], hi[u]);
+            // this row's emit entries of both bands (scalar); everything that differs between the halves is one select of two scalars
+            const uint32_t eA = __builtin_amdgcn_readlane(EA, i & 63), eB = __builtin_amdgcn_readlane(EB, i & 63);
+            const uint32_t yrA = eA & 127u, yrB = eB & 127u;
+            const bool emit = upper ? yrB < (uint32_t)rowsB : yrA < (uint32_t)rowsA;
+            if (emit && col_ok) {
+                const uint32_t b0 = upper ? (eB & (0xfffu << 7)) : (eA & (0xfffu << 7)), b1 = upper ? ((eB >> 12) & (0xfffu << 7)) : ((eA >> 12) & (0xfffu << 7));
+                const uint32_t yoA = __builtin_amdgcn_readfirstlane((y0A + (int)yrA) * A.dst_stride), yoB = __builtin_amdgcn_readfirstlane((y0B + (int)yrB) * A.dst_stride);
+                const uint32_t yo = upper ? yoB : yoA;
+                uint32_t h0[4] = {hp[0], hp[1], hp[2], hp[3]};
+                if ((int)(eA | eB) < 0) {                                                   // bottom clamp (last output rows only): both source rows are this one
+                    const bool same = upper ? (int)eB < 0 : (int)eA < 0;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) h0[j] = same ? hc[j] : hp[j];
+                }
+                uint32_t v[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const uint32_t t0 = (uint32_t)(((unsigned long long)h0[j] * b0) >> 32), t1 = (uint32_t)(((unsigned long long)hc[j] * b1) >> 32);
+                    v[j] = (t0 + t1 + 2u) >> 2;
+                }
+                const uint32_t w01 = v[0] | (v[1] << 8), w23 = v[2] | (v[3] << 8);
+                *reinterpret_cast<uint32_t*>(pd + yo) = w01 | (w23 << 16);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) hp[j] = hc[j];
+        }
+    }
+}
+
 // FAST-9-16 corner strength of the pixel at p (byte pointer into an LDS tile with `pitch` bytes per
 // row): max over the 16 arcs of 9 contiguous ring pixels of min(v - ring) and of min(ring - v),
 // minus 1 == cv::cornerScore<16>; the pixel is a FAST corner at threshold t iff strength >= t.
@@ -388,6 +503,7 @@ __device__ __forceinline__ int wave_inclusive_scan(int v) {
     return v;
 }
 #define FAST_FETCH_TRIPS 7
+#define FAST_LAUNCHES 8
 #define FAST_CELLS_PER_WAVE 2         // measured per 256 images: 1: 0.578 ms, 2: 0.553, 4: 0.565, 8: 0.582
 __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t* __restrict__ planes, size_t frame_bytes,
                                                    const LevelDev* __restrict__ lv,
@@ -984,10 +1100,6 @@ __global__ __launch_bounds__(64) void k_octree(const LevelDev* __restrict__ lv, 
 #define BS_LANES 32
 #define BS_PF 6
 __constant__ int c_gauss[7];
-typedef unsigned short ushort2v __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ uint32_t dot2_u16(uint32_t a, uint32_t k, uint32_t c) {
-    return __builtin_amdgcn_udot2(__builtin_bit_cast(ushort2v, a), __builtin_bit_cast(ushort2v, k), c, false);
-}
 __global__ __launch_bounds__(64) void k_blur(const uint8_t* __restrict__ planes, uint8_t* __restrict__ blur,
                                              size_t frame_bytes, const LevelDev* __restrict__ lv,
                                              const int4* __restrict__ items, XcdPlace PL) {
@@ -1388,6 +1500,9 @@ struct viorb_extractor {
     // second resize form (k_resize2): per-level tile table, LDS pitch, whether the level qualifies; whether level 1's kernel may also write level 0
     std::vector<int4> rs2_tiles; std::vector<int> rs2_off, rs2_pitch_dw, rs2_ok; bool rs2_copy_ok = false;
     int4* d_rs2_tiles = nullptr;
+    // third resize form (k_resize_stream): per-level work items {strip, band}, emit table over the source rows, whether the level qualifies
+    std::vector<int4> rss_items; std::vector<uint2> rss_etab; std::vector<int> rss_item_off, rss_etab_off, rss_ok;
+    int4* d_rss_items = nullptr; uint2* d_rss_etab = nullptr;
     // device memory
     uint8_t *d_planes = nullptr, *d_blur = nullptr, *d_desc = nullptr, *d_stage = nullptr;
     LevelDev* d_lv = nullptr; CellDesc* d_cells = nullptr; int4* d_blur_tiles = nullptr;
@@ -1405,9 +1520,9 @@ struct viorb_extractor {
 static void free_device(viorb_extractor* h) {
     void* ptrs[] = {h->d_planes, h->d_blur, h->d_desc, h->d_stage, h->d_lv, h->d_cells, h->d_blur_tiles, h->d_xtab,
                     h->d_ytab, h->d_slots, h->d_lvl_kp, h->d_cell_cnt, h->d_lvl_cnt, h->d_lvl_ncand, h->d_count,
-                    h->d_status, h->d_kps, h->d_rs2_tiles};
+                    h->d_status, h->d_kps, h->d_rs2_tiles, h->d_rss_items, h->d_rss_etab};
     for (void* p : ptrs) if (p) (void)hipFree(p);
-    h->d_rs2_tiles = nullptr;
+    h->d_rs2_tiles = nullptr; h->d_rss_items = nullptr; h->d_rss_etab = nullptr;
     h->d_planes = h->d_blur = h->d_desc = h->d_stage = nullptr; h->d_lv = nullptr; h->d_cells = nullptr;
     h->d_blur_tiles = nullptr; h->d_xtab = h->d_ytab = nullptr; h->d_slots = h->d_lvl_kp = nullptr;
     h->d_cell_cnt = h->d_lvl_cnt = h->d_lvl_ncand = h->d_count = h->d_status = nullptr; h->d_kps = nullptr;
@@ -1423,6 +1538,7 @@ static int configure(viorb_extractor* h, int w, int hgt) {
     std::vector<int2> xtab, ytab;
     h->rs_pitch_dw.assign(nl, 0); h->rs_rows.assign(nl, 0);
     h->rs2_tiles.clear(); h->rs2_off.assign(nl, 0); h->rs2_pitch_dw.assign(nl, 1); h->rs2_ok.assign(nl, 0); h->rs2_copy_ok = false;
+    h->rss_items.clear(); h->rss_etab.clear(); h->rss_item_off.assign(nl + 1, 0); h->rss_etab_off.assign(nl, 0); h->rss_ok.assign(nl, 0);
     size_t off = 0;
     int kp_off = 0, max_cw = 0, max_ch = 0;
     for (int l = 0; l < nl; l++) {
@@ -1539,6 +1655,43 @@ static int configure(viorb_extractor* h, int w, int hgt) {
                 h->rs2_ok[l] = (prow <= 48 && pdw * prow <= 256 * RS2_TRIPS) ? 1 : 0;
                 if (l == 1) h->rs2_copy_ok = cover && h->rs2_ok[1];
             }
+            {   // streaming form: emit table over the source rows, strips x band pairs, and the conditions it needs
+                static const bool no_stream = getenv("VIORB_RESIZE_TILES") != nullptr;           // debugging / tests: keep the tile forms
+                bool ok = !no_stream && sw >= 8;
+                h->rss_etab_off[l] = (int)h->rss_etab.size();
+                std::vector<uint2> et(sh, make_uint2(0x7fffu, 0u));
+                for (int dy = 0; dy < L.h && ok; dy++) {
+                    const int sy0 = yt[dy].x & 0xffff, sy1 = yt[dy].x >> 16;
+                    if ((sy1 != sy0 && sy1 != sy0 + 1) || et[sy1].x != 0x7fffu || dy >= 0x7fff) { ok = false; break; }
+                    const int b0 = yt[dy].y & 0xffff, b1 = (yt[dy].y >> 16) & 0xffff;
+                    if (b0 > 2048 || b1 > 2048) { ok = false; break; }
+                    et[sy1] = make_uint2((uint32_t)dy | (sy1 == sy0 ? 0x8000u : 0u), (uint32_t)b0 | ((uint32_t)b1 << 16));
+                }
+                const int ndw = (L.w + 3) / 4;
+                for (int dcol = 0; dcol < ndw && ok; dcol++) {                                 // the 8-byte source window of every output dword
+                    const int first = xt[std::min(4 * dcol, L.w - 1)].x & 0xffff;
+                    for (int j = 0; j < 4; j++) {
+                        const int2 e = xt[std::min(4 * dcol + j, L.w - 1)];
+                        if ((e.x >> 16) - first > 7 || (e.x & 0xffff) < first || (e.y & 0xffff) > 2048 || ((e.y >> 16) & 0xffff) > 2048) ok = false;
+                    }
+                }
+                h->rss_item_off[l] = (int)h->rss_items.size();
+                if (ok) {
+                    const double sy = (double)sh / L.h;
+                    const int rbmax = std::max(1, std::min(100, (int)((RSS_MAX_SRC_ROWS - 2) / sy)));
+                    const int nb = 2 * ((L.h + 2 * rbmax - 1) / (2 * rbmax)), rb = (L.h + nb - 1) / nb;
+                    for (int k = 0; k < nb && ok; k++) {                                        // every band's source rows fit the lane-held table
+                        const int ya = k * rb, yb = std::min(ya + rb, L.h) - 1;
+                        if (ya <= yb && (yt[yb].x >> 16) - (yt[ya].x & 0xffff) + 1 > RSS_MAX_SRC_ROWS) ok = false;
+                    }
+                    for (int sx = 0; sx < ndw && ok; sx += RSS_LANES)
+                        for (int k = 0; k < nb; k += 2)
+                            if (k * rb < L.h) h->rss_items.push_back(make_int4(sx, k * rb, rb, 0));
+                }
+                if (!ok) h->rss_items.resize(h->rss_item_off[l]);
+                h->rss_ok[l] = ok ? 1 : 0;
+                h->rss_etab.insert(h->rss_etab.end(), et.begin(), et.end());
+            }
         }
         {   // blur work items: one wavefront = one 32-dword strip x two bands of rows (an even number of bands of <= 64 rows)
             const int nb = 2 * ((L.h + 127) / 128), rb = (L.h + nb - 1) / nb, ndw = (L.w + 3) / 4;
@@ -1583,6 +1736,8 @@ static int configure(viorb_extractor* h, int w, int hgt) {
     VIORB_HIP_TRY(hipMalloc(&h->d_cells, sizeof(CellDesc) * ncells));
     VIORB_HIP_TRY(hipMalloc(&h->d_blur_tiles, sizeof(int4) * h->blur_tiles.size()));
     VIORB_HIP_TRY(hipMalloc(&h->d_rs2_tiles, sizeof(int4) * std::max<size_t>(h->rs2_tiles.size(), 1)));
+    VIORB_HIP_TRY(hipMalloc(&h->d_rss_items, sizeof(int4) * std::max<size_t>(h->rss_items.size(), 1)));
+    VIORB_HIP_TRY(hipMalloc(&h->d_rss_etab, sizeof(uint2) * std::max<size_t>(h->rss_etab.size(), 1)));
     VIORB_HIP_TRY(hipMalloc(&h->d_xtab, sizeof(int2) * std::max<size_t>(xtab.size(), 1)));
     VIORB_HIP_TRY(hipMalloc(&h->d_ytab, sizeof(int2) * std::max<size_t>(ytab.size(), 1)));
     VIORB_HIP_TRY(hipMalloc(&h->d_slots, B * ncells * h->slot_cap * sizeof(uint32_t)));
@@ -1603,6 +1758,8 @@ static int configure(viorb_extractor* h, int w, int hgt) {
     VIORB_HIP_TRY(hipMemcpy(h->d_cells, h->cells.data(), sizeof(CellDesc) * ncells, hipMemcpyHostToDevice));
     VIORB_HIP_TRY(hipMemcpy(h->d_blur_tiles, h->blur_tiles.data(), sizeof(int4) * h->blur_tiles.size(), hipMemcpyHostToDevice));
     if (!h->rs2_tiles.empty()) VIORB_HIP_TRY(hipMemcpy(h->d_rs2_tiles, h->rs2_tiles.data(), sizeof(int4) * h->rs2_tiles.size(), hipMemcpyHostToDevice));
+    if (!h->rss_items.empty()) VIORB_HIP_TRY(hipMemcpy(h->d_rss_items, h->rss_items.data(), sizeof(int4) * h->rss_items.size(), hipMemcpyHostToDevice));
+    if (!h->rss_etab.empty()) VIORB_HIP_TRY(hipMemcpy(h->d_rss_etab, h->rss_etab.data(), sizeof(uint2) * h->rss_etab.size(), hipMemcpyHostToDevice));
     if (!xtab.empty()) VIORB_HIP_TRY(hipMemcpy(h->d_xtab, xtab.data(), sizeof(int2) * xtab.size(), hipMemcpyHostToDevice));
     if (!ytab.empty()) VIORB_HIP_TRY(hipMemcpy(h->d_ytab, ytab.data(), sizeof(int2) * ytab.size(), hipMemcpyHostToDevice));
     if (!h->tables_uploaded) {
@@ -1653,6 +1810,19 @@ static int launch_all(viorb_extractor* h, const uint8_t* d_images, int batch, in
     }
     for (int l = 1; l < nl; l++) {
         const LevelDev& L = h->lv[l];
+        if (h->rss_ok[l] && !(l == 1 && fuse_copy)) {
+            const LevelDev& P = h->lv[l - 1];
+            ResizeStreamArgs A;
+            A.planes = h->d_planes; A.frame_bytes = h->frame_bytes; A.src_off = P.plane_off; A.dst_off = L.plane_off;
+            A.src_stride = P.stride; A.src_h = P.h; A.dst_stride = L.stride; A.dst_w = L.w; A.dst_h = L.h;
+            A.xtab = h->d_xtab + L.xtab_off; A.ytab = h->d_ytab + L.ytab_off; A.etab = h->d_rss_etab + h->rss_etab_off[l];
+            A.items = h->d_rss_items + h->rss_item_off[l];
+            const int nitems = (l + 1 < nl ? h->rss_item_off[l + 1] : (int)h->rss_items.size()) - h->rss_item_off[l];
+            const XcdPlace PL = make_place(nitems, batch);
+            ProfScope ps("k_resize", st);
+            hipLaunchKernelGGL(k_resize_stream, dim3(place_blocks(PL)), dim3(64), 0, st, A, PL);
+            continue;
+        }
         if (h->rs2_ok[l]) {
             const LevelDev& P = h->lv[l - 1];
             Resize2Args A;
@@ -1679,10 +1849,21 @@ static int launch_all(viorb_extractor* h, const uint8_t* d_images, int batch, in
     {
         const size_t lds = (size_t)h->fast_tile_pitch * h->fast_tile_rows + h->fast_score_bytes + (size_t)h->fast_list_cap * 4;
         ProfScope ps("k_fast_cells", st);
-        const XcdPlace PL = make_place((ncells + FAST_CELLS_PER_WAVE - 1) / FAST_CELLS_PER_WAVE, batch);
-        hipLaunchKernelGGL(k_fast_cells, dim3(place_blocks(PL)), dim3(64), lds, st, h->d_planes, h->frame_bytes, h->d_lv, h->d_cells,
-                           h->p.ini_th_fast, h->p.min_th_fast, h->d_slots, h->slot_cap, h->d_cell_cnt, ncells,
-                           h->fast_tile_pitch, h->fast_tile_rows, h->fast_score_bytes, h->fast_list_cap, PL);
+        // FAST goes out as FAST_LAUNCHES launches over sub-ranges of the batch (multiples of 8 images). A launch boundary is the only point
+        // where the tracking stream's large workgroups (a search: 16 waves + 73 KB of LDS; the pose solver: 240 registers per lane) can be
+        // placed on a CU: while this kernel still has workgroups to hand out, every slot that frees goes to its next single-wave
+        // workgroup, and SearchLocalPoints (54 us alone) finished only when FAST did (380 us). FAST's workgroups live a few
+        // microseconds, so a sub-launch drains at once and the cost is a few launch gaps that the other stream fills: 118 k -> 139 k
+        // frames/s at 256 streams (4 launches: 129 k, 16: 134 k, 32: 121 k). Splitting the quadtree, blur or descriptor kernels the same
+        // way loses (their workgroups live long, every boundary is a tail).
+        static const int nlaunch = getenv("VIORB_FAST_LAUNCHES") ? std::max(1, atoi(getenv("VIORB_FAST_LAUNCHES"))) : FAST_LAUNCHES;
+        const int step = std::max(8, ((batch + nlaunch - 1) / nlaunch + 7) & ~7);
+        for (int i0 = 0; i0 < batch; i0 += step) {
+            const XcdPlace PL = make_place((ncells + FAST_CELLS_PER_WAVE - 1) / FAST_CELLS_PER_WAVE, batch, i0, std::min(batch, i0 + step));
+            hipLaunchKernelGGL(k_fast_cells, dim3(place_blocks(PL)), dim3(64), lds, st, h->d_planes, h->frame_bytes, h->d_lv, h->d_cells,
+                               h->p.ini_th_fast, h->p.min_th_fast, h->d_slots, h->slot_cap, h->d_cell_cnt, ncells,
+                               h->fast_tile_pitch, h->fast_tile_rows, h->fast_score_bytes, h->fast_list_cap, PL);
+        }
     }
     {
         // common case first: <= OCT_NCAP_SMALL candidates per level fit a ~35 KB footprint (4 single-wave workgroups per CU);
