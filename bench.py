@@ -215,6 +215,15 @@ def run_tracking(args, cfg, rank, dev_index, dev, world):
     names = C.create_string_buffer(4096); ms = (C.c_double * 64)(); calls = (C.c_int * 64)(); n = C.c_int()
     L.viorb_profile_read(names, 4096, ms, calls, 64, C.byref(n))
     prof = {nm_: (ms[i], calls[i]) for i, nm_ in enumerate(names.value.decode().split("\n")[:n.value])}
+    if args.timeline:                                       # dev aid: the two streams' kernel intervals on one clock (HIP events, no tracer)
+        cap = 16384
+        t_a = (C.c_double * cap)(); t_b = (C.c_double * cap)(); t_s = (C.c_int * cap)(); t_n = C.c_int()
+        L.viorb_profile_timeline(t_a, t_b, t_s, cap, C.byref(t_n))
+        nms = names.value.decode().split("\n")
+        rows = sorted((t_a[i], t_b[i], nms[t_s[i]]) for i in range(min(t_n.value, cap)))
+        with open(args.timeline, "w") as f:
+            for a, b, nm_ in rows[-int(args.timeline_rows):]:
+                f.write("%10.1f %10.1f %8.1f %s\n" % (a * 1e3, b * 1e3, (b - a) * 1e3, nm_))
 
     out = dict(units=S * args.steps, elapsed=elapsed)
     if rank == 0:
@@ -431,6 +440,8 @@ def main():
     ap.add_argument("--no-track-local-map", action="store_true", help="stop after TrackWithIMU's pose solve")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip the per-kernel HIP events (rooflines become null); dev aid")
+    ap.add_argument("--timeline", default=None, help="dev aid (with --all-kernel-events): write start / end / duration (us) of the last kernels to this file")
+    ap.add_argument("--timeline-rows", type=int, default=120)
     ap.add_argument("--all-kernel-events", action="store_true", help="time every kernel of the step, not only the roofline kernels (costs ~5 %% of the step)")
     args = ap.parse_args()
     cfg = CONFIGS[args.config]

@@ -385,6 +385,9 @@ int viorb_profile_reset(void);
  * time, so timing all ~30 launches of a tracking step slows the step by ~5 %; bench.py times only its roofline kernel. */
 int viorb_profile_select(const char* kernel_name);
 int viorb_profile_read(char* names_buf, int names_cap, double* total_ms, int* calls, int cap, int* n);
+/* Start / end of every recorded interval (ms since the first record; both streams on one clock), in recording order; slot[i]
+ * indexes the names viorb_profile_read returns. */
+int viorb_profile_timeline(double* start_ms, double* end_ms, int* slot, int cap, int* n);
 
 /* Host-buffer drop-ins for single calls (they stage through the device and include the PCIe copies). */
 int viorb_descriptor_distance(const uint8_t* a, const uint8_t* b);       /* ORBmatcher::DescriptorDistance */

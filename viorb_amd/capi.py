@@ -5,7 +5,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "libviorb_hip.so")
+SO_PATH = os.environ.get("VIORB_LIBRARY") or os.path.join(_HERE, "libviorb_hip.so")      # VIORB_LIBRARY: another build of the library (kernel experiments)
 
 KP_DTYPE = np.dtype([("x", "f4"), ("y", "f4"), ("size", "f4"), ("angle", "f4"),
                      ("response", "f4"), ("octave", "i4"), ("class_id", "i4")])
@@ -154,6 +154,7 @@ SIGNATURES = {
     "viorb_profile_reset": (i32, []),
     "viorb_profile_select": (i32, [C.c_char_p]),
     "viorb_profile_read": (i32, [C.c_char_p, i32, vp, vp, i32, PP(i32)]),
+    "viorb_profile_timeline": (i32, [vp, vp, vp, i32, vp]),
     "viorb_descriptor_distance": (i32, [vp, vp]),
     "viorb_search_by_projection_frame": (i32, [vp, vp, i32, vp, vp, vp, vp, i32, vp, i32, vp, vp, vp, f32, i32, vp, PP(i32)]),
     "viorb_search_by_projection_frame_stereo": (i32, [vp, vp, vp, i32, vp, vp, vp, vp, f32, f32, vp, i32, vp, i32, vp, vp, vp, f32, i32, vp, PP(i32)]),

@@ -1942,6 +1942,20 @@ int viorb_profile_read(char* names_buf, int names_cap, double* total_ms, int* ca
     }
     return VIORB_OK;
 }
+// Start / end of every recorded interval in milliseconds since the first record (the records of both streams share one clock),
+// in recording order; slot[i] indexes the names of viorb_profile_read. A timeline without a tracer's per-launch host cost.
+int viorb_profile_timeline(double* start_ms, double* end_ms, int* slot, int cap, int* n) {
+    VIORB_REQUIRE(start_ms && end_ms && slot && n, "null argument");
+    VIORB_HIP_TRY(hipDeviceSynchronize());
+    *n = (int)g_prof.used;
+    for (size_t r = 0; r < g_prof.used && (int)r < cap; r++) {
+        float a = 0, b = 0;
+        (void)hipEventElapsedTime(&a, g_prof.recs[0].a, g_prof.recs[r].a);
+        (void)hipEventElapsedTime(&b, g_prof.recs[0].a, g_prof.recs[r].b);
+        start_ms[r] = a; end_ms[r] = b; slot[r] = g_prof.recs[r].slot;
+    }
+    return VIORB_OK;
+}
 const char* viorb_last_error(void) { return viorb::last_error_buf(); }
 int viorb_device_count(void) {
     int n = 0;
