@@ -46,7 +46,7 @@ struct Profiler {
 } g_prof;
 }
 ProfScope::ProfScope(const char* name, hipStream_t s) : idx(-1), st(s) {
-    if (!g_prof.enabled) return;
+    if (!g_prof.enabled || !name) return;
     if (!g_prof.only.empty()) {                  // comma-separated list of kernel names
         const std::string key = "," + g_prof.only + ",", me = std::string(",") + name + ",";
         if (key.find(me) == std::string::npos) return;
@@ -64,6 +64,7 @@ ProfScope::ProfScope(const char* name, hipStream_t s) : idx(-1), st(s) {
     g_prof.recs[idx].slot = slot;
     (void)hipEventRecord(g_prof.recs[idx].a, st);
 }
+bool prof_times_everything() { return g_prof.only.empty(); }
 ProfScope::~ProfScope() { if (idx >= 0) (void)hipEventRecord(g_prof.recs[idx].b, st); }
 
 hipError_t raise_dynamic_lds(const void* kernel, size_t bytes) {
@@ -1512,6 +1513,7 @@ struct viorb_extractor {
     viorb_keypoint* d_kps = nullptr;
     size_t stage_bytes = 0;
     hipStream_t own_stream = nullptr;
+    hipStream_t aux_stream = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;      // the blur's side stream (launch_all)
     hipStream_t last_stream = nullptr;
     int last_batch = 0;
     bool tables_uploaded = false;
@@ -1794,6 +1796,12 @@ static int configure(viorb_extractor* h, int w, int hgt) {
     return VIORB_OK;
 }
 
+// images per FAST launch (see launch_all)
+static int fast_launch_images(int batch) {
+    static const int nlaunch = getenv("VIORB_FAST_LAUNCHES") ? std::max(1, atoi(getenv("VIORB_FAST_LAUNCHES"))) : FAST_LAUNCHES;
+    return std::min(std::max(batch, 1), std::max(8, ((batch + nlaunch - 1) / nlaunch + 7) & ~7));
+}
+
 static int launch_all(viorb_extractor* h, const uint8_t* d_images, int batch, int stride, size_t pitch, hipStream_t st) {
     const int nl = h->p.nlevels;
     const int ncells = (int)h->cells.size();
@@ -1848,7 +1856,6 @@ static int launch_all(viorb_extractor* h, const uint8_t* d_images, int batch, in
     }
     {
         const size_t lds = (size_t)h->fast_tile_pitch * h->fast_tile_rows + h->fast_score_bytes + (size_t)h->fast_list_cap * 4;
-        ProfScope ps("k_fast_cells", st);
         // FAST goes out as FAST_LAUNCHES launches over sub-ranges of the batch (multiples of 8 images). A launch boundary is the only point
         // where the tracking stream's large workgroups (a search: 16 waves + 73 KB of LDS; the pose solver: 240 registers per lane) can be
         // placed on a CU: while this kernel still has workgroups to hand out, every slot that frees goes to its next single-wave
@@ -1856,15 +1863,37 @@ static int launch_all(viorb_extractor* h, const uint8_t* d_images, int batch, in
         // microseconds, so a sub-launch drains at once and the cost is a few launch gaps that the other stream fills: 118 k -> 139 k
         // frames/s at 256 streams (4 launches: 129 k, 16: 134 k, 32: 121 k). Splitting the quadtree, blur or descriptor kernels the same
         // way loses (their workgroups live long, every boundary is a tail).
-        static const int nlaunch = getenv("VIORB_FAST_LAUNCHES") ? std::max(1, atoi(getenv("VIORB_FAST_LAUNCHES"))) : FAST_LAUNCHES;
-        const int step = std::max(8, ((batch + nlaunch - 1) / nlaunch + 7) & ~7);
+        const int step = fast_launch_images(batch);
         for (int i0 = 0; i0 < batch; i0 += step) {
+            ProfScope ps(i0 == 0 || prof_times_everything() ? "k_fast_cells" : nullptr, st);   // with a kernel selection the profiler times the first sub-launch only (an event pair costs ~8 us of stream time)
             const XcdPlace PL = make_place((ncells + FAST_CELLS_PER_WAVE - 1) / FAST_CELLS_PER_WAVE, batch, i0, std::min(batch, i0 + step));
             hipLaunchKernelGGL(k_fast_cells, dim3(place_blocks(PL)), dim3(64), lds, st, h->d_planes, h->frame_bytes, h->d_lv, h->d_cells,
                                h->p.ini_th_fast, h->p.min_th_fast, h->d_slots, h->slot_cap, h->d_cell_cnt, ncells,
                                h->fast_tile_pitch, h->fast_tile_rows, h->fast_score_bytes, h->fast_list_cap, PL);
         }
     }
+    // The blur only needs the pyramid, the quadtree only FAST: from here they run side by side, the blur on the handle's second stream.
+    // The quadtree is one wavefront per (image, level) walking LDS lists — latency, 4 workgroups per CU by LDS, almost no vector issue —
+    // and the streaming blur is pure vector issue without LDS, so the pair costs little more than the longer of the two.
+    static const bool fork_blur = !(getenv("VIORB_BLUR_FORK") && atoi(getenv("VIORB_BLUR_FORK")) == 0);
+    hipStream_t bst = st;
+    if (fork_blur && batch >= 16) {
+        if (!h->aux_stream) {
+            VIORB_HIP_TRY(hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking));
+            VIORB_HIP_TRY(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+            VIORB_HIP_TRY(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+        }
+        bst = h->aux_stream;
+        VIORB_HIP_TRY(hipEventRecord(h->ev_fork, st));
+        VIORB_HIP_TRY(hipStreamWaitEvent(bst, h->ev_fork, 0));
+    }
+    {
+        ProfScope ps("k_blur", bst);
+        const XcdPlace PL = make_place((int)h->blur_tiles.size(), batch);
+        hipLaunchKernelGGL(k_blur, dim3(place_blocks(PL)), dim3(64), 0, bst, h->d_planes, h->d_blur, h->frame_bytes,
+                           h->d_lv, h->d_blur_tiles, PL);
+    }
+    if (bst != st) VIORB_HIP_TRY(hipEventRecord(h->ev_join, bst));
     {
         // common case first: <= OCT_NCAP_SMALL candidates per level fit a ~35 KB footprint (4 single-wave workgroups per CU);
         // the second launch covers the rest with the full capacity (its workgroups return at once when they have no work)
@@ -1883,13 +1912,7 @@ static int launch_all(viorb_extractor* h, const uint8_t* d_images, int batch, in
                                h->oct_nodecap, h->oct_sortcap, small, 0x7fffffff);
         }
     }
-    {
-        // (running the blur on a second stream beside FAST + quadtree was measured: no gain, the kernels contend for the same CUs)
-        ProfScope ps("k_blur", st);
-        const XcdPlace PL = make_place((int)h->blur_tiles.size(), batch);
-        hipLaunchKernelGGL(k_blur, dim3(place_blocks(PL)), dim3(64), 0, st, h->d_planes, h->d_blur, h->frame_bytes,
-                           h->d_lv, h->d_blur_tiles, PL);
-    }
+    if (bst != st) VIORB_HIP_TRY(hipStreamWaitEvent(st, h->ev_join, 0));
     {
         ProfScope ps("k_orient_describe", st);
         const XcdPlace PL = make_place((h->out_cap + 3) / 4, batch);
@@ -1998,6 +2021,9 @@ int viorb_extractor_destroy(viorb_extractor* h) {
     if (!h) return VIORB_OK;
     if (h->d_planes) { (void)hipSetDevice(h->device); free_device(h); }
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+    if (h->aux_stream) (void)hipStreamDestroy(h->aux_stream);
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     delete h;
     return VIORB_OK;
 }
@@ -2014,6 +2040,8 @@ int viorb_extractor_tables(const viorb_extractor* h, float* scale, float* inv_sc
     }
     return VIORB_OK;
 }
+
+int viorb_extractor_fast_launch_images(int batch) { return fast_launch_images(batch); }
 
 int viorb_extractor_max_keypoints(const viorb_extractor* h, int* cap) {
     VIORB_REQUIRE(h && cap, "null handle/cap");

@@ -19,6 +19,7 @@ struct ProfScope {
     ProfScope(const char* name, hipStream_t s);
     ~ProfScope();
 };
+bool prof_times_everything();          // no kernel selection (viorb_profile_select(NULL)): every launch is timed
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is a process-wide, per-kernel setting: every handle asks for its own size, so the limit is
 // only ever raised (a later, smaller handle must not lower it under a long-lived one's launches).
