@@ -237,7 +237,9 @@ def run_tracking(args, cfg, rank, dev_index, dev, world):
             bpl = AB["k_fast_cells"] * per_launch
             tr_b = None
             if traffic and traffic.get("config") == args.config and "k_fast_cells" in traffic.get("bytes_per_launch", {}):
-                tr_b = int(traffic["bytes_per_launch"]["k_fast_cells"] * per_launch / traffic["units_per_launch"])
+                upl = traffic["units_per_launch"]
+                upl = upl["k_fast_cells"] if isinstance(upl, dict) else upl
+                tr_b = int(traffic["bytes_per_launch"]["k_fast_cells"] * per_launch / upl)
             roof = {"bound": "hbm", "kernel": "k_fast_cells", "achieved": round(bpl / avg_s / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(bpl / avg_s / 1e9 / HBM_PEAK_GBS, 5), "traffic": tr_b, "avg_launch_us": round(avg_s * 1e6, 2),
                     "algorithmic_bytes_per_launch": int(bpl),
