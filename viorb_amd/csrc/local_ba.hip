@@ -37,6 +37,7 @@ struct BaDev {
     const double *e_obs;            // [NE][3] u v invSigma2
     uint8_t* level;                 // [NE]
     double *err, *Jp, *Jk, *wgt;    // [NE][2], [NE][6], [NE][12], [NE]
+    double *We;                     // [NE][6][3] = wgt * Jk^T Jp, the edge's block of W (block_solver.hpp's Hpl), written with the linearisation
     const int *pt_start;            // [NP+1]
     const int *kf_start, *kf_list;  // CSR of the edges of each local key frame
     double *Hll, *bl, *Dinv, *db;   // [NP][9], [NP][3], [NP][9], [NP][3] = Dinv bl
@@ -137,6 +138,10 @@ __device__ __forceinline__ void k_ba_lin_points_body(const BaDev& D, int mono_ke
         D.wgt[k] = w;
         for (int a = 0; a < 6; a++) D.Jp[6 * k + a] = Jp[a];
         for (int a = 0; a < 12; a++) D.Jk[12 * k + a] = Jk[a];
+#pragma unroll
+        for (int r = 0; r < 6; r++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) D.We[18 * (size_t)k + 3 * r + c] = w * (Jk[r] * Jp[c] + Jk[6 + r] * Jp[3 + c]);
         H[0] += w * (Jp[0] * Jp[0] + Jp[3] * Jp[3]); H[1] += w * (Jp[0] * Jp[1] + Jp[3] * Jp[4]); H[2] += w * (Jp[0] * Jp[2] + Jp[3] * Jp[5]);
         H[3] += w * (Jp[1] * Jp[1] + Jp[4] * Jp[4]); H[4] += w * (Jp[1] * Jp[2] + Jp[4] * Jp[5]); H[5] += w * (Jp[2] * Jp[2] + Jp[5] * Jp[5]);
         for (int a = 0; a < 3; a++) b[a] -= w * (Jp[a] * e0 + Jp[3 + a] * e1);
@@ -269,41 +274,42 @@ __device__ __forceinline__ void k_ba_dinv_body(const BaDev& D, double lambda_arg
     const double b0 = D.bl[3 * p], b1 = D.bl[3 * p + 1], b2 = D.bl[3 * p + 2];
     D.db[3 * p] = i00 * b0 + i01 * b1 + i02 * b2; D.db[3 * p + 1] = i01 * b0 + i11 * b1 + i12 * b2; D.db[3 * p + 2] = i02 * b0 + i12 * b1 + i22 * b2;
 }
-// Schur complement of the point block (block_solver.hpp:381-432): one workgroup per local key frame a accumulates the block row
+// Schur complement of the point block (block_solver.hpp:381-432): the workgroups (a, part) of local key frame a accumulate the block row
 // [a][0..a] of -sum_p W_pa Dinv_p W_pb^T (6 x 12(a+1) values; the Cholesky never reads above the diagonal) and -W_pa Dinv_p bl_p in
-// LDS with ds_add_f64, walking a's observations and, for each, the other observations of that point; the row is then added to S
-// and bs without global atomics (rows of key frame a belong to this workgroup alone).
-__device__ __forceinline__ void k_ba_schur_body(const BaDev& D) {
+// LDS with ds_add_f64, each walking every nparts-th observation of a and, for each, the other observations of that point; the partial
+// row is then added to S and bs (plain adds with one part, global_atomic_add_f64 with several). W_e = wgt Jk^T Jp comes precomputed with
+// the linearisation (D.We): a trial only changes Dinv. One window alone spreads a key frame over BA_SCHUR_PARTS workgroups — with one
+// per key frame the kernel was 20 workgroups of dependent global loads (102 us of a 365 us trial); a batch has workgroups enough.
+#define BA_SCHUR_PARTS 8
+__device__ __forceinline__ void k_ba_schur_body(const BaDev& D, int ka, int part, int nparts) {
     if (ba_skip(D)) return;
     __shared__ double s_row[6][240], s_b[6];
-    const int ka = blockIdx.x, t = threadIdx.x, ld = D.ld, rows = D.rows, pd = D.pose_dim, ncol = pd * (ka + 1);
+    const int t = threadIdx.x, ld = D.ld, pd = D.pose_dim, ncol = pd * (ka + 1);
     for (int q = t; q < 6 * 240; q += blockDim.x) (&s_row[0][0])[q] = 0.0;
     if (t < 6) s_b[t] = 0.0;
     __syncthreads();
-    for (int q = D.kf_start[ka] + t; q < D.kf_start[ka + 1]; q += blockDim.x) {
+    for (int q = D.kf_start[ka] + part * (int)blockDim.x + t; q < D.kf_start[ka + 1]; q += nparts * (int)blockDim.x) {
         const int ea = D.kf_list[q];
         if (D.level[ea] != 0) continue;
         const int p = D.e_pt[ea];
+        const int eb0 = D.pt_start[p], eb1 = D.pt_start[p + 1];
         const double* Di = D.Dinv + (size_t)p * 9;
-        const double* Ja = D.Jk + (size_t)6 * rows * ea; const double* Pa = D.Jp + (size_t)3 * rows * ea; const double wa = D.wgt[ea];
+        const double* Wa = D.We + (size_t)18 * ea;
+        const double db0 = D.db[3 * p], db1 = D.db[3 * p + 1], db2 = D.db[3 * p + 2];
         double BD[18];
 #pragma unroll
         for (int r = 0; r < 6; r++) {
-            double w0 = 0, w1 = 0, w2 = 0;
-            for (int row = 0; row < rows; row++) { const double j = Ja[6 * row + r]; w0 += j * Pa[3 * row]; w1 += j * Pa[3 * row + 1]; w2 += j * Pa[3 * row + 2]; }
-            w0 *= wa; w1 *= wa; w2 *= wa;
+            const double w0 = Wa[3 * r], w1 = Wa[3 * r + 1], w2 = Wa[3 * r + 2];
             BD[r * 3] = w0 * Di[0] + w1 * Di[1] + w2 * Di[2]; BD[r * 3 + 1] = w0 * Di[3] + w1 * Di[4] + w2 * Di[5]; BD[r * 3 + 2] = w0 * Di[6] + w1 * Di[7] + w2 * Di[8];
-            atomicAdd(&s_b[r], -(w0 * D.db[3 * p] + w1 * D.db[3 * p + 1] + w2 * D.db[3 * p + 2]));
+            atomicAdd(&s_b[r], -(w0 * db0 + w1 * db1 + w2 * db2));
         }
-        for (int eb = D.pt_start[p]; eb < D.pt_start[p + 1]; eb++) {
+        for (int eb = eb0; eb < eb1; eb++) {
             const int kb = D.e_kf[eb];
-            if (D.level[eb] != 0 || kb > ka) continue;                   // kb > ka: the transposed block, accumulated by key frame kb's workgroup
-            const double* Jb = D.Jk + (size_t)6 * rows * eb; const double* Pb = D.Jp + (size_t)3 * rows * eb; const double wb = D.wgt[eb];
+            if (D.level[eb] != 0 || kb > ka) continue;                   // kb > ka: the transposed block, accumulated by key frame kb's workgroups
+            const double* Wb = D.We + (size_t)18 * eb;
 #pragma unroll
             for (int cc = 0; cc < 6; cc++) {
-                double w0 = 0, w1 = 0, w2 = 0;
-                for (int row = 0; row < rows; row++) { const double j = Jb[6 * row + cc]; w0 += j * Pb[3 * row]; w1 += j * Pb[3 * row + 1]; w2 += j * Pb[3 * row + 2]; }
-                w0 *= wb; w1 *= wb; w2 *= wb;
+                const double w0 = Wb[3 * cc], w1 = Wb[3 * cc + 1], w2 = Wb[3 * cc + 2];
                 const int col = pd * kb + ba_loc(D, cc);
 #pragma unroll
                 for (int r = 0; r < 6; r++) atomicAdd(&s_row[r][col], -(BD[r * 3] * w0 + BD[r * 3 + 1] * w1 + BD[r * 3 + 2] * w2));
@@ -313,9 +319,15 @@ __device__ __forceinline__ void k_ba_schur_body(const BaDev& D) {
     __syncthreads();
     for (int q = t; q < 6 * ncol; q += blockDim.x) {
         const int r = q / ncol, c = q - r * ncol, row = pd * ka + ba_loc(D, r);
-        if (c <= row) D.S[(size_t)row * ld + c] += s_row[r][c];
+        if (c <= row) {
+            if (nparts == 1) D.S[(size_t)row * ld + c] += s_row[r][c];
+            else if (s_row[r][c] != 0.0) unsafeAtomicAdd(&D.S[(size_t)row * ld + c], s_row[r][c]);
+        }
     }
-    if (t < 6) D.bs[pd * ka + ba_loc(D, t)] += s_b[t];
+    if (t < 6) {
+        if (nparts == 1) D.bs[pd * ka + ba_loc(D, t)] += s_b[t];
+        else unsafeAtomicAdd(&D.bs[pd * ka + ba_loc(D, t)], s_b[t]);
+    }
 }
 
 // Dense Cholesky solve S xp = bs of the reduced system by ONE 1024-thread workgroup, blocked by 16 (n <= 240, padded to ld):
@@ -344,8 +356,16 @@ __device__ __forceinline__ double ba_rsqrt(double d) {
     y = fma(0.5 * y, fma(-(d * y), y, 1.0), y);
     return y;
 }
+#ifdef VIORB_CHOL_TIMING
+#define CT_LAP(i) do { __syncthreads(); if (threadIdx.x == 0) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); ct_[i] += now_ - ct_last; ct_last = now_; } } while (0)
+#else
+#define CT_LAP(i) do { } while (0)
+#endif
 __device__ __forceinline__ void k_ba_chol_solve_body(const BaDev& D) {
     if (ba_skip(D)) return;
+#ifdef VIORB_CHOL_TIMING
+    unsigned long long ct_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ct_last = __builtin_amdgcn_s_memtime();
+#endif
     __shared__ double s_L[16][17], s_P[256][17], s_y[256], s_rd[16];
     __shared__ int s_ok;
     const int n = D.np, ld = D.ld, nb = ld >> 4, t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -382,6 +402,7 @@ __device__ __forceinline__ void k_ba_chol_solve_body(const BaDev& D) {
     }
     for (int q = t; q < 15 * ld; q += blockDim.x) A[(size_t)ld * ld + ld + q] = 0.0;       // rows 1..15 of the rhs block row (never read back, kept defined)
     __syncthreads();
+    CT_LAP(0);
     for (int kb = 0; kb < nb; kb++) {
         const int k0 = kb << 4;
         // (0) the owners publish block column kb: the diagonal tile to s_L, the tiles below it to s_P
@@ -398,6 +419,7 @@ __device__ __forceinline__ void k_ba_chol_solve_body(const BaDev& D) {
             }
         }
         __syncthreads();
+        CT_LAP(1);
         if (wv == 0) {                                           // (1) diagonal block: row (lane & 15) of it in registers, pivots and
             const int li = lane & 15;                            //     multipliers by v_readlane, 1/sqrt by rsq + two Newton steps
             double a[16];
@@ -426,6 +448,7 @@ __device__ __forceinline__ void k_ba_chol_solve_body(const BaDev& D) {
             }
         }
         __syncthreads();
+        CT_LAP(2);
         const int below = rows - k0 - 16;                        // rows under the diagonal block (the rhs block row included)
         if (t < below) {                                         // (2) panel: row r of L21 = A21 L11^-T
             const int r = k0 + 16 + t;
@@ -455,6 +478,7 @@ __device__ __forceinline__ void k_ba_chol_solve_body(const BaDev& D) {
             for (int i = 0; i < 16; i++) inv[(size_t)kb * 256 + i * 16 + c] = x[i];
         }
         __syncthreads();
+        CT_LAP(3);
         // (3) trailing update of the owned tiles right of block column kb (the rhs row's tiles included), v_mfma_f64_16x16x4
 #pragma unroll
         for (int u = 0; u < BA_MAX_TILES_PER_WAVE; u++) {
@@ -465,6 +489,7 @@ __device__ __forceinline__ void k_ba_chol_solve_body(const BaDev& D) {
                 acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(-s_P[Io][4 * kc + (lane >> 4)], s_P[Jo][4 * kc + (lane >> 4)], acc[u], 0, 0, 0);
         }
         __syncthreads();                                         // s_P / s_L are rewritten by the next block column
+        CT_LAP(4);
     }
     // y = L^-1 bs now sits in the rhs row; backward substitution L^T x = y, 16 unknowns at a time
     for (int i = t; i < ld; i += blockDim.x) s_y[i] = A[(size_t)ld * ld + i];
@@ -487,7 +512,11 @@ __device__ __forceinline__ void k_ba_chol_solve_body(const BaDev& D) {
         }
         __syncthreads();
     }
+    CT_LAP(5);
     for (int i = t; i < n; i += blockDim.x) D.xp[i] = s_ok ? s_y[i] : 0.0;
+#ifdef VIORB_CHOL_TIMING
+    if (t == 0 && blockIdx.x == 0) printf("chol cycles: load %llu publish %llu diag %llu panel %llu trailing %llu backward %llu\n", ct_[0], ct_[1], ct_[2], ct_[3], ct_[4], ct_[5]);
+#endif
     if (t == 0) { D.scal[2] = s_ok ? 1.0 : 0.0; D.scal[1] = 0.0; D.scal[0] = 0.0; }      // [1], [0]: accumulators of k_ba_backsub and k_ba_*_errors, which follow
 }
 
@@ -496,19 +525,18 @@ __device__ __forceinline__ void k_ba_backsub_body(const BaDev& D, double lambda_
     if (ba_skip(D)) return;
     const double lambda = ba_lambda(D, lambda_arg);
     __shared__ double s_red[4];
-    const int p = blockIdx.x * blockDim.x + threadIdx.x, rows = D.rows;
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
     double sc = 0;
     if (p < D.NP) {
         double c0 = D.bl[3 * p], c1 = D.bl[3 * p + 1], c2 = D.bl[3 * p + 2];
         for (int k = D.pt_start[p]; k < D.pt_start[p + 1]; k++) {
             if (D.level[k] != 0 || D.e_kf[k] >= D.W) continue;
-            const double* J = D.Jk + (size_t)6 * rows * k; const double* Pp = D.Jp + (size_t)3 * rows * k; const double w = D.wgt[k];
+            const double* Wk = D.We + (size_t)18 * k;
             const int ba = D.pose_dim * D.e_kf[k];
+#pragma unroll
             for (int r = 0; r < 6; r++) {
                 const double x = D.xp[ba + ba_loc(D, r)];
-                double w0 = 0, w1 = 0, w2 = 0;
-                for (int row = 0; row < rows; row++) { const double j = J[6 * row + r]; w0 += j * Pp[3 * row]; w1 += j * Pp[3 * row + 1]; w2 += j * Pp[3 * row + 2]; }
-                c0 -= w * w0 * x; c1 -= w * w1 * x; c2 -= w * w2 * x;
+                c0 -= Wk[3 * r] * x; c1 -= Wk[3 * r + 1] * x; c2 -= Wk[3 * r + 2] * x;
             }
         }
         const double* Di = D.Dinv + (size_t)p * 9;
@@ -608,7 +636,7 @@ __global__ __launch_bounds__(256) void k_ba_imu(BaDev D) { k_ba_imu_body(D); }
 __global__ void k_ba_init_reduced(BaDev D, double lambda_arg) { k_ba_init_reduced_body(D, lambda_arg); }
 __global__ void k_ba_max_diag(BaDev D) { k_ba_max_diag_body(D); }
 __global__ void k_ba_dinv(BaDev D, double lambda_arg) { k_ba_dinv_body(D, lambda_arg); }
-__global__ __launch_bounds__(256) void k_ba_schur(BaDev D) { k_ba_schur_body(D); }
+__global__ __launch_bounds__(256) void k_ba_schur(BaDev D) { k_ba_schur_body(D, blockIdx.x / BA_SCHUR_PARTS, blockIdx.x % BA_SCHUR_PARTS, BA_SCHUR_PARTS); }
 __global__ __launch_bounds__(BA_CHOL_THREADS) void k_ba_chol_solve(BaDev D) { k_ba_chol_solve_body(D); }
 __global__ void k_ba_backsub(BaDev D, double lambda_arg) { k_ba_backsub_body(D, lambda_arg); }
 __global__ void k_ba_update(BaDev D) { k_ba_update_body(D); }
@@ -659,7 +687,7 @@ __global__ void k_bab_lambda0(const BaDev* __restrict__ Dv, int nwin) {
 }
 __global__ void k_bab_init_reduced(const BaDev* __restrict__ Dv) { BA_B_WINDOW(); k_ba_init_reduced_body(D, 0.0); }
 __global__ void k_bab_dinv(const BaDev* __restrict__ Dv) { BA_B_WINDOW(); k_ba_dinv_body(D, 0.0); }
-__global__ __launch_bounds__(256) void k_bab_schur(const BaDev* __restrict__ Dv) { BA_B_WINDOW(); if ((int)blockIdx.x >= D.W) return; k_ba_schur_body(D); }
+__global__ __launch_bounds__(256) void k_bab_schur(const BaDev* __restrict__ Dv) { BA_B_WINDOW(); if ((int)blockIdx.x >= D.W) return; k_ba_schur_body(D, blockIdx.x, 0, 1); }
 __global__ __launch_bounds__(BA_CHOL_THREADS) void k_bab_chol_solve(const BaDev* __restrict__ Dv) { BA_B_WINDOW(); k_ba_chol_solve_body(D); }
 __global__ void k_bab_backsub(const BaDev* __restrict__ Dv) { BA_B_WINDOW(); k_ba_backsub_body(D, 0.0); }
 __global__ void k_bab_update(const BaDev* __restrict__ Dv) { BA_B_WINDOW(); k_ba_update_body(D); }
@@ -791,6 +819,10 @@ __global__ void k_ba_se3_lin_points(BaDev D, int kernels) {
         D.wgt[k] = w;
         for (int a = 0; a < 9; a++) D.Jp[9 * (size_t)k + a] = Jp[a];
         for (int a = 0; a < 18; a++) D.Jk[18 * (size_t)k + a] = Jk[a];
+#pragma unroll
+        for (int r = 0; r < 6; r++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) D.We[18 * (size_t)k + 3 * r + c] = w * (Jk[r] * Jp[c] + Jk[6 + r] * Jp[3 + c] + Jk[12 + r] * Jp[6 + c]);
         H[0] += w * (Jp[0] * Jp[0] + Jp[3] * Jp[3] + Jp[6] * Jp[6]); H[1] += w * (Jp[0] * Jp[1] + Jp[3] * Jp[4] + Jp[6] * Jp[7]); H[2] += w * (Jp[0] * Jp[2] + Jp[3] * Jp[5] + Jp[6] * Jp[8]);
         H[3] += w * (Jp[1] * Jp[1] + Jp[4] * Jp[4] + Jp[7] * Jp[7]); H[4] += w * (Jp[1] * Jp[2] + Jp[4] * Jp[5] + Jp[7] * Jp[8]); H[5] += w * (Jp[2] * Jp[2] + Jp[5] * Jp[5] + Jp[8] * Jp[8]);
         for (int a = 0; a < 3; a++) b[a] -= w * (Jp[a] * e0 + Jp[3 + a] * e1 + Jp[6 + a] * e2);
@@ -992,7 +1024,7 @@ struct BaSolve {
                     }
                     hipLaunchKernelGGL(k_ba_init_reduced, dim3((unsigned)((nl2 + TB - 1) / TB)), dim3(TB), 0, st, D, 0.0);
                     hipLaunchKernelGGL(k_ba_dinv, dim3(gP), dim3(TB), 0, st, D, 0.0);
-                    hipLaunchKernelGGL(k_ba_schur, dim3(n_local), dim3(256), 0, st, D);
+                    hipLaunchKernelGGL(k_ba_schur, dim3(n_local * BA_SCHUR_PARTS), dim3(256), 0, st, D);
                     hipLaunchKernelGGL(k_ba_chol_solve, dim3(1), dim3(BA_CHOL_THREADS), 0, st, D);
                     hipLaunchKernelGGL(k_ba_backsub, dim3(gP), dim3(TB), 0, st, D, 0.0);
                     if (model == 0) hipLaunchKernelGGL(k_ba_update, dim3(std::max(gP, 1)), dim3(TB), 0, st, D);
@@ -1047,7 +1079,7 @@ struct BaSolve {
             case ST_TRIAL_ENQ:
                 hipLaunchKernelGGL(k_ba_init_reduced, dim3((unsigned)((nl2 + TB - 1) / TB)), dim3(TB), 0, st, D, lambda);
                 hipLaunchKernelGGL(k_ba_dinv, dim3(gP), dim3(TB), 0, st, D, lambda);
-                hipLaunchKernelGGL(k_ba_schur, dim3(n_local), dim3(256), 0, st, D);
+                hipLaunchKernelGGL(k_ba_schur, dim3(n_local * BA_SCHUR_PARTS), dim3(256), 0, st, D);
                 hipLaunchKernelGGL(k_ba_chol_solve, dim3(1), dim3(BA_CHOL_THREADS), 0, st, D);
                 hipLaunchKernelGGL(k_ba_backsub, dim3(gP), dim3(TB), 0, st, D, lambda);
                 if (model == 0) hipLaunchKernelGGL(k_ba_update, dim3(std::max(gP, 1)), dim3(TB), 0, st, D);
@@ -1158,7 +1190,7 @@ static int ba_prepare_navstate(BaSolve& S, const double* kfs, int nk, int n_loca
     const size_t n2 = (size_t)D.np * D.np, nl2 = (size_t)D.ld * D.ld;
     bool ok = B.alloc(&D.kf, (size_t)nk * 22, kfs) && B.alloc(&D.kf_bak, (size_t)nk * 22) && B.alloc(&D.pt, (size_t)npts * 3, points) && B.alloc(&D.pt_bak, (size_t)npts * 3) &&
               B.alloc(&d_ept, ne, e_pt.data()) && B.alloc(&d_ekf, ne, e_kf.data()) && B.alloc(&d_obs, (size_t)ne * 3, edge_obs) && B.alloc(&D.level, ne) &&
-              B.alloc(&D.err, (size_t)ne * 2) && B.alloc(&D.Jp, (size_t)ne * 6) && B.alloc(&D.Jk, (size_t)ne * 12) && B.alloc(&D.wgt, ne) &&
+              B.alloc(&D.err, (size_t)ne * 2) && B.alloc(&D.Jp, (size_t)ne * 6) && B.alloc(&D.Jk, (size_t)ne * 12) && B.alloc(&D.wgt, ne) && B.alloc(&D.We, (size_t)ne * 18) &&
               B.alloc(&d_pts, npts + 1, pt_start.data()) && B.alloc(&d_kfs, n_local + 1, kf_start.data()) && B.alloc(&d_kfl, kf_list.size(), kf_list.data()) &&
               B.alloc(&D.Hll, (size_t)npts * 9) && B.alloc(&D.bl, (size_t)npts * 3) && B.alloc(&D.Dinv, (size_t)npts * 9) &&
               B.alloc(&D.Hpp, n2) && B.alloc(&D.bp, D.np) && B.alloc(&D.S, nl2 + (size_t)16 * D.ld + (size_t)(D.ld / 16) * 256) && B.alloc(&D.bs, D.ld) && B.alloc(&D.xp, D.ld) && B.alloc(&D.db, (size_t)npts * 3) && B.alloc(&D.xl, (size_t)npts * 3) &&
@@ -1387,7 +1419,7 @@ static int ba_prepare_se3(BaSolve& S, const double* kfs, int nk, int n_local, co
     D.preint = nullptr; D.info_pvr = nullptr; D.e_pvr = nullptr; D.e_b = nullptr;
     bool ok = B.alloc(&D.kf, (size_t)nk * 7, kfs) && B.alloc(&D.kf_bak, (size_t)nk * 7) && B.alloc(&D.pt, (size_t)npts * 3, points) && B.alloc(&D.pt_bak, (size_t)npts * 3) &&
               B.alloc(&d_ept, ne, e_pt.data()) && B.alloc(&d_ekf, ne, e_kf.data()) && B.alloc(&d_obs, (size_t)ne * 4, edge_obs) && B.alloc(&D.level, ne) &&
-              B.alloc(&D.err, (size_t)ne * 3) && B.alloc(&D.Jp, (size_t)ne * 9) && B.alloc(&D.Jk, (size_t)ne * 18) && B.alloc(&D.wgt, ne) &&
+              B.alloc(&D.err, (size_t)ne * 3) && B.alloc(&D.Jp, (size_t)ne * 9) && B.alloc(&D.Jk, (size_t)ne * 18) && B.alloc(&D.wgt, ne) && B.alloc(&D.We, (size_t)ne * 18) &&
               B.alloc(&d_pts, npts + 1, pt_start.data()) && B.alloc(&d_kfs, n_local + 1, kf_start.data()) && B.alloc(&d_kfl, kf_list.size(), kf_list.data()) &&
               B.alloc(&D.Hll, (size_t)npts * 9) && B.alloc(&D.bl, (size_t)npts * 3) && B.alloc(&D.Dinv, (size_t)npts * 9) &&
               B.alloc(&D.Hpp, n2) && B.alloc(&D.bp, D.np) && B.alloc(&D.S, nl2 + (size_t)16 * D.ld + (size_t)(D.ld / 16) * 256) && B.alloc(&D.bs, D.ld) && B.alloc(&D.xp, D.ld) &&
