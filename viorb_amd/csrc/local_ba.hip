@@ -340,9 +340,10 @@ __device__ __forceinline__ void k_ba_schur_body(const BaDev& D, int ka, int part
 // per block. The matrix stays in L2; the panel is staged in LDS. scal[2] = 1 on success; a pivot that is not positive and finite
 // fails the solve like the reference's LLT (linear_solver_eigen.h / Eigen info()).
 typedef double v4d __attribute__((ext_vector_type(4)));
-#define BA_CHOL_THREADS 512                  // 8 waves: 17 register tiles (136 registers) per wave leave room for the panel solve's row
+#define BA_CHOL_THREADS 512                  // 8 waves: 7 tile owners + the factor wave
 #define BA_CHOL_WAVES (BA_CHOL_THREADS / 64)
-#define BA_MAX_TILES_PER_WAVE 17             // ceil((15 * 16 / 2 + 15) / 8) register tiles per wave at ld = 240 (the lower block triangle + the rhs block row)
+#define BA_CHOL_OWNERS (BA_CHOL_WAVES - 1)
+#define BA_MAX_TILES_PER_WAVE 18             // ceil((15 * 16 / 2) / 7) register tiles (144 registers) per owner wave at ld = 240 (the lower block triangle; the right-hand side lives in LDS)
 // lane broadcast of a double and a full-precision reciprocal square root (hardware estimate + two Newton steps) for the factorisation's
 // diagonal blocks
 __device__ __forceinline__ double ba_readlane(double v, int l) {
@@ -357,143 +358,198 @@ __device__ __forceinline__ double ba_rsqrt(double d) {
     return y;
 }
 #ifdef VIORB_CHOL_TIMING
-#define CT_LAP(i) do { __syncthreads(); if (threadIdx.x == 0) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); ct_[i] += now_ - ct_last; ct_last = now_; } } while (0)
+#define CT_LAP(i) do { if ((threadIdx.x & 63) == 0) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); ct_[i] += now_ - ct_last; ct_last = now_; } } while (0)     /* per wave, no barrier of its own */
 #else
 #define CT_LAP(i) do { } while (0)
 #endif
-__device__ __forceinline__ void k_ba_chol_solve_body(const BaDev& D) {
+// dynamic LDS of the Cholesky kernels: two panel buffers [256][17], the inverted diagonal block, the next diagonal tile, y
+#define BA_CHOL_LDS_BYTES ((2 * 256 * 17 + 2 * 16 * 17 + 256) * sizeof(double))
+__device__ __forceinline__ void k_ba_chol_solve_body(const BaDev& D, double* s_dyn) {
     if (ba_skip(D)) return;
 #ifdef VIORB_CHOL_TIMING
     unsigned long long ct_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ct_last = __builtin_amdgcn_s_memtime();
 #endif
-    __shared__ double s_L[16][17], s_P[256][17], s_y[256], s_rd[16];
+    typedef double row17[17];
+    row17* s_P0 = reinterpret_cast<row17*>(s_dyn);               // [256][17] panel of an even block column
+    row17* s_P1 = s_P0 + 256;                                    // ... of an odd one
+    row17* s_L = s_P1 + 256;                                     // [16][17] L11^-1 of the current block column
+    row17* s_D = s_L + 16;                                       // [16][17] the next diagonal tile, as published
+    double* s_y = reinterpret_cast<double*>(s_D + 16);           // [256]
     __shared__ int s_ok;
     const int n = D.np, ld = D.ld, nb = ld >> 4, t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);
     const int rows = ld + 16;                                    // + the block row that carries bs^T in its first row
     double* A = D.S;
     double* inv = A + (size_t)rows * ld;                         // [nb][16][16] inverted diagonal blocks
     if (t == 0) s_ok = 1;
-    // The lower block triangle (and the rhs block row) lives in REGISTERS for the whole factorisation: tile idx = wv + 16 u of the
-    // row-major enumeration (I, J <= min(I, nb - 1)), I = nb being the rhs row, belongs to slot u of wave wv, 4 doubles per lane in the
-    // MFMA accumulator layout (row = lane / 16 + 4 reg, col = lane % 16). Per block column kb the owners hand the diagonal tile and the
-    // panel tiles to LDS, one wave factors the diagonal tile, a thread per row solves the panel, and every wave applies the rank-16 update
-    // to the tiles it owns — no global-memory round trip inside the loop (round 1 re-read and re-wrote the trailing matrix in L2 for every
-    // panel: ~35 k cycles per panel where the arithmetic needs ~6 k). L and the solved rhs row are still written to global memory for the
-    // backward substitution.
-    v4d acc[BA_MAX_TILES_PER_WAVE]; int tI[BA_MAX_TILES_PER_WAVE], tJ[BA_MAX_TILES_PER_WAVE];
-    const int ntiles_all = nb * (nb + 1) / 2 + nb;
+    for (int i = t; i < 256; i += blockDim.x) s_y[i] = i < ld ? D.bs[i] : 0.0;             // the right-hand side; the forward substitution rides along with the panels
+    // Two roles. Waves 0 .. BA_CHOL_OWNERS-1 own the lower block triangle in REGISTERS for the whole factorisation:
+    // tile idx = wv + BA_CHOL_OWNERS u of the row-major enumeration (I, J <= I) is slot u of wave
+    // wv, 4 doubles per lane in the MFMA accumulator layout (row = lane / 16 + 4 reg, col = lane % 16). The last wave owns nothing and
+    // factors the diagonal blocks, ONE BLOCK COLUMN AHEAD of the owners. Per block column kb, three phases between barriers:
+    //   P   the owners multiply their panel tiles of column kb by L11^-T (v_mfma_f64_16x16x4; operands in LDS) -> L21, final;
+    //   3a  they apply panel kb's rank-16 update to their tiles of column kb + 1 FIRST and publish those to LDS (diagonal tile, next panel);
+    //   3b  they update the rest of the trailing matrix WHILE the factor wave turns the published diagonal tile into L11 and L11^-1.
+    // No global-memory round trip inside the loop; the factorisation of a diagonal block (a chain of 16 dependent 1/sqrt) hides behind
+    // the trailing update. The two roles run separate loops with the same barriers, so the factor wave's ~100 live registers (block row,
+    // inverse row, broadcasts) and the owners' 160 accumulator registers never have to fit one allocation. L and the solved rhs row are
+    // written to global memory for the backward substitution.
+    auto factor_block = [&](int kb) {
+        // lane li holds row li of the (symmetrised) block and row li of X = L11^-1, which grows with the factorisation (row j is scaled by
+        // 1 / l_jj, then eliminated from the rows below like column j itself). The dependent chain of a column step is pivot -> 1/sqrt
+        // (rsq + two Newton steps) -> s = a_ij / d -> 16 independent FMAs; the row broadcasts (v_readlane of row j's entries of the block
+        // and of X) do not depend on it. 8.2 k cycles per block including the inverse (an LDS round trip per broadcast row: 11.8 k).
+        const int li = lane & 15, k0 = kb << 4;
+        double a[16], x[16];
 #pragma unroll
-    for (int u = 0; u < BA_MAX_TILES_PER_WAVE; u++) {
-        const int idx = wv + BA_CHOL_WAVES * u;
-        tI[u] = -1; tJ[u] = -1;
-        acc[u] = (v4d){0.0, 0.0, 0.0, 0.0};
-        if (idx < ntiles_all) {
-            int I, J;
-            if (idx < nb * (nb + 1) / 2) { I = 0; int rem = idx; while (rem > I) { rem -= I + 1; I++; } J = rem; }
-            else { I = nb; J = idx - nb * (nb + 1) / 2; }
-            tI[u] = I; tJ[u] = J;
-            if (I < nb) {
+        for (int c = 0; c < 16; c++) { a[c] = c <= li ? s_D[li][c] : s_D[c][li]; x[c] = c == li ? 1.0 : 0.0; }
+        bool good = true;
 #pragma unroll
-                for (int r = 0; r < 4; r++) acc[u][r] = A[(size_t)(I * 16 + (lane >> 4) + 4 * r) * ld + J * 16 + (lane & 15)];
-            } else if ((lane >> 4) == 0) {
-                acc[u][0] = D.bs[J * 16 + (lane & 15)];                   // the rhs block row: bs^T in its first row, zeros below
+        for (int j = 0; j < 16; j++) {
+            const double d = ba_readlane(a[j], j);
+            double u[16], v[16];
+#pragma unroll
+            for (int k = j + 1; k < 16; k++) u[k] = ba_readlane(a[k], j);              // row j of the block = column j below the diagonal
+#pragma unroll
+            for (int c = 0; c <= j; c++) v[c] = ba_readlane(x[c], j);                   // row j of X before its scaling
+            const bool gj = (d > 0) && isfinite(d);
+            good = good && gj;
+            const double ri = ba_rsqrt(gj ? d : 1.0);
+            const double sj = a[j] * (ri * ri);                                         // l_ij / l_jj
+            a[j] = a[j] * ri;                                                           // l_ij (rows >= j; the rest never reaches a result)
+#pragma unroll
+            for (int k = j + 1; k < 16; k++) a[k] = fma(-sj, u[k], a[k]);
+            if (li == j) {
+#pragma unroll
+                for (int c = 0; c <= j; c++) x[c] *= ri;
+            } else if (li > j) {
+#pragma unroll
+                for (int c = 0; c <= j; c++) x[c] = fma(-sj, v[c], x[c]);
             }
         }
-    }
-    for (int q = t; q < 15 * ld; q += blockDim.x) A[(size_t)ld * ld + ld + q] = 0.0;       // rows 1..15 of the rhs block row (never read back, kept defined)
-    __syncthreads();
-    CT_LAP(0);
-    for (int kb = 0; kb < nb; kb++) {
-        const int k0 = kb << 4;
-        // (0) the owners publish block column kb: the diagonal tile to s_L, the tiles below it to s_P
-#pragma unroll
-        for (int u = 0; u < BA_MAX_TILES_PER_WAVE; u++) {
-            if (tJ[u] != kb) continue;
-            if (tI[u] == kb) {
-#pragma unroll
-                for (int r = 0; r < 4; r++) s_L[(lane >> 4) + 4 * r][lane & 15] = acc[u][r];
-            } else {
-                const int rb = (tI[u] - kb - 1) * 16;
-#pragma unroll
-                for (int r = 0; r < 4; r++) s_P[rb + (lane >> 4) + 4 * r][lane & 15] = acc[u][r];
-            }
-        }
-        __syncthreads();
-        CT_LAP(1);
-        if (wv == 0) {                                           // (1) diagonal block: row (lane & 15) of it in registers, pivots and
-            const int li = lane & 15;                            //     multipliers by v_readlane, 1/sqrt by rsq + two Newton steps
-            double a[16];
-#pragma unroll
-            for (int c = 0; c < 16; c++) a[c] = s_L[li][c];
-            bool good = true;
-#pragma unroll
-            for (int j = 0; j < 16; j++) {
-                const double d = ba_readlane(a[j], j);
-                const bool gj = (d > 0) && isfinite(d);
-                good = good && gj;
-                const double inv = ba_rsqrt(gj ? d : 1.0);
-                const double lij = a[j] * inv;                   // rows >= j; the rest never reaches a result
-                a[j] = lij;
-                if (lane == j) s_rd[j] = inv;                    // the panel rows multiply by the reciprocal pivots
-#pragma unroll
-                for (int k = j + 1; k < 16; k++) a[k] = fma(-lij, ba_readlane(lij, k), a[k]);
-            }
-            if (!good && lane == 0) s_ok = 0;
-            if (lane < 16) {
-#pragma unroll
-                for (int c = 0; c < 16; c++) {
-                    s_L[li][c] = a[c];
-                    if (c <= li) A[(size_t)(k0 + li) * ld + k0 + c] = a[c];
-                }
-            }
-        }
-        __syncthreads();
-        CT_LAP(2);
-        const int below = rows - k0 - 16;                        // rows under the diagonal block (the rhs block row included)
-        if (t < below) {                                         // (2) panel: row r of L21 = A21 L11^-T
-            const int r = k0 + 16 + t;
-            double x[16];
-#pragma unroll
-            for (int c = 0; c < 16; c++) x[c] = s_P[t][c];
+        if (!good && lane == 0) s_ok = 0;
+        if (lane < 16) {
 #pragma unroll
             for (int c = 0; c < 16; c++) {
-                double v = x[c];
-#pragma unroll
-                for (int u = 0; u < c; u++) v -= x[u] * s_L[c][u];
-                x[c] = v * s_rd[c];
+                s_L[li][c] = x[c];                                                      // L11^-1 (lower triangular)
+                inv[(size_t)kb * 256 + li * 16 + c] = x[c];                             // for the backward substitution
+                if (c <= li) A[(size_t)(k0 + li) * ld + k0 + c] = a[c];
             }
-#pragma unroll
-            for (int c = 0; c < 16; c++) { A[(size_t)r * ld + k0 + c] = x[c]; s_P[t][c] = x[c]; }
-        } else if (t >= BA_CHOL_THREADS - 16) {                  // 16 idle threads invert the diagonal block: column c of L11^-1
-            const int c = t - (BA_CHOL_THREADS - 16);
-            double x[16];
-#pragma unroll
-            for (int i = 0; i < 16; i++) {
-                double v = (i == c) ? 1.0 : 0.0;
-#pragma unroll
-                for (int u = 0; u < i; u++) v -= s_L[i][u] * x[u];
-                x[i] = v * s_rd[i];
-            }
-#pragma unroll
-            for (int i = 0; i < 16; i++) inv[(size_t)kb * 256 + i * 16 + c] = x[i];
         }
+    };
+    if (wv == BA_CHOL_OWNERS) {
+        __syncthreads();                                         // column 0 is published
+        factor_block(0);
         __syncthreads();
-        CT_LAP(3);
-        // (3) trailing update of the owned tiles right of block column kb (the rhs row's tiles included), v_mfma_f64_16x16x4
+        for (int kb = 0; kb < nb; kb++) {
+            __syncthreads();                                     // (owners: P)
+            __syncthreads();                                     // (owners: 3a) — the next diagonal tile is in s_D
+            CT_LAP(1);
+            if (kb + 1 < nb) factor_block(kb + 1);
+            CT_LAP(2);
+            __syncthreads();                                     // (owners: 3b)
+            CT_LAP(3);
+        }
+    } else {
+        v4d acc[BA_MAX_TILES_PER_WAVE]; int tI[BA_MAX_TILES_PER_WAVE], tJ[BA_MAX_TILES_PER_WAVE];
+        const int ntiles_all = nb * (nb + 1) / 2;
 #pragma unroll
         for (int u = 0; u < BA_MAX_TILES_PER_WAVE; u++) {
-            if (tJ[u] <= kb) continue;                           // tJ > kb implies tI > kb
-            const int Io = (tI[u] - kb - 1) * 16 + (lane & 15), Jo = (tJ[u] - kb - 1) * 16 + (lane & 15);
+            const int idx = wv + BA_CHOL_OWNERS * u;
+            tI[u] = -1; tJ[u] = -1;
+            acc[u] = (v4d){0.0, 0.0, 0.0, 0.0};
+            if (idx < ntiles_all) {
+                int I = 0, rem = idx;
+                while (rem > I) { rem -= I + 1; I++; }
+                const int J = rem;
+                tI[u] = I; tJ[u] = J;
 #pragma unroll
-            for (int kc = 0; kc < 4; kc++)
-                acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(-s_P[Io][4 * kc + (lane >> 4)], s_P[Jo][4 * kc + (lane >> 4)], acc[u], 0, 0, 0);
+                for (int r = 0; r < 4; r++) acc[u][r] = A[(size_t)(I * 16 + (lane >> 4) + 4 * r) * ld + J * 16 + (lane & 15)];
+            }
         }
-        __syncthreads();                                         // s_P / s_L are rewritten by the next block column
-        CT_LAP(4);
+        // publish the tiles of block column c: the diagonal tile to s_D, the tiles below it to the panel buffer of that column's parity
+        auto publish = [&](int c) {
+            row17* Pn = (c & 1) ? s_P1 : s_P0;
+#pragma unroll
+            for (int u = 0; u < BA_MAX_TILES_PER_WAVE; u++) {
+                if (tJ[u] != c) continue;
+                if (tI[u] == c) {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) s_D[(lane >> 4) + 4 * r][lane & 15] = acc[u][r];
+                } else {
+                    const int rb = (tI[u] - c - 1) * 16;
+#pragma unroll
+                    for (int r = 0; r < 4; r++) Pn[rb + (lane >> 4) + 4 * r][lane & 15] = acc[u][r];
+                }
+            }
+        };
+        publish(0);
+        __syncthreads();
+        __syncthreads();                                         // (factor wave: block 0)
+        double yn = 0;
+        for (int kb = 0; kb < nb; kb++) {
+            const int k0 = kb << 4;
+            row17* Pc = (kb & 1) ? s_P1 : s_P0;
+            // P: L21 = A21 L11^-T per owned tile of block column kb of block column kb: A operand = the published tile, B[k][j] =
+            //    L11^-1[j][k]; the result overwrites the tile's rows of the panel buffer (they belong to this wave alone in this phase). (A thread per row solving against L11 was a chain of 120 dependent FMAs fed by
+            //    LDS reads: 7.3 k cycles per panel.)
+#pragma unroll
+            for (int u = 0; u < BA_MAX_TILES_PER_WAVE; u++) {
+                if (tJ[u] != kb || tI[u] == kb) continue;
+                const int rb = (tI[u] - kb - 1) * 16;
+                v4d xt = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int kc = 0; kc < 4; kc++)
+                    xt = __builtin_amdgcn_mfma_f64_16x16x4f64(Pc[rb + (lane & 15)][4 * kc + (lane >> 4)], s_L[lane & 15][4 * kc + (lane >> 4)], xt, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; r++) Pc[rb + (lane >> 4) + 4 * r][lane & 15] = xt[r];
+            }
+            if (t < 16) {                                        // forward substitution of the right-hand side: y_kb <- L11^-1 y_kb
+                double yk = 0;
+#pragma unroll
+                for (int c = 0; c < 16; c++) yk += s_L[t][c] * s_y[k0 + c];
+                yn = yk;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (t < 16) s_y[k0 + t] = yn;
+            CT_LAP(1);
+            __syncthreads();
+            // 3a: y_I -= L21_I y_kb for the rows below (one thread per row of the panel), the rank-16 update of the tiles of block column kb + 1,
+            //     then their publication
+            if (t < ld - k0 - 16) {
+                double yv = s_y[k0 + 16 + t];
+                double* Arow = A + (size_t)(k0 + 16 + t) * ld + k0;      // L21 goes to global memory here, a row per thread (per-tile stores in P kept
+#pragma unroll                                                           // 4 hoisted 64-bit addresses per tile alive: spills)
+                for (int c = 0; c < 16; c++) { const double l = Pc[t][c]; yv -= l * s_y[k0 + c]; Arow[c] = l; }
+                s_y[k0 + 16 + t] = yv;
+            }
+#pragma unroll
+            for (int u = 0; u < BA_MAX_TILES_PER_WAVE; u++) {
+                if (tJ[u] != kb + 1) continue;                   // tJ > kb implies tI > kb
+                const int Io = (tI[u] - kb - 1) * 16 + (lane & 15), Jo = (tJ[u] - kb - 1) * 16 + (lane & 15);
+#pragma unroll
+                for (int kc = 0; kc < 4; kc++)
+                    acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(-Pc[Io][4 * kc + (lane >> 4)], Pc[Jo][4 * kc + (lane >> 4)], acc[u], 0, 0, 0);
+            }
+            if (kb + 1 < nb) publish(kb + 1);
+            CT_LAP(2);
+            __syncthreads();
+            // 3b: the rest of the trailing matrix, beside the factor wave
+#pragma unroll
+            for (int u = 0; u < BA_MAX_TILES_PER_WAVE; u++) {
+                if (tJ[u] <= kb + 1) continue;
+                const int Io = (tI[u] - kb - 1) * 16 + (lane & 15), Jo = (tJ[u] - kb - 1) * 16 + (lane & 15);
+#pragma unroll
+                for (int kc = 0; kc < 4; kc++)
+                    acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(-Pc[Io][4 * kc + (lane >> 4)], Pc[Jo][4 * kc + (lane >> 4)], acc[u], 0, 0, 0);
+            }
+            CT_LAP(3);
+            __syncthreads();
+            CT_LAP(4);
+        }
     }
-    // y = L^-1 bs now sits in the rhs row; backward substitution L^T x = y, 16 unknowns at a time
-    for (int i = t; i < ld; i += blockDim.x) s_y[i] = A[(size_t)ld * ld + i];
     __syncthreads();
+    CT_LAP(0);
+    // y = L^-1 bs now sits in s_y; backward substitution L^T x = y, 16 unknowns at a time
     for (int kb = nb - 1; kb >= 0; kb--) {
         const int k0 = kb << 4;
         double xi = 0;
@@ -515,7 +571,7 @@ __device__ __forceinline__ void k_ba_chol_solve_body(const BaDev& D) {
     CT_LAP(5);
     for (int i = t; i < n; i += blockDim.x) D.xp[i] = s_ok ? s_y[i] : 0.0;
 #ifdef VIORB_CHOL_TIMING
-    if (t == 0 && blockIdx.x == 0) printf("chol cycles: load %llu publish %llu diag %llu panel %llu trailing %llu backward %llu\n", ct_[0], ct_[1], ct_[2], ct_[3], ct_[4], ct_[5]);
+    if (lane == 0 && (wv == 0 || wv == BA_CHOL_OWNERS) && blockIdx.x == 0) printf("chol cycles wave %d: [0] %llu [1] %llu [2] %llu [3] %llu [4] %llu [5] %llu [6] %llu\n", wv, ct_[0], ct_[1], ct_[2], ct_[3], ct_[4], ct_[5], ct_[6]);
 #endif
     if (t == 0) { D.scal[2] = s_ok ? 1.0 : 0.0; D.scal[1] = 0.0; D.scal[0] = 0.0; }      // [1], [0]: accumulators of k_ba_backsub and k_ba_*_errors, which follow
 }
@@ -637,7 +693,7 @@ __global__ void k_ba_init_reduced(BaDev D, double lambda_arg) { k_ba_init_reduce
 __global__ void k_ba_max_diag(BaDev D) { k_ba_max_diag_body(D); }
 __global__ void k_ba_dinv(BaDev D, double lambda_arg) { k_ba_dinv_body(D, lambda_arg); }
 __global__ __launch_bounds__(256) void k_ba_schur(BaDev D) { k_ba_schur_body(D, blockIdx.x / BA_SCHUR_PARTS, blockIdx.x % BA_SCHUR_PARTS, BA_SCHUR_PARTS); }
-__global__ __launch_bounds__(BA_CHOL_THREADS) void k_ba_chol_solve(BaDev D) { k_ba_chol_solve_body(D); }
+__global__ __launch_bounds__(BA_CHOL_THREADS) void k_ba_chol_solve(BaDev D) { extern __shared__ __attribute__((aligned(16))) double s_chol[]; k_ba_chol_solve_body(D, s_chol); }
 __global__ void k_ba_backsub(BaDev D, double lambda_arg) { k_ba_backsub_body(D, lambda_arg); }
 __global__ void k_ba_update(BaDev D) { k_ba_update_body(D); }
 __global__ void k_ba_restore(BaDev D) { k_ba_restore_body(D); }
@@ -688,7 +744,7 @@ __global__ void k_bab_lambda0(const BaDev* __restrict__ Dv, int nwin) {
 __global__ void k_bab_init_reduced(const BaDev* __restrict__ Dv) { BA_B_WINDOW(); k_ba_init_reduced_body(D, 0.0); }
 __global__ void k_bab_dinv(const BaDev* __restrict__ Dv) { BA_B_WINDOW(); k_ba_dinv_body(D, 0.0); }
 __global__ __launch_bounds__(256) void k_bab_schur(const BaDev* __restrict__ Dv) { BA_B_WINDOW(); if ((int)blockIdx.x >= D.W) return; k_ba_schur_body(D, blockIdx.x, 0, 1); }
-__global__ __launch_bounds__(BA_CHOL_THREADS) void k_bab_chol_solve(const BaDev* __restrict__ Dv) { BA_B_WINDOW(); k_ba_chol_solve_body(D); }
+__global__ __launch_bounds__(BA_CHOL_THREADS) void k_bab_chol_solve(const BaDev* __restrict__ Dv) { extern __shared__ __attribute__((aligned(16))) double s_chol[]; BA_B_WINDOW(); k_ba_chol_solve_body(D, s_chol); }
 __global__ void k_bab_backsub(const BaDev* __restrict__ Dv) { BA_B_WINDOW(); k_ba_backsub_body(D, 0.0); }
 __global__ void k_bab_update(const BaDev* __restrict__ Dv) { BA_B_WINDOW(); k_ba_update_body(D); }
 __global__ void k_bab_errors(const BaDev* __restrict__ Dv) { BA_B_WINDOW(); k_ba_errors_body(D, c[BA_B_MONO] != 0.0); }
@@ -1025,7 +1081,8 @@ struct BaSolve {
                     hipLaunchKernelGGL(k_ba_init_reduced, dim3((unsigned)((nl2 + TB - 1) / TB)), dim3(TB), 0, st, D, 0.0);
                     hipLaunchKernelGGL(k_ba_dinv, dim3(gP), dim3(TB), 0, st, D, 0.0);
                     hipLaunchKernelGGL(k_ba_schur, dim3(n_local * BA_SCHUR_PARTS), dim3(256), 0, st, D);
-                    hipLaunchKernelGGL(k_ba_chol_solve, dim3(1), dim3(BA_CHOL_THREADS), 0, st, D);
+                    (void)raise_dynamic_lds(reinterpret_cast<const void*>(k_ba_chol_solve), BA_CHOL_LDS_BYTES);
+                    hipLaunchKernelGGL(k_ba_chol_solve, dim3(1), dim3(BA_CHOL_THREADS), BA_CHOL_LDS_BYTES, st, D);
                     hipLaunchKernelGGL(k_ba_backsub, dim3(gP), dim3(TB), 0, st, D, 0.0);
                     if (model == 0) hipLaunchKernelGGL(k_ba_update, dim3(std::max(gP, 1)), dim3(TB), 0, st, D);
                     else hipLaunchKernelGGL(k_ba_se3_update, dim3(std::max(gP, 1)), dim3(TB), 0, st, D);
@@ -1080,7 +1137,8 @@ struct BaSolve {
                 hipLaunchKernelGGL(k_ba_init_reduced, dim3((unsigned)((nl2 + TB - 1) / TB)), dim3(TB), 0, st, D, lambda);
                 hipLaunchKernelGGL(k_ba_dinv, dim3(gP), dim3(TB), 0, st, D, lambda);
                 hipLaunchKernelGGL(k_ba_schur, dim3(n_local * BA_SCHUR_PARTS), dim3(256), 0, st, D);
-                hipLaunchKernelGGL(k_ba_chol_solve, dim3(1), dim3(BA_CHOL_THREADS), 0, st, D);
+                (void)raise_dynamic_lds(reinterpret_cast<const void*>(k_ba_chol_solve), BA_CHOL_LDS_BYTES);
+                    hipLaunchKernelGGL(k_ba_chol_solve, dim3(1), dim3(BA_CHOL_THREADS), BA_CHOL_LDS_BYTES, st, D);
                 hipLaunchKernelGGL(k_ba_backsub, dim3(gP), dim3(TB), 0, st, D, lambda);
                 if (model == 0) hipLaunchKernelGGL(k_ba_update, dim3(std::max(gP, 1)), dim3(TB), 0, st, D);
                 else hipLaunchKernelGGL(k_ba_se3_update, dim3(std::max(gP, 1)), dim3(TB), 0, st, D);
@@ -1327,7 +1385,8 @@ static int ba_run_lockstep(viorb_lba_window* w, int n) {
                 hipLaunchKernelGGL(k_bab_init_reduced, dim3(gR, na), dim3(TB), 0, st, Dv);
                 hipLaunchKernelGGL(k_bab_dinv, YP, dim3(TB), 0, st, Dv);
                 hipLaunchKernelGGL(k_bab_schur, YW, dim3(256), 0, st, Dv);
-                hipLaunchKernelGGL(k_bab_chol_solve, Y1, dim3(BA_CHOL_THREADS), 0, st, Dv);
+                (void)raise_dynamic_lds(reinterpret_cast<const void*>(k_bab_chol_solve), BA_CHOL_LDS_BYTES);
+                hipLaunchKernelGGL(k_bab_chol_solve, Y1, dim3(BA_CHOL_THREADS), BA_CHOL_LDS_BYTES, st, Dv);
                 hipLaunchKernelGGL(k_bab_backsub, YP, dim3(TB), 0, st, Dv);
                 hipLaunchKernelGGL(k_bab_update, YP, dim3(TB), 0, st, Dv);
                 hipLaunchKernelGGL(k_bab_errors, YE, dim3(TB), 0, st, Dv);
