@@ -8,10 +8,10 @@
 //
 // Kernels (all FP64): k_ba_errors (per edge residuals + robust chi2), k_ba_lin_points (one thread per point: Jacobians,
 // weights, Hll, bl), k_ba_hpp (one workgroup per local key frame: its 6x6 (P,Phi) block), k_ba_imu (one workgroup per IMU
-// factor), k_ba_schur (one thread per point: (Hll + lambda I)^-1 and the -W D^-1 W^T scatter with FP64 atomics),
-// k_ba_chol_solve (dense Cholesky of the <= 240x240 reduced system by one 1024-thread workgroup), k_ba_backsub,
-// k_ba_update. The LM control flow (accept / reject, lambda schedule, stop rule, stop flag) runs on the host and reads
-// three scalars back per trial. The Schur products use FP64 atomics, not MFMA yet.
+// factor), k_ba_dinv (one thread per point: (Hll + lambda I)^-1), k_ba_schur (workgroups per key frame: the -W D^-1 W^T block row in
+// LDS with FP64 atomics, W blocks precomputed with the linearisation), k_ba_chol_solve (dense Cholesky of the <= 240x240 reduced system by
+// one 512-thread workgroup, register tiles + v_mfma_f64_16x16x4), k_ba_backsub, k_ba_update. The LM control flow (accept / reject, lambda
+// schedule, stop rule) runs on the device (k_ba_decide / the lock-step batch's control block); the host polls a few scalars per chunk.
 #include <hip/hip_runtime.h>
 #include <memory>
 #include <string>
@@ -330,15 +330,13 @@ __device__ __forceinline__ void k_ba_schur_body(const BaDev& D, int ka, int part
     }
 }
 
-// Dense Cholesky solve S xp = bs of the reduced system by ONE 1024-thread workgroup, blocked by 16 (n <= 240, padded to ld):
-// per block column: (1) one wave factors the 16x16 diagonal block in LDS, (2) a thread per row solves the panel below it against
-// that block, (3) the 16 waves apply the rank-16 update to the trailing lower triangle, one 16x16 tile at a time, with
-// v_mfma_f64_16x16x4_f64 (operands A[i][k]: lane 16k+i, B[k][j]: lane 16k+j; result row = lane/16 + 4*reg, col = lane%16 — probed
-// on gfx950, tools/ubench/mfma_f64_layout.hip). The right-hand side rides along as one more row under the matrix (row ld of the
-// ld+16 row buffer), so the forward substitution L y = bs is done by the panel solves and updates themselves; the backward
-// substitution uses the inverted diagonal blocks (one thread per column of each inverse) and is a 16x16 mat-vec + a rank-16 update
-// per block. The matrix stays in L2; the panel is staged in LDS. scal[2] = 1 on success; a pivot that is not positive and finite
-// fails the solve like the reference's LLT (linear_solver_eigen.h / Eigen info()).
+// Dense Cholesky solve S xp = bs of the reduced system by ONE 512-thread workgroup, blocked by 16 (n <= 240, padded to ld): the lower
+// block triangle lives in the registers of seven waves as 16x16 tiles in the layout of v_mfma_f64_16x16x4_f64 (operands A[i][k]: lane
+// 16k+i, B[k][j]: lane 16k+j; result row = lane/16 + 4*reg, col = lane%16 — probed on gfx950, tools/ubench/mfma_f64_layout.hip), the
+// eighth wave factors the 16x16 diagonal blocks one block column ahead (see the body). The right-hand side lives in LDS and its forward
+// substitution L y = bs rides along with the panels; the backward substitution uses the inverted diagonal blocks and is a 16x16 mat-vec
+// + a rank-16 update per block. scal[2] = 1 on success; a pivot that is not positive and finite fails the solve like the reference's
+// LLT (linear_solver_eigen.h / Eigen info()).
 typedef double v4d __attribute__((ext_vector_type(4)));
 #define BA_CHOL_THREADS 512                  // 8 waves: 7 tile owners + the factor wave
 #define BA_CHOL_WAVES (BA_CHOL_THREADS / 64)
