@@ -32,7 +32,7 @@ HBM_PEAK_GBS = 8000.0                         # MI355X HBM3E spec peak (MI355X_M
 FP64_VECTOR_PEAK_TFLOPS = 78.6                # MI355X FP64 vector spec (AMD data sheet: 256 CUs x 128 FLOP/clk x 2.4 GHz; the guide has no FP64 row)
 CONFIGS = {
     # name: width, height, features, default units per GPU, BASELINE.json configs index
-    "euroc": dict(w=752, h=480, nfeat=1000, streams=256, baseline_config=1),
+    "euroc": dict(w=752, h=480, nfeat=1000, streams=512, baseline_config=1),
     "synth720p": dict(w=1280, h=720, nfeat=1500, streams=8, baseline_config=4),
     "kitti_stereo": dict(w=1241, h=376, nfeat=2000, streams=64, baseline_config=2),
     "local_ba": dict(w=752, h=480, nfeat=1000, streams=64, baseline_config=3),
@@ -154,8 +154,9 @@ def run_tracking(args, cfg, rank, dev_index, dev, world):
     from viorb_amd.tracker import NativeTracker
     W_IMG, H_IMG, NFEAT, S = cfg["w"], cfg["h"], cfg["nfeat"], args.streams
     TLM = not args.no_track_local_map
-    # at most 64 distinct synthetic streams are generated per rank (CPU time); beyond that the streams repeat (independent state each)
-    distinct = min(S, 64 if (W_IMG, H_IMG) == (752, 480) and S > 256 else S)
+    # at most 256 distinct synthetic streams are generated per rank (CPU time); beyond that the streams repeat (own copy of the images, independent
+    # tracker state each)
+    distinct = min(S, 256)
     base = generate_streams(stream_seeds(rank, distinct), W_IMG, H_IMG)
     streams = [base[i % distinct] for i in range(S)]
     up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
@@ -283,7 +284,7 @@ def run_tracking(args, cfg, rank, dev_index, dev, world):
                          " + SearchLocalPoints(~2000 local points) + PoseOptimization(marg)  [TrackWithIMU + TrackLocalMapWithIMU]" if TLM else " [TrackWithIMU only]"),
             "baseline_config": cfg["baseline_config"], "keyframe_boundary_every_frames": N_FRAMES,
             "keyframe_variant": "PoseOptimization(Frame, KeyFrame) on the frame after every boundary (mbMapUpdated), (Frame, Frame) otherwise",
-            "track_local_map": TLM, "streams_per_gpu": S, "frames_per_step": S * world, "solver_dtype": "f64",
+            "track_local_map": TLM, "streams_per_gpu": S, "distinct_synthetic_streams_per_gpu": distinct, "frames_per_step": S * world, "solver_dtype": "f64",
             "host_enqueue_ms_per_step": round(hs["enqueue_s"] / max(hs["steps"], 1) * 1e3, 4),
             "host_throttle_wait_ms_per_step": round(hs["throttle_s"] / max(hs["steps"], 1) * 1e3, 4),
             "host_step_call_ms_per_step": round(t_calls / args.steps * 1e3, 4),
@@ -444,7 +445,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--config", choices=sorted(CONFIGS), default="euroc", help="BASELINE.json config: euroc = configs[1] (default), kitti_stereo = configs[2], "
                     "local_ba = configs[3], synth720p = configs[4]")
-    ap.add_argument("--streams", type=int, default=None, help="independent units per GPU per step: camera streams (euroc 256, synth720p 8), stereo pairs "
+    ap.add_argument("--streams", type=int, default=None, help="independent units per GPU per step: camera streams (euroc 512, synth720p 8), stereo pairs "
                     "(kitti_stereo 64), windows (local_ba 64)")
     ap.add_argument("--in-flight", type=int, default=16, help="local_ba: windows kept in flight by the batch driver")
     ap.add_argument("--no-track-local-map", action="store_true", help="stop after TrackWithIMU's pose solve")
