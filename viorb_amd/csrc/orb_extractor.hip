@@ -1220,7 +1220,7 @@ __global__ __launch_bounds__(256) void k_orient_describe(const uint8_t* __restri
     const int lane = threadIdx.x & 63;
     int b, item;
     if (!xcd_place(PL, b, item)) return;
-    const int k = item * 4 + (threadIdx.x >> 6);             // keypoint slot inside the image
+    const int k = item * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);             // keypoint slot inside the image (wave-uniform: the level search below stays on the scalar unit)
     const int* cnt = lvl_cnt + b * nlevels;
     int level = -1, local = 0, total = 0;
     for (int l = 0; l < nlevels; l++) {
@@ -1271,8 +1271,8 @@ __global__ __launch_bounds__(256) void k_orient_describe(const uint8_t* __restri
             m01 += vv[it] * s1;
         }
     }
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) { m10 += __shfl_xor(m10, d); m01 += __shfl_xor(m01, d); }
+    // wave sums by DPP (the inclusive scan's last lane holds the total) instead of six ds_bpermute butterflies per moment
+    m10 = __builtin_amdgcn_readlane(wave_inclusive_scan(m10), 63); m01 = __builtin_amdgcn_readlane(wave_inclusive_scan(m01), 63);
     const float angle = fast_atan2_deg((float)m01, (float)m10);
     // ---- descriptor
     const float factor_pi = (float)(3.14159265358979323846 / 180.f);
