@@ -234,7 +234,7 @@ def run_tracking(args, cfg, rank, dev_index, dev, world):
         if "k_fast_cells" in prof and prof["k_fast_cells"][1]:
             tot_ms, ncalls = prof["k_fast_cells"]
             avg_s = tot_ms / ncalls * 1e-3
-            per_launch = L.viorb_extractor_fast_launch_images(S)     # FAST goes out in sub-launches over the batch; the profiler times the first
+            per_launch = L.viorb_extractor_fast_launch_images(S)     # FAST goes out in sub-launches over the batch; the profiler times one of them per step, in rotation
             bpl = AB["k_fast_cells"] * per_launch
             tr_b = None
             if traffic and traffic.get("config") == args.config and "k_fast_cells" in traffic.get("bytes_per_launch", {}):
@@ -252,7 +252,7 @@ def run_tracking(args, cfg, rank, dev_index, dev, world):
                 roof["extractor_all_kernels_GBps"] = round(ext_bytes / (ext_ms * 1e-3) / 1e9, 2)
                 roof["extractor_all_kernels_frac"] = round(ext_bytes / (ext_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
             roof["kernel_ms_per_step"] = {kname: round(v[0] / args.steps, 4) for kname, v in sorted(prof.items())}
-            if not args.all_kernel_events:                  # only the first of FAST's sub-launches was timed
+            if not args.all_kernel_events:                  # one of FAST's sub-launches per step was timed
                 roof["kernel_ms_per_step"]["k_fast_cells"] = round(tot_ms / args.steps * (-(-S // per_launch)), 4)
             roof["launches_per_step"] = -(-S // per_launch); roof["images_per_launch"] = per_launch
         if "k_pose_opt_vi" in prof and prof["k_pose_opt_vi"][1]:
@@ -350,7 +350,7 @@ def run_stereo(args, cfg, rank, dev_index, dev, world):
         roof = None
         if "k_fast_cells" in prof and prof["k_fast_cells"][1]:
             tot_ms, ncalls = prof["k_fast_cells"]; avg_s = tot_ms / ncalls * 1e-3
-            per_launch = L.viorb_extractor_fast_launch_images(2 * Pn)    # FAST goes out in sub-launches over the batch; the profiler times the first
+            per_launch = L.viorb_extractor_fast_launch_images(2 * Pn)    # FAST goes out in sub-launches over the batch; the profiler times one of them per step, in rotation
             bpl = AB["k_fast_cells"] * per_launch
             roof = {"bound": "hbm", "kernel": "k_fast_cells", "achieved": round(bpl / avg_s / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(bpl / avg_s / 1e9 / HBM_PEAK_GBS, 5), "traffic": None, "avg_launch_us": round(avg_s * 1e6, 2),

@@ -82,7 +82,7 @@ int viorb_extractor_tables(const viorb_extractor* h, float* scale, float* inv_sc
 /* Upper bound on keypoints per image (sum of per-level quota + 2): size output buffers with it. */
 int viorb_extractor_max_keypoints(const viorb_extractor* h, int* cap);
 /* Images per k_fast_cells launch of a batched call (the FAST stage of a batch goes out as several launches over sub-ranges of the
- * batch; the kernel profiler times the first of them). For bench.py's bytes-per-launch figure. */
+ * batch; with a kernel selection the profiler times one of them per call, in rotation). For bench.py's bytes-per-launch figure. */
 int viorb_extractor_fast_launch_images(int batch);
 
 /* Drop-in for ORBextractor::operator()(image, mask [ignored], keypoints, descriptors) with host

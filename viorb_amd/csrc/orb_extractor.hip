@@ -1516,6 +1516,7 @@ struct viorb_extractor {
     hipStream_t aux_stream = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;      // the blur's side stream (launch_all)
     hipStream_t last_stream = nullptr;
     int last_batch = 0;
+    unsigned fast_prof_rot = 0;          // which FAST sub-launch the profiler times on this call
     bool tables_uploaded = false;
 };
 
@@ -1864,8 +1865,11 @@ static int launch_all(viorb_extractor* h, const uint8_t* d_images, int batch, in
         // frames/s at 256 streams (4 launches: 129 k, 16: 134 k, 32: 121 k). Splitting the quadtree, blur or descriptor kernels the same
         // way loses (their workgroups live long, every boundary is a tail).
         const int step = fast_launch_images(batch);
+        h->fast_prof_rot++;
         for (int i0 = 0; i0 < batch; i0 += step) {
-            ProfScope ps(i0 == 0 || prof_times_everything() ? "k_fast_cells" : nullptr, st);   // with a kernel selection the profiler times the first sub-launch only (an event pair costs ~8 us of stream time)
+            // with a kernel selection the profiler times ONE sub-launch per call, a different one every call (an event pair costs ~8 us of stream
+            // time; the sub-launches differ in what runs beside them, so the rotation is what makes the mean agree with a tracer's per-launch mean)
+            ProfScope ps(prof_times_everything() || (i0 / step) == (int)(h->fast_prof_rot % (unsigned)((batch + step - 1) / step)) ? "k_fast_cells" : nullptr, st);
             const XcdPlace PL = make_place((ncells + FAST_CELLS_PER_WAVE - 1) / FAST_CELLS_PER_WAVE, batch, i0, std::min(batch, i0 + step));
             hipLaunchKernelGGL(k_fast_cells, dim3(place_blocks(PL)), dim3(64), lds, st, h->d_planes, h->frame_bytes, h->d_lv, h->d_cells,
                                h->p.ini_th_fast, h->p.min_th_fast, h->d_slots, h->slot_cap, h->d_cell_cnt, ncells,
