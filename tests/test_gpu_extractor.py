@@ -126,6 +126,25 @@ def test_batched_device_api_matches_single(gpu, oracle):
         np.testing.assert_array_equal(d, od)
 
 
+def test_batch_of_21_takes_the_sub_launch_and_side_stream_paths(gpu, oracle):
+    """A batch of 16 or more goes through the XCD-aware placement with image offsets, FAST in several sub-launches (a batch that is not a
+    multiple of 8 leaves a short last one) and the blur on the handle's second stream: every image must come out as the oracle's."""
+    import torch
+    B = 21
+    imgs = np.stack([make_image(300 + b, 200, 150) for b in range(B)])
+    ex = viorb_amd.ORBextractor(300, 1.2, 8, 20, 7, max_batch=B)
+    ox = oracle.Extractor(300, 1.2, 8, 20, 7)
+    t = torch.from_numpy(imgs).cuda()
+    for _ in range(2):                                  # the second call re-uses the side stream and its events
+        ex.extract_batch_device(t)
+        torch.cuda.synchronize()
+        for b in range(B):
+            k, d = ex.download(b)
+            ok, od = ox(imgs[b])
+            np.testing.assert_array_equal(k, ok, err_msg="image %d" % b)
+            np.testing.assert_array_equal(d, od, err_msg="image %d" % b)
+
+
 def test_edge_inputs(gpu, oracle):
     ex = viorb_amd.ORBextractor(300, 1.2, 8, 20, 7)
     k, d = ex(np.full((120, 160), 77, np.uint8))               # textureless: zero keypoints everywhere

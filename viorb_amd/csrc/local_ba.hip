@@ -392,45 +392,56 @@ __device__ __forceinline__ void k_ba_chol_solve_body(const BaDev& D, double* s_d
     // inverse row, broadcasts) and the owners' 160 accumulator registers never have to fit one allocation. L and the solved rhs row are
     // written to global memory for the backward substitution.
     auto factor_block = [&](int kb) {
-        // lane li holds row li of the (symmetrised) block and row li of X = L11^-1, which grows with the factorisation (row j is scaled by
-        // 1 / l_jj, then eliminated from the rows below like column j itself). The dependent chain of a column step is pivot -> 1/sqrt
-        // (rsq + two Newton steps) -> s = a_ij / d -> 16 independent FMAs; the row broadcasts (v_readlane of row j's entries of the block
-        // and of X) do not depend on it. 8.2 k cycles per block including the inverse (an LDS round trip per broadcast row: 11.8 k).
+        // Lane li holds row li of the (symmetrised) block. A column step's dependent chain is pivot -> 1/sqrt (rsq + two Newton steps) ->
+        // s = a_ij / d -> up to 15 independent FMAs; the broadcast of row j (v_readlane from lane j's registers: A[j][k] = A[k][j] is the
+        // multiplier column k needs) does not depend on it. L11^-1 follows by a right-looking forward substitution with lane c on column
+        // c: L goes through LDS once and comes back as broadcast reads that do not depend on the substitution's chain (two dependent
+        // operations per row). (Building the inverse inside the factorisation loop doubled its v_readlane traffic: 8.8 k cycles per
+        // block; row broadcasts through LDS inside the loop 11.8 k; the first form, broadcasting l_kj after the chain, 6.5 k without inverse.)
         const int li = lane & 15, k0 = kb << 4;
-        double a[16], x[16];
+        double a[16], rinv[16];
 #pragma unroll
-        for (int c = 0; c < 16; c++) { a[c] = c <= li ? s_D[li][c] : s_D[c][li]; x[c] = c == li ? 1.0 : 0.0; }
+        for (int c = 0; c < 16; c++) a[c] = c <= li ? s_D[li][c] : s_D[c][li];
         bool good = true;
 #pragma unroll
         for (int j = 0; j < 16; j++) {
             const double d = ba_readlane(a[j], j);
-            double u[16], v[16];
+            double u[16];
 #pragma unroll
-            for (int k = j + 1; k < 16; k++) u[k] = ba_readlane(a[k], j);              // row j of the block = column j below the diagonal
-#pragma unroll
-            for (int c = 0; c <= j; c++) v[c] = ba_readlane(x[c], j);                   // row j of X before its scaling
+            for (int k = j + 1; k < 16; k++) u[k] = ba_readlane(a[k], j);
             const bool gj = (d > 0) && isfinite(d);
             good = good && gj;
             const double ri = ba_rsqrt(gj ? d : 1.0);
+            rinv[j] = ri;
             const double sj = a[j] * (ri * ri);                                         // l_ij / l_jj
             a[j] = a[j] * ri;                                                           // l_ij (rows >= j; the rest never reaches a result)
 #pragma unroll
             for (int k = j + 1; k < 16; k++) a[k] = fma(-sj, u[k], a[k]);
-            if (li == j) {
-#pragma unroll
-                for (int c = 0; c <= j; c++) x[c] *= ri;
-            } else if (li > j) {
-#pragma unroll
-                for (int c = 0; c <= j; c++) x[c] = fma(-sj, v[c], x[c]);
-            }
         }
         if (!good && lane == 0) s_ok = 0;
         if (lane < 16) {
 #pragma unroll
             for (int c = 0; c < 16; c++) {
-                s_L[li][c] = x[c];                                                      // L11^-1 (lower triangular)
-                inv[(size_t)kb * 256 + li * 16 + c] = x[c];                             // for the backward substitution
+                s_D[li][c] = a[c];                                                      // L11 (lower triangle valid)
                 if (c <= li) A[(size_t)(k0 + li) * ld + k0 + c] = a[c];
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // X = L11^-1, column li per lane: x_u = acc_u / l_uu, then acc_i -= l_iu x_u for the rows below
+        double x[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) x[i] = i == li ? 1.0 : 0.0;
+#pragma unroll
+        for (int u = 0; u < 16; u++) {
+            x[u] *= rinv[u];
+#pragma unroll
+            for (int i = u + 1; i < 16; i++) x[i] = fma(-s_D[i][u], x[u], x[i]);
+        }
+        if (lane < 16) {
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                s_L[i][li] = x[i];                                                      // L11^-1 (lower triangular: x[i] = 0 for i < li)
+                inv[(size_t)kb * 256 + i * 16 + li] = x[i];                             // for the backward substitution
             }
         }
     };
