@@ -107,7 +107,7 @@ struct LevelDev {
     int pad;
 };
 struct CellDesc {              // one FAST cell = sub-image [x0,x0+cw) x [y0,y0+ch) of its level
-    int32_t level, x0, y0, cw, ch, shx, shy, pad;   // 32-bit fields: the wave-uniform descriptor then arrives by scalar loads (16-bit fields took a vector-memory round trip)
+    int32_t level, x0, y0, cw, ch, shx, shy, pitch;   // pitch = bytes per row of the cell's LDS tile (multiple of 4: cw + alignment slack + one spare dword). 32-bit fields: the wave-uniform descriptor then arrives by scalar loads (16-bit fields took a vector-memory round trip)
     uint32_t src_off;          // byte offset, inside one image's plane block, of the aligned dword holding pixel (x0, y0)
     int32_t stride;            // row pitch of the level (so the kernel needs no second, dependent table look-up)
 };
@@ -511,46 +511,49 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t* __restrict__ p
                                                    const CellDesc* __restrict__ cells, int ini_th, int min_th,
                                                    uint32_t* __restrict__ slots, int slot_cap,
                                                    int* __restrict__ cell_cnt, int ncells_total,
-                                                   int tile_pitch, int tile_rows, int score_bytes, int list_cap, XcdPlace PL) {
+                                                   int tile_bytes, int score_bytes, int list_cap, XcdPlace PL) {
     extern __shared__ uint32_t s_mem[];
     int img_b, item;
     if (!xcd_place(PL, img_b, item)) return;
     uint8_t* tile = reinterpret_cast<uint8_t*>(s_mem);
-    uint8_t* sc = tile + tile_pitch * tile_rows;
+    uint8_t* sc = tile + tile_bytes;
     uint16_t* surv = reinterpret_cast<uint16_t*>(sc + score_bytes);     // [list_cap] (r << 8 | q) of pass-1 survivors
     uint16_t* corn = surv + list_cap;                                    // [list_cap] corners (strength >= minTh)
     const int lane = threadIdx.x;
-    const int pitch_dw = tile_pitch >> 2;
     // A wave takes FAST_CELLS_PER_WAVE consecutive cells. The tile of the next cell is requested (into registers) as soon as the current
     // one has been handed to LDS, so its L2 round trip runs under the current cell's three passes instead of in front of them.
     const int cell0 = item * FAST_CELLS_PER_WAVE;
     const int ncell = min((int)FAST_CELLS_PER_WAVE, ncells_total - cell0);
-    uint32_t v[FAST_FETCH_TRIPS]; int at[FAST_FETCH_TRIPS];
+    uint32_t v[FAST_FETCH_TRIPS];
     const uint8_t* img = planes + (size_t)img_b * frame_bytes;
+    // Dword lane + 64 k of the cell's tile image (cd.pitch / 4 dwords per row), unconditionally: columns right of the cell's last dword are real
+    // pixels of the same row (a cell ends >= 16 px before the level's right edge), rows below the cell are clamped to its last row, and the LDS
+    // tile region holds all 64 * FAST_FETCH_TRIPS dwords (host), so neither the loads nor the stores need a per-dword validity test. The pitch
+    // is the cell's own (the widest cells of a pyramid, on its small levels, would cost the 30-px cells of the large levels a fifth more dwords
+    // and an eighth trip); lane / pitch_dw by a 16-bit reciprocal (exact for lane < 64).
     auto request_tile = [&](const CellDesc& cd) {
-        const int x0a_ = cd.x0 & ~3, ndw_ = ((cd.x0 + cd.cw - 1 - x0a_) >> 2) + 1;
-        const int st_r = 64 / pitch_dw, st_q = 64 - st_r * pitch_dw;      // one division per wave instead of one per dword
-        int r = lane / pitch_dw, q = lane - r * pitch_dw;
+        const int pdw = cd.pitch >> 2;
+        const int rcp = (65536 + pdw - 1) / pdw;                         // scalar
+        int r = (lane * rcp) >> 16, q = lane - r * pdw;
+        const int sr = (64 * rcp) >> 16, sq = 64 - sr * pdw;
         const uint8_t* src = img + cd.src_off;
-        const int ntile = cd.ch * pitch_dw;
 #pragma unroll
         for (int k = 0; k < FAST_FETCH_TRIPS; k++) {
-            const int i = lane + 64 * k;
-            at[k] = (i < ntile && q < ndw_) ? i : -1;
-            v[k] = *reinterpret_cast<const uint32_t*>(src + min(r, cd.ch - 1) * cd.stride + 4 * min(q, ndw_ - 1));      // unconditional, clamped: no branch per load
-            r += st_r; q += st_q;
-            if (q >= pitch_dw) { q -= pitch_dw; r++; }
+            v[k] = *reinterpret_cast<const uint32_t*>(src + (uint32_t)(min(r, cd.ch - 1) * cd.stride + 4 * q));
+            r += sr; q += sq;
+            if (q >= pdw) { q -= pdw; r++; }
         }
     };
     CellDesc c = cells[cell0];
     request_tile(c);
     for (int kk = 0; kk < ncell; kk++) {
     const int cell = cell0 + kk;
+    const int tile_pitch = c.pitch, pitch_dw = tile_pitch >> 2;
     const int x0a = c.x0 & ~3, xoff = c.x0 - x0a;
     const int ndw = ((c.x0 + c.cw - 1 - x0a) >> 2) + 1;
     {
 #pragma unroll
-        for (int k = 0; k < FAST_FETCH_TRIPS; k++) if (at[k] >= 0) s_mem[at[k]] = v[k];
+        for (int k = 0; k < FAST_FETCH_TRIPS; k++) s_mem[lane + 64 * k] = v[k];
         const int ntile = c.ch * pitch_dw;
         if (ntile > 64 * FAST_FETCH_TRIPS) {                                      // larger tiles than the default geometry
             const uint8_t* src = img + c.src_off;
@@ -1495,7 +1498,7 @@ struct viorb_extractor {
     std::vector<int4> blur_tiles;
     size_t frame_bytes = 0;
     int slot_cap = 0, kp_pitch = 0, out_cap = 0;
-    int fast_tile_pitch = 0, fast_tile_rows = 0, fast_score_bytes = 0, fast_list_cap = 0;
+    int fast_tile_pitch = 0, fast_tile_rows = 0, fast_tile_bytes = 0, fast_score_bytes = 0, fast_list_cap = 0;
     int oct_ncap = 0, oct_nodecap = 0, oct_sortcap = 0;
     std::vector<int> rs_pitch_dw, rs_rows;
     // second resize form (k_resize2): per-level tile table, LDS pitch, whether the level qualifies; whether level 1's kernel may also write level 0
@@ -1577,7 +1580,7 @@ static int configure(viorb_extractor* h, int w, int hgt) {
                     CellDesc c;
                     c.level = l; c.x0 = (int)iniX; c.y0 = (int)iniY;
                     c.cw = (int)maxX - (int)iniX; c.ch = (int)maxY - (int)iniY;
-                    c.shx = j * wCell; c.shy = i * hCell; c.pad = 0;
+                    c.shx = j * wCell; c.shy = i * hCell; c.pitch = (int)align_up(c.cw + 3, 4) + 4;
                     c.src_off = (uint32_t)(L.plane_off + (size_t)c.y0 * L.stride + (size_t)(c.x0 & ~3)); c.stride = L.stride;
                     if (c.cw < 7 || c.ch < 7) continue;            // cv::FAST finds nothing in such a sub-image
                     h->cells.push_back(c);
@@ -1712,6 +1715,11 @@ static int configure(viorb_extractor* h, int w, int hgt) {
     // FAST LDS: tile rows x pitch (dword aligned start => up to 3 extra bytes) + score map
     h->fast_tile_pitch = (int)align_up(max_cw + 3, 4) + 4;
     h->fast_tile_rows = max_ch;
+    {   // LDS tile region: the largest cell tile (every cell has its own pitch), and at least the 64 * FAST_FETCH_TRIPS dwords the kernel stores unconditionally
+        int tb = 64 * FAST_FETCH_TRIPS * 4;
+        for (const CellDesc& c : h->cells) tb = std::max(tb, c.pitch * c.ch);
+        h->fast_tile_bytes = (int)align_up((size_t)tb, 16);
+    }
     h->fast_score_bytes = (int)align_up((size_t)(max_cw - 6 + 2) * (max_ch - 6 + 2), 4);
     h->slot_cap = ((max_cw - 6 + 1) / 2) * ((max_ch - 6 + 1) / 2);       // independent set of the king's graph
     h->fast_list_cap = (int)align_up((size_t)(max_cw - 6) * (max_ch - 6), 2);
@@ -1856,7 +1864,7 @@ static int launch_all(viorb_extractor* h, const uint8_t* d_images, int batch, in
                            h->rs_pitch_dw[l], h->rs_rows[l], PL, gx);
     }
     {
-        const size_t lds = (size_t)h->fast_tile_pitch * h->fast_tile_rows + h->fast_score_bytes + (size_t)h->fast_list_cap * 4;
+        const size_t lds = (size_t)h->fast_tile_bytes + h->fast_score_bytes + (size_t)h->fast_list_cap * 4;
         // FAST goes out as FAST_LAUNCHES launches over sub-ranges of the batch (multiples of 8 images). A launch boundary is the only point
         // where the tracking stream's large workgroups (a search: 16 waves + 73 KB of LDS; the pose solver: 240 registers per lane) can be
         // placed on a CU: while this kernel still has workgroups to hand out, every slot that frees goes to its next single-wave
@@ -1873,7 +1881,7 @@ static int launch_all(viorb_extractor* h, const uint8_t* d_images, int batch, in
             const XcdPlace PL = make_place((ncells + FAST_CELLS_PER_WAVE - 1) / FAST_CELLS_PER_WAVE, batch, i0, std::min(batch, i0 + step));
             hipLaunchKernelGGL(k_fast_cells, dim3(place_blocks(PL)), dim3(64), lds, st, h->d_planes, h->frame_bytes, h->d_lv, h->d_cells,
                                h->p.ini_th_fast, h->p.min_th_fast, h->d_slots, h->slot_cap, h->d_cell_cnt, ncells,
-                               h->fast_tile_pitch, h->fast_tile_rows, h->fast_score_bytes, h->fast_list_cap, PL);
+                               h->fast_tile_bytes, h->fast_score_bytes, h->fast_list_cap, PL);
         }
     }
     // The blur only needs the pyramid, the quadtree only FAST: from here they run side by side, the blur on the handle's second stream.
