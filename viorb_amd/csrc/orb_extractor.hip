@@ -596,6 +596,9 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t* __restrict__ p
                 const int ntrip = (dh * G2 + 63) >> 6;
                 const uint32_t M = 0x00ff00ffu, Hb = 0x80008000u;
                 const uint32_t K1 = Hb + (uint32_t)th * 0x00010001u, K2 = Hb - (uint32_t)(th + 1) * 0x00010001u;
+                const int sh0 = (xoff + 3) - 4 * g0;                             // first interior pixel's byte in its dword
+                const int hi_last = min((G & 1) ? 4 : 8, dw - (8 * (G2 - 1) - sh0));
+                const uint32_t mask_first = (0xffu << sh0) & 0xffu, mask_last = (1u << hi_last) - 1u;
                 for (int trip = 0; trip < ntrip; trip++) {
                     const int rc = min(r, dh - 1);                                // lanes past the last row read a valid address and are masked
                     const int ga = 2 * gp, gb = min(ga + 1, G - 1);               // second dword of the last (odd) pair: clamped, masked below
@@ -614,11 +617,13 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t* __restrict__ p
                     // bit 15 of (p + c2) says "p is brighter than v + t"; no field can carry into its neighbour. Some adjacent pair of the four
                     // compass pixels (0, 4, 8, 12) is dark-dark iff (dark0 | dark8) & (dark4 | dark12), same for bright: plain and/or/add
                     // at full rate instead of four extract + sixteen min/max per pixel.
-                    uint32_t bits = 0;
+                    // The four (dword, half) results carry pixel k's verdict in bit 15 (field 0) and bit 31 (field 1); shift + and-or gathers them
+                    // into X = bits {0, 1, 4, 5} (fields 0 of the even / odd bytes of dword 0 / 1) and {16, 17, 20, 21} (fields 1), one fold
+                    // puts pixel k on bit k.
+                    uint32_t X = 0;
     #pragma unroll
                     for (int dwi = 0; dwi < 2; dwi++) {
                         const uint32_t C = dwi ? C1 : C0, U = dwi ? U1 : U0, D = dwi ? D1 : D0, W = dwi ? W1 : W0, E = dwi ? E1 : E0;
-                        uint32_t cand[2];
     #pragma unroll
                         for (int half = 0; half < 2; half++) {
                             // even bytes: one and; odd bytes: one v_perm_b32 (bytes 1 and 3 into the low byte of each 16-bit field)
@@ -627,17 +632,14 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t* __restrict__ p
                             const uint32_t p0 = field(D), p4 = field(E), p8 = field(U), p12 = field(W);
                             const uint32_t nd = ((p0 + c1) & (p8 + c1)) | ((p4 + c1) & (p12 + c1));      // bit 15: no adjacent dark pair
                             const uint32_t br = ((p0 + c2) | (p8 + c2)) & ((p4 + c2) | (p12 + c2));      // bit 15: an adjacent bright pair
-                            cand[half] = (~nd | br) & Hb;
+                            const uint32_t cand = ~nd | br;
+                            X |= (cand >> (15 - half - 4 * dwi)) & (0x00010001u << (half + 4 * dwi));
                         }
-                        // pixel k of the dword: k = 0, 2 in cand[0] bits 15, 31; k = 1, 3 in cand[1] bits 15, 31
-                        const uint32_t b4 = ((cand[0] >> 15) & 1u) | ((cand[1] >> 14) & 2u) | ((cand[0] >> 29) & 4u) | ((cand[1] >> 28) & 8u);
-                        bits |= b4 << (4 * dwi);
                     }
-                    {   // columns outside the interior (and the clamped second dword of an odd row end)
-                        const int lo = max(0, -q0), hi = min(gb == ga ? 4 : 8, dw - q0);              // valid k in [lo, hi)
-                        const uint32_t rng = hi > lo ? (((1u << hi) - 1u) & ~((1u << lo) - 1u)) : 0u;
-                        bits &= rng;
-                    }
+                    uint32_t bits = (X | (X >> 14)) & 0xffu;                             // fields 1 are pixels 2, 3 (6, 7) of their dword
+                    // columns outside the interior: only the first pair of a row (pixels left of it) and the last (right of it, and the clamped
+                    // second dword of an odd row end) have any; their masks are per-cell constants
+                    bits &= (gp == 0 ? mask_first : 0xffu) & (gp == G2 - 1 ? mask_last : 0xffu);
                     if (r >= dh) bits = 0;
                     // ordered compaction: position = survivors in lower lanes + survivors in lower bytes of this lane, from a DPP prefix sum
                     // of the per-lane counts
