@@ -503,6 +503,7 @@ __device__ __forceinline__ int wave_inclusive_scan(int v) {
     v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);     // row_bcast:31 into rows 2 and 3
     return v;
 }
+__constant__ uint32_t c_rcp16[64];            // ceil(65536 / d), d = 1 .. 63 (c_rcp16[0] unused)
 #define FAST_FETCH_TRIPS 7
 #define FAST_LAUNCHES 8
 #define FAST_CELLS_PER_WAVE 2         // measured per 256 images: 1: 0.578 ms, 2: 0.553, 4: 0.565, 8: 0.582
@@ -533,13 +534,13 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t* __restrict__ p
     // and an eighth trip); lane / pitch_dw by a 16-bit reciprocal (exact for lane < 64).
     auto request_tile = [&](const CellDesc& cd) {
         const int pdw = cd.pitch >> 2;
-        const int rcp = (65536 + pdw - 1) / pdw;                         // scalar
-        int r = (lane * rcp) >> 16, q = lane - r * pdw;
+        const int rcp = (int)c_rcp16[min(pdw, 63)];                      // ceil(65536 / pdw): a scalar table load instead of an integer division
+        int r = __mul24(lane, rcp) >> 16, q = lane - __mul24(r, pdw);          // 24-bit multiplies: full rate (v_mul_lo_u32 is quarter rate)
         const int sr = (64 * rcp) >> 16, sq = 64 - sr * pdw;
         const uint8_t* src = img + cd.src_off;
 #pragma unroll
         for (int k = 0; k < FAST_FETCH_TRIPS; k++) {
-            v[k] = *reinterpret_cast<const uint32_t*>(src + (uint32_t)(min(r, cd.ch - 1) * cd.stride + 4 * q));
+            v[k] = *reinterpret_cast<const uint32_t*>(src + (uint32_t)(__mul24(min(r, cd.ch - 1), cd.stride) + 4 * q));
             r += sr; q += sq;
             if (q >= pdw) { q -= pdw; r++; }
         }
@@ -591,8 +592,9 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t* __restrict__ p
                 const int g0 = (xoff + 3) >> 2;                                  // tile dword holding the first interior pixel
                 const int G = ((xoff + 3 + dw - 1) >> 2) - g0 + 1;               // dwords per interior row
                 const int G2 = (G + 1) >> 1;                                     // dword pairs per interior row
-                const int step_r = 64 / G2, step_g = 64 - step_r * G2;
-                int r = lane / G2, gp = lane - r * G2;
+                const int rcpG = (int)c_rcp16[min(G2, 63)];                      // ceil(65536 / G2); n / G2 = (n * rcpG) >> 16 exactly for n <= 64
+                const int step_r = (64 * rcpG) >> 16, step_g = 64 - step_r * G2;
+                int r = __mul24(lane, rcpG) >> 16, gp = lane - __mul24(r, G2);
                 const int ntrip = (dh * G2 + 63) >> 6;
                 const uint32_t M = 0x00ff00ffu, Hb = 0x80008000u;
                 const uint32_t K1 = Hb + (uint32_t)th * 0x00010001u, K2 = Hb - (uint32_t)(th + 1) * 0x00010001u;
@@ -602,7 +604,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t* __restrict__ p
                 for (int trip = 0; trip < ntrip; trip++) {
                     const int rc = min(r, dh - 1);                                // lanes past the last row read a valid address and are masked
                     const int ga = 2 * gp, gb = min(ga + 1, G - 1);               // second dword of the last (odd) pair: clamped, masked below
-                    const uint32_t* row = reinterpret_cast<const uint32_t*>(tile + (rc + 3) * tile_pitch) + g0;
+                    const uint32_t* row = reinterpret_cast<const uint32_t*>(tile + __mul24(rc + 3, tile_pitch)) + g0;
                     const uint32_t* rowU = reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(row) - 3 * tile_pitch);
                     const uint32_t* rowD = reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(row) + 3 * tile_pitch);
                     const uint32_t Lf = row[ga - 1], C0 = row[ga], C1 = row[gb], Rt = row[gb + 1];
@@ -669,8 +671,8 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t* __restrict__ p
                 if (base + lane < nsurv) {
                     rq = surv[base + lane];
                     const int r = rq >> 8, q = rq & 0xff;
-                    const int s = fast_strength(tile + (r + 3) * tile_pitch + xoff + q + 3, tile_pitch);
-                    if (s >= th) { is_c = true; sc[(r + 1) * sp + q + 1] = (uint8_t)s; }
+                    const int s = fast_strength(tile + __mul24(r + 3, tile_pitch) + xoff + q + 3, tile_pitch);
+                    if (s >= th) { is_c = true; sc[__mul24(r + 1, sp) + q + 1] = (uint8_t)s; }
                 }
                 const unsigned long long m = __ballot(is_c);
                 if (is_c) corn[ncorn + __popcll(m & lt)] = rq;
@@ -685,7 +687,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t* __restrict__ p
                     if (base + lane < ncorn) {
                         const uint16_t rq = corn[base + lane];
                         r = rq >> 8; q = rq & 0xff;
-                        const uint8_t* z = sc + (r + 1) * sp + q + 1;
+                        const uint8_t* z = sc + __mul24(r + 1, sp) + q + 1;
                         s = z[0];
                         // all eight neighbours are read before any is tested: one LDS round trip instead of a short-circuit chain of eight
                         int nb[8];
@@ -1788,6 +1790,11 @@ static int configure(viorb_extractor* h, int w, int hgt) {
             pat[i] = (uint32_t)(uint8_t)kPatternHost[4 * i] | ((uint32_t)(uint8_t)kPatternHost[4 * i + 1] << 8) |
                      ((uint32_t)(uint8_t)kPatternHost[4 * i + 2] << 16) | ((uint32_t)(uint8_t)kPatternHost[4 * i + 3] << 24);
         VIORB_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_gauss), g, sizeof(g)));
+        {
+            uint32_t rc[64]; rc[0] = 0;
+            for (int d = 1; d < 64; d++) rc[d] = (65536u + d - 1) / d;
+            VIORB_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_rcp16), rc, sizeof(rc)));
+        }
         VIORB_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_pattern), pat, sizeof(pat)));
         VIORB_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_umax), h->umax, sizeof(int) * 16));
         uint32_t om[256];
