@@ -1255,7 +1255,7 @@ __global__ __launch_bounds__(256) void k_orient_describe(const uint8_t* __restri
     for (int it = 0; it < DESC_WIN_TRIPS; it++) {
         const int i = min(lane + 64 * it, DESC_WIN_ROWS * DESC_WIN_DW - 1);
         const int wr = i / DESC_WIN_DW, wc = i - wr * DESC_WIN_DW;
-        wv[it] = *reinterpret_cast<const u32_unaligned*>(bim + (wr - DESC_WIN_HALF) * L.stride - DESC_WIN_HALF + 4 * wc);
+        wv[it] = *reinterpret_cast<const u32_unaligned*>(bim + __mul24(wr - DESC_WIN_HALF, L.stride) - DESC_WIN_HALF + 4 * wc);      // 24-bit multiplies: v_mul_lo_u32 is quarter rate
     }
     int m10 = 0, m01 = 0;
     {
@@ -1267,15 +1267,15 @@ __global__ __launch_bounds__(256) void k_orient_describe(const uint8_t* __restri
         for (int it = 0; it < 4; it++) {
             const int row = min(it * 8 + r8, PATCH - 1);                   // slab 3 has 7 rows; the 8th is masked off
             vv[it] = row - HALF_PATCH;
-            px[it] = *reinterpret_cast<const u32_unaligned*>(col + vv[it] * L.stride);
+            px[it] = *reinterpret_cast<const u32_unaligned*>(col + __mul24(vv[it], L.stride));
         }
 #pragma unroll
         for (int it = 0; it < 4; it++) {
             const uint32_t q = px[it] & c_orient_mask[it * 64 + lane];
             const int s1 = (int)__builtin_amdgcn_udot4(q, 0x01010101u, 0u, false);
             const int su = (int)__builtin_amdgcn_udot4(q, wu, 0u, false);
-            m10 += su - HALF_PATCH * s1;
-            m01 += vv[it] * s1;
+            m10 += su - __mul24(HALF_PATCH, s1);
+            m01 += __mul24(vv[it], s1);
         }
     }
     // wave sums by DPP (the inclusive scan's last lane holds the total) instead of six ds_bpermute butterflies per moment
@@ -1303,7 +1303,7 @@ __global__ __launch_bounds__(256) void k_orient_describe(const uint8_t* __restri
         const float x1 = (float)(int8_t)((q >> 16) & 0xff), y1 = (float)(int8_t)(q >> 24);
         const int r0 = round_half_even(x0 * bb + y0 * a), c0 = round_half_even(x0 * a - y0 * bb);
         const int r1 = round_half_even(x1 * bb + y1 * a), c1 = round_half_even(x1 * a - y1 * bb);
-        const int t0 = w8[r0 * (DESC_WIN_DW * 4) + c0], t1 = w8[r1 * (DESC_WIN_DW * 4) + c1];
+        const int t0 = w8[__mul24(r0, DESC_WIN_DW * 4) + c0], t1 = w8[__mul24(r1, DESC_WIN_DW * 4) + c1];
         nib |= (uint32_t)(t0 < t1) << t;
     }
     // lane i holds bits 4i..4i+3: bytes from lane pairs, dwords from 8-lane groups
