@@ -447,7 +447,7 @@ def main():
                     "local_ba = configs[3], synth720p = configs[4]")
     ap.add_argument("--streams", type=int, default=None, help="independent units per GPU per step: camera streams (euroc 512, synth720p 8), stereo pairs "
                     "(kitti_stereo 64), windows (local_ba 64)")
-    ap.add_argument("--in-flight", type=int, default=16, help="local_ba: windows kept in flight by the batch driver")
+    ap.add_argument("--in-flight", type=int, default=32, help="local_ba: windows kept in flight by the batch driver")
     ap.add_argument("--no-track-local-map", action="store_true", help="stop after TrackWithIMU's pose solve")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip the per-kernel HIP events (rooflines become null); dev aid")
