@@ -100,7 +100,9 @@ struct SearchArgs {
 // LDS plan (dynamic, per workgroup): the current frame's grid (u16 CSR), keypoint x/y/octave/angle, the first
 // SLOT candidates of every last-frame point, and the four per-keypoint work arrays. Candidates beyond SLOT
 // spill to the global scratch list.
+#ifndef SEARCH_SLOT
 #define SEARCH_SLOT 8
+#endif
 __host__ __device__ inline size_t search_lds_bytes(int cap) {
     return (size_t)(GRID_CELLS + 1) * 2 + 2 /*pad*/ + (size_t)cap * (2 + 8 + 4 + 1 + 3 /*pad to 4*/) + (size_t)cap * SEARCH_SLOT * 4 + (size_t)cap * 4 * 4 + 64;
 }
