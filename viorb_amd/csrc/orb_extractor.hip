@@ -4,13 +4,15 @@
 // HBM, nothing returns to the host between stages.
 //
 // Stage -> kernel map (reference lines in brackets):
-//   ComputePyramid [:1107-1132]            k_copy_level0 + k_resize (one launch per level, LDS-staged
-//                                          source tile, OpenCV 11-bit fixed-point bilinear)
+//   ComputePyramid [:1107-1132]            k_copy_level0 + k_resize_stream (one launch per level: strips of 32 output dword columns
+//                                          streaming down the source rows, no LDS; OpenCV 11-bit fixed-point bilinear; LDS tile
+//                                          forms k_resize2 / k_resize for geometries it cannot take)
 //   per-cell FAST, two thresholds [:765-830] k_fast_cells: one wavefront per 30-px cell, cell tile in
 //                                          LDS, score map in LDS, 3x3 NMS, ordered ballot compaction
 //   DistributeOctTree [:481-763]           k_octree: one wavefront per (image, level); stable 4-way
 //                                          segment partitions in LDS (see octree_arrays.h)
-//   GaussianBlur 7x7 s=2 [:1085-1086]      k_blur: separable, LDS tile, u16 intermediate
+//   GaussianBlur 7x7 s=2 [:1085-1086]      k_blur: separable, strips streaming down the rows (v_dot4 row sums, v_dot2 column sums over
+//                                          a register ring), no LDS; on the handle's second stream beside the quadtree
 //   IC_Angle + rBRIEF [:77-147]            k_orient_describe: one wavefront per keypoint, wave-reduced
 //                                          integer moments, 4 tests per lane, shuffle-packed bytes
 // No 19-px border is stored around the levels: nothing on this path reads it.
