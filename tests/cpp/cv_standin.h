@@ -13,6 +13,9 @@ struct KeyPoint {
 };
 struct Mat {
     int rows = 0, cols = 0; size_t step = 0; unsigned char* data = nullptr; std::vector<unsigned char> buf;
+    std::vector<float> fbuf;                                   // CV_32F payload of the few float matrices the tracking shim reads (GetWorldPos)
+    template <class T> T& at(int i) { return reinterpret_cast<T*>(fbuf.data())[i]; }
+    template <class T> const T& at(int i) const { return reinterpret_cast<const T*>(fbuf.data())[i]; }
     Mat() {}
     Mat(int r, int c, int) { create(r, c, 0); }
     void create(int r, int c, int) { rows = r; cols = c; step = (size_t)c; buf.assign((size_t)r * c, 0); data = buf.data(); }
@@ -22,8 +25,8 @@ struct Mat {
     void release() { rows = cols = 0; buf.clear(); data = nullptr; }
     Mat rowRange(int a, int b) const { Mat m(b - a, cols, 0); std::memcpy(m.data, data + (size_t)a * step, (size_t)(b - a) * cols); return m; }
     void copyTo(Mat& o) const { o = *this; o.data = o.buf.data(); }
-    Mat(const Mat& o) : rows(o.rows), cols(o.cols), step(o.step), buf(o.buf) { data = buf.empty() ? o.data : buf.data(); }
-    Mat& operator=(const Mat& o) { rows = o.rows; cols = o.cols; step = o.step; buf = o.buf; data = buf.empty() ? o.data : buf.data(); return *this; }
+    Mat(const Mat& o) : rows(o.rows), cols(o.cols), step(o.step), buf(o.buf), fbuf(o.fbuf) { data = buf.empty() ? o.data : buf.data(); }
+    Mat& operator=(const Mat& o) { rows = o.rows; cols = o.cols; step = o.step; buf = o.buf; fbuf = o.fbuf; data = buf.empty() ? o.data : buf.data(); return *this; }
 };
 typedef const Mat& InputArray;
 typedef Mat& OutputArray;

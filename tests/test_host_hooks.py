@@ -227,3 +227,23 @@ def test_cpp_shim_header_compiles_links_and_runs(tmp_path):
                            "-L", lib_dir, "-lviorb_hip", "-Wl,-rpath," + lib_dir, "-o", exe])
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and out.stdout.startswith("OK"), out.stdout + out.stderr
+
+
+def _build_tracking_shim_test(tmp_path):
+    import subprocess
+    exe = str(tmp_path / "shim_tracking_test")
+    lib_dir = os.path.join(ROOT, "viorb_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "viorb_amd", "shim"),
+                           "-I", os.path.join(ROOT, "tests", "cpp"), os.path.join(ROOT, "tests", "cpp", "shim_tracking_test.cpp"),
+                           "-L", lib_dir, "-lviorb_hip", "-Wl,-rpath," + lib_dir, "-o", exe])
+    return exe
+
+
+def test_cpp_tracking_shim_compiles_links_and_runs(tmp_path):
+    """viorb_amd/shim/viorb_tracking_shim.h (the templates behind Optimizer::PoseOptimization(Frame*, Frame* | KeyFrame*, ...) in
+    INTEGRATION.md) compiles against stand-ins that carry the reference's member names, links libviorb_hip.so and returns cleanly
+    (0 inliers, frame untouched) when there is no device — no CPU fallback."""
+    import subprocess
+    exe = _build_tracking_shim_test(tmp_path)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and out.stdout.startswith("OK"), out.stdout + out.stderr
