@@ -729,7 +729,6 @@ __global__ void k_bab_round_begin(const BaDev* __restrict__ Dv, int nwin) {
     if (c[BA_B_NEED_CHI] != 0.0) D.scal[0] = 0.0;                        // accumulator of the phase's first computeActiveErrors
     if (c[BA_B_NEED_LIN] != 0.0 && c[BA_B_FIRST] != 0.0) D.scal[3] = 0.0;  // accumulator of k_ba_max_diag
 }
-__global__ void k_bab_errors_chi(const BaDev* __restrict__ Dv) { BA_B_WINDOW(); if (c[BA_B_NEED_CHI] == 0.0) return; k_ba_errors_body(D, c[BA_B_MONO] != 0.0); }
 __global__ void k_bab_take_chi(const BaDev* __restrict__ Dv, int nwin) {
     const int w = blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= nwin) return;
@@ -738,9 +737,8 @@ __global__ void k_bab_take_chi(const BaDev* __restrict__ Dv, int nwin) {
     c[BA_CTL_CHI] = D.scal[0]; c[BA_B_NEED_CHI] = 0.0;
 }
 __global__ void k_bab_clear(const BaDev* __restrict__ Dv) { BA_B_WINDOW(); if (c[BA_B_NEED_LIN] == 0.0) return; k_ba_clear_body(D, 0); }
-__global__ void k_bab_lin_points(const BaDev* __restrict__ Dv) { BA_B_WINDOW(); if (c[BA_B_NEED_LIN] == 0.0) return; k_ba_lin_points_body(D, c[BA_B_MONO] != 0.0); }
 __global__ __launch_bounds__(256) void k_bab_hpp(const BaDev* __restrict__ Dv) { BA_B_WINDOW(); if (c[BA_B_NEED_LIN] == 0.0 || (int)blockIdx.x >= D.W) return; k_ba_hpp_body(D); }
-__global__ __launch_bounds__(256) void k_bab_imu(const BaDev* __restrict__ Dv) { BA_B_WINDOW(); if (c[BA_B_NEED_LIN] == 0.0 || (int)blockIdx.x >= D.W) return; k_ba_imu_body(D); }
+__global__ __launch_bounds__(256) void k_bab_imu(const BaDev* __restrict__ Dv) { BA_B_WINDOW(); if (c[BA_B_NEED_LIN] == 0.0 || (int)blockIdx.x >= D.W || D.pose_dim != 12) return; k_ba_imu_body(D); }
 __global__ void k_bab_max_diag(const BaDev* __restrict__ Dv) { BA_B_WINDOW(); if (c[BA_B_NEED_LIN] == 0.0 || c[BA_B_FIRST] == 0.0) return; k_ba_max_diag_body(D); }
 __global__ void k_bab_lambda0(const BaDev* __restrict__ Dv, int nwin) {
     const int w = blockIdx.x * blockDim.x + threadIdx.x;
@@ -755,8 +753,6 @@ __global__ void k_bab_dinv(const BaDev* __restrict__ Dv) { BA_B_WINDOW(); k_ba_d
 __global__ __launch_bounds__(256) void k_bab_schur(const BaDev* __restrict__ Dv) { BA_B_WINDOW(); if ((int)blockIdx.x >= D.W) return; k_ba_schur_body(D, blockIdx.x, 0, 1); }
 __global__ __launch_bounds__(BA_CHOL_THREADS) void k_bab_chol_solve(const BaDev* __restrict__ Dv) { extern __shared__ __attribute__((aligned(16))) double s_chol[]; BA_B_WINDOW(); k_ba_chol_solve_body(D, s_chol); }
 __global__ void k_bab_backsub(const BaDev* __restrict__ Dv) { BA_B_WINDOW(); k_ba_backsub_body(D, 0.0); }
-__global__ void k_bab_update(const BaDev* __restrict__ Dv) { BA_B_WINDOW(); k_ba_update_body(D); }
-__global__ void k_bab_errors(const BaDev* __restrict__ Dv) { BA_B_WINDOW(); k_ba_errors_body(D, c[BA_B_MONO] != 0.0); }
 // the Levenberg decisions of one trial, per window (:129-161), and the end of an optimize() call
 __global__ void k_bab_decide(const BaDev* __restrict__ Dv, int nwin) {
     const int w = blockIdx.x * blockDim.x + threadIdx.x;
@@ -797,11 +793,6 @@ __global__ void k_bab_decide(const BaDev* __restrict__ Dv, int nwin) {
     else c[BA_B_NEED_LIN] = 1.0;
 }
 __global__ void k_bab_restore(const BaDev* __restrict__ Dv) { BA_B_WINDOW(); if (c[BA_B_RESTORE] == 0.0) return; k_ba_restore_body(D); }
-__global__ void k_bab_gate(const BaDev* __restrict__ Dv, uint8_t* const* __restrict__ erase) {
-    const BaDev& D = Dv[blockIdx.y]; const double* c = D.ctl;
-    if (c[BA_B_DONE] != 0.0 || c[BA_B_GATE] == 0.0) return;
-    k_ba_gate_body(D, erase[blockIdx.y], c[BA_B_GATE] == 1.0 ? 1 : 0);
-}
 // after the gate: phase 0 -> second optimize() without the mono kernel (src/Optimizer.cc:2037-2099), phase 1 -> the window is finished
 __global__ void k_bab_phase(const BaDev* __restrict__ Dv, int nwin, int* __restrict__ n_done) {
     const int w = blockIdx.x * blockDim.x + threadIdx.x;
@@ -822,7 +813,7 @@ __global__ void k_bab_phase(const BaDev* __restrict__ Dv, int nwin, int* __restr
 // EdgeSE3ProjectXYZ / EdgeStereoSE3ProjectXYZ (Thirdparty/g2o/g2o/types/types_six_dof_expmap.cpp:66-250). e_obs[k] = u v uRight invSigma2
 // (uRight < 0: mono); cam[0..4] = fx fy cx cy bf. Three residual rows per edge (the third is zero for mono edges).
 __device__ __forceinline__ se3q ba_ld_se3(const double* k) { se3q s; s.r = mkq(k[0], k[1], k[2], k[3]); s.t = mk3(k[4], k[5], k[6]); return s; }
-__global__ void k_ba_se3_errors(BaDev D, int kernels) {
+__device__ __forceinline__ void k_ba_se3_errors_body(const BaDev& D, int kernels) {
     if (ba_skip(D)) return;
     __shared__ double s_red[8];
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -843,7 +834,7 @@ __global__ void k_ba_se3_errors(BaDev D, int kernels) {
     __syncthreads();
     if (threadIdx.x == 0) { double t = 0; for (int w = 0; w < (int)(blockDim.x >> 6); w++) t += s_red[w]; atomicAdd(&D.scal[0], t); }
 }
-__global__ void k_ba_se3_lin_points(BaDev D, int kernels) {
+__device__ __forceinline__ void k_ba_se3_lin_points_body(const BaDev& D, int kernels) {
     if (ba_skip(D)) return;
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= D.NP) return;
@@ -896,7 +887,7 @@ __global__ void k_ba_se3_lin_points(BaDev D, int kernels) {
     Ho[0] = H[0]; Ho[1] = H[1]; Ho[2] = H[2]; Ho[3] = H[1]; Ho[4] = H[3]; Ho[5] = H[4]; Ho[6] = H[2]; Ho[7] = H[4]; Ho[8] = H[5];
     for (int a = 0; a < 3; a++) D.bl[(size_t)p * 3 + a] = b[a];
 }
-__global__ void k_ba_se3_update(BaDev D) {
+__device__ __forceinline__ void k_ba_se3_update_body(const BaDev& D) {
     if (ba_skip(D)) return;
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q < D.W) {                                                   // VertexSE3Expmap::oplusImpl: T <- exp(update) * T
@@ -908,7 +899,7 @@ __global__ void k_ba_se3_update(BaDev D) {
     if (q < D.NP) for (int c = 0; c < 3; c++) { D.pt_bak[3 * q + c] = D.pt[3 * q + c]; D.pt[3 * q + c] += D.xl[3 * q + c]; }
 }
 // chi2 (5.991 mono / 7.815 stereo, stale error on excluded edges) / depth gate, Optimizer.cc:4170-4200 and :4207-4235
-__global__ void k_ba_se3_gate(BaDev D, uint8_t* out, int set_level) {
+__device__ __forceinline__ void k_ba_se3_gate_body(const BaDev& D, uint8_t* out, int set_level) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= D.NE) return;
     const double* ob = D.e_obs + 4 * (size_t)k;
@@ -916,6 +907,30 @@ __global__ void k_ba_se3_gate(BaDev D, uint8_t* out, int set_level) {
     const double chi = ob[3] * (D.err[3 * k] * D.err[3 * k] + D.err[3 * k + 1] * D.err[3 * k + 1] + D.err[3 * k + 2] * D.err[3 * k + 2]);
     const int bad = (chi > (ob[2] < 0 ? 5.991 : 7.815) || !(pc.z > 0.0)) ? 1 : 0;
     if (set_level) { if (bad) D.level[k] = 1; } else out[k] = (uint8_t)bad;
+}
+__global__ void k_ba_se3_errors(BaDev D, int kernels) { k_ba_se3_errors_body(D, kernels); }
+__global__ void k_ba_se3_lin_points(BaDev D, int kernels) { k_ba_se3_lin_points_body(D, kernels); }
+__global__ void k_ba_se3_update(BaDev D) { k_ba_se3_update_body(D); }
+__global__ void k_ba_se3_gate(BaDev D, uint8_t* out, int set_level) { k_ba_se3_gate_body(D, out, set_level); }
+// lock-step batch, the launches whose body depends on the kind of window (pose_dim 12: NavState, 6: vision-only SE3)
+__global__ void k_bab_errors_chi(const BaDev* __restrict__ Dv) {
+    BA_B_WINDOW(); if (c[BA_B_NEED_CHI] == 0.0) return;
+    if (D.pose_dim == 12) k_ba_errors_body(D, c[BA_B_MONO] != 0.0); else k_ba_se3_errors_body(D, c[BA_B_MONO] != 0.0);
+}
+__global__ void k_bab_lin_points(const BaDev* __restrict__ Dv) {
+    BA_B_WINDOW(); if (c[BA_B_NEED_LIN] == 0.0) return;
+    if (D.pose_dim == 12) k_ba_lin_points_body(D, c[BA_B_MONO] != 0.0); else k_ba_se3_lin_points_body(D, c[BA_B_MONO] != 0.0);
+}
+__global__ void k_bab_update(const BaDev* __restrict__ Dv) { BA_B_WINDOW(); if (D.pose_dim == 12) k_ba_update_body(D); else k_ba_se3_update_body(D); }
+__global__ void k_bab_errors(const BaDev* __restrict__ Dv) {
+    BA_B_WINDOW();
+    if (D.pose_dim == 12) k_ba_errors_body(D, c[BA_B_MONO] != 0.0); else k_ba_se3_errors_body(D, c[BA_B_MONO] != 0.0);
+}
+__global__ void k_bab_gate(const BaDev* __restrict__ Dv, uint8_t* const* __restrict__ erase) {
+    const BaDev& D = Dv[blockIdx.y]; const double* c = D.ctl;
+    if (c[BA_B_DONE] != 0.0 || c[BA_B_GATE] == 0.0) return;
+    if (D.pose_dim == 12) k_ba_gate_body(D, erase[blockIdx.y], c[BA_B_GATE] == 1.0 ? 1 : 0);
+    else k_ba_se3_gate_body(D, erase[blockIdx.y], c[BA_B_GATE] == 1.0 ? 1 : 0);
 }
 
 } // namespace viorb
@@ -1333,7 +1348,8 @@ static int ba_run_batch(int n, int max_in_flight, Prepare prepare, SetStatus set
 }
 
 // Lock-step batch of NavState windows (kernels k_bab_*): returns the first error; every window's status through set_status.
-static int ba_run_lockstep(viorb_lba_window* w, int n) {
+template <class Win, class Prepare>
+static int ba_run_lockstep(Win* w, int n, Prepare prepare) {
     if (viorb_device_count() < 1) { set_error("no HIP device: libviorb_hip has no CPU fallback"); return VIORB_ERR_NO_DEVICE; }
     VIORB_HIP_TRY(hipSetDevice(lba_device()));
     int first_error = VIORB_OK;
@@ -1343,10 +1359,9 @@ static int ba_run_lockstep(viorb_lba_window* w, int n) {
         std::vector<std::unique_ptr<BaSolve>> S(ng);
         std::vector<int> act;
         for (int i = 0; i < ng; i++) {
-            viorb_lba_window& q = w[g0 + i];
+            Win& q = w[g0 + i];
             S[i] = std::make_unique<BaSolve>();
-            const int rc = ba_prepare_navstate(*S[i], q.kfs, q.nk, q.n_local, q.prev_kf, q.preint, q.points, q.np, q.edge_idx, q.edge_obs, q.ne, q.gw, q.cam,
-                                               q.stop, q.kfs_out, q.points_out, q.erase, q.info);
+            const int rc = prepare(*S[i], q);
             q.status = rc;
             if (rc != VIORB_OK) { if (first_error == VIORB_OK) first_error = rc; continue; }
             if (S[i]->state == BaSolve::ST_DONE) continue;               // stop flag already set: inputs copied to the outputs
@@ -1439,7 +1454,10 @@ static int ba_run_lockstep(viorb_lba_window* w, int n) {
 extern "C" int viorb_local_ba_navstate_batch(viorb_lba_window* w, int n, int max_in_flight) {
     VIORB_REQUIRE(w && n >= 0, "null windows");
     static const bool per_stream = getenv("VIORB_LBA_STREAMS") != nullptr;      // the round-1 driver: one stream and host LM loop per window
-    if (!per_stream) return ba_run_lockstep(w, n);
+    if (!per_stream) return ba_run_lockstep(w, n, [](BaSolve& S, viorb_lba_window& q) {
+        return ba_prepare_navstate(S, q.kfs, q.nk, q.n_local, q.prev_kf, q.preint, q.points, q.np, q.edge_idx, q.edge_obs, q.ne, q.gw, q.cam, q.stop,
+                                   q.kfs_out, q.points_out, q.erase, q.info);
+    });
     return ba_run_batch(n, max_in_flight,
         [&](int i, BaSolve& S) {
             viorb_lba_window& q = w[i];
@@ -1509,6 +1527,10 @@ extern "C" int viorb_local_ba_se3(const double* kfs, int nk, int n_local, const 
 
 extern "C" int viorb_local_ba_se3_batch(viorb_lba_se3_window* w, int n, int max_in_flight) {
     VIORB_REQUIRE(w && n >= 0, "null windows");
+    static const bool per_stream = getenv("VIORB_LBA_STREAMS") != nullptr;      // the round-1 driver: one stream and host LM loop per window
+    if (!per_stream) return ba_run_lockstep(w, n, [](BaSolve& S, viorb_lba_se3_window& q) {
+        return ba_prepare_se3(S, q.kfs, q.nk, q.n_local, q.points, q.np, q.edge_idx, q.edge_obs, q.ne, q.intr5, q.stop, q.kfs_out, q.points_out, q.erase, q.info);
+    });
     return ba_run_batch(n, max_in_flight,
         [&](int i, BaSolve& S) {
             viorb_lba_se3_window& q = w[i];
