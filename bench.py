@@ -34,7 +34,7 @@ CONFIGS = {
     # name: width, height, features, default units per GPU, BASELINE.json configs index
     "euroc": dict(w=752, h=480, nfeat=1000, streams=512, baseline_config=1),
     "synth720p": dict(w=1280, h=720, nfeat=1500, streams=8, baseline_config=4),
-    "kitti_stereo": dict(w=1241, h=376, nfeat=2000, streams=64, baseline_config=2),
+    "kitti_stereo": dict(w=1241, h=376, nfeat=2000, streams=256, baseline_config=2),
     "local_ba": dict(w=752, h=480, nfeat=1000, streams=64, baseline_config=3),
 }
 EXTRACT_KERNELS = ("k_copy_level0", "k_resize", "k_fast_cells", "k_octree", "k_octree_large", "k_blur", "k_orient_describe")
@@ -446,7 +446,7 @@ def main():
     ap.add_argument("--config", choices=sorted(CONFIGS), default="euroc", help="BASELINE.json config: euroc = configs[1] (default), kitti_stereo = configs[2], "
                     "local_ba = configs[3], synth720p = configs[4]")
     ap.add_argument("--streams", type=int, default=None, help="independent units per GPU per step: camera streams (euroc 512, synth720p 8), stereo pairs "
-                    "(kitti_stereo 64), windows (local_ba 64)")
+                    "(kitti_stereo 256), windows (local_ba 64)")
     ap.add_argument("--in-flight", type=int, default=32, help="local_ba: windows kept in flight by the batch driver")
     ap.add_argument("--no-track-local-map", action="store_true", help="stop after TrackWithIMU's pose solve")
     ap.add_argument("--no-cpu-baseline", action="store_true")
