@@ -255,6 +255,33 @@ def run_tracking(args, cfg, rank, dev_index, dev, world):
             if not args.all_kernel_events:                  # one of FAST's sub-launches per step was timed
                 roof["kernel_ms_per_step"]["k_fast_cells"] = round(tot_ms / args.steps * (-(-S // per_launch)), 4)
             roof["launches_per_step"] = -(-S // per_launch); roof["images_per_launch"] = per_launch
+            roof["note"] += ("; avg_launch_us / achieved / frac are the launch beside the tracking stream's kernels (the two streams share "
+                             "every CU); 'alone' = the same launch in an extraction-only pass after the timed region")
+            try:                                            # context, outside the timed region: the extractor alone, same batch, same images
+                ex_alone = viorb_amd.ORBextractor(NFEAT, 1.2, 8, 20, 7, max_batch=S, device=dev_index)
+                for _ in range(2):
+                    ex_alone.extract_batch_device(frames[0])
+                torch.cuda.synchronize()
+                L.viorb_profile_select(b"k_fast_cells"); L.viorb_profile_reset(); L.viorb_profile_enable(1)
+                t_a = time.perf_counter()
+                for i in range(8):
+                    ex_alone.extract_batch_device(frames[i % N_FRAMES])
+                torch.cuda.synchronize()
+                wall = (time.perf_counter() - t_a) / 8
+                L.viorb_profile_enable(0)
+                nm2 = C.create_string_buffer(4096); ms2 = (C.c_double * 64)(); cl2 = (C.c_int * 64)(); n2 = C.c_int()
+                L.viorb_profile_read(nm2, 4096, ms2, cl2, 64, C.byref(n2))
+                pa = {nm_: (ms2[i], cl2[i]) for i, nm_ in enumerate(nm2.value.decode().split("\n")[:n2.value])}
+                if pa.get("k_fast_cells", (0, 0))[1]:
+                    a_s = pa["k_fast_cells"][0] / pa["k_fast_cells"][1] * 1e-3
+                    ext_bytes = (4 * P + NFEAT * (709 + 961 + 60)) * S
+                    roof["alone"] = {"avg_launch_us": round(a_s * 1e6, 2), "achieved": round(bpl / a_s / 1e9, 2), "frac": round(bpl / a_s / 1e9 / HBM_PEAK_GBS, 5),
+                                     "extractor_ms_per_batch": round(wall * 1e3, 3), "extractor_images_per_s": round(S / wall, 1),
+                                     "extractor_algorithmic_GBps": round(ext_bytes / wall / 1e9, 1),
+                                     "extractor_frac": round(ext_bytes / wall / 1e9 / HBM_PEAK_GBS, 5)}
+                del ex_alone
+            except Exception as e:                          # never fail the bench line over the context figure
+                roof["alone"] = {"error": str(e)[:200]}
         if "k_pose_opt_vi" in prof and prof["k_pose_opt_vi"][1]:
             # FLOP model of one solve (counted from the kernel source): every evaluation of the objective costs
             # 190 FLOP per reprojection edge (projection, Huber weight, 2 x 6 camera-frame Jacobian, 20 + 6 accumulations) plus
