@@ -940,7 +940,12 @@ using namespace viorb;
 namespace {
 // A solve borrows a context (a HIP stream + a device arena) from a small pool, so that concurrent callers (the LocalMapping threads
 // of several SLAM instances) run on different streams and no call pays hipMalloc / hipFree, which synchronise the whole device.
-struct BaCtx { hipStream_t st = nullptr; void* arena = nullptr; size_t bytes = 0; double* pinned = nullptr; /* 64 doubles of page-locked host memory for the LM scalars */ int device = 0; };
+struct BaCtx {
+    hipStream_t st = nullptr; void* arena = nullptr; size_t bytes = 0;
+    double* pinned = nullptr;           // 64 doubles of page-locked host memory for the LM scalars
+    uint8_t* stage = nullptr; size_t stage_bytes = 0;       // page-locked staging copy of a window's inputs (lives until the context's next window)
+    int device = 0;
+};
 std::mutex g_ctx_mu;
 std::vector<BaCtx*> g_ctx_free;
 std::atomic<int> g_lba_device{-1};
@@ -1007,9 +1012,21 @@ struct BaBuf {
             c->bytes = want;
         }
         uint8_t* base = static_cast<uint8_t*>(c->arena);
-        if (!mirror.empty() && hipMemcpyAsync(base, mirror.data(), mirror.size(), hipMemcpyHostToDevice, c->st) != hipSuccess) return false;
+        // The inputs go through the context's page-locked staging buffer: a truly asynchronous copy, and no synchronisation per window (a
+        // pageable source made every upload a blocking staged copy + a stream synchronise: half of a batch's wall time was spent here).
+        // The staging buffer belongs to the context, and a context serves one window at a time.
+        if (!mirror.empty()) {
+            if (c->stage_bytes < mirror.size()) {
+                if (c->stage) (void)hipHostFree(c->stage);
+                c->stage = nullptr; c->stage_bytes = 0;
+                const size_t want = mirror.size() + mirror.size() / 4;
+                if (hipHostMalloc(reinterpret_cast<void**>(&c->stage), want) != hipSuccess) { c->stage = nullptr; return false; }
+                c->stage_bytes = want;
+            }
+            memcpy(c->stage, mirror.data(), mirror.size());
+            if (hipMemcpyAsync(base, c->stage, mirror.size(), hipMemcpyHostToDevice, c->st) != hipSuccess) return false;
+        }
         if (work_bytes && hipMemsetAsync(base + in_bytes, 0, work_bytes, c->st) != hipSuccess) return false;
-        if (hipStreamSynchronize(c->st) != hipSuccess) return false;          // the mirror dies with this object
         for (const Item& it : items) *it.slot = base + (it.work ? in_bytes + it.off : it.off);
         return true;
     }
@@ -1434,17 +1451,33 @@ static int ba_run_lockstep(Win* w, int n, Prepare prepare) {
             }
         }
         if (done < na) { set_error("window solve did not finish in %d rounds", MAX_ROUNDS); return VIORB_ERR_HIP; }
-        std::vector<double> ch((size_t)na * BA_B_N);
+        // results come back through every window's page-locked staging buffer (its inputs are long consumed): asynchronous copies, one
+        // synchronisation for the group, then plain memcpy into the callers' (pageable) arrays
         for (int a = 0; a < na; a++) {
             BaSolve& B = *S[act[a]];
-            VIORB_HIP_TRY(hipMemcpyAsync(B.kfs_out, B.D.kf, (size_t)B.D.W * B.D.kf_stride * sizeof(double), hipMemcpyDeviceToHost, st));
-            VIORB_HIP_TRY(hipMemcpyAsync(B.points_out, B.D.pt, (size_t)B.D.NP * 3 * sizeof(double), hipMemcpyDeviceToHost, st));
-            VIORB_HIP_TRY(hipMemcpyAsync(B.erase, B.d_erase, B.D.NE, hipMemcpyDeviceToHost, st));
-            VIORB_HIP_TRY(hipMemcpyAsync(&ch[(size_t)a * BA_B_N], B.D.ctl, sizeof(double) * BA_B_N, hipMemcpyDeviceToHost, st));
+            BaCtx* c = B.lease.c;
+            const size_t nkf = (size_t)B.D.W * B.D.kf_stride * sizeof(double), npt = (size_t)B.D.NP * 3 * sizeof(double), ner = (size_t)B.D.NE, nct = sizeof(double) * BA_B_N;
+            const size_t o1 = (nkf + 255) & ~(size_t)255, o2 = o1 + ((npt + 255) & ~(size_t)255), o3 = o2 + ((ner + 255) & ~(size_t)255), need = o3 + nct;
+            if (c->stage_bytes < need) {
+                if (c->stage) (void)hipHostFree(c->stage);
+                c->stage = nullptr; c->stage_bytes = 0;
+                VIORB_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->stage), need));
+                c->stage_bytes = need;
+            }
+            VIORB_HIP_TRY(hipMemcpyAsync(c->stage, B.D.kf, nkf, hipMemcpyDeviceToHost, st));
+            VIORB_HIP_TRY(hipMemcpyAsync(c->stage + o1, B.D.pt, npt, hipMemcpyDeviceToHost, st));
+            VIORB_HIP_TRY(hipMemcpyAsync(c->stage + o2, B.d_erase, ner, hipMemcpyDeviceToHost, st));
+            VIORB_HIP_TRY(hipMemcpyAsync(c->stage + o3, B.D.ctl, nct, hipMemcpyDeviceToHost, st));
         }
         VIORB_HIP_TRY(hipStreamSynchronize(st));
         for (int a = 0; a < na; a++) {
-            double* info = S[act[a]]->info; const double* c = &ch[(size_t)a * BA_B_N];
+            BaSolve& B = *S[act[a]];
+            const uint8_t* sg = B.lease.c->stage;
+            const size_t nkf = (size_t)B.D.W * B.D.kf_stride * sizeof(double), npt = (size_t)B.D.NP * 3 * sizeof(double), ner = (size_t)B.D.NE;
+            const size_t o1 = (nkf + 255) & ~(size_t)255, o2 = o1 + ((npt + 255) & ~(size_t)255), o3 = o2 + ((ner + 255) & ~(size_t)255);
+            memcpy(B.kfs_out, sg, nkf); memcpy(B.points_out, sg + o1, npt); memcpy(B.erase, sg + o2, ner);
+            const double* c = reinterpret_cast<const double*>(sg + o3);
+            double* info = B.info;
             info[0] = c[BA_B_CHI0]; info[1] = c[BA_B_CHI1]; info[2] = c[BA_B_ITS0]; info[3] = c[BA_B_ITS1];
         }
     }
