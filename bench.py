@@ -74,10 +74,14 @@ def _gen_stream(args):
     return dict(frames=s["frames"], imu=s["imu"], t=s["t"], ns_true=s["ns_true"], pose_true=s["pose_true"], period=s["period"], cam=s["cam"], gw=s["gw"])
 
 
-def generate_streams(seeds, w=752, h=480):
-    """CPU-side synthetic data (before anything touches the GPU)."""
+def generate_streams(seeds, w=752, h=480, procs=None):
+    """CPU-side synthetic data (before anything touches the GPU). `procs=1` generates in-process: under `rocprofv3 --pmc` the profiler's
+    preloaded library has initialised the GPU before Python starts, and forked pool workers of such a process never exit (that, not a
+    kernel-ordering bug, is why the round-2 bench "did not finish" under --pmc: profiles/README.md, round 3)."""
     import multiprocessing as mp
     nproc = max(1, min(len(seeds), (os.cpu_count() or 2) // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1"))), 16))
+    if procs:
+        nproc = max(1, min(nproc, procs))
     jobs = [(s, w, h) for s in seeds]
     if nproc == 1:
         return [_gen_stream(j) for j in jobs]
@@ -156,8 +160,8 @@ def run_tracking(args, cfg, rank, dev_index, dev, world):
     TLM = not args.no_track_local_map
     # at most 256 distinct synthetic streams are generated per rank (CPU time); beyond that the streams repeat (own copy of the images, independent
     # tracker state each)
-    distinct = min(S, 256)
-    base = generate_streams(stream_seeds(rank, distinct), W_IMG, H_IMG)
+    distinct = min(S, args.distinct or 256)
+    base = generate_streams(stream_seeds(rank, distinct), W_IMG, H_IMG, args.gen_procs)
     streams = [base[i % distinct] for i in range(S)]
     up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     frames = up(np.stack([s["frames"] for s in streams], 1))                   # [F, S, h, w] u8
@@ -474,6 +478,9 @@ def main():
                     "local_ba = configs[3], synth720p = configs[4]")
     ap.add_argument("--streams", type=int, default=None, help="independent units per GPU per step: camera streams (euroc 512, synth720p 8), stereo pairs "
                     "(kitti_stereo 256), windows (local_ba 64)")
+    ap.add_argument("--distinct", type=int, default=None, help="tracking configs: distinct synthetic streams generated per rank (default min(streams, 256))")
+    ap.add_argument("--gen-procs", type=int, default=None, help="worker processes of the synthetic-stream generator; 1 = in-process, no fork (needed under "
+                    "rocprofv3 --pmc, whose preloaded library initialises the GPU before Python starts)")
     ap.add_argument("--in-flight", type=int, default=32, help="local_ba: windows kept in flight by the batch driver")
     ap.add_argument("--no-track-local-map", action="store_true", help="stop after TrackWithIMU's pose solve")
     ap.add_argument("--no-cpu-baseline", action="store_true")

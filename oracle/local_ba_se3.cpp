@@ -32,7 +32,7 @@ void edge_error(const BaSe3Problem& P, const Se3Pose& T, V3 Xw, const BaSe3Edge&
     const V3 p = map_pt(T, Xw);
     if (ed.ur < 0) { e[0] = ed.u - (p.x / p.z * P.fx + P.cx); e[1] = ed.v - (p.y / p.z * P.fy + P.cy); e[2] = 0; }
     else {
-        const float invz = 1.0f / (float)p.z;
+        const float invz = (float)(1.0 / p.z);                          // double division, one rounding to float (types_six_dof_expmap.cpp:151)
         const double r0 = p.x * invz * P.fx + P.cx, r1 = p.y * invz * P.fy + P.cy, r2 = r0 - P.bf * invz;
         e[0] = ed.u - r0; e[1] = ed.v - r1; e[2] = ed.ur - r2;
     }

@@ -453,7 +453,7 @@ Se3Result pose_opt_se3(const float* pose12, double fx, double fy, double cx, dou
         const V3 p = est.map(e.o.Xw);
         if (!e.stereo) { e.err[0] = e.o.u - (p.x / p.z * fx + cx); e.err[1] = e.o.v - (p.y / p.z * fy + cy); e.err[2] = 0; }
         else {
-            const float invz = 1.0f / (float)p.z;                      // the reference computes this reciprocal in float
+            const float invz = (float)(1.0 / p.z);                      // `1.0f/trans_xyz[2]` with a double z: divided in double, rounded once to float (types_six_dof_expmap.cpp:300)
             const double r0 = p.x * invz * fx + cx, r1 = p.y * invz * fy + cy, r2 = r0 - bf * invz;
             e.err[0] = e.o.u - r0; e.err[1] = e.o.v - r1; e.err[2] = e.o.ur - r2;
         }

@@ -237,7 +237,7 @@ VIO_HD int se3_edge(const se3q& s, d3 Xw, double u, double v, double ur, double 
     const bool stereo = !(ur < 0);
     if (!stereo) { e[0] = u - (p.x / p.z * fx + cx); e[1] = v - (p.y / p.z * fy + cy); e[2] = 0; }
     else {
-        const float invzf = 1.0f / (float)p.z;
+        const float invzf = (float)(1.0 / p.z);                     // `1.0f/trans_xyz[2]`: double division rounded once to float (types_six_dof_expmap.cpp:300)
         const double r0 = p.x * invzf * fx + cx, r1 = p.y * invzf * fy + cy, r2 = r0 - bf * invzf;
         e[0] = u - r0; e[1] = v - r1; e[2] = ur - r2;
     }
