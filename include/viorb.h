@@ -166,10 +166,25 @@ typedef struct viorb_frontend_config {
     int32_t check_orientation;            /* ORBmatcher(nnratio, checkOri) second argument */
     double  gyr_meas_cov, acc_meas_cov;   /* IMUData::_gyrMeasCov / _accMeasCov diagonal; <= 0 selects */
     double  acc_bias_rw2;                 /* the reference constants (src/IMU/imudata.cpp:31-41)       */
+    float   dist_coef[5];                 /* Frame::mDistCoef = k1 k2 p1 p2 k3 (Tracking.cc:105-117). dist_coef[0] == 0: the camera is
+                                             treated as undistorted, mvKeysUn = mvKeys (Frame.cc:586-590) */
+    int32_t reserved0;
 } viorb_frontend_config;
 
 int viorb_frontend_create(const viorb_frontend_config* cfg, int max_batch, int cap, int device, viorb_frontend** out);
 int viorb_frontend_destroy(viorb_frontend* h);
+
+/* Frame::UndistortKeyPoints (reference src/Frame.cc:584-614) for a batch: kps_un[b][i] = kps[b][i] with pt replaced by
+ * cv::undistortPoints(pt, mK, mDistCoef, R = Mat(), P = mK) — OpenCV 2.4: double inside, five fixed-point iterations of the
+ * radial-tangential model, float out. Everything downstream of the extractor (grid, searches, edges) reads mvKeysUn. With
+ * cfg.dist_coef[0] == 0 the records are copied unchanged. kps_un may alias kps. */
+int viorb_frontend_undistort_device(viorb_frontend* h, const viorb_keypoint* kps, const int32_t* count, int batch,
+                                    viorb_keypoint* kps_un, void* stream);
+/* Host-buffer forms (run on the current HIP device): cv::undistortPoints on n float pixel pairs, intr4 = fx fy cx cy (Frame::mK),
+ * dist5 = k1 k2 p1 p2 k3; and Frame::ComputeImageBounds (src/Frame.cc:616-644): bounds4 = mnMinX mnMaxX mnMinY mnMaxY from the four
+ * undistorted image corners (0, width, 0, height when dist5[0] == 0). */
+int viorb_undistort_points(const float* xy, int n, const float* intr4, const float* dist5, float* xy_out);
+int viorb_image_bounds(int width, int height, const float* intr4, const float* dist5, float* bounds4);
 
 /* cell_start[b][64*48+1], cell_idx[b][cap]: CSR of Frame::mGrid in storage order cell = ix*48 + iy. */
 int viorb_frontend_grid_device(viorb_frontend* h, const viorb_keypoint* kps, const int32_t* count, int batch,
@@ -325,7 +340,7 @@ int viorb_frontend_self_index_device(viorb_frontend* h, const uint8_t* flags, co
 typedef struct viorb_tracker viorb_tracker;   /* opaque */
 typedef struct viorb_tracker_config {
     viorb_extractor_params extractor;
-    viorb_frontend_config  frontend;      /* bounds, scale tables and nlevels are filled from width / height / the extractor */
+    viorb_frontend_config  frontend;      /* bounds (Frame::ComputeImageBounds from width / height / dist_coef), scale tables and nlevels are filled in */
     int32_t width, height, batch, device;
     float   th_projection;                /* SearchByProjection window: 15 mono, 7 stereo (src/Tracking.cc:427-431) */
     int32_t track_local_map;              /* 0: TrackWithIMU only */

@@ -505,3 +505,23 @@ def local_ba_se3(kfs, n_local, points, edge_idx, edge_obs, intr5, stop=None):
     L.ora_local_ba_se3(_p(kfs), len(kfs), n_local, _p(points), len(points), _p(ei), _p(eo), len(ei), _p(_f64(intr5, 5)), _p(st) if st is not None else None,
                        _p(ko), _p(po), _p(er), _p(info))
     return dict(kfs=ko, points=po, erase=er[:len(ei)], chi2_first=info[0], chi2_final=info[1], its_first=int(info[2]), its_second=int(info[3]))
+
+
+def undistort_points(xy, K4, dist5):
+    """cv::undistortPoints(mat, mat, mK, mDistCoef, Mat(), mK) of Frame::UndistortKeyPoints (reference src/Frame.cc:584-614): xy [n,2] float32
+    pixels -> undistorted float32 pixels. K4 = fx fy cx cy, dist5 = k1 k2 p1 p2 k3 (float32, as Frame::mK / mDistCoef)."""
+    L = lib()
+    L.ora_undistort_points.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    xy = np.ascontiguousarray(xy, np.float32).reshape(-1, 2)
+    out = np.empty_like(xy)
+    L.ora_undistort_points(_p(xy), len(xy), _p(np.ascontiguousarray(K4, np.float32)), _p(np.ascontiguousarray(dist5, np.float32)), _p(out))
+    return out
+
+
+def image_bounds(width, height, K4, dist5):
+    """Frame::ComputeImageBounds (reference src/Frame.cc:616-644): float32 [mnMinX, mnMaxX, mnMinY, mnMaxY]."""
+    L = lib()
+    L.ora_image_bounds.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    b = np.zeros(4, np.float32)
+    L.ora_image_bounds(int(width), int(height), _p(np.ascontiguousarray(K4, np.float32)), _p(np.ascontiguousarray(dist5, np.float32)), _p(b))
+    return b

@@ -11,14 +11,25 @@ from viorb_amd import synth
 class OracleTracker:
     LOCAL_FRAMES = 2
 
-    def __init__(self, cam, gw, width=752, height=480, nfeatures=1000, th=15.0, compute_marg=True, track_local_map=False):
+    def __init__(self, cam, gw, width=752, height=480, nfeatures=1000, th=15.0, compute_marg=True, track_local_map=False, dist_coef=None):
         self.ex = ora.Extractor(nfeatures, 1.2, 8, 20, 7)
         self.tab = self.ex.tables()
         self.cam, self.gw, self.th = np.asarray(cam, np.float64), np.asarray(gw, np.float64), float(th)
-        self.bounds = (0.0, float(width), 0.0, float(height))
+        # Frame::ComputeImageBounds / UndistortKeyPoints (Frame.cc:584-644): mK and mDistCoef are float matrices
+        self.K4 = np.asarray(cam[:4], np.float32)
+        self.dist = np.zeros(5, np.float32) if dist_coef is None else np.asarray(dist_coef, np.float32)
+        self.bounds = tuple(float(v) for v in ora.image_bounds(width, height, self.K4, self.dist))
         self.compute_marg = compute_marg
         self.track_local_map = track_local_map
         self.local = []                      # newest first: (pts_f, flags, desc) of the frames before the last one
+
+    def _extract(self, image):
+        """ExtractORB + UndistortKeyPoints (Frame.cc:168-171): everything downstream reads mvKeysUn."""
+        k, d = self.ex(image)
+        if self.dist[0] != 0 and len(k):
+            un = ora.undistort_points(np.stack([k["x"], k["y"]], 1), self.K4, self.dist)
+            k = k.copy(); k["x"] = un[:, 0]; k["y"] = un[:, 1]
+        return k, d
 
     def _adopt(self, kps, desc, pose_true, ns, t):
         if self.track_local_map and hasattr(self, "last_pts_f"):
@@ -31,7 +42,7 @@ class OracleTracker:
             self.last_pts_f = synth.local_points_f32(kps["octave"], pose_true, self.last_Pw, self.tab["scale"])
 
     def bootstrap(self, image, pose_true, t0, ns0, marg_cov_inv):
-        k, d = self.ex(image)
+        k, d = self._extract(image)
         self.marg_cov_inv = np.asarray(marg_cov_inv, np.float64).reshape(12, 12).copy()
         self._adopt(k, d, pose_true, np.asarray(ns0, np.float64), t0)
 
@@ -42,7 +53,7 @@ class OracleTracker:
         relocalisation and mnMatchesInliers < 30 (false without revert, :330-331). map_updated selects PoseOptimization(Frame, KeyFrame)
         with the last frame as the key frame it was just promoted to (:454, :243). last_points = (Pw, flags, pts_f) overrides the synthetic
         map points the NEW last frame gets (tests of the failure paths)."""
-        kps, desc = self.ex(image)
+        kps, desc = self._extract(image)
         last = self.last_ns
         pre = ora.preintegrate(imu, last[10:13], last[13:16], self.t_last, t_cur)
         cur_ns = ora.predict_navstate(last, pre, self.gw)

@@ -450,3 +450,10 @@ int ora_local_ba_se3(const double* kfs, int nk, int n_local, const double* point
     return 0;
 }
 } // extern "C"
+
+// ---- Frame::UndistortKeyPoints / ComputeImageBounds (undistort.cpp)
+#include "undistort.h"
+extern "C" {
+void ora_undistort_points(const float* xy, int n, const float* K4, const float* dist5, float* xy_out) { ora::undistort_points(xy, n, K4, dist5, xy_out); }
+void ora_image_bounds(int width, int height, const float* K4, const float* dist5, float* bounds4) { ora::image_bounds(width, height, K4, dist5, bounds4); }
+}

@@ -68,7 +68,7 @@ StereoResult compute_stereo_matches(const std::vector<KeyPoint>& keysL, const st
             float bestuR = sf[kpL.octave] * ((float)scaleduR0 + (float)bestincR + deltaR);
             float disparity = (uL - bestuR);
             if (disparity >= minD && disparity < maxD) {
-                if (disparity <= 0) { disparity = 0.01f; bestuR = uL - 0.01f; }
+                if (disparity <= 0) { disparity = 0.01f; bestuR = (float)((double)uL - 0.01); }   // "bestuR = uL-0.01": a double subtraction rounded once (Frame.cc:797)
                 R.depth[iL] = mbf / disparity; R.uRight[iL] = bestuR; R.best_sad[iL] = best;
                 vDistIdx.push_back(std::make_pair(best, iL));
             }

@@ -77,7 +77,7 @@ void update_ns(NavState& ns, const Preint& p, V3 gw) {
     const V3 Pwbpre = ns.P, Vwbpre = ns.V; const M3 Rwbpre = ns.R.matrix();
     const double dt = p.dt;
     const M3 Rwb = Rwbpre * p.dR;
-    const V3 Pwb = Pwbpre + Vwbpre * dt + gw * (0.5 * dt * dt) + Rwbpre * p.dP;
+    const V3 Pwb = Pwbpre + Vwbpre * dt + ((gw * 0.5) * dt) * dt + Rwbpre * p.dP;
     const V3 Vwb = Vwbpre + gw * dt + Rwbpre * p.dV;
     ns.P = Pwb; ns.V = Vwb; ns.R = SO3(Rwb);
 }

@@ -15,12 +15,14 @@ def _run(width, height, nfeat, nframes, plan):
     from viorb_amd.tracker import NativeTracker
     from oracle.harness import OracleTracker
     B = plan["B"]
-    streams = [make_periodic_stream(200 + (b % plan.get("distinct", B)), nframes, width, height) for b in range(B)]
+    dist = plan.get("dist")
+    seeds = plan.get("seeds") or [200 + (b % plan.get("distinct", B)) for b in range(B)]
+    streams = [make_periodic_stream(seeds[b], nframes, width, height, dist=dist) for b in range(B)]
     dev = torch.device("cuda", 0)
     up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     cam, gw = streams[0]["cam"], streams[0]["gw"]
-    tr = NativeTracker(cam, gw, B, width, height, nfeat, track_local_map=True)
-    twins = [OracleTracker(cam, gw, width, height, nfeat, track_local_map=True) for _ in range(B)]
+    tr = NativeTracker(cam, gw, B, width, height, nfeat, track_local_map=True, dist_coef=dist)
+    twins = [OracleTracker(cam, gw, width, height, nfeat, track_local_map=True, dist_coef=dist) for _ in range(B)]
     mci = np.eye(12) * 1e3
     fr = lambda j: np.stack([plan["image"](b, j, streams) for b in range(B)])
     tr.bootstrap(up(fr(0)), up(np.stack([s["pose_true"][0] for s in streams])), up(np.array([s["t"][0] for s in streams])),
@@ -66,6 +68,10 @@ def _run(width, height, nfeat, nframes, plan):
                 assert abs(g["info2"][b, 1] - r["final_chi2_2"]) <= 1e-5 * abs(r["final_chi2_2"]), tag
             assert np.allclose(g["final_ns"][b], r["final_ns"], rtol=0, atol=1e-7), tag
             assert np.allclose(g["last_ns"][b], tw.last_ns, rtol=0, atol=1e-7), tag
+            # the prior information handed to the next frame (mMargCovInv): the new marginal after a tracked frame (states 0 / 4), the
+            # old one after a failure (k_track_final's select)
+            M = tw.marg_cov_inv
+            assert np.allclose(g["final_marg"][b].reshape(12, 12), M, rtol=1e-4, atol=1e-6 * np.abs(M).max()), tag
     return seen
 
 
@@ -96,14 +102,19 @@ def test_native_tracker_failure_paths_equal_oracle_twin():
                 pf[:, :3] = Pw
                 return Pw, fl, pf
             return f
+        if b in (5, 6) and j in (1, 2, 3, 4):        # only a handful of the map points have observations: 2 of them on the frames that become
+            K = 2 if j <= 2 else 16                  # the local map, 16 on the last frame -> stage 1 keeps >= 10 map matches (no REVERT_1) but
+            def f(Pw, fl, pf):                       # TrackLocalMap counts < 15 inliers: REVERT_2 on stream 5, RELOC_FEW on stream 6
+                fl = np.full(len(fl), 1, np.uint8); fl[::max(1, len(fl) // K)][:K] |= 4
+                return Pw, fl, pf
+            return f
         return None
 
-    plan = dict(B=5, distinct=4, image=image, last_points=last_points,
+    plan = dict(B=7, seeds=[200, 201, 202, 203, 200, 203, 203], image=image, last_points=last_points,
                 map_updated=lambda b, j: (b == 0 and j in (2, 5)) or (b == 2 and j == 4),
-                recent_reloc=lambda b, j: b == 4 or (b == 0 and j == 3))
-    seen = _run(752, 480, 1000, 6, plan)
-    assert {0, 1}.issubset(seen), seen
-    assert seen & {2, 3, 4}, seen                    # at least one revert / relocalisation gate was taken
+                recent_reloc=lambda b, j: b in (4, 6) or (b == 0 and j == 3))
+    seen = _run(752, 480, 1000, 7, plan)
+    assert {0, 1, 2, 3, 4}.issubset(seen), seen      # every outcome of the two-stage sequence occurred and matched the oracle twin
 
 
 def test_native_tracker_1280x720_1500_features_equals_twin():
@@ -111,4 +122,15 @@ def test_native_tracker_1280x720_1500_features_equals_twin():
     plan = dict(B=2, image=lambda b, j, streams: streams[b]["frames"][j], last_points=lambda b, j: None,
                 map_updated=lambda b, j: b == 1 and j == 2, recent_reloc=lambda b, j: False)
     seen = _run(1280, 720, 1500, 4, plan)
+    assert seen == {0}, seen
+
+
+def test_native_tracker_euroc_lens_distortion_equals_twin():
+    """Row x2: Frame::UndistortKeyPoints + ComputeImageBounds (reference src/Frame.cc:584-644) on the device path. The EuRoC camera of the
+    reference's settings file (Examples/ROS/ORB_VIO/launch/euroc.yaml:64-67, k1 = -0.283) — images rendered through that lens, keypoints
+    undistorted ahead of the grid, bounds from the undistorted corners — frame by frame against the oracle twin."""
+    from viorb_amd.synth import EUROC_DIST
+    plan = dict(B=3, dist=EUROC_DIST, image=lambda b, j, streams: streams[b]["frames"][j], last_points=lambda b, j: None,
+                map_updated=lambda b, j: b == 1 and j == 2, recent_reloc=lambda b, j: False)
+    seen = _run(752, 480, 1000, 5, plan)
     assert seen == {0}, seen

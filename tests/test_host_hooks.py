@@ -46,7 +46,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(L, n), "include/viorb.h declares %s but libviorb_hip.so does not export it" % n
         assert n in capi.SIGNATURES, "capi.py has no ctypes signature for %s" % n
-    assert L.viorb_abi_version() == 1
+    assert L.viorb_abi_version() == 2
     assert isinstance(L.viorb_last_error(), bytes)
 
 

@@ -6,4 +6,4 @@ fallback: if the library is missing, `viorb_amd.lib()` raises.
 """
 from .capi import lib, ViorbError, KP_DTYPE  # noqa: F401
 from .extractor import ORBextractor  # noqa: F401
-from .frontend import Frontend, ORBmatcher, PoseOptimization, PoseOptimizationSE3, LocalBundleAdjustmentNavState, LocalBundleAdjustmentNavStateBatch, LocalBundleAdjustment, LocalBundleAdjustmentBatch, ORBVocabulary, SearchByBoW, SearchForTriangulation, Fuse, preintegrate, descriptor_distance, match_bruteforce, SearchLocalPoints  # noqa: F401
+from .frontend import Frontend, ORBmatcher, PoseOptimization, PoseOptimizationSE3, LocalBundleAdjustmentNavState, LocalBundleAdjustmentNavStateBatch, LocalBundleAdjustment, LocalBundleAdjustmentBatch, ORBVocabulary, SearchByBoW, SearchForTriangulation, Fuse, preintegrate, descriptor_distance, match_bruteforce, SearchLocalPoints, UndistortKeyPoints, ComputeImageBounds  # noqa: F401

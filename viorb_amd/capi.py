@@ -25,7 +25,8 @@ class FrontendConfig(C.Structure):
                 ("cam", C.c_double * 16), ("gravity", C.c_double * 3),
                 ("scale_factors", C.c_float * 16), ("inv_level_sigma2", C.c_float * 16),
                 ("nlevels", C.c_int32), ("check_orientation", C.c_int32),
-                ("gyr_meas_cov", C.c_double), ("acc_meas_cov", C.c_double), ("acc_bias_rw2", C.c_double)]
+                ("gyr_meas_cov", C.c_double), ("acc_meas_cov", C.c_double), ("acc_bias_rw2", C.c_double),
+                ("dist_coef", C.c_float * 5), ("reserved0", C.c_int32)]
 
 
 class LbaWindow(C.Structure):
@@ -100,6 +101,9 @@ SIGNATURES = {
     "viorb_frontend_create": (i32, [PP(FrontendConfig), i32, i32, i32, PP(vp)]),
     "viorb_frontend_destroy": (i32, [vp]),
     "viorb_frontend_grid_device": (i32, [vp, vp, vp, i32, vp, vp, vp]),
+    "viorb_frontend_undistort_device": (i32, [vp, vp, vp, i32, vp, vp]),
+    "viorb_undistort_points": (i32, [vp, i32, vp, vp, vp]),
+    "viorb_image_bounds": (i32, [i32, i32, vp, vp, vp]),
     "viorb_frontend_imu_predict_device": (i32, [vp, vp, i32, vp, vp, vp, i32, vp, vp, vp, vp]),
     "viorb_frontend_search_projection_device": (i32, [vp] * 12 + [f32, i32, vp, vp, vp, vp]),
     "viorb_frontend_search_projection_retry_device": (i32, [vp] * 12 + [f32, i32, i32, vp, vp, vp, vp]),

@@ -36,6 +36,39 @@ __device__ __forceinline__ void block_bitonic_sort(uint32_t* a, int m) {
         }
 }
 
+// Frame::UndistortKeyPoints (reference src/Frame.cc:584-614): cv::undistortPoints(mat, mat, mK, mDistCoef, Mat(), mK) of OpenCV 2.4
+// (cvUndistortPoints, modules/imgproc/src/undistort.cpp): camera matrix and coefficients widened to double, per point the normalised
+// coordinates, FIVE fixed-point iterations of the radial-tangential model, re-projection with RR = K * I in homogeneous form, one
+// rounding to float. Operation order as published (no contraction: the library is built with -ffp-contract=off). One thread per keypoint record: the record is copied with pt replaced (mvKeysUn[i] = mvKeys[i]
+// with kp.pt changed). n == nullptr: a flat array of `cap` records (the host-buffer forms).
+struct UndistortArgs { double fx, fy, cx, cy, k[5]; };
+__device__ __forceinline__ void undistort_pt(const UndistortArgs& A, float u, float v, float* ou, float* ov) {
+    const double ifx = 1. / A.fx, ify = 1. / A.fy;
+    double x = u, y = v;
+    const double x0 = x = (x - A.cx) * ifx;
+    const double y0 = y = (y - A.cy) * ify;
+#pragma unroll 1
+    for (int j = 0; j < 5; j++) {
+        const double r2 = x * x + y * y;
+        const double icdist = 1. / (1 + ((A.k[4] * r2 + A.k[1]) * r2 + A.k[0]) * r2);     // numerator 1 + ((k6 r2 + k5) r2 + k4) r2 with k4 = k5 = k6 = 0: exactly 1
+        const double deltaX = 2 * A.k[2] * x * y + A.k[3] * (r2 + 2 * x * x);
+        const double deltaY = A.k[2] * (r2 + 2 * y * y) + 2 * A.k[3] * x * y;
+        x = (x0 - deltaX) * icdist;
+        y = (y0 - deltaY) * icdist;
+    }
+    // RR = K: xx = fx*x + 0*y + cx, yy = 0*x + fy*y + cy, ww = 1./(0*x + 0*y + 1) = 1 — the zero products are +-0 and change no finite sum
+    *ou = (float)(A.fx * x + A.cx); *ov = (float)(A.fy * y + A.cy);
+}
+__global__ __launch_bounds__(256) void k_undistort(const viorb_keypoint* __restrict__ kps, const int* __restrict__ count, int cap, UndistortArgs A,
+                                                   int enabled, viorb_keypoint* __restrict__ out) {
+    const int b = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = count ? min(count[b], cap) : cap;
+    if (i >= n) return;
+    viorb_keypoint kp = kps[(size_t)b * cap + i];
+    if (enabled) undistort_pt(A, kp.x, kp.y, &kp.x, &kp.y);
+    out[(size_t)b * cap + i] = kp;
+}
+
 __global__ __launch_bounds__(256) void k_frame_grid(const viorb_keypoint* __restrict__ kps, const int* __restrict__ count, int cap,
                                                     float minX, float minY, float wInv, float hInv,
                                                     int* __restrict__ cell_start, int* __restrict__ cell_idx, int sort_n) {
@@ -2012,6 +2045,61 @@ int viorb_frontend_grid_device(viorb_frontend* h, const viorb_keypoint* kps, con
     hipLaunchKernelGGL(k_frame_grid, dim3(batch), dim3(256), (size_t)h->sort_n * 4, (hipStream_t)stream, kps, count, h->cap,
                        h->cfg.min_x, h->cfg.min_y, h->wInv, h->hInv, cell_start, cell_idx, h->sort_n);
     VIORB_HIP_TRY(hipGetLastError());
+    return VIORB_OK;
+}
+
+static UndistortArgs undistort_args(const float* intr4, const float* dist5) {
+    UndistortArgs A;
+    A.fx = intr4[0]; A.fy = intr4[1]; A.cx = intr4[2]; A.cy = intr4[3];
+    for (int i = 0; i < 5; i++) A.k[i] = dist5[i];
+    return A;
+}
+
+int viorb_frontend_undistort_device(viorb_frontend* h, const viorb_keypoint* kps, const int32_t* count, int batch, viorb_keypoint* kps_un, void* stream) {
+    FE_CHECK_BATCH(h, batch);
+    VIORB_REQUIRE(kps && count && kps_un, "null array");
+    const float intr4[4] = {h->cfg.fx, h->cfg.fy, h->cfg.cx, h->cfg.cy};
+    ProfScope ps("k_undistort", (hipStream_t)stream);
+    hipLaunchKernelGGL(k_undistort, dim3((h->cap + 255) / 256, batch), dim3(256), 0, (hipStream_t)stream, kps, count, h->cap,
+                       undistort_args(intr4, h->cfg.dist_coef), h->cfg.dist_coef[0] != 0.0f ? 1 : 0, kps_un);
+    VIORB_HIP_TRY(hipGetLastError());
+    return VIORB_OK;
+}
+
+int viorb_undistort_points(const float* xy, int n, const float* intr4, const float* dist5, float* xy_out) {
+    VIORB_REQUIRE(xy && intr4 && dist5 && xy_out && n >= 0, "null argument");
+    if (viorb_device_count() < 1) { set_error("no HIP device: libviorb_hip has no CPU fallback"); return VIORB_ERR_NO_DEVICE; }
+    if (n == 0) return VIORB_OK;
+    std::vector<viorb_keypoint> rec((size_t)n);
+    for (int i = 0; i < n; i++) { rec[i] = viorb_keypoint{}; rec[i].x = xy[2 * i]; rec[i].y = xy[2 * i + 1]; }
+    viorb_keypoint* d = nullptr;
+    VIORB_HIP_TRY(hipMalloc(&d, sizeof(viorb_keypoint) * (size_t)n));
+    hipError_t e = hipMemcpy(d, rec.data(), sizeof(viorb_keypoint) * (size_t)n, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_undistort, dim3((n + 255) / 256, 1), dim3(256), 0, (hipStream_t)0, d, (const int*)nullptr, n, undistort_args(intr4, dist5),
+                           dist5[0] != 0.0f ? 1 : 0, d);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(rec.data(), d, sizeof(viorb_keypoint) * (size_t)n, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    VIORB_HIP_TRY(e);
+    for (int i = 0; i < n; i++) { xy_out[2 * i] = rec[i].x; xy_out[2 * i + 1] = rec[i].y; }
+    return VIORB_OK;
+}
+
+// Frame::ComputeImageBounds, reference src/Frame.cc:616-644
+int viorb_image_bounds(int width, int height, const float* intr4, const float* dist5, float* b) {
+    VIORB_REQUIRE(intr4 && dist5 && b && width > 0 && height > 0, "null argument / empty image");
+    if (dist5[0] != 0.0f) {
+        float mat[8] = {0.0f, 0.0f, (float)width, 0.0f, 0.0f, (float)height, (float)width, (float)height};
+        int rc = viorb_undistort_points(mat, 4, intr4, dist5, mat);
+        if (rc != VIORB_OK) return rc;
+        b[0] = std::min(mat[0], mat[4]); b[1] = std::max(mat[2], mat[6]);
+        b[2] = std::min(mat[1], mat[3]); b[3] = std::max(mat[5], mat[7]);
+    } else {
+        if (viorb_device_count() < 1) { set_error("no HIP device: libviorb_hip has no CPU fallback"); return VIORB_ERR_NO_DEVICE; }
+        b[0] = 0.0f; b[1] = (float)width; b[2] = 0.0f; b[3] = (float)height;
+    }
     return VIORB_OK;
 }
 

@@ -47,6 +47,7 @@ struct BaDev {
     double *scal;                   // [8]: 0 chi2, 1 scale, 2 ok, 3 max diag
     double *ctl;                    // device-side LM control (BA_CTL_*), used when use_ctl != 0: kernels return at once while ctl[HALT] != 0
     int use_ctl;                    // and take lambda from ctl[LAMBDA] instead of their argument
+    const unsigned long long* abort_host;   // page-locked word the waiting host thread sets when the caller's pbStopFlag goes up (nullptr: no flag)
     double cam[16], gw[3];
     double acc_bias_rw2;
 };
@@ -57,6 +58,11 @@ struct BaDev {
 // state and the trial's scalars untouched and continues with its own trial loop (lambda *= ni, restore, retry).
 enum { BA_CTL_LAMBDA = 0, BA_CTL_NI, BA_CTL_CHI, BA_CTL_INICHI, BA_CTL_NBAD, BA_CTL_HALT, BA_CTL_ITS, BA_CTL_IT, BA_CTL_RHO, BA_CTL_N = 32 };
 __device__ __forceinline__ bool ba_skip(const BaDev& D) { return D.use_ctl && D.ctl[BA_CTL_HALT] != 0.0; }
+// g2o polls terminate() once per iteration and once per LM trial (optimization_algorithm_levenberg.cpp / sparse_optimizer.cpp:354-432); the
+// device-side LM control does the same through a system-scope load of the mirrored flag, so an abort costs at most the trial in flight
+__device__ __forceinline__ bool ba_abort_requested(const BaDev& D) {
+    return D.abort_host && __hip_atomic_load(D.abort_host, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0ull;
+}
 __device__ __forceinline__ double ba_lambda(const BaDev& D, double arg) { return D.use_ctl ? D.ctl[BA_CTL_LAMBDA] : arg; }
 
 __device__ __forceinline__ void ba_edge_geom(const BaDev& D, int k, const double* kfv, const double* ptv, d3& Pc, m33& RwbT, d3& Paux, cam_t& K) {
@@ -689,7 +695,7 @@ __global__ void k_ba_decide(BaDev D, int last_of_phase) {
     double nBad = c[BA_CTL_NBAD];
     if ((iniChi - tempChi) * 1e3 < iniChi) nBad += 1.0; else nBad = 0.0;
     c[BA_CTL_NBAD] = nBad;
-    if (nBad >= 3.0 || last_of_phase) c[BA_CTL_HALT] = 2.0;      // this optimize() call is over
+    if (nBad >= 3.0 || last_of_phase || ba_abort_requested(D)) c[BA_CTL_HALT] = 2.0;      // this optimize() call is over (or "!terminate()" failed)
 }
 
 
@@ -759,7 +765,7 @@ __global__ void k_bab_decide(const BaDev* __restrict__ Dv, int nwin) {
     if (w >= nwin) return;
     const BaDev& D = Dv[w]; double* c = D.ctl;
     if (c[BA_B_DONE] != 0.0) return;
-    if (c[BA_B_ABORT] != 0.0) { c[BA_B_GATE] = 2.0; return; }            // the caller's stop flag: final gate and outputs of the state as it is
+    if (c[BA_B_ABORT] != 0.0 || ba_abort_requested(D)) { c[BA_B_GATE] = 2.0; return; }            // the caller's stop flag: final gate and outputs of the state as it is
     double tempChi = D.scal[0];
     const bool ok2 = D.scal[2] > 0.5;
     if (!ok2) tempChi = 1.7976931348623157e308;
@@ -1050,8 +1056,12 @@ bool host_inverse9(const double* a_in, double* inv) {
 // optimize(5) -> gate / drop kernels -> optimize(10) -> erase flags. model 0: NavState window, 1: SE3 (vision-only) window.
 // The LM driver reads three scalars per trial: it polls the stream instead of blocking in hipStreamSynchronize (whose wake-up costs more
 // than the kernels of a trial take).
-static hipError_t ba_wait(hipStream_t st) {
+struct BaSolve;
+static void ba_mirror_stop_flags(BaSolve* const* S, int n);
+// Waits for the stream; meanwhile mirrors the callers' stop flags into the page-locked words the device-side LM control polls.
+static hipError_t ba_wait(hipStream_t st, BaSolve* const* S = nullptr, int n = 0) {
     for (;;) {
+        if (n) ba_mirror_stop_flags(S, n);
         const hipError_t e = hipStreamQuery(st);
         if (e != hipErrorNotReady) return e;
     }
@@ -1060,7 +1070,7 @@ static hipError_t ba_wait(hipStream_t st) {
 // resumable state machine: advance() runs the host logic up to the next point where device scalars are needed, enqueues the work on
 // the solve's stream and returns BA_WAIT; the caller resumes it once the stream has drained. One window blocks on its stream between
 // calls; a batch keeps several windows in flight from one host thread (several host threads slow each other down inside the HIP runtime).
-enum { BA_WAIT = 0, BA_DONE = 1 };
+enum { BA_WAIT = 0, BA_DONE = 1, BA_PIN_ABORT = 48 };              // pinned[48]: the mirrored stop flag (as a 64-bit word)
 struct BaSolve {
     BaCtxLease lease;
     BaDev D; hipStream_t st = nullptr; double* h = nullptr;       // h: 64 page-locked doubles (0..7 scal, 8..39 ctl)
@@ -1244,6 +1254,23 @@ struct BaSolve {
     }
 };
 
+static void ba_mirror_stop_flags(BaSolve* const* S, int n) {
+    for (int i = 0; i < n; i++)
+        if (S[i] && S[i]->h && S[i]->D.abort_host && S[i]->terminate())
+            reinterpret_cast<volatile unsigned long long*>(S[i]->h)[BA_PIN_ABORT] = 1ull;
+}
+// the page-locked mirror of the caller's stop flag, mapped for the device (called by ba_prepare_* once S.h and S.stop are set)
+static hipError_t ba_map_stop_flag(BaSolve& S) {
+    S.D.abort_host = nullptr;
+    if (!S.stop) return hipSuccess;
+    reinterpret_cast<volatile unsigned long long*>(S.h)[BA_PIN_ABORT] = 0ull;
+    void* dp = nullptr;
+    const hipError_t e = hipHostGetDevicePointer(&dp, S.h + BA_PIN_ABORT, 0);
+    if (e == hipSuccess) S.D.abort_host = reinterpret_cast<const unsigned long long*>(dp);
+    return e;
+}
+
+
 // Argument checks, host-side graph bookkeeping and the upload of one NavState window; leaves `S` ready for advance() (or already done
 // when the stop flag was set on entry).
 static int ba_prepare_navstate(BaSolve& S, const double* kfs, int nk, int n_local, int prev_kf, const double* preint, const double* points, int npts,
@@ -1298,6 +1325,7 @@ static int ba_prepare_navstate(BaSolve& S, const double* kfs, int nk, int n_loca
     if (!ok) { set_error("device allocation / upload failed"); return VIORB_ERR_HIP; }
     D.e_pt = d_ept; D.e_kf = d_ekf; D.e_obs = d_obs; D.pt_start = d_pts; D.kf_start = d_kfs; D.kf_list = d_kfl; D.preint = d_pre; D.info_pvr = d_info;
     S.st = lease.c->st; S.h = lease.c->pinned; S.model = 0; S.stop = stop; S.d_erase = d_erase;
+    VIORB_HIP_TRY(ba_map_stop_flag(S));
     S.kfs_out = kfs_out; S.points_out = points_out; S.erase = erase; S.info = info;
     return VIORB_OK;
 }
@@ -1445,7 +1473,7 @@ static int ba_run_lockstep(Win* w, int n, Prepare prepare) {
                 BaSolve& B = *S[act[a]];
                 if (!aborted[a] && B.terminate()) {
                     aborted[a] = 1;
-                    const double one = 1.0;
+                    static const double one = 1.0;                 // static storage: outlives the asynchronous copy
                     VIORB_HIP_TRY(hipMemcpyAsync(B.D.ctl + BA_B_ABORT, &one, sizeof(double), hipMemcpyHostToDevice, st));
                 }
             }
@@ -1546,6 +1574,7 @@ static int ba_prepare_se3(BaSolve& S, const double* kfs, int nk, int n_local, co
     if (!ok) { set_error("device allocation / upload failed"); return VIORB_ERR_HIP; }
     D.e_pt = d_ept; D.e_kf = d_ekf; D.e_obs = d_obs; D.pt_start = d_pts; D.kf_start = d_kfs; D.kf_list = d_kfl;
     S.st = lease.c->st; S.h = lease.c->pinned; S.model = 1; S.stop = stop; S.d_erase = d_erase;
+    VIORB_HIP_TRY(ba_map_stop_flag(S));
     S.kfs_out = kfs_out; S.points_out = points_out; S.erase = erase; S.info = info;
     return VIORB_OK;
 }

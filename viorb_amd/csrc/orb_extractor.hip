@@ -69,20 +69,30 @@ ProfScope::ProfScope(const char* name, hipStream_t s) : idx(-1), st(s) {
 bool prof_times_everything() { return g_prof.only.empty(); }
 ProfScope::~ProfScope() { if (idx >= 0) (void)hipEventRecord(g_prof.recs[idx].b, st); }
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) applies to the function object of the CURRENT device, so the cache is keyed by
+// (device, kernel): a handle on a second device of the same process raises the limit there too. Lock-free fast path for the callers
+// inside solver loops: a per-thread memo of the last (device, kernel, bytes) that succeeded.
 hipError_t raise_dynamic_lds(const void* kernel, size_t bytes) {
+    int dev = 0;
+    hipError_t rc = hipGetDevice(&dev);
+    if (rc != hipSuccess) return rc;
+    struct Memo { int dev; const void* k; size_t bytes; };
+    static thread_local Memo memo[4] = {{-1, nullptr, 0}, {-1, nullptr, 0}, {-1, nullptr, 0}, {-1, nullptr, 0}};
+    for (const Memo& m : memo) if (m.dev == dev && m.k == kernel && bytes <= m.bytes) return hipSuccess;
     static std::mutex mu;
-    static std::vector<std::pair<const void*, size_t>> seen;
+    struct Seen { int dev; const void* k; size_t bytes; };
+    static std::vector<Seen> seen;
     std::lock_guard<std::mutex> lk(mu);
-    for (auto& e : seen)
-        if (e.first == kernel) {
-            if (bytes <= e.second) return hipSuccess;
-            const hipError_t rc = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-            if (rc == hipSuccess) e.second = bytes;
-            return rc;
-        }
-    const hipError_t rc = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-    if (rc == hipSuccess) seen.push_back({kernel, bytes});
-    return rc;
+    Seen* hit = nullptr;
+    for (auto& e : seen) if (e.dev == dev && e.k == kernel) hit = &e;
+    if (!hit || bytes > hit->bytes) {
+        rc = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (rc != hipSuccess) return rc;
+        if (hit) hit->bytes = bytes; else { seen.push_back({dev, kernel, bytes}); hit = &seen.back(); }
+    }
+    static thread_local int next = 0;
+    memo[next] = {dev, kernel, hit->bytes}; next = (next + 1) & 3;
+    return hipSuccess;
 }
 
 static const int8_t kPatternHost[1024] = {
@@ -1444,7 +1454,7 @@ __global__ __launch_bounds__(1024) void k_stereo_match(StereoArgs A) {
                                 float bestuR = A.scale[levelL] * ((float)cr + (float)bestinc + deltaR);
                                 float disparity = uL - bestuR;
                                 if (disparity >= minD && disparity < maxD) {
-                                    if (disparity <= 0) { disparity = 0.01f; bestuR = uL - 0.01f; }
+                                    if (disparity <= 0) { disparity = 0.01f; bestuR = (float)((double)uL - 0.01); }   // "bestuR = uL-0.01": a double subtraction rounded once (Frame.cc:797)
                                     out_d = A.bf / disparity; out_u = bestuR; out_sad = bestSad;
                                 }
                             }
@@ -1949,7 +1959,7 @@ static int launch_all(viorb_extractor* h, const uint8_t* d_images, int batch, in
 
 extern "C" {
 
-int viorb_abi_version(void) { return 1; }
+int viorb_abi_version(void) { return 2; }   // 2: viorb_frontend_config.dist_coef
 
 int viorb_memcpy_dtod_async(void* dst, const void* src, size_t bytes, void* stream) {
     VIORB_REQUIRE(dst && src, "null pointer");

@@ -152,6 +152,7 @@ struct viorb_tracker {
     int *cur_match, *nmatches, *status_s1, *status_s2, *status; double *obs_cur, *obs_last, *obs_cur2; int *idx_cur, *idx_last, *idx_cur2;
     int *n_cur, *n_last, *n_cur2; double *out_ns, *out_last_ns, *out_ns2, *ns1, *final_ns, *final_marg, *marg_out, *info, *info2;
     uint8_t *outlier_cur, *outlier_last, *outlier_cur2, *owner_obs, *skip1, *skip2, *variant; int *n_map, *loc_match, *n_loc, *state, *inliers;
+    bool undistort = false; viorb_keypoint* kps_un = nullptr;      // mvKeysUn of the frame in flight (Frame::UndistortKeyPoints)
     // host statistics
     double enqueue_s = 0, throttle_s = 0; long long steps = 0;
 };
@@ -192,7 +193,13 @@ int viorb_tracker_create(const viorb_tracker_config* cfg, viorb_tracker** out) {
     TR_TRY(viorb_extractor_tables(h->ex[0], sf, nullptr, nullptr, is2, nullptr));
     for (int i = 0; i < 16; i++) { fc.scale_factors[i] = sf[i < h->nlevels ? i : h->nlevels - 1]; fc.inv_level_sigma2[i] = is2[i < h->nlevels ? i : h->nlevels - 1]; }
     fc.nlevels = h->nlevels;
-    fc.min_x = 0; fc.max_x = (float)cfg->width; fc.min_y = 0; fc.max_y = (float)cfg->height;
+    {   // Frame::ComputeImageBounds (src/Frame.cc:616-644): the four undistorted corners when the camera is distorted
+        const float intr4[4] = {fc.fx, fc.fy, fc.cx, fc.cy};
+        float b4[4];
+        TR_TRY(viorb_image_bounds(cfg->width, cfg->height, intr4, fc.dist_coef, b4));
+        fc.min_x = b4[0]; fc.max_x = b4[1]; fc.min_y = b4[2]; fc.max_y = b4[3];
+    }
+    h->undistort = fc.dist_coef[0] != 0.0f;
     TR_TRY(viorb_frontend_create(&fc, cfg->batch, h->cap, cfg->device, &h->fe));
     {
         int lo = 0, hi = 0;
@@ -221,6 +228,7 @@ int viorb_tracker_create(const viorb_tracker_config* cfg, viorb_tracker** out) {
     h->info = M.get<double>(B * 4); h->info2 = M.get<double>(B * 4);
     h->outlier_cur = M.get<uint8_t>(B * cap); h->outlier_last = M.get<uint8_t>(B * cap); h->outlier_cur2 = M.get<uint8_t>(B * cap); h->owner_obs = M.get<uint8_t>(B * cap);
     h->skip1 = M.get<uint8_t>(B); h->skip2 = M.get<uint8_t>(B); h->variant = M.get<uint8_t>(B);
+    if (h->undistort) h->kps_un = M.get<viorb_keypoint>(B * cap);
     h->n_map = M.get<int>(B); h->loc_match = M.get<int>(B * cap); h->n_loc = M.get<int>(B); h->state = M.get<int>(B); h->inliers = M.get<int>(B);
     if (M.err != hipSuccess) { set_error("device allocation failed: %s", hipGetErrorString(M.err)); return VIORB_ERR_HIP; }
     {
@@ -266,6 +274,7 @@ int viorb_tracker_bootstrap(viorb_tracker* h, const uint8_t* d_images, int strid
     TR_TRY(viorb_extract_batch_device(h->ex[0], d_images, h->B, h->cfg.width, h->cfg.height, stride, image_pitch_bytes, h->s_tr));
     const viorb_keypoint* kps; const uint8_t* desc; const int32_t* count; const int32_t* st; int cap;
     TR_TRY(viorb_extractor_results_device(h->ex[0], &kps, &desc, &count, &st, &cap));
+    if (h->undistort) { TR_TRY(viorb_frontend_undistort_device(h->fe, kps, count, h->B, h->kps_un, h->s_tr)); kps = h->kps_un; }
     VIORB_HIP_TRY(hipMemcpyAsync(h->marg_cov_inv, d_marg_cov_inv, sizeof(double) * 144 * h->B, hipMemcpyDeviceToDevice, h->s_tr));
     TR_TRY(tracker_roll(h, kps, desc, count, d_ns0, d_t0, nullptr, d_synth_pose12, h->s_tr));
     VIORB_HIP_TRY(hipStreamSynchronize(h->s_tr));
@@ -309,6 +318,8 @@ int viorb_tracker_step(viorb_tracker* h, const viorb_tracker_inputs* in, void* c
     const viorb_keypoint* kps; const uint8_t* desc; const int32_t* count; const int32_t* ex_status; int cap;
     TR_TRY(viorb_extractor_results_device(ex, &kps, &desc, &count, &ex_status, &cap));
     h->cur_slot = slot;
+    // Frame::UndistortKeyPoints (Frame.cc:171): grid, searches, edges and the frame handed on all read mvKeysUn
+    if (h->undistort) { TR_TRY(viorb_frontend_undistort_device(h->fe, kps, count, B, h->kps_un, st)); kps = h->kps_un; }
     // ---- TrackWithIMU
     TR_TRY(viorb_frontend_grid_device(h->fe, kps, count, B, h->cell_start, h->cell_idx, st));
     TR_TRY(viorb_frontend_search_projection_device(h->fe, kps, desc, count, h->cell_start, h->cell_idx, h->pose12, h->last_kps, h->last_count, h->last_flags,

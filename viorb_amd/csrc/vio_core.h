@@ -160,7 +160,7 @@ VIO_HD double m33_at(const m33& m, int r, int c) {
 VIO_HD pvr update_ns(const pvr& s, d3 dP, d3 dV, const m33& dR, double dt, d3 gw) {
     const m33 Rw = qmat(s.q);
     pvr r;
-    r.P = s.P + s.V * dt + gw * (0.5 * dt * dt) + mulv(Rw, dP);
+    r.P = s.P + s.V * dt + ((gw * 0.5) * dt) * dt + mulv(Rw, dP);
     r.V = s.V + gw * dt + mulv(Rw, dV);
     r.q = qnorm(mat2q(mul(Rw, dR)));
     return r;

@@ -24,6 +24,24 @@ def match_bruteforce(q_desc, c_desc):
     return best[:len(q)], second[:len(q)], idx[:len(q)]
 
 
+def UndistortKeyPoints(xy, intr4, dist_coef):
+    """Frame::UndistortKeyPoints' cv::undistortPoints(mat, mat, mK, mDistCoef, Mat(), mK) (reference src/Frame.cc:584-614): xy [n,2]
+    float32 pixels -> undistorted float32 pixels; intr4 = fx fy cx cy, dist_coef = k1 k2 p1 p2 [k3]."""
+    xy = np.ascontiguousarray(xy, np.float32).reshape(-1, 2)
+    d = np.zeros(5, np.float32); d[:len(dist_coef)] = np.asarray(dist_coef, np.float32)[:5]
+    out = np.empty_like(xy)
+    check(lib().viorb_undistort_points(ptr(xy), len(xy), ptr(np.ascontiguousarray(intr4, np.float32)), ptr(d), ptr(out)))
+    return out
+
+
+def ComputeImageBounds(width, height, intr4, dist_coef):
+    """Frame::ComputeImageBounds (reference src/Frame.cc:616-644): float32 [mnMinX, mnMaxX, mnMinY, mnMaxY]."""
+    d = np.zeros(5, np.float32); d[:len(dist_coef)] = np.asarray(dist_coef, np.float32)[:5]
+    b = np.zeros(4, np.float32)
+    check(lib().viorb_image_bounds(int(width), int(height), ptr(np.ascontiguousarray(intr4, np.float32)), ptr(d), ptr(b)))
+    return b
+
+
 class ORBmatcher:
     """Mirror of ORB_SLAM2::ORBmatcher for the frame-side searches (reference include/ORBmatcher.h:37-102)."""
     TH_LOW, TH_HIGH, HISTO_LENGTH = 50, 100, 30
@@ -300,9 +318,12 @@ class Frontend:
     """Batched device-resident front-end: every method only enqueues kernels on the given torch stream."""
 
     def __init__(self, cam, gw, scale_factors, inv_level_sigma2, bounds=(0.0, 752.0, 0.0, 480.0), max_batch=1, cap=1016,
-                 check_orientation=True, device=0):
+                 check_orientation=True, device=0, dist_coef=None):
         self.L = lib()
         cfg = capi.FrontendConfig()
+        if dist_coef is not None:
+            for i, v in enumerate(list(dist_coef)[:5]):
+                cfg.dist_coef[i] = float(np.float32(v))
         cfg.min_x, cfg.max_x, cfg.min_y, cfg.max_y = [float(b) for b in bounds]
         cfg.fx, cfg.fy, cfg.cx, cfg.cy = [float(np.float32(v)) for v in cam[:4]]
         for i in range(16):
@@ -329,6 +350,10 @@ class Frontend:
         import torch
         st = stream if stream is not None else torch.cuda.current_stream()
         return C.c_void_p(st.cuda_stream)
+
+    def undistort(self, kps_ptr, count_ptr, batch, kps_un, stream=None):
+        """Frame::UndistortKeyPoints for the batch: kps_un [batch, cap] keypoint records (uint8 view [batch, cap, 28])."""
+        check(self.L.viorb_frontend_undistort_device(self.h, C.c_void_p(kps_ptr), C.c_void_p(count_ptr), batch, ptr(kps_un), self._st(stream)))
 
     def grid(self, kps_ptr, count_ptr, batch, cell_start, cell_idx, stream=None):
         check(self.L.viorb_frontend_grid_device(self.h, C.c_void_p(kps_ptr), C.c_void_p(count_ptr), batch, ptr(cell_start),

@@ -5,6 +5,7 @@ import numpy as np
 from scipy import ndimage
 
 EUROC_K = dict(fx=458.654, fy=457.296, cx=367.215, cy=248.375)   # reference Examples/ROS/ORB_VIO/launch/euroc.yaml
+EUROC_DIST = (-0.28340811, 0.07395907, 0.00019359, 1.762e-05, 0.0)   # Camera.k1 k2 p1 p2 (euroc.yaml:64-67), k3 = 0
 
 
 def make_image(seed, w=752, h=480, n_shapes=None):
@@ -178,12 +179,29 @@ PLANE_Z0 = 5.0
 GRAVITY_CAM_WORLD = np.array([0.0, 9.81, 0.0])       # world = reference camera frame, y points down
 
 
-def render_view(base, cam, Rcw, tcw, seed=0, noise=1.0):
-    """Image of the plane z = PLANE_Z0 (textured with `base` as seen from Tcw = I) from pose (Rcw, tcw)."""
+def undistort_normalized(xd, yd, dist, iters=30):
+    """Inverse of the radial-tangential model by fixed-point iteration run to convergence (the TRUE camera of the synthetic world;
+    the reference's cv::undistortPoints stops after five iterations)."""
+    k1, k2, p1, p2, k3 = [float(v) for v in dist]
+    x, y = xd.copy(), yd.copy()
+    for _ in range(iters):
+        r2 = x * x + y * y
+        ic = 1.0 / (1 + ((k3 * r2 + k2) * r2 + k1) * r2)
+        dx = 2 * p1 * x * y + p2 * (r2 + 2 * x * x); dy = p1 * (r2 + 2 * y * y) + 2 * p2 * x * y
+        x = (xd - dx) * ic; y = (yd - dy) * ic
+    return x, y
+
+
+def render_view(base, cam, Rcw, tcw, seed=0, noise=1.0, dist=None):
+    """Image of the plane z = PLANE_Z0 (textured with `base` as seen from Tcw = I) from pose (Rcw, tcw). dist = k1 k2 p1 p2 k3: the
+    camera has that lens distortion (pixel -> ray through the inverse model), as the EuRoC camera of the reference's settings file."""
     h, w = base.shape
     fx, fy, cx, cy = cam[:4]
     v, u = np.mgrid[0:h, 0:w].astype(np.float64)
-    d = np.stack([(u - cx) / fx, (v - cy) / fy, np.ones_like(u)], -1) @ Rcw          # Rcw^T d, row-vector form
+    xn, yn = (u - cx) / fx, (v - cy) / fy
+    if dist is not None and dist[0] != 0:
+        xn, yn = undistort_normalized(xn, yn, dist)
+    d = np.stack([xn, yn, np.ones_like(u)], -1) @ Rcw          # Rcw^T d, row-vector form
     O = -Rcw.T @ tcw
     s = (PLANE_Z0 - O[2]) / d[..., 2]
     X = O[0] + s * d[..., 0]
@@ -255,7 +273,7 @@ def make_vi_stream(seed, n_frames, w=752, h=480, n_imu=10, imu_dt=0.005):
                 gw=GRAVITY_CAM_WORLD.copy(), base=base)
 
 
-def make_periodic_stream(seed, n_frames=8, w=752, h=480, n_imu=10, imu_dt=0.005, nfeat_hint=None):
+def make_periodic_stream(seed, n_frames=8, w=752, h=480, n_imu=10, imu_dt=0.005, nfeat_hint=None, dist=None):
     """A closed-loop mono-inertial stream: poses, velocities and images are periodic with period
     n_frames * n_imu * imu_dt, so a tracker can run over it for any number of steps (frame k of the run is
     frame k % n_frames of the stream; time keeps increasing). IMU samples come from the analytic trajectory.
@@ -295,7 +313,7 @@ def make_periodic_stream(seed, n_frames=8, w=752, h=480, n_imu=10, imu_dt=0.005,
         P, V, _, R, _ = traj(t)
         ns = navstate(P, V, R, bg, ba)
         Rcw, tcw = cam_pose_from_navstate(ns, cam)
-        frames.append(render_view(base, cam, Rcw, tcw, seed=seed * 1013 + j))
+        frames.append(render_view(base, cam, Rcw, tcw, seed=seed * 1013 + j, dist=dist))
         states.append(ns); poses.append(np.concatenate([Rcw.ravel(), tcw])); ts.append(t)
         # IMU between frame j-1 and j (j = 0 closes the loop: stamps in (T - dtf, T))
         tstart = (j - 1) * dtf if j > 0 else T - dtf

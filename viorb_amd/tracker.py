@@ -255,12 +255,15 @@ class NativeTracker:
     STATE_NAMES = ("ok", "few_matches", "revert_1", "revert_2", "reloc_few")
 
     def __init__(self, cam, gw, batch, width=752, height=480, nfeatures=1000, th=15.0, device=0, compute_marg=True, track_local_map=True,
-                 local_frames=2, max_steps_ahead=8, scale_factor=1.2, nlevels=8, ini_th=20, min_th=7):
+                 local_frames=2, max_steps_ahead=8, scale_factor=1.2, nlevels=8, ini_th=20, min_th=7, dist_coef=None):
         import torch
         self.torch = torch
         self.B, self.w, self.h = batch, width, height
         self.dev = torch.device("cuda", device)
         cfg = capi_mod.TrackerConfig()
+        if dist_coef is not None:                     # Frame::mDistCoef = k1 k2 p1 p2 [k3]: keypoints are undistorted ahead of the grid
+            for i, v in enumerate(list(dist_coef)[:5]):
+                cfg.frontend.dist_coef[i] = float(np.float32(v))
         cfg.extractor.nfeatures, cfg.extractor.scale_factor, cfg.extractor.nlevels = nfeatures, scale_factor, nlevels
         cfg.extractor.ini_th_fast, cfg.extractor.min_th_fast = ini_th, min_th
         fe = cfg.frontend
@@ -280,7 +283,7 @@ class NativeTracker:
         check(lib().viorb_tracker_capacity(h, C.byref(cap)))
         self.cap = cap.value
         self.track_local_map = bool(track_local_map)
-        self._keep = []
+        self._keep, self._pending = [], []
         self.max_steps_ahead = max_steps_ahead
 
     def close(self):
@@ -296,7 +299,7 @@ class NativeTracker:
         assert images.is_cuda and images.dim() == 3 and images.stride(2) == 1
         check(lib().viorb_tracker_bootstrap(self.hnd, ptr(images), images.stride(1), images.stride(0), ptr(ns0), ptr(t0), ptr(marg_cov_inv),
                                             ptr(true_pose12), self._stream()))
-        self._keep = []
+        self._keep, self._pending = [], []
 
     def step(self, images, imu, t_cur, true_pose12=None, map_updated=None, recent_reloc=None, t_next_last=None, reset_ns=None, reset_marg=None):
         """images [B,h,w] u8, imu [B,n,7] f64, t_cur [B] f64 — CUDA tensors. true_pose12 [B,12] f64: map points of the new last frame from
@@ -308,17 +311,23 @@ class NativeTracker:
         inp.d_map_updated = opt(map_updated); inp.d_recent_reloc = opt(recent_reloc); inp.d_t_next_last = opt(t_next_last)
         inp.d_reset_ns = opt(reset_ns); inp.d_reset_marg = opt(reset_marg); inp.d_synth_pose12 = opt(true_pose12)
         check(lib().viorb_tracker_step(self.hnd, C.byref(inp), self._stream()))
-        self._keep.append((images, imu, t_cur, true_pose12, map_updated, recent_reloc, t_next_last, reset_ns, reset_marg))
-        if len(self._keep) > self.max_steps_ahead + 1:          # the C++ throttle has waited for everything older
+        # ONE record per step: its inputs plus whatever set_last_points handed over since the previous step (those copies are
+        # enqueued ahead of this step on the tracking stream, so they have completed once this step's event has). The C++ throttle returns
+        # only when at most `ahead` steps are still in flight (max_steps_ahead <= 0 means 8 there), i.e. every record older than that has
+        # been consumed.
+        self._keep.append((images, imu, t_cur, true_pose12, map_updated, recent_reloc, t_next_last, reset_ns, reset_marg, self._pending))
+        self._pending = []
+        ahead = self.max_steps_ahead if self.max_steps_ahead > 0 else 8
+        while len(self._keep) > ahead + 1:
             self._keep.pop(0)
 
     def set_last_points(self, Pw, flags, pts_f=None):
         check(lib().viorb_tracker_set_last_points_device(self.hnd, ptr(Pw), ptr(flags), ptr(pts_f) if pts_f is not None else None, self._stream()))
-        self._keep.append((Pw, flags, pts_f))
+        self._pending.append((Pw, flags, pts_f))
 
     def sync(self):
         check(lib().viorb_tracker_sync(self.hnd))
-        self._keep = []
+        self._keep, self._pending = [], []
 
     def host_stats(self, reset=False):
         a, b, n = C.c_double(), C.c_double(), C.c_longlong()
