@@ -455,7 +455,9 @@ int viorb_pose_opt_se3(const float pose12[12], const float intr5[5], const doubl
  * mono kernel dropped, optimize(10) (src/Optimizer.cc:2027-2063); erase[k] = 1 for observations the caller must remove
  * (:2105-2118). kfs [nk][22] (local window first, chronological), preint [n_local][142] of the interval ending at local
  * key frame i, points [np][3], edge_idx [ne][2] = (point, key frame) sorted by point, edge_obs [ne][3] = u v invSigma2.
- * stop: the reference's pbStopFlag (polled between LM trials; may be NULL). Outputs: kfs_out [n_local][22],
+ * stop: the reference's pbStopFlag (may be NULL). g2o polls it once per iteration and once per LM trial; here the waiting host thread
+ * mirrors it into a page-locked word that the device-side Levenberg control reads after every trial, so a raised flag ends the solve
+ * after the trial in flight (a rejected one is restored first), as "&& !terminate()" does in the reference. Outputs: kfs_out [n_local][22],
  * points_out [np][3], erase [ne], info = chi2 after optimize(5), final chi2, iterations of both runs, 0, 0.
  * Host buffers in and out (the caller is the LocalMapping thread); all arithmetic runs on the GPU in FP64, on the device
  * chosen with viorb_local_ba_set_device (default: the calling thread's current HIP device). Re-entrant: concurrent callers get their own stream and device arena. */
@@ -467,11 +469,13 @@ int viorb_local_ba_navstate(const double* kfs, int nk, int n_local, int prev_kf,
                             double* points_out, uint8_t* erase, double info[6]);
 
 /* Several windows at once (one per camera stream in a multi-stream deployment; the reference runs one LocalMapping thread per system):
- * each entry carries the arguments of one viorb_local_ba_navstate call and receives its return code in `status`. Up to max_in_flight
- * windows (<= 0: 16) are kept going concurrently, each on its own HIP stream of that device, by ONE host thread that resumes a window's
- * LM driver whenever its stream has drained — a single window is a chain of small latency-bound launches that leaves most of the GPU
- * idle, and several host threads calling the single-window entry point slow each other down inside the HIP runtime. Results are those
- * of the individual calls (to rounding: the Schur accumulation uses LDS atomics, whose order is not fixed from run to run). */
+ * each entry carries the arguments of one viorb_local_ba_navstate call and receives its return code in `status`. All windows advance in
+ * LOCK STEP, 128 at a time: one launch per solver step covers every window of the group (blockIdx.y = window) and each window's
+ * Levenberg / two-phase state machine lives in its control block on the device — a single window is a chain of small latency-bound
+ * launches that leaves most of the GPU idle. max_in_flight only applies to the per-stream driver kept behind VIORB_LBA_STREAMS=1
+ * (one HIP stream and host LM loop per window, <= 0: 16). When a group fails (a HIP error), every window of it that has no result
+ * yet and every later window gets that error in `status`. Results are those of the individual calls (to rounding: the Schur
+ * accumulation uses LDS atomics, whose order is not fixed from run to run). */
 typedef struct viorb_lba_window {
     const double* kfs; int32_t nk, n_local, prev_kf; const double* preint; const double* points; int32_t np;
     const int32_t* edge_idx; const double* edge_obs; int32_t ne; const double* gw; const double* cam; const volatile int* stop;

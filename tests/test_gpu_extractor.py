@@ -205,3 +205,31 @@ def test_constructor_parameter_variations(gpu, oracle, w, h, nf, sf, nl, ini, mn
     ok, od = oracle.Extractor(nf, sf, nl, ini, mn)(img)
     np.testing.assert_array_equal(k, ok)
     np.testing.assert_array_equal(d, od)
+
+
+@pytest.mark.parametrize("kind", ["sin5", "noise", "salt"])
+def test_dense_corner_images(gpu, oracle, kind):
+    """Images on which FAST fires almost everywhere: a 5-px two-dimensional sinusoid (48 % of the pixels are corners: more than the FAST
+    kernel's corner list holds per cell, so its dense NMS path runs), uniform noise (26 % corners, every pre-test polarity combination)
+    and sparse salt noise (isolated corners, cells that come back empty at iniThFAST and are redone at minThFAST). Candidate lists in
+    cv::FAST order, the quadtree's selection and the final keypoints / descriptors must equal the oracle's."""
+    w, h = (336, 256) if kind == "noise" else (400, 300)
+    y, x = np.mgrid[0:h, 0:w]
+    rng = np.random.default_rng(17)
+    if kind == "sin5":
+        img = np.clip(128 + 63 * np.sin(2 * np.pi * x / 5) + 63 * np.sin(2 * np.pi * y / 5), 0, 255).astype(np.uint8)
+    elif kind == "noise":
+        img = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    else:
+        img = np.full((h, w), 90, np.uint8)
+        img[rng.integers(0, h, 600), rng.integers(0, w, 600)] = rng.integers(100, 125, 600)       # weak dots: only minThFAST sees most of them
+        img[rng.integers(0, h, 60), rng.integers(0, w, 60)] = 255
+    ex = viorb_amd.ORBextractor(1000, 1.2, 8, 20, 7)
+    kps, desc = ex(img)
+    ox = oracle.Extractor(1000, 1.2, 8, 20, 7)
+    okps, odesc = ox(img)
+    for l in range(8):
+        oc = ox.level_keypoints(l, candidates=True)
+        want = np.stack([oc["x"], oc["y"], oc["response"]], 1).astype(np.int32).reshape(-1, 3)
+        np.testing.assert_array_equal(ex.debug_level_points(l, kept=False), want, err_msg="%s: FAST candidates level %d" % (kind, l))
+    assert len(kps) == len(okps) and (kps == okps).all() and (desc == odesc).all()

@@ -102,6 +102,26 @@ def test_local_ba_without_prev_keyframe(oracle):
     np.testing.assert_allclose(got["kfs"], ref["kfs"], rtol=0, atol=1e-7)
 
 
+def test_local_ba_stop_flag_raised_during_the_solve(oracle):
+    """pbStopFlag goes up from another thread while the window is being solved (LocalMapping::InterruptBA): the call returns the state after
+    the trial in flight — fewer Levenberg iterations than the full 5 + 10, a chi2 no worse than the start, finite outputs."""
+    import threading, time
+    from viorb_amd import LocalBundleAdjustmentNavState
+    p = make_local_ba_problem(3, W=20, n_points=2000)
+    pre = _preints(oracle, p)
+    full = LocalBundleAdjustmentNavState(*_args(p, pre))
+    for delay in (0.0, 0.0005, 0.0015):
+        stop = np.zeros(1, np.int32)
+        t = threading.Thread(target=lambda: (time.sleep(delay), stop.__setitem__(0, 1)))
+        t.start()
+        got = LocalBundleAdjustmentNavState(*_args(p, pre), stop=stop)
+        t.join()
+        assert np.isfinite(got["kfs"]).all() and np.isfinite(got["points"]).all()
+        assert got["its_first"] + got["its_second"] <= full["its_first"] + full["its_second"]
+        if got["its_first"] + got["its_second"] == 0:
+            assert np.array_equal(got["points"], p["points"])
+
+
 def test_local_ba_stop_flag_and_argument_checks(oracle):
     from viorb_amd import LocalBundleAdjustmentNavState, ViorbError
     p = make_local_ba_problem(6, W=5, n_points=200)

@@ -765,7 +765,8 @@ __global__ void k_bab_decide(const BaDev* __restrict__ Dv, int nwin) {
     if (w >= nwin) return;
     const BaDev& D = Dv[w]; double* c = D.ctl;
     if (c[BA_B_DONE] != 0.0) return;
-    if (c[BA_B_ABORT] != 0.0 || ba_abort_requested(D)) { c[BA_B_GATE] = 2.0; return; }            // the caller's stop flag: final gate and outputs of the state as it is
+    if (c[BA_B_ABORT] != 0.0) { c[BA_B_GATE] = 2.0; return; }            // the host saw the stop flag between rounds (this round's trial kernels were skipped): final gate on the state as it is
+    const bool abort_now = ba_abort_requested(D);                        // the flag went up during this trial: take the trial's decision, then leave both loops ("&& !terminate()")
     double tempChi = D.scal[0];
     const bool ok2 = D.scal[2] > 0.5;
     if (!ok2) tempChi = 1.7976931348623157e308;
@@ -783,6 +784,7 @@ __global__ void k_bab_decide(const BaDev* __restrict__ Dv, int nwin) {
         c[BA_B_RESTORE] = 1.0;
     }
     qmax++;
+    if (abort_now) { c[BA_B_GATE] = 2.0; return; }                       // a rejected trial is restored by k_bab_restore before the gate
     if (rho < 0 && qmax < 10) { c[BA_B_QMAX] = qmax; return; }           // another trial of the same iteration (no re-linearisation)
     // the iteration is over
     const int phase = (int)c[BA_B_PHASE];
@@ -1070,7 +1072,7 @@ static hipError_t ba_wait(hipStream_t st, BaSolve* const* S = nullptr, int n = 0
 // resumable state machine: advance() runs the host logic up to the next point where device scalars are needed, enqueues the work on
 // the solve's stream and returns BA_WAIT; the caller resumes it once the stream has drained. One window blocks on its stream between
 // calls; a batch keeps several windows in flight from one host thread (several host threads slow each other down inside the HIP runtime).
-enum { BA_WAIT = 0, BA_DONE = 1, BA_PIN_ABORT = 48 };              // pinned[48]: the mirrored stop flag (as a 64-bit word)
+enum { BA_WAIT = 0, BA_DONE = 1, BA_PIN_ABORT = 56 };              // pinned[56]: the mirrored stop flag (a 64-bit word; 0..39 LM scalars, 48 the batch's done counter)
 struct BaSolve {
     BaCtxLease lease;
     BaDev D; hipStream_t st = nullptr; double* h = nullptr;       // h: 64 page-locked doubles (0..7 scal, 8..39 ctl)
@@ -1249,7 +1251,8 @@ struct BaSolve {
         for (;;) {
             const int r = advance();
             if (r < 0 || r == BA_DONE) return r < 0 ? r : VIORB_OK;
-            VIORB_HIP_TRY(ba_wait(st));
+            BaSolve* self = this;
+            VIORB_HIP_TRY(ba_wait(st, &self, 1));
         }
     }
 };
@@ -1414,6 +1417,8 @@ static int ba_run_lockstep(Win* w, int n, Prepare prepare) {
         }
         const int na = (int)act.size();
         if (na == 0) continue;
+        // the group's solve; an early return (a HIP error, MAX_ROUNDS) must not leave status == VIORB_OK on windows whose outputs were never written
+        auto solve_group = [&]() -> int {
         hipStream_t st = S[act[0]]->st;
         std::vector<BaDev> Dh(na); std::vector<uint8_t*> Eh(na);
         int gE = 1, gP = 1, Wmax = 1; size_t nl2 = 1, n2 = 1;
@@ -1440,6 +1445,8 @@ static int ba_run_lockstep(Win* w, int n, Prepare prepare) {
         const dim3 Y1(1, na), YE(gE, na), YP(std::max(gP, 1), na), YW(Wmax, na);
         int rounds = 0, done = 0;
         std::vector<char> aborted(na, 0);
+        std::vector<BaSolve*> Sp(na);
+        for (int a = 0; a < na; a++) Sp[a] = S[act[a]].get();
         while (done < na && rounds < MAX_ROUNDS) {
             for (int r = 0; r < ROUNDS_PER_CHECK; r++, rounds++) {
                 hipLaunchKernelGGL(k_bab_round_begin, dim3(gw), dim3(64), 0, st, Dv, na);
@@ -1466,9 +1473,10 @@ static int ba_run_lockstep(Win* w, int n, Prepare prepare) {
             }
             VIORB_HIP_TRY(hipGetLastError());
             VIORB_HIP_TRY(hipMemcpyAsync(h_done, d_done, sizeof(int), hipMemcpyDeviceToHost, st));
-            VIORB_HIP_TRY(ba_wait(st));
+            VIORB_HIP_TRY(ba_wait(st, Sp.data(), na));
             done = *h_done;
-            // the callers' stop flags (g2o polls pbStopFlag once per iteration; here once per ROUNDS_PER_CHECK trials)
+            // the callers' stop flags: g2o polls pbStopFlag once per iteration and per trial; k_bab_decide does the same through the mirrored
+            // words ba_wait keeps up to date, and the host marks the window here so that the next rounds skip its kernels altogether
             for (int a = 0; a < na; a++) {
                 BaSolve& B = *S[act[a]];
                 if (!aborted[a] && B.terminate()) {
@@ -1507,6 +1515,14 @@ static int ba_run_lockstep(Win* w, int n, Prepare prepare) {
             const double* c = reinterpret_cast<const double*>(sg + o3);
             double* info = B.info;
             info[0] = c[BA_B_CHI0]; info[1] = c[BA_B_CHI1]; info[2] = c[BA_B_ITS0]; info[3] = c[BA_B_ITS1];
+        }
+        return VIORB_OK;
+        };
+        const int grc = solve_group();
+        if (grc != VIORB_OK) {
+            for (int i : act) w[g0 + i].status = grc;
+            for (int j = g0 + ng; j < n; j++) w[j].status = grc;
+            return grc;
         }
     }
     return first_error;

@@ -728,6 +728,264 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t* __restrict__ p
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_fast_cells3 (round 3): the same three passes with a third fewer vector instructions per cell. The kernel is bound by vector issue
+// (SQ_INSTS_VALU per cell, profiles/r03_*), so every change removes instructions, none touches a result:
+//   * compile-time LDS geometry (tile pitch 52 B, score-map pitch 44 B): every row / neighbour offset of the three passes is an
+//     instruction immediate. Cells wider than 13 dwords or taller than 44 rows take the generic kernel above (host check).
+//   * tile fetch as (4 rows x 16 dwords) per trip: lane -> (lane / 16, lane % 16) once per cell, a trip's four rows are the same per-lane
+//     offset from a wave-uniform base (scalar adds), LDS stores at immediate offsets — 12 vector instructions per cell instead of ~70.
+//   * pre-test by packed min / max: "some adjacent pair of the compass pixels (0, 4, 8, 12) is darker than v - t" is
+//     max(min(p0, p8), min(p4, p12)) < v - t, brighter: min(max(p0, p8), max(p4, p12)) > v + t — 6 packed min / max + 2 adds for two pixels
+//     instead of 8 adds + 6 logic operations.
+//   * polarity-split strength: the pre-test says WHICH polarity can be a corner; a survivor entry carries it, and pass 2 evaluates only
+//     that polarity of cv::cornerScore — max over the 16 arcs of the min of s (v - ring), s = +1 dark / -1 bright — half the min / max
+//     tree. Exact: a pixel whose bright pre-test failed at t has no bright arc at t, so its bright score is below t and cannot be the
+//     maximum of a corner's score nor make it a corner; a pixel cannot be a corner in both polarities (two 9-arcs do not fit in 16).
+//     A pixel passing both pre-tests gets two consecutive entries (8 % of the survivors on the bench images).
+// ---------------------------------------------------------------------------------------------
+#define F3_TPD 13                     // LDS tile pitch, dwords
+#define F3_TP (4 * F3_TPD)            // ... bytes
+#define F3_TRIPS 11                   // 4 rows per trip: tiles of up to 44 rows
+#define F3_SP 44                      // score-map pitch, bytes (interior width + 2 <= 44)
+#define F3_SROWS 40                   // score-map rows (interior height + 2 <= 40)
+__device__ __forceinline__ uint32_t pk_mul16(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, __builtin_bit_cast(short2v, a) * __builtin_bit_cast(short2v, b));
+}
+// cv::cornerScore<16> of ONE polarity: sgn = 0x00010001 (dark: d = v - ring) or 0xffffffff (bright: d = ring - v); returns
+// max over the 16 arcs of 9 of min(d) - 1. p points at the centre pixel inside the LDS tile (pitch F3_TP).
+__device__ __forceinline__ int fast_strength_pol(const uint8_t* p, uint32_t sgn) {
+    const uint32_t v = p[0], vv = v | (v << 16);
+    uint32_t P[8];
+    P[0] = pk_sub16(vv, (uint32_t)p[3 * F3_TP] | ((uint32_t)p[-3 * F3_TP] << 16));
+    P[1] = pk_sub16(vv, (uint32_t)p[3 * F3_TP + 1] | ((uint32_t)p[-3 * F3_TP - 1] << 16));
+    P[2] = pk_sub16(vv, (uint32_t)p[2 * F3_TP + 2] | ((uint32_t)p[-2 * F3_TP - 2] << 16));
+    P[3] = pk_sub16(vv, (uint32_t)p[F3_TP + 3] | ((uint32_t)p[-F3_TP - 3] << 16));
+    P[4] = pk_sub16(vv, (uint32_t)p[3] | ((uint32_t)p[-3] << 16));
+    P[5] = pk_sub16(vv, (uint32_t)p[-F3_TP + 3] | ((uint32_t)p[F3_TP - 3] << 16));
+    P[6] = pk_sub16(vv, (uint32_t)p[-2 * F3_TP + 2] | ((uint32_t)p[2 * F3_TP - 2] << 16));
+    P[7] = pk_sub16(vv, (uint32_t)p[-3 * F3_TP + 1] | ((uint32_t)p[3 * F3_TP - 1] << 16));
+    uint32_t S[8], lo2[8], lo4[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) { P[k] = pk_mul16(P[k], sgn); S[k] = swap16(P[k]); }          // (d[k], d[k+8]) and (d[k+8], d[k])
+#pragma unroll
+    for (int k = 0; k < 8; k++) lo2[k] = pk_min16(P[k], k < 7 ? P[k + 1] : S[0]);
+#pragma unroll
+    for (int k = 0; k < 8; k++) lo4[k] = pk_min16(lo2[k], k < 6 ? lo2[k + 2] : swap16(lo2[k - 6]));
+    uint32_t A = 0x80008000u;
+#pragma unroll
+    for (int k = 0; k < 8; k++) A = pk_max16(A, pk_min16(pk_min16(lo4[k], k < 4 ? lo4[k + 4] : swap16(lo4[k - 4])), S[k]));
+    return max((int)(short)(A & 0xffff), (int)(short)(A >> 16)) - 1;
+}
+// bit k of an 8-bit mask -> bit 2k
+__host__ __device__ __forceinline__ uint32_t spread8(uint32_t x) {
+    x = (x | (x << 4)) & 0x0f0fu; x = (x | (x << 2)) & 0x3333u; x = (x | (x << 1)) & 0x5555u;
+    return x;
+}
+// LDS per wavefront (the kernel is latency-bound at the occupancy its LDS footprint allows — r03 counters: vector pipes 33 % busy, LDS 27 %,
+// ~11 resident waves per CU at 11.4 KB each — so the footprint is what is tuned): tile | score map | survivor buffer | corner list.
+//   * survivors are consumed as they come: after every pass-1 trip the full groups of 64 go through pass 2 and the remainder (< 64) moves to
+//     the front, so the buffer holds at most 63 + 64 * 16 entries however many pixels survive;
+//   * the corner list holds F3_CORN_CAP entries; a cell with more corners than that (more than a third of its pixels) takes a dense NMS
+//     pass over the score map instead — same output, no list.
+#define F3_SURV_CAP (63 + 64 * 16 + 1)
+#define F3_CORN_CAP 512
+__global__ __launch_bounds__(64) void k_fast_cells3(const uint8_t* __restrict__ planes, size_t frame_bytes,
+                                                    const CellDesc* __restrict__ cells, int ini_th, int min_th,
+                                                    uint32_t* __restrict__ slots, int slot_cap,
+                                                    int* __restrict__ cell_cnt, int ncells_total, int tile_bytes, int score_bytes, XcdPlace PL) {
+    extern __shared__ uint32_t s_mem[];
+    int img_b, item;
+    if (!xcd_place(PL, img_b, item)) return;
+    uint8_t* tile = reinterpret_cast<uint8_t*>(s_mem);                   // [rows][F3_TP]
+    uint8_t* sc = tile + tile_bytes;                                      // [rows][F3_SP]
+    uint16_t* surv = reinterpret_cast<uint16_t*>(sc + score_bytes);      // [F3_SURV_CAP] (r << 7 | q << 1 | polarity) of pass-1 survivors
+    uint16_t* corn = surv + F3_SURV_CAP;                                 // [F3_CORN_CAP] corners (r << 7 | q << 1)
+    const int lane = threadIdx.x;
+    const int cell0 = item * FAST_CELLS_PER_WAVE;
+    const int ncell = min((int)FAST_CELLS_PER_WAVE, ncells_total - cell0);
+    const uint8_t* img = planes + (size_t)img_b * frame_bytes;
+    // tile fetch: trip k holds rows 4k .. 4k + 3, 16 dwords of each (lanes whose dword lies beyond the tile pitch stay idle)
+    const int lrow = lane >> 4, lq = lane & 15;
+    const bool fetch_lane = lq < F3_TPD;
+    uint32_t v[F3_TRIPS];
+    auto request_tile = [&](const CellDesc& cd) {
+        const uint8_t* src = img + cd.src_off;
+        const int ntrip = (cd.ch + 3) >> 2;
+        const uint32_t voff = (uint32_t)(__mul24(lrow, cd.stride) + 4 * lq);
+        // the last trip may reach below the cell: its rows are clamped to the cell's last row (the tile rows past ch are never read)
+        const uint32_t voff_last = (uint32_t)(__mul24(min(4 * (ntrip - 1) + lrow, cd.ch - 1) - 4 * (ntrip - 1), cd.stride) + 4 * lq);
+        if (fetch_lane) {
+#pragma unroll
+            for (int k = 0; k < F3_TRIPS; k++)
+                if (k < ntrip) {                                          // wave-uniform
+                    const uint8_t* base = src + (size_t)(4 * k) * (size_t)cd.stride;
+                    v[k] = *reinterpret_cast<const uint32_t*>(base + (k == ntrip - 1 ? voff_last : voff));
+                }
+        }
+    };
+    CellDesc c = cells[cell0];
+    request_tile(c);
+    const int lds_lane = __mul24(lrow, F3_TP) + 4 * lq;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    for (int kk = 0; kk < ncell; kk++) {
+    const int cell = cell0 + kk;
+    const int x0a = c.x0 & ~3, xoff = c.x0 - x0a;
+    {
+        const int ntrip = (c.ch + 3) >> 2;
+        if (fetch_lane) {
+#pragma unroll
+            for (int k = 0; k < F3_TRIPS; k++)
+                if (k < ntrip) *reinterpret_cast<uint32_t*>(tile + lds_lane + 4 * k * F3_TP) = v[k];
+        }
+    }
+    const bool has_next = kk + 1 < ncell;
+    const CellDesc cn = cells[has_next ? cell + 1 : cell];
+    const int dw = c.cw - 6, dh = c.ch - 6;          // interior (detection) region
+    {   // score map: rows 0 .. dh + 1, 16 bytes per lane and trip
+        const int nq = ((dh + 2) * F3_SP + 15) >> 4;
+        for (int i = lane; i < nq; i += 64) reinterpret_cast<uint4*>(sc)[i] = make_uint4(0, 0, 0, 0);
+    }
+    __syncthreads();
+    if (has_next) request_tile(cn);
+    uint32_t* my_slots = slots + ((size_t)img_b * ncells_total + cell) * slot_cap;
+    int total = 0;
+    if (dw > 0 && dh > 0) {
+        const uint8_t* tile_c = tile + 3 * F3_TP + xoff + 3;             // interior pixel (0, 0)
+        for (int attempt = 0; attempt < 2 && total == 0; attempt++) {
+            const int th = attempt ? min_th : ini_th;
+            // ---- pass 1 (pre-test on 8 pixels per lane, see k_fast_cells; verdicts as an interleaved 16-bit mask, bit 2k = pixel k can be a
+            // dark corner, bit 2k + 1 = a bright one) with pass 2 (the strength of each entry's polarity; corners (>= th) to the score map
+            // and, in order, to the corner list) run on every full group of 64 survivors as soon as it exists
+            int pending = 0, ncorn = 0;
+            {
+                const int g0 = (xoff + 3) >> 2;
+                const int G = ((xoff + 3 + dw - 1) >> 2) - g0 + 1;
+                const int G2 = (G + 1) >> 1;
+                const int rcpG = (int)c_rcp16[min(G2, 63)];
+                const int step_r = (64 * rcpG) >> 16, step_g = 64 - step_r * G2;
+                int r = __mul24(lane, rcpG) >> 16, gp = lane - __mul24(r, G2);
+                const int ntrip = (dh * G2 + 63) >> 6;
+                const uint32_t M = 0x00ff00ffu, Hb = 0x80008000u;
+                const uint32_t K1 = Hb - (uint32_t)(th + 1) * 0x00010001u;       // + v - A: bit 15 set <=> A < v - t  (an adjacent dark pair)
+                const uint32_t K2 = Hb - (uint32_t)(th + 1) * 0x00010001u;       // - v + B: bit 15 set <=> B > v + t  (an adjacent bright pair)
+                const int sh0 = (xoff + 3) - 4 * g0;
+                const int hi_last = min((G & 1) ? 4 : 8, dw - (8 * (G2 - 1) - sh0));
+                const uint32_t m8_first = (0xffu << sh0) & 0xffu, m8_last = (1u << hi_last) - 1u;
+                const uint32_t mask_first = spread8(m8_first) * 3u, mask_last = spread8(m8_last) * 3u;
+                for (int trip = 0; trip < ntrip; trip++) {
+                    const int rc = min(r, dh - 1);
+                    const int ga = 2 * gp, gb = min(ga + 1, G - 1);
+                    const uint32_t* rowU = reinterpret_cast<const uint32_t*>(tile + __mul24(rc, F3_TP)) + g0;      // ring row 3 above the centre row
+                    const uint32_t Lf = rowU[3 * F3_TPD + ga - 1], C0 = rowU[3 * F3_TPD + ga], C1 = rowU[3 * F3_TPD + gb], Rt = rowU[3 * F3_TPD + gb + 1];
+                    const uint32_t U0 = rowU[ga], U1 = rowU[gb], D0 = rowU[6 * F3_TPD + ga], D1 = rowU[6 * F3_TPD + gb];
+                    const uint32_t Cl1 = gb == ga ? Lf : C0;
+                    const uint32_t W0 = __builtin_amdgcn_alignbyte(C0, Lf, 1), E0 = __builtin_amdgcn_alignbyte(gb == ga ? Rt : C1, C0, 3);
+                    const uint32_t W1 = __builtin_amdgcn_alignbyte(C1, Cl1, 1), E1 = __builtin_amdgcn_alignbyte(Rt, C1, 3);
+                    const int q0 = 4 * (g0 + ga) - (xoff + 3);
+                    uint32_t X = 0;
+    #pragma unroll
+                    for (int dwi = 0; dwi < 2; dwi++) {
+                        const uint32_t C = dwi ? C1 : C0, U = dwi ? U1 : U0, D = dwi ? D1 : D0, W = dwi ? W1 : W0, E = dwi ? E1 : E0;
+    #pragma unroll
+                        for (int half = 0; half < 2; half++) {
+                            auto field = [&](uint32_t x) { return half ? __builtin_amdgcn_perm(x, x, 0x0c030c01u) : (x & M); };
+                            const uint32_t v2 = field(C);
+                            const uint32_t p0 = field(D), p4 = field(E), p8 = field(U), p12 = field(W);
+                            const uint32_t A = pk_max16(pk_min16(p0, p8), pk_min16(p4, p12));
+                            const uint32_t B = pk_min16(pk_max16(p0, p8), pk_max16(p4, p12));
+                            const uint32_t dk = (K1 + v2) - A, br = (K2 - v2) + B;                 // bits 15 / 31: the verdicts of the two pixels
+                            // pixel 4 dwi + 2 field + half -> bits 8 dwi + 4 field + 2 half (dark) and + 1 (bright); field 1 arrives 16 bits up, folded below
+                            X |= (dk >> (15 - 8 * dwi - 2 * half)) & (0x00010001u << (8 * dwi + 2 * half));
+                            X |= (br >> (14 - 8 * dwi - 2 * half)) & (0x00010001u << (8 * dwi + 2 * half + 1));
+                        }
+                    }
+                    uint32_t bits = (X | (X >> 12)) & 0xffffu;
+                    bits &= (gp == 0 ? mask_first : 0xffffu) & (gp == G2 - 1 ? mask_last : 0xffffu);
+                    if (r >= dh) bits = 0;
+                    const int cnt = __popc(bits), incl = wave_inclusive_scan(cnt);
+                    const int trip_total = __builtin_amdgcn_readlane(incl, 63);
+                    if (trip_total) {
+                        int pos = pending + incl - cnt;
+                        const uint32_t rq0 = ((uint32_t)r << 7) + (uint32_t)(2 * q0);
+                        uint32_t bb = bits;
+                        while (bb) {
+                            const int k = __builtin_ctz(bb);
+                            surv[pos++] = (uint16_t)(rq0 + k);
+                            bb &= bb - 1;
+                        }
+                        pending += trip_total;
+                    }
+                    r += step_r; gp += step_g;
+                    if (gp >= G2) { gp -= G2; r++; }
+                    // ---- pass 2 on the full groups (after the last trip: on whatever is left)
+                    const int need = trip + 1 < ntrip ? 64 : 1;
+                    if (pending >= need) {
+                        __syncthreads();
+                        int done = 0;
+                        while (pending - done >= need) {
+                            const int n = min(64, pending - done);
+                            bool is_c = false;
+                            uint32_t e = 0;
+                            if (lane < n) {
+                                e = surv[done + lane];
+                                const int er = e >> 7, eq = (e >> 1) & 63;
+                                const int s = fast_strength_pol(tile_c + __mul24(er, F3_TP) + eq, (e & 1) ? 0xffffffffu : 0x00010001u);
+                                if (s >= th) { is_c = true; sc[__mul24(er + 1, F3_SP) + eq + 1] = (uint8_t)s; }
+                            }
+                            const unsigned long long m = __ballot(is_c);
+                            if (is_c) { const int cp = ncorn + __popcll(m & lt); if (cp < F3_CORN_CAP) corn[cp] = (uint16_t)(e & ~1u); }
+                            ncorn += __popcll(m);
+                            done += n;
+                        }
+                        const int left = pending - done;                          // < 64: to the front of the buffer
+                        if (left > 0) {
+                            const uint16_t t = lane < left ? surv[done + lane] : (uint16_t)0;
+                            __syncthreads();
+                            if (lane < left) surv[lane] = t;
+                        }
+                        pending = left;
+                        __syncthreads();
+                    }
+                }
+            }
+            __syncthreads();
+            // ---- pass 3: strict 3x3 NMS, over the corner list — or, for a cell with more corners than the list holds, over every pixel of the
+            // score map in the same (row-major) order
+            const bool dense = ncorn > F3_CORN_CAP;
+            const int n3 = dense ? dh * dw : ncorn;
+            for (int base = 0; base < n3; base += 64) {
+                bool keep = false;
+                int r = 0, q = 0, s = 0;
+                if (base + lane < n3) {
+                    if (dense) { r = (base + lane) / dw; q = (base + lane) - r * dw; }
+                    else { const uint32_t e = corn[base + lane]; r = e >> 7; q = (e >> 1) & 63; }
+                    const uint8_t* z = sc + __mul24(r + 1, F3_SP) + q + 1;
+                    s = z[0];
+                    int nb[8];
+                    nb[0] = z[-F3_SP - 1]; nb[1] = z[-F3_SP]; nb[2] = z[-F3_SP + 1]; nb[3] = z[-1]; nb[4] = z[1]; nb[5] = z[F3_SP - 1]; nb[6] = z[F3_SP]; nb[7] = z[F3_SP + 1];
+                    int mx = 0;
+    #pragma unroll
+                    for (int k = 0; k < 8; k++) mx = max(mx, nb[k]);
+                    keep = s > mx;                                                 // a pixel that is no corner has s == 0
+                }
+                const unsigned long long m = __ballot(keep);
+                if (keep) {
+                    const int pos = total + __popcll(m & lt);
+                    if (pos < slot_cap)
+                        my_slots[pos] = (uint32_t)(q + 3 + c.shx) | ((uint32_t)(r + 3 + c.shy) << 12) | ((uint32_t)s << 24);
+                }
+                total += __popcll(m);
+            }
+            __syncthreads();
+        }
+    }
+    if (lane == 0) cell_cnt[(size_t)img_b * ncells_total + cell] = min(total, slot_cap);
+    __syncthreads();
+    c = cn;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Quadtree distribution: one wavefront per (level, image). Mirrors distribute_octree_arrays()
 // (octree_arrays.h) step for step; every control decision is wave-uniform.
 // ---------------------------------------------------------------------------------------------
@@ -1515,6 +1773,8 @@ struct viorb_extractor {
     size_t frame_bytes = 0;
     int slot_cap = 0, kp_pitch = 0, out_cap = 0;
     int fast_tile_pitch = 0, fast_tile_rows = 0, fast_tile_bytes = 0, fast_score_bytes = 0, fast_list_cap = 0;
+    bool fast_v3 = false;            // every cell fits k_fast_cells3's compile-time LDS geometry
+    int fast3_tile_bytes = 0, fast3_score_bytes = 0;
     int oct_ncap = 0, oct_nodecap = 0, oct_sortcap = 0;
     std::vector<int> rs_pitch_dw, rs_rows;
     // second resize form (k_resize2): per-level tile table, LDS pitch, whether the level qualifies; whether level 1's kernel may also write level 0
@@ -1740,6 +2000,14 @@ static int configure(viorb_extractor* h, int w, int hgt) {
     h->slot_cap = ((max_cw - 6 + 1) / 2) * ((max_ch - 6 + 1) / 2);       // independent set of the king's graph
     h->fast_list_cap = (int)align_up((size_t)(max_cw - 6) * (max_ch - 6), 2);
     if (max_cw - 6 > 255 || max_ch - 6 > 255) { set_error("FAST cell larger than 255 px"); return VIORB_ERR_UNSUPPORTED; }
+    {   // k_fast_cells3: tile of <= 13 dwords x 44 rows, score map of <= 44 x 40 bytes (every cell of the default 1.2-scale pyramids fits)
+        bool ok = true;
+        for (const CellDesc& c : h->cells) ok = ok && ((c.x0 & 3) + c.cw <= 4 * F3_TPD - 4) && c.ch <= 4 * F3_TRIPS && c.cw - 6 + 2 <= F3_SP && c.ch - 6 + 2 <= F3_SROWS;
+        static const bool force_v2 = getenv("VIORB_FAST_V2") != nullptr;          // A/B switch: the round-2 kernel
+        h->fast_v3 = ok && !force_v2;
+        h->fast3_tile_bytes = (int)align_up((size_t)(4 * ((max_ch + 3) / 4)) * F3_TP, 16);          // whole trips of 4 rows
+        h->fast3_score_bytes = (int)align_up((size_t)(max_ch - 6 + 2) * F3_SP + 16, 16);              // + the 16-byte granule of the clearing stores
+    }
     // quadtree capacities
     int maxq = 1; for (int l = 0; l < nl; l++) maxq = std::max(maxq, h->quota[l]);
     h->oct_ncap = 8192;
@@ -1885,7 +2153,8 @@ static int launch_all(viorb_extractor* h, const uint8_t* d_images, int batch, in
                            h->rs_pitch_dw[l], h->rs_rows[l], PL, gx);
     }
     {
-        const size_t lds = (size_t)h->fast_tile_bytes + h->fast_score_bytes + (size_t)h->fast_list_cap * 4;
+        const size_t lds = h->fast_v3 ? (size_t)h->fast3_tile_bytes + h->fast3_score_bytes + (size_t)(F3_SURV_CAP + F3_CORN_CAP) * 2
+                                      : (size_t)h->fast_tile_bytes + h->fast_score_bytes + (size_t)h->fast_list_cap * 4;
         // FAST goes out as FAST_LAUNCHES launches over sub-ranges of the batch (multiples of 8 images). A launch boundary is the only point
         // where the tracking stream's large workgroups (a search: 16 waves + 73 KB of LDS; the pose solver: 240 registers per lane) can be
         // placed on a CU: while this kernel still has workgroups to hand out, every slot that frees goes to its next single-wave
@@ -1900,9 +2169,13 @@ static int launch_all(viorb_extractor* h, const uint8_t* d_images, int batch, in
             // time; the sub-launches differ in what runs beside them, so the rotation is what makes the mean agree with a tracer's per-launch mean)
             ProfScope ps(prof_times_everything() || (i0 / step) == (int)(h->fast_prof_rot % (unsigned)((batch + step - 1) / step)) ? "k_fast_cells" : nullptr, st);
             const XcdPlace PL = make_place((ncells + FAST_CELLS_PER_WAVE - 1) / FAST_CELLS_PER_WAVE, batch, i0, std::min(batch, i0 + step));
-            hipLaunchKernelGGL(k_fast_cells, dim3(place_blocks(PL)), dim3(64), lds, st, h->d_planes, h->frame_bytes, h->d_lv, h->d_cells,
-                               h->p.ini_th_fast, h->p.min_th_fast, h->d_slots, h->slot_cap, h->d_cell_cnt, ncells,
-                               h->fast_tile_bytes, h->fast_score_bytes, h->fast_list_cap, PL);
+            if (h->fast_v3)
+                hipLaunchKernelGGL(k_fast_cells3, dim3(place_blocks(PL)), dim3(64), lds, st, h->d_planes, h->frame_bytes, h->d_cells,
+                                   h->p.ini_th_fast, h->p.min_th_fast, h->d_slots, h->slot_cap, h->d_cell_cnt, ncells, h->fast3_tile_bytes, h->fast3_score_bytes, PL);
+            else
+                hipLaunchKernelGGL(k_fast_cells, dim3(place_blocks(PL)), dim3(64), lds, st, h->d_planes, h->frame_bytes, h->d_lv, h->d_cells,
+                                   h->p.ini_th_fast, h->p.min_th_fast, h->d_slots, h->slot_cap, h->d_cell_cnt, ncells,
+                                   h->fast_tile_bytes, h->fast_score_bytes, h->fast_list_cap, PL);
         }
     }
     // The blur only needs the pyramid, the quadtree only FAST: from here they run side by side, the blur on the handle's second stream.
