@@ -96,7 +96,7 @@ def test_imu_predict_matches_oracle(torch_cuda, oracle, streams):
     np.testing.assert_allclose(hp[:60], oracle.preintegrate(st["imu"][1], st["ns_true"][0][10:13], st["ns_true"][0][13:16], st["t"][0], st["t"][1])[:60], atol=1e-12)
 
 
-@pytest.mark.parametrize("th", [15.0, 30.0, 7.0])
+@pytest.mark.parametrize("th", [15.0, 30.0, 7.0, 160.0])      # 160: windows of most of the image, far more than the 128 candidates a point's stored list holds
 def test_search_by_projection_matches_oracle(torch_cuda, oracle, streams, th):
     torch = torch_cuda
     B, cap = len(streams), 1016
@@ -300,7 +300,7 @@ def test_host_dropin_search_by_projection_stereo_branch(torch_cuda, oracle, moti
         np.testing.assert_array_equal(match, om)
 
 
-@pytest.mark.parametrize("th,nnratio", [(1.0, 0.8), (5.0, 0.8)])
+@pytest.mark.parametrize("th,nnratio", [(1.0, 0.8), (5.0, 0.8), (60.0, 0.8)])     # 60: windows with hundreds of candidates (no capacity limit)
 def test_search_local_points_matches_oracle(torch_cuda, oracle, th, nnratio):
     """a12: isInFrustum + SearchByProjection(Frame, local map points), two streams in one launch."""
     torch = torch_cuda

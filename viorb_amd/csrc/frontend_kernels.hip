@@ -159,7 +159,7 @@ __global__ __launch_bounds__(SEARCH_THREADS) void k_search_projection(SearchArgs
     uint16_t* cs = reinterpret_cast<uint16_t*>(cang + cap);              // [GRID_CELLS + 1] (+1 pad)
     uint16_t* ci = cs + GRID_CELLS + 2;                                   // [cap]
     uint8_t* coct = reinterpret_cast<uint8_t*>(ci + cap);                // [cap]
-    __shared__ int s_changed, s_hist[HISTO_LENGTH], s_keep[HISTO_LENGTH], s_nm, s_overflow;
+    __shared__ int s_changed, s_hist[HISTO_LENGTH], s_keep[HISTO_LENGTH], s_nm;
     const float* P = A.pose12 + (size_t)b * 12;
     const viorb_keypoint* ck = A.cur_kps + (size_t)b * cap;
     const viorb_keypoint* lk = A.last_kps + (size_t)b * cap;
@@ -176,7 +176,7 @@ __global__ __launch_bounds__(SEARCH_THREADS) void k_search_projection(SearchArgs
             cxy[i] = make_float2(k.x, k.y); cang[i] = k.angle; coct[i] = (uint8_t)k.octave;
         }
     }
-    if (t == 0) { s_overflow = 0; s_nm = 0; }
+    if (t == 0) s_nm = 0;
     for (int i = t; i < HISTO_LENGTH; i += blockDim.x) { s_hist[i] = 0; s_keep[i] = 0; }
     __syncthreads();
     // stereo: does the camera move forward / backward by more than the baseline? (tlc = Rlw * twc + tlw, twc = -Rcw^T tcw; :1339-1349)
@@ -190,8 +190,10 @@ __global__ __launch_bounds__(SEARCH_THREADS) void k_search_projection(SearchArgs
         const float tz = (Lp[6] * twc[0] + Lp[7] * twc[1] + Lp[8] * twc[2]) + Lp[11];
         motion = tz > A.mb ? 1 : (-tz > A.mb ? 2 : 0);
     }
-    // ---- phase A
-    for (int i = t; i < nlast; i += blockDim.x) {
+    // Candidates of last-frame point i in the reference's order (GetFeaturesInArea: columns outer, rows inner, insertion order inside a
+    // cell), each with its Hamming distance: f(k, dist << 16 | index). Phase A stores the first CAND_CAP of them; a point with more
+    // (a window of half the image) is enumerated again by every sweep of phase B instead of being cut short — no capacity limit.
+    auto enumerate = [&](int i, auto&& f) -> int {
         int nc = 0;
         const int fl = lf[i];
         if ((fl & 1) && !(fl & 2)) {
@@ -231,17 +233,21 @@ __global__ __launch_bounds__(SEARCH_THREADS) void k_search_projection(SearchArgs
                             const uint4 ea = dc[0], eb = dc[1];
                             const int dist = __popc(da.x ^ ea.x) + __popc(da.y ^ ea.y) + __popc(da.z ^ ea.z) + __popc(da.w ^ ea.w) +
                                              __popc(db.x ^ eb.x) + __popc(db.y ^ eb.y) + __popc(db.z ^ eb.z) + __popc(db.w ^ eb.w);
-                            const uint32_t e = ((uint32_t)dist << 16) | (uint32_t)i2;
-                            if (nc < SEARCH_SLOT) slot[(size_t)i * SEARCH_SLOT + nc] = e;
-                            else if (nc < CAND_CAP) cand[(size_t)i * CAND_CAP + nc] = e;
+                            f(nc, ((uint32_t)dist << 16) | (uint32_t)i2);
                             nc++;
                         }
                     }
                 }
             }
         }
-        if (nc > CAND_CAP) { nc = CAND_CAP; s_overflow = 1; }
-        cand_n[i] = nc;
+        return nc;
+    };
+    // ---- phase A
+    for (int i = t; i < nlast; i += blockDim.x) {
+        cand_n[i] = enumerate(i, [&](int k, uint32_t e) {
+            if (k < SEARCH_SLOT) slot[(size_t)i * SEARCH_SLOT + k] = e;
+            else if (k < CAND_CAP) cand[(size_t)i * CAND_CAP + k] = e;
+        });                                                            // the true count, also beyond CAND_CAP
         choice[i] = -1;
     }
     __syncthreads();
@@ -257,12 +263,14 @@ __global__ __launch_bounds__(SEARCH_THREADS) void k_search_projection(SearchArgs
         for (int i = t; i < nlast; i += blockDim.x) {
             const int nc = cand_n[i];
             int best = 256, bidx = -1;
-            for (int k = 0; k < nc; k++) {
-                const uint32_t e = k < SEARCH_SLOT ? slot[(size_t)i * SEARCH_SLOT + k] : cand[(size_t)i * CAND_CAP + k];
+            auto consider = [&](int, uint32_t e) {
                 const int i2 = (int)(e & 0xffff), dist = (int)(e >> 16);
-                if (taken[i2] < i) continue;                      // owned by an earlier point that has observations
+                if (taken[i2] < i) return;                        // owned by an earlier point that has observations
                 if (dist < best) { best = dist; bidx = i2; }
-            }
+            };
+            if (nc <= CAND_CAP) {
+                for (int k = 0; k < nc; k++) consider(k, k < SEARCH_SLOT ? slot[(size_t)i * SEARCH_SLOT + k] : cand[(size_t)i * CAND_CAP + k]);
+            } else enumerate(i, consider);                        // more candidates than the stored list holds: walk the grid again
             const int nw = best <= TH_HIGH ? bidx : -1;
             changed = changed || (nw != choice[i]);
             rej[i] = nw;                                           // committed after every thread has read `taken`
@@ -329,7 +337,7 @@ __global__ __launch_bounds__(SEARCH_THREADS) void k_search_projection(SearchArgs
     }
     int* out = A.cur_match + (size_t)b * cap;
     for (int c = t; c < cap; c += blockDim.x) out[c] = (c < ncur && !rej[c]) ? owner[c] : -1;
-    if (t == 0) { A.nmatches[b] = s_nm; A.status[b] = s_overflow ? VIORB_ERR_CAPACITY : VIORB_OK; }
+    if (t == 0) { A.nmatches[b] = s_nm; A.status[b] = VIORB_OK; }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -370,7 +378,7 @@ __global__ __launch_bounds__(SEARCH_THREADS) void k_search_local_points(LocalSea
     uint16_t* ci = cs + GRID_CELLS + 2;                                          // [cap]
     uint8_t* coct = reinterpret_cast<uint8_t*>(ci + cap);                        // [cap]
     uint8_t* cown = coct + cap;                                                  // [cap]
-    __shared__ int s_changed, s_nm, s_overflow;
+    __shared__ int s_changed, s_nm;
     const float* P = A.pose12 + (size_t)b * 12;
     const viorb_keypoint* ck = A.cur_kps + (size_t)b * cap;
     const uint8_t* pf = A.pts_flags + (size_t)b * pcap;
@@ -387,15 +395,17 @@ __global__ __launch_bounds__(SEARCH_THREADS) void k_search_local_points(LocalSea
             cown[i] = A.cur_owner_obs[(size_t)b * cap + i] ? 1 : 0;
         }
     }
-    if (t == 0) { s_overflow = 0; s_nm = 0; }
+    if (t == 0) s_nm = 0;
     __syncthreads();
     // mOw = -Rcw^T tcw
     float Ow[3];
 #pragma unroll
     for (int r = 0; r < 3; r++) { const float tt = P[r] * P[9] + P[3 + r] * P[10] + P[6 + r] * P[11]; Ow[r] = -tt; }
     const bool bFactor = A.th != 1.0f;
-    // ---- phase A: frustum + candidates
-    for (int i = t; i < npts; i += blockDim.x) {
+    // isInFrustum + the candidates of local point i in the reference's order: f(k, dist << 16 | index); fr (when not null) receives
+    // mbTrackInView, mTrackProjX, mTrackProjY, mTrackViewCos, mnTrackScaleLevel. Phase A stores the first CAND_CAP candidates; a point
+    // with more is enumerated again by every sweep of phase B (no capacity limit).
+    auto enumerate = [&](int i, float* fr, auto&& f) -> int {
         int nc = 0;
         const int fl = pf[i];
         float fr_in = 0, fr_u = 0, fr_v = 0, fr_cos = 0, fr_lvl = 0;
@@ -444,18 +454,22 @@ __global__ __launch_bounds__(SEARCH_THREADS) void k_search_local_points(LocalSea
                             const uint4 ea = dc[0], eb = dc[1];
                             const int dist2 = __popc(da.x ^ ea.x) + __popc(da.y ^ ea.y) + __popc(da.z ^ ea.z) + __popc(da.w ^ ea.w) +
                                               __popc(db.x ^ eb.x) + __popc(db.y ^ eb.y) + __popc(db.z ^ eb.z) + __popc(db.w ^ eb.w);
-                            const uint32_t e = ((uint32_t)dist2 << 16) | (uint32_t)i2;
-                            if (nc < LOCAL_SLOT) slot[(size_t)i * LOCAL_SLOT + nc] = e;
-                            else if (nc < CAND_CAP) cand[(size_t)i * CAND_CAP + nc] = e;
+                            f(nc, ((uint32_t)dist2 << 16) | (uint32_t)i2);
                             nc++;
                         }
                     }
                 }
             }
         }
-        if (A.frustum) { float* f = A.frustum + ((size_t)b * pcap + i) * 5; f[0] = fr_in; f[1] = fr_u; f[2] = fr_v; f[3] = fr_cos; f[4] = fr_lvl; }
-        if (nc > CAND_CAP) { nc = CAND_CAP; s_overflow = 1; }
-        cand_n[i] = nc;
+        if (fr) { fr[0] = fr_in; fr[1] = fr_u; fr[2] = fr_v; fr[3] = fr_cos; fr[4] = fr_lvl; }
+        return nc;
+    };
+    // ---- phase A: frustum + candidates
+    for (int i = t; i < npts; i += blockDim.x) {
+        cand_n[i] = enumerate(i, A.frustum ? A.frustum + ((size_t)b * pcap + i) * 5 : nullptr, [&](int k, uint32_t e) {
+            if (k < LOCAL_SLOT) slot[(size_t)i * LOCAL_SLOT + k] = e;
+            else if (k < CAND_CAP) cand[(size_t)i * CAND_CAP + k] = e;
+        });                                                            // the true count, also beyond CAND_CAP
         choice[i] = -1;
     }
     __syncthreads();
@@ -471,13 +485,15 @@ __global__ __launch_bounds__(SEARCH_THREADS) void k_search_local_points(LocalSea
         for (int i = t; i < npts; i += blockDim.x) {
             const int nc = cand_n[i];
             int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
-            for (int k = 0; k < nc; k++) {
-                const uint32_t e = k < LOCAL_SLOT ? slot[(size_t)i * LOCAL_SLOT + k] : cand[(size_t)i * CAND_CAP + k];
+            auto consider = [&](int, uint32_t e) {
                 const int i2 = (int)(e & 0xffff), dist = (int)(e >> 16);
-                if (taken[i2] < i) continue;
+                if (taken[i2] < i) return;
                 if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestLevel2 = bestLevel; bestLevel = coct[i2]; bestIdx = i2; }
                 else if (dist < bestDist2) { bestLevel2 = coct[i2]; bestDist2 = dist; }
-            }
+            };
+            if (nc <= CAND_CAP) {
+                for (int k = 0; k < nc; k++) consider(k, k < LOCAL_SLOT ? slot[(size_t)i * LOCAL_SLOT + k] : cand[(size_t)i * CAND_CAP + k]);
+            } else enumerate(i, nullptr, consider);               // more candidates than the stored list holds: walk the grid again
             int nw = -1;
             if (bestDist <= TH_HIGH && !(bestLevel == bestLevel2 && (float)bestDist > A.nnratio * (float)bestDist2)) nw = bestIdx;
             changed = changed || (nw != choice[i]);
@@ -502,7 +518,7 @@ __global__ __launch_bounds__(SEARCH_THREADS) void k_search_local_points(LocalSea
     __syncthreads();
     int* out = A.match + (size_t)b * cap;
     for (int c = t; c < cap; c += blockDim.x) out[c] = c < ncur ? taken[c] : -1;
-    if (t == 0) { A.nmatches[b] = s_nm; if (s_overflow) A.status[b] = VIORB_ERR_CAPACITY; }
+    if (t == 0) A.nmatches[b] = s_nm;
 }
 
 // ---------------------------------------------------------------------------------------------
