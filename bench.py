@@ -177,7 +177,12 @@ def run_tracking(args, cfg, rank, dev_index, dev, world):
     tr = NativeTracker(cam, gw, S, W_IMG, H_IMG, NFEAT, th=15.0, device=dev_index, compute_marg=True, track_local_map=TLM)
     tr.bootstrap(frames[0], pose_true[0], t_frames[0], ns_true[0], mci0)
 
+    # live feed: the same frames in page-locked host memory, uploaded by the tracker's copy stream inside the step (viorb_tracker_inputs.h_images)
+    frames_host = torch.from_numpy(np.stack([s["frames"] for s in streams], 1)).pin_memory()
+    feed = {"frames": frames_host if args.host_input else frames}
+
     def run_step(k):
+        frames = feed["frames"]
         j = k % N_FRAMES
         if j == 0:
             # closing the loop: frame F == frame 0, its stamp is the period; next "last" stamp is 0. It is also the harness's key-frame
@@ -213,6 +218,22 @@ def run_tracking(args, cfg, rank, dev_index, dev, world):
     elapsed = time.perf_counter() - t0
     L.viorb_profile_enable(0)
     hs = tr.host_stats()
+    # ---- the other input mode, outside the timed region: HBM-resident frames when the line was measured on the live feed and vice versa
+    other = {}
+    if not args.no_host_input_pass:
+        feed["frames"] = frames if args.host_input else frames_host
+        n_other = max(8, min(args.steps, 48))
+        for _ in range(4):
+            run_step(k); k += 1
+        tr.sync(); torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(n_other):
+            run_step(k); k += 1
+        tr.sync(); torch.cuda.synchronize()
+        dt_other = time.perf_counter() - t1
+        other = {"frames_per_s": round(S * n_other / dt_other, 1), "ms_per_step": round(dt_other / n_other * 1e3, 4), "steps": n_other}
+        feed["frames"] = frames_host if args.host_input else frames
+    img_bytes = W_IMG * H_IMG
 
     # ---- sanity of the timed work (outside the timed region)
     res = tr.results(["state", "status", "nmatches", "n_loc", "info", "info2", "inliers"])
@@ -315,6 +336,8 @@ def run_tracking(args, cfg, rank, dev_index, dev, world):
                          " + SearchLocalPoints(~2000 local points) + PoseOptimization(marg)  [TrackWithIMU + TrackLocalMapWithIMU]" if TLM else " [TrackWithIMU only]"),
             "baseline_config": cfg["baseline_config"], "keyframe_boundary_every_frames": N_FRAMES,
             "keyframe_variant": "PoseOptimization(Frame, KeyFrame) on the frame after every boundary (mbMapUpdated), (Frame, Frame) otherwise",
+            "input": ("page-locked host memory, uploaded inside the timed region by the tracker's copy stream (live feed)" if args.host_input
+                      else "HBM-resident frames (uploaded before the timed region)"),
             "track_local_map": TLM, "streams_per_gpu": S, "distinct_synthetic_streams_per_gpu": distinct, "frames_per_step": S * world, "solver_dtype": "f64",
             "host_enqueue_ms_per_step": round(hs["enqueue_s"] / max(hs["steps"], 1) * 1e3, 4),
             "host_throttle_wait_ms_per_step": round(hs["throttle_s"] / max(hs["steps"], 1) * 1e3, 4),
@@ -322,6 +345,14 @@ def run_tracking(args, cfg, rank, dev_index, dev, world):
             "tracked_streams_last_step": tracked, "state_histogram_last_step": np.bincount(res["state"], minlength=5).tolist(),
             "mean_matches_last_step": round(float(res["nmatches"].mean()), 1), "mean_local_matches_last_step": round(float(res["n_loc"].mean()), 1),
             "mean_inliers_last_step": round(float(info[:, 0].mean()), 1), "status_ok": bool((res["status"] == 0).all())}
+        if other:                                           # per rank (rank 0's figure): the driver's line stays the aggregate of the timed region
+            host_fps = other["frames_per_s"] if not args.host_input else S * args.steps / elapsed
+            out["config"]["host_input_frames_per_s"] = round(host_fps, 1)
+            out["config"]["host_input_pcie_GBps"] = round(host_fps * img_bytes / 1e9, 2)
+            out["config"]["host_input_note"] = ("per GPU; frames of %d bytes from page-locked host memory through viorb_tracker_inputs.h_images (copy stream, ring of "
+                                                "max_steps_ahead + 2 device buffers); PCIe Gen5 x16 spec 63 GB/s" % img_bytes)
+            if args.host_input:
+                out["config"]["hbm_resident_frames_per_s"] = other["frames_per_s"]
         if not (res["status"] == 0).all():
             raise SystemExit("a stream reported a capacity / status error: %s" % res["status"])
         if not args.no_cpu_baseline:
@@ -484,6 +515,9 @@ def main():
     ap.add_argument("--in-flight", type=int, default=32, help="local_ba: windows kept in flight by the batch driver")
     ap.add_argument("--no-track-local-map", action="store_true", help="stop after TrackWithIMU's pose solve")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--host-input", action="store_true", help="tracking configs: frames come from page-locked HOST memory and are uploaded inside the "
+                    "timed region (live feed); default: HBM-resident frames, with the live-feed rate reported as config.host_input_frames_per_s")
+    ap.add_argument("--no-host-input-pass", action="store_true", help="skip the extra pass that measures the other input mode")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip the per-kernel HIP events (rooflines become null); dev aid")
     ap.add_argument("--timeline", default=None, help="dev aid (with --all-kernel-events): write start / end / duration (us) of the last kernels to this file")
     ap.add_argument("--timeline-rows", type=int, default=120)
@@ -502,10 +536,28 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
-    from viorb_amd.distributed import reduce_throughput, init as dist_init
+    from viorb_amd.distributed import reduce_throughput, init as dist_init, stream_seeds
     import torch
     import torch.distributed as dist
     import viorb_amd
+    if os.environ.get("VIORB_BENCH_PLUMBING_ONLY"):
+        # Everything of the N > 1 path up to (not including) the first GPU call, for the CPU test-suite (tests/test_distributed_cpu.py): argument and
+        # rank plumbing, gloo rendezvous, stream ownership, and the {sum units, max time} reduction of a made-up measurement. Prints no metric.
+        if world > 1:
+            dist_init("gloo")
+        seeds = stream_seeds(rank, min(args.streams, 4))
+        units, elapsed = reduce_throughput(args.streams * args.steps, 1.0 + 0.5 * rank)
+        owned = [None] * world
+        if world > 1:
+            dist.all_gather_object(owned, seeds)
+        else:
+            owned = [seeds]
+        if rank == 0:
+            print(json.dumps({"plumbing_only": True, "config": args.config, "n_gpus": world, "local_rank": local_rank, "streams_per_gpu": args.streams,
+                              "steps": args.steps, "warmup": args.warmup, "units": units, "elapsed": elapsed, "seeds": owned}))
+        if world > 1:
+            dist.barrier(); dist.destroy_process_group()
+        return
     if viorb_amd.lib().viorb_device_count() < 1:
         raise SystemExit("bench.py needs a HIP device (viorb_amd has no CPU fallback)")
     # VIORB_BENCH_REHEARSAL=1: run the N > 1 code path on a box with fewer GPUs than ranks (ranks share devices, gloo instead of

@@ -361,6 +361,11 @@ typedef struct viorb_tracker_inputs {     /* device pointers; row b belongs to s
     const double*  d_reset_marg;          /* [b][144] ... and this prior information (NULL: chained) */
     const double*  d_synth_pose12;        /* [b][12] double Rcw tcw: map points of the new last frame from the synthetic plane world
                                              (NULL: the caller supplies them with viorb_tracker_set_last_points_device before the next step) */
+    const uint8_t* h_images;              /* live feed: the batch's images in HOST memory (same stride / pitch; page-locked for the copy to be
+                                             asynchronous). When set, d_images is ignored: the step uploads them on the tracker's copy stream
+                                             into a ring of max_steps_ahead + 2 device buffers and the extraction waits for that upload only —
+                                             the upload of frame k + 1 overlaps the extraction and tracking of frame k. The host buffer may be
+                                             reused once viorb_tracker_step has been called max_steps_ahead + 1 more times (or after _sync). */
 } viorb_tracker_inputs;
 typedef struct viorb_tracker_results {    /* device pointers into the tracker, valid after viorb_tracker_sync until the next step */
     int32_t cap;

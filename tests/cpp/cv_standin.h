@@ -6,6 +6,7 @@
 #include <cassert>
 #define CV_8U 0
 #define CV_8UC1 0
+#define CV_32F 5
 namespace cv {
 struct KeyPoint {
     struct Pt { float x, y; } pt; float size, angle, response; int octave, class_id;
@@ -16,9 +17,15 @@ struct Mat {
     std::vector<float> fbuf;                                   // CV_32F payload of the few float matrices the tracking shim reads (GetWorldPos)
     template <class T> T& at(int i) { return reinterpret_cast<T*>(fbuf.data())[i]; }
     template <class T> const T& at(int i) const { return reinterpret_cast<const T*>(fbuf.data())[i]; }
+    template <class T> T& at(int r, int c) { return reinterpret_cast<T*>(fbuf.data())[(size_t)r * cols + c]; }
+    template <class T> const T& at(int r, int c) const { return reinterpret_cast<const T*>(fbuf.data())[(size_t)r * cols + c]; }
     Mat() {}
-    Mat(int r, int c, int) { create(r, c, 0); }
-    void create(int r, int c, int) { rows = r; cols = c; step = (size_t)c; buf.assign((size_t)r * c, 0); data = buf.data(); }
+    Mat(int r, int c, int type) { create(r, c, type); }
+    void create(int r, int c, int type) {
+        rows = r; cols = c;
+        if (type == CV_32F) { step = (size_t)c * 4; fbuf.assign((size_t)r * c, 0.f); buf.clear(); data = nullptr; }
+        else { step = (size_t)c; buf.assign((size_t)r * c, 0); data = buf.data(); }
+    }
     bool empty() const { return rows == 0 || cols == 0; }
     int type() const { return CV_8UC1; }
     Mat getMat() const { return *this; }

@@ -1,0 +1,362 @@
+// tests/cpp/shim_callsites_test.cpp — compile / link / run test of the call-site templates of viorb_amd/shim/{ORBmatcher,Frame,Optimizer}_shim.h:
+// the nine drop-in bodies a maintainer calls from ORBmatcher / Frame / Optimizer. The reference's Frame /
+// KeyFrame / MapPoint / Map and DBoW2 / Eigen / Sophus are absent from this image, so minimal stand-ins WITH THE REFERENCE'S MEMBER NAMES
+// (include/Frame.h, include/KeyFrame.h, include/MapPoint.h, Thirdparty/DBoW2/DBoW2/{BowVector,FeatureVector}.h) are defined here — test
+// scaffolding only. Every template is run on seeded random data and its effect on the objects is compared with a direct C-ABI call on
+// arrays flattened independently here. Without a device every template must THROW (no CPU fallback, no silent "0 matches").
+#include <cstdio>
+#include <cstdlib>
+#include <cmath>
+#include <map>
+#include <list>
+#include <vector>
+#include <mutex>
+#define VIORB_SHIM_CV_STANDIN
+#include "cv_standin.h"
+#include "ORBextractor.h"
+#include "ORBmatcher_shim.h"
+#include "Frame_shim.h"
+#include "Optimizer_shim.h"
+
+namespace standin {
+struct Rng { unsigned s; explicit Rng(unsigned seed) : s(seed) {} unsigned next() { s = s * 1664525u + 1013904223u; return s >> 8; } float uni(float a, float b) { return a + (b - a) * (float)(next() & 0xffff) / 65535.f; } };
+
+struct Vec3 { double v[3]; Vec3(double x = 0, double y = 0, double z = 0) { v[0] = x; v[1] = y; v[2] = z; } double operator[](int i) const { return v[i]; } };
+struct Quat { double w_, x_, y_, z_; Quat(double w = 1, double x = 0, double y = 0, double z = 0) : w_(w), x_(x), y_(y), z_(z) {}
+              double x() const { return x_; } double y() const { return y_; } double z() const { return z_; } double w() const { return w_; } };
+struct SO3 { Quat q; SO3() {} explicit SO3(const Quat& q_) : q(q_) {} const Quat& unit_quaternion() const { return q; } };
+template <int R, int C> struct Mat { double m[R][C]; Mat() { for (auto& r : m) for (double& x : r) x = 0; } double& operator()(int r, int c) { return m[r][c]; } double operator()(int r, int c) const { return m[r][c]; } };
+struct NavState {
+    Vec3 P, V, bg, ba, dbg, dba; SO3 R;
+    Vec3 Get_P() const { return P; } Vec3 Get_V() const { return V; } SO3 Get_R() const { return R; }
+    Vec3 Get_BiasGyr() const { return bg; } Vec3 Get_BiasAcc() const { return ba; } Vec3 Get_dBias_Gyr() const { return dbg; } Vec3 Get_dBias_Acc() const { return dba; }
+    void Set_Pos(const Vec3& x) { P = x; } void Set_Vel(const Vec3& x) { V = x; } void Set_Rot(const SO3& x) { R = x; }
+    void Set_BiasGyr(const Vec3& x) { bg = x; } void Set_BiasAcc(const Vec3& x) { ba = x; } void Set_DeltaBiasGyr(const Vec3& x) { dbg = x; } void Set_DeltaBiasAcc(const Vec3& x) { dba = x; }
+};
+struct Preint {
+    Vec3 dP, dV; Mat<3, 3> dR, JPg, JPa, JVg, JVa, JRg; Mat<9, 9> cov; double dt = 0;
+    Vec3 getDeltaP() const { return dP; } Vec3 getDeltaV() const { return dV; } const Mat<3, 3>& getDeltaR() const { return dR; }
+    const Mat<3, 3>& getJPBiasg() const { return JPg; } const Mat<3, 3>& getJPBiasa() const { return JPa; } const Mat<3, 3>& getJVBiasg() const { return JVg; }
+    const Mat<3, 3>& getJVBiasa() const { return JVa; } const Mat<3, 3>& getJRBiasg() const { return JRg; } const Mat<9, 9>& getCovPVPhi() const { return cov; }
+    double getDeltaTime() const { return dt; }
+};
+// DBoW2 host containers (Thirdparty/DBoW2/DBoW2/BowVector.h, FeatureVector.h)
+enum LNorm { L1, L2 };
+struct BowVector : std::map<unsigned, double> {
+    void addWeight(unsigned id, double v) { (*this)[id] += v; }
+    void normalize(LNorm) { double n = 0; for (auto& e : *this) n += std::fabs(e.second); if (n > 0) for (auto& e : *this) e.second /= n; }
+};
+struct FeatureVector : std::map<unsigned, std::vector<unsigned> > { void addFeature(unsigned id, unsigned i) { (*this)[id].push_back(i); } };
+
+struct KeyFrame;
+struct MapPoint {                                   // include/MapPoint.h: the members the matchers / window solves touch
+    cv::Mat Pw, Pn, desc; int nobs = 1; bool bad = false; float minD = 0.5f, maxD = 30.f;
+    long mnLastFrameSeen = -1; unsigned long mnBALocalForKF = 0, mnId = 0;
+    bool mbTrackInView = false; float mTrackProjX = 0, mTrackProjY = 0, mTrackViewCos = 0; int mnTrackScaleLevel = 0, visible = 0, replaced = 0, updates = 0;
+    std::map<KeyFrame*, size_t> obs;
+    MapPoint() : Pw(3, 1, CV_32F), Pn(3, 1, CV_32F), desc(1, 32, CV_8U) {}
+    cv::Mat GetWorldPos() const { return Pw; } cv::Mat GetNormal() const { return Pn; } cv::Mat GetDescriptor() const { return desc; }
+    int Observations() const { return nobs; } bool isBad() const { return bad; }
+    float GetMinDistance() const { return minD; } float GetMaxDistance() const { return maxD; }         // the two accessors the shim asks for
+    void IncreaseVisible() { visible++; }
+    bool IsInKeyFrame(KeyFrame* k) const { return obs.count(k) != 0; }
+    void Replace(MapPoint*) { replaced++; }
+    void AddObservation(KeyFrame* k, size_t i) { obs[k] = i; nobs++; }
+    std::map<KeyFrame*, size_t> GetObservations() const { return obs; }
+    void EraseObservation(KeyFrame* k) { obs.erase(k); }
+    void SetWorldPos(const cv::Mat& p) { Pw = p; } void UpdateNormalAndDepth() { updates++; }
+};
+struct Frame {                                      // include/Frame.h
+    int N = 0; long mnId = 7;
+    std::vector<cv::KeyPoint> mvKeys, mvKeysUn; std::vector<float> mvuRight, mvDepth; cv::Mat mDescriptors, mTcw, mK, mDistCoef;
+    std::vector<MapPoint*> mvpMapPoints; std::vector<bool> mvbOutlier;
+    float fx = 458.654f, fy = 457.296f, cx = 367.215f, cy = 248.375f, mbf = 40.f, mb = 0.1f;
+    static float mnMinX, mnMaxX, mnMinY, mnMaxY;
+    std::vector<float> mvScaleFactors, mvInvLevelSigma2; int mnScaleLevels = 8;
+    BowVector mBowVec; FeatureVector mFeatVec;
+    ORB_SLAM2::ORBextractor *mpORBextractorLeft = nullptr, *mpORBextractorRight = nullptr;
+    int pose_sets = 0;
+    void SetPose(const cv::Mat& T) { mTcw = T; pose_sets++; }
+};
+float Frame::mnMinX = 0, Frame::mnMaxX = 752, Frame::mnMinY = 0, Frame::mnMaxY = 480;
+struct KeyFrame {                                   // include/KeyFrame.h
+    int N = 0; unsigned long mnId = 1, mnBALocalForKF = 0, mnBAFixedForKF = 0; bool bad = false;
+    std::vector<cv::KeyPoint> mvKeysUn; std::vector<float> mvuRight; cv::Mat mDescriptors, Tcw;
+    FeatureVector mFeatVec; std::vector<MapPoint*> mps;
+    float fx = 458.654f, fy = 457.296f, cx = 367.215f, cy = 248.375f, mbf = 40.f;
+    float mnMinX = 0, mnMaxX = 752, mnMinY = 0, mnMaxY = 480;
+    std::vector<float> mvScaleFactors, mvLevelSigma2, mvInvLevelSigma2; int mnScaleLevels = 8;
+    NavState ns; Preint preint; KeyFrame* prev = nullptr; std::vector<KeyFrame*> covisible; int pose_updates = 0, erased = 0, pose_sets = 0;
+    MapPoint* GetMapPoint(size_t i) const { return mps[i]; } std::vector<MapPoint*> GetMapPointMatches() const { return mps; }
+    void AddMapPoint(MapPoint* p, size_t i) { mps[i] = p; }
+    void EraseMapPointMatch(MapPoint* p) { for (auto& q : mps) if (q == p) { q = nullptr; erased++; } }
+    cv::Mat GetPose() const { return Tcw; } void SetPose(const cv::Mat& T) { Tcw = T; pose_sets++; }
+    cv::Mat GetCameraCenter() const { cv::Mat C(3, 1, CV_32F); for (int r = 0; r < 3; r++) { float t = 0; for (int k = 0; k < 3; k++) t += Tcw.at<float>(k, r) * Tcw.at<float>(k, 3); C.at<float>(r) = -t; } return C; }
+    bool isBad() const { return bad; } KeyFrame* GetPrevKeyFrame() const { return prev; }
+    const NavState& GetNavState() const { return ns; } const Preint& GetIMUPreInt() const { return preint; }
+    void SetNavStatePos(const Vec3& x) { ns.P = x; } void SetNavStateVel(const Vec3& x) { ns.V = x; } void SetNavStateRot(const SO3& x) { ns.R = x; }
+    void SetNavStateDeltaBg(const Vec3& x) { ns.dbg = x; } void SetNavStateDeltaBa(const Vec3& x) { ns.dba = x; }
+    void UpdatePoseFromNS(const cv::Mat&) { pose_updates++; }
+    std::vector<KeyFrame*> GetVectorCovisibleKeyFrames() const { return covisible; }
+};
+struct Map { std::mutex mMutexMapUpdate; };
+}
+using namespace standin;
+
+static int g_fail = 0;
+#define EXPECT(c) do { if (!(c)) { std::printf("FAIL %s:%d %s\n", __FILE__, __LINE__, #c); g_fail++; } } while (0)
+
+static cv::Mat eye4() { cv::Mat T(4, 4, CV_32F); for (int i = 0; i < 4; i++) T.at<float>(i, i) = 1.f; return T; }
+static void level_tables(std::vector<float>& sf, std::vector<float>& s2, std::vector<float>& is2) {
+    sf.assign(8, 1.f); s2.assign(8, 1.f); is2.assign(8, 1.f);
+    for (int l = 1; l < 8; l++) sf[l] = sf[l - 1] * 1.2f;
+    for (int l = 0; l < 8; l++) { s2[l] = sf[l] * sf[l]; is2[l] = 1.0f / s2[l]; }
+}
+// n random keypoints + descriptors; descriptors of point-bearing keypoints are copied from their map point with a few flipped bits
+static void random_features(Rng& R, int n, std::vector<cv::KeyPoint>& k, cv::Mat& d) {
+    k.resize(n); d.create(n, 32, CV_8U);
+    for (int i = 0; i < n; i++) {
+        k[i] = cv::KeyPoint(R.uni(20, 730), R.uni(20, 460), 31.f, R.uni(0, 359), R.uni(20, 90), (int)(R.next() % 4), -1);
+        for (int b = 0; b < 32; b++) d.data[(size_t)i * 32 + b] = (unsigned char)R.next();
+    }
+}
+// a map point that projects onto keypoint kp (identity pose) at depth z, descriptor = the keypoint's with `flip` bits changed
+static void point_behind(Rng& R, const Frame& F, const cv::KeyPoint& kp, const unsigned char* kd, float z, int flip, MapPoint& p) {
+    p.Pw.at<float>(0) = (kp.pt.x - F.cx) / F.fx * z; p.Pw.at<float>(1) = (kp.pt.y - F.cy) / F.fy * z; p.Pw.at<float>(2) = z;
+    const float nrm = std::sqrt(p.Pw.at<float>(0) * p.Pw.at<float>(0) + p.Pw.at<float>(1) * p.Pw.at<float>(1) + z * z);
+    for (int c = 0; c < 3; c++) p.Pn.at<float>(c) = p.Pw.at<float>(c) / nrm;
+    for (int b = 0; b < 32; b++) p.desc.data[b] = kd[b];
+    for (int f = 0; f < flip; f++) { const unsigned bit = R.next() % 256; p.desc.data[bit >> 3] ^= (unsigned char)(1u << (bit & 7)); }
+    // MapPoint::PredictScale gives ceil(log(maxD / dist) / log(1.2)): the keypoint's own octave for this max distance
+    p.maxD = nrm * std::pow(1.2f, (float)kp.octave - 0.5f); p.minD = 0.05f * nrm;
+}
+
+template <class Fn> static bool throws(Fn f) { try { f(); } catch (const std::runtime_error&) { return true; } return false; }
+
+int main() {
+    const bool gpu = viorb_device_count() >= 1;
+    Rng R(2024);
+    std::vector<float> sf, s2, is2; level_tables(sf, s2, is2);
+    // ---------------------------------------------------------------- two frames sharing map points
+    const int N = 600;
+    Frame Last, Cur;
+    for (Frame* F : {&Last, &Cur}) { F->N = N; F->mvScaleFactors = sf; F->mvInvLevelSigma2 = is2; F->mTcw = eye4(); F->mvuRight.assign(N, -1.f); F->mvDepth.assign(N, -1.f);
+                                     F->mvpMapPoints.assign(N, nullptr); F->mvbOutlier.assign(N, false); }
+    random_features(R, N, Last.mvKeys, Last.mDescriptors); Last.mvKeysUn = Last.mvKeys;
+    random_features(R, N, Cur.mvKeys, Cur.mDescriptors);
+    std::vector<MapPoint> pts(N);
+    for (int i = 0; i < N; i++) {
+        if (i % 3 == 2) continue;                                          // two thirds of the last frame's keypoints hold a map point
+        point_behind(R, Last, Last.mvKeys[i], Last.mDescriptors.data + (size_t)i * 32, R.uni(2, 9), 6, pts[i]);
+        pts[i].mnId = i; pts[i].nobs = (i % 7 == 0) ? 0 : 2;
+        Last.mvpMapPoints[i] = &pts[i]; Last.mvbOutlier[i] = (i % 31 == 0);
+        // the current frame sees it 3 px away with a near descriptor
+        Cur.mvKeys[i].pt.x = Last.mvKeys[i].pt.x + R.uni(-3, 3); Cur.mvKeys[i].pt.y = Last.mvKeys[i].pt.y + R.uni(-3, 3);
+        Cur.mvKeys[i].octave = Last.mvKeys[i].octave; Cur.mvKeys[i].angle = Last.mvKeys[i].angle;
+        for (int b = 0; b < 32; b++) Cur.mDescriptors.data[(size_t)i * 32 + b] = pts[i].desc.data[b];
+    }
+    Cur.mvKeysUn = Cur.mvKeys;
+
+    // 1. SearchByProjection(Frame, Frame)
+    {
+        std::vector<viorb_keypoint> ck(N), lk(N); std::vector<unsigned char> lf(N, 0), ld((size_t)N * 32, 0); std::vector<float> lp((size_t)N * 3, 0.f);
+        for (int i = 0; i < N; i++) {
+            ck[i] = viorb_shim::to_viorb(Cur.mvKeysUn[i]); lk[i] = viorb_shim::to_viorb(Last.mvKeysUn[i]);
+            if (MapPoint* p = Last.mvpMapPoints[i]) { lf[i] = (unsigned char)(1 | (Last.mvbOutlier[i] ? 2 : 0) | (p->nobs > 0 ? 4 : 0)); for (int c = 0; c < 3; c++) lp[3 * i + c] = p->Pw.at<float>(c); for (int b = 0; b < 32; b++) ld[(size_t)i * 32 + b] = p->desc.data[b]; }
+        }
+        float pose[12] = {1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0}; const float bounds[4] = {0, 752, 0, 480}, intr[4] = {Cur.fx, Cur.fy, Cur.cx, Cur.cy};
+        std::vector<int32_t> m(N, -1); int nm = 0, got = -1;
+        const int rc = viorb_search_by_projection_frame(ck.data(), Cur.mDescriptors.data, N, bounds, pose, intr, sf.data(), 8, lk.data(), N, lf.data(), lp.data(), ld.data(), 15.f, 1, m.data(), &nm);
+        const bool th = throws([&] { got = viorb_shim::search_by_projection_frame(Cur, Last, 15.f, true, true); });
+        if (!gpu) { EXPECT(rc == VIORB_ERR_NO_DEVICE && th); }
+        else {
+            EXPECT(rc == VIORB_OK && !th && got == nm && nm > 200);
+            for (int i = 0; i < N; i++) EXPECT(Cur.mvpMapPoints[i] == (m[i] >= 0 ? Last.mvpMapPoints[m[i]] : nullptr));
+        }
+    }
+    // 2. isInFrustum + SearchByProjection(Frame, MapPoints)
+    {
+        Frame F = Cur; F.mvpMapPoints.assign(N, nullptr);
+        std::vector<MapPoint*> vp; for (int i = 0; i < N; i++) if (Last.mvpMapPoints[i]) vp.push_back(&pts[i]);
+        pts[0].mnLastFrameSeen = F.mnId;                                     // already matched in this frame: skipped by both loops
+        const int np = (int)vp.size();
+        std::vector<viorb_keypoint> ck(N); for (int i = 0; i < N; i++) ck[i] = viorb_shim::to_viorb(F.mvKeysUn[i]);
+        std::vector<float> pf((size_t)np * 8), fr((size_t)np * 5); std::vector<unsigned char> fl(np), pd((size_t)np * 32), own(N, 0);
+        for (int p = 0; p < np; p++) { fl[p] = (unsigned char)(1 | (vp[p]->mnLastFrameSeen == F.mnId ? 2 : 0) | (vp[p]->nobs > 0 ? 4 : 0)); viorb_shim::flatten_point(vp[p], &pf[(size_t)p * 8], &pd[(size_t)p * 32]); }
+        float pose[12] = {1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0}; const float bounds[4] = {0, 752, 0, 480}, intr[4] = {F.fx, F.fy, F.cx, F.cy};
+        std::vector<int32_t> m(N, -1); int nm = 0, got = -1;
+        const int rc = viorb_search_by_projection_points(ck.data(), F.mDescriptors.data, N, bounds, pose, intr, sf.data(), 8, pf.data(), fl.data(), pd.data(), np, 3.f, 0.8f, own.data(), m.data(), &nm, fr.data());
+        const bool th = throws([&] { got = viorb_shim::search_by_projection_points(F, vp, 3.f, 0.8f); });
+        if (!gpu) { EXPECT(rc == VIORB_ERR_NO_DEVICE && th); }
+        else {
+            EXPECT(rc == VIORB_OK && !th && got == nm && nm > 100);
+            for (int i = 0; i < N; i++) EXPECT(F.mvpMapPoints[i] == (m[i] >= 0 ? vp[m[i]] : nullptr));
+            int inview = 0; for (int p = 0; p < np; p++) { inview += fr[(size_t)p * 5] != 0; EXPECT(vp[p]->mbTrackInView == (fr[(size_t)p * 5] != 0 && !(fl[p] & 2))); }
+            EXPECT(inview > 100 && pts[1].visible == 1 && pts[0].visible == 0);
+        }
+    }
+    // ---------------------------------------------------------------- two key frames (bag-of-words searches, Fuse)
+    KeyFrame K1, K2;
+    for (KeyFrame* K : {&K1, &K2}) { K->N = N; K->mvScaleFactors = sf; K->mvLevelSigma2 = s2; K->mvInvLevelSigma2 = is2; K->Tcw = eye4(); K->mvuRight.assign(N, -1.f); K->mps.assign(N, nullptr); }
+    K1.mvKeysUn = Last.mvKeysUn; K1.mDescriptors = Last.mDescriptors; K2.mvKeysUn = Cur.mvKeysUn; K2.mDescriptors = Cur.mDescriptors; K2.mnId = 2;
+    K2.Tcw.at<float>(0, 3) = -0.2f;                                           // a baseline for the epipolar test
+    for (int i = 0; i < N; i++) { if (Last.mvpMapPoints[i] && i % 2 == 0) K1.mps[i] = &pts[i]; const unsigned node = K1.mDescriptors.data[(size_t)i * 32] & 7u; if (i % 11) K1.mFeatVec.addFeature(node, i); }
+    for (int i = 0; i < N; i++) { const unsigned node = (Last.mvpMapPoints[i] ? K1.mDescriptors.data[(size_t)i * 32] : K2.mDescriptors.data[(size_t)i * 32]) & 7u; if (i % 13) K2.mFeatVec.addFeature(node, i); }
+    // 3. SearchByBoW(KeyFrame, Frame)
+    {
+        Frame F = Cur; F.mFeatVec = K2.mFeatVec;
+        std::vector<MapPoint*> vm; int got = -1;
+        std::vector<viorb_keypoint> kk(N), fk(N); std::vector<int32_t> kn, fn; std::vector<unsigned char> has(N);
+        for (int i = 0; i < N; i++) { kk[i] = viorb_shim::to_viorb(K1.mvKeysUn[i]); fk[i] = viorb_shim::to_viorb(F.mvKeys[i]); has[i] = K1.mps[i] ? 1 : 0; }
+        viorb_shim::flatten_featvec(K1.mFeatVec, N, kn); viorb_shim::flatten_featvec(F.mFeatVec, N, fn);
+        std::vector<int32_t> m(N, -1); int nm = 0;
+        const int rc = viorb_search_by_bow(kk.data(), K1.mDescriptors.data, kn.data(), has.data(), N, fk.data(), F.mDescriptors.data, fn.data(), N, 0.7f, 1, m.data(), &nm);
+        const bool th = throws([&] { got = viorb_shim::search_by_bow(&K1, F, vm, 0.7f, true); });
+        if (!gpu) { EXPECT(rc == VIORB_ERR_NO_DEVICE && th); }
+        else { EXPECT(rc == VIORB_OK && !th && got == nm && nm > 50 && (int)vm.size() == N); for (int i = 0; i < N; i++) EXPECT(vm[i] == (m[i] >= 0 ? K1.mps[m[i]] : nullptr)); }
+    }
+    // 4. SearchForTriangulation
+    {
+        cv::Mat F12(3, 3, CV_32F);                                            // F = [t]x for a pure x translation between identical intrinsics-normalised views (any matrix exercises the path)
+        F12.at<float>(1, 2) = -1e-3f; F12.at<float>(2, 1) = 1e-3f;
+        std::vector<std::pair<size_t, size_t> > pairs; int got = -1;
+        const bool th = throws([&] { got = viorb_shim::search_for_triangulation(&K1, &K2, F12, pairs, false, false); });
+        if (!gpu) EXPECT(th);
+        else { EXPECT(!th && got == (int)pairs.size()); for (auto& pr : pairs) EXPECT(pr.first < (size_t)N && pr.second < (size_t)N && !K1.mps[pr.first] && !K2.mps[pr.second]); }
+    }
+    // 5. Fuse
+    {
+        std::vector<MapPoint> fresh(200); std::vector<MapPoint*> vp;
+        for (int p = 0; p < 200; p++) { const int i = 3 * p; point_behind(R, Cur, K2.mvKeysUn[i], K2.mDescriptors.data + (size_t)i * 32, R.uni(2, 9), 4, fresh[p]); fresh[p].nobs = 1 + p % 3; vp.push_back(&fresh[p]); }
+        vp[5] = nullptr; fresh[6].bad = true;
+        K2.Tcw = eye4();
+        for (int i = 0; i < N; i += 6) K2.mps[i] = &pts[i];                   // some target keypoints already hold a point: Replace path
+        int got = -1, before_obs = 0; for (auto& p : fresh) before_obs += p.nobs;
+        const bool th = throws([&] { got = viorb_shim::fuse(&K2, vp, 3.f); });
+        if (!gpu) EXPECT(th);
+        else {
+            int after_obs = 0, repl = 0; for (auto& p : fresh) { after_obs += p.nobs; repl += p.replaced; } for (auto& p : pts) repl += p.replaced;
+            EXPECT(!th && got > 100 && (after_obs - before_obs) + repl == got);
+        }
+    }
+    // ---------------------------------------------------------------- Frame: undistortion, bounds, stereo, bag of words
+    {
+        Frame F = Cur; F.mK = cv::Mat(3, 3, CV_32F); F.mK.at<float>(0, 0) = F.fx; F.mK.at<float>(1, 1) = F.fy; F.mK.at<float>(0, 2) = F.cx; F.mK.at<float>(1, 2) = F.cy; F.mK.at<float>(2, 2) = 1;
+        F.mDistCoef = cv::Mat(4, 1, CV_32F); const float dc[4] = {-0.28340811f, 0.07395907f, 0.00019359f, 1.76187114e-05f}; for (int i = 0; i < 4; i++) F.mDistCoef.at<float>(i) = dc[i];
+        const bool t1 = throws([&] { viorb_shim::undistort_keypoints(F); });
+        const bool t2 = throws([&] { viorb_shim::compute_image_bounds(F, 752, 480); });
+        if (!gpu) EXPECT(t1 && t2);
+        else {
+            EXPECT(!t1 && !t2 && (int)F.mvKeysUn.size() == N && Frame::mnMinX < -100 && Frame::mnMaxX > 850);
+            float moved = 0; for (int i = 0; i < N; i++) { moved += std::fabs(F.mvKeysUn[i].pt.x - F.mvKeys[i].pt.x); EXPECT(F.mvKeysUn[i].octave == F.mvKeys[i].octave && F.mvKeysUn[i].angle == F.mvKeys[i].angle); }
+            EXPECT(moved / N > 1.f);
+            Frame::mnMinX = 0; Frame::mnMaxX = 752; Frame::mnMinY = 0; Frame::mnMaxY = 480;
+        }
+        Frame Z = Cur; Z.mK = F.mK; Z.mDistCoef = cv::Mat(4, 1, CV_32F); Z.mvKeysUn.clear();
+        viorb_shim::undistort_keypoints(Z);                                   // mDistCoef(0) == 0: mvKeysUn = mvKeys, no device call (Frame.cc:586-590)
+        EXPECT((int)Z.mvKeysUn.size() == N && Z.mvKeysUn[3].pt.x == Z.mvKeys[3].pt.x);
+    }
+    if (gpu) {                                                                // ComputeStereoMatches needs two extractions
+        ORB_SLAM2::ORBextractor exL(1200, 1.2f, 8, 20, 7), exR(1200, 1.2f, 8, 20, 7);
+        const int w = 640, h = 360; cv::Mat L(h, w, CV_8U), Rr(h, w, CV_8U), mask; unsigned s = 99;
+        for (int y = 0; y < h; y++) for (int x = 0; x < w + 24; x++) { s = s * 1664525u + 1013904223u; const unsigned char v = (unsigned char)((((x / 12) + (y / 12)) % 2) * 110 + 50 + (s >> 27));
+            if (x < w) L.data[(size_t)y * w + x] = v; if (x >= 24) Rr.data[(size_t)y * w + x - 24] = v; }          // right image = left shifted by 24 px of disparity
+        Frame F; std::vector<cv::KeyPoint> kr; cv::Mat dr;
+        exL(L, mask, F.mvKeys, F.mDescriptors); exR(Rr, mask, kr, dr);
+        EXPECT(exL.mvImagePyramid.downloads() == 0);                          // the pyramid stays on the device until somebody indexes it
+        F.N = (int)F.mvKeys.size(); F.mpORBextractorLeft = &exL; F.mpORBextractorRight = &exR; F.mbf = 40.f; F.fx = 458.f;
+        viorb_shim::compute_stereo_matches(F);
+        std::vector<float> ur(F.N, -1.f), dp(F.N, -1.f); int n = 0;
+        EXPECT(viorb_stereo_match(exL.handle(), exR.handle(), F.mbf, F.fx, ur.data(), dp.data(), F.N, &n) == VIORB_OK);
+        int nm = 0; for (int i = 0; i < F.N; i++) { EXPECT(F.mvuRight[i] == ur[i] && F.mvDepth[i] == dp[i]); nm += ur[i] >= 0; }
+        EXPECT(F.N > 300 && nm > 50);
+        EXPECT(exL.mvImagePyramid[2].cols == 444 && exL.mvImagePyramid.downloads() == 1);       // 640 / 1.44 = 444: one level fetched on demand
+        // ComputeBoW over a two-level binary tree
+        const int32_t cs[8] = {0, 2, 4, 6, 6, 6, 6, 6}, ci[6] = {1, 2, 3, 4, 5, 6}, wid[7] = {-1, -1, -1, 0, 1, 2, 3}; const double wt[7] = {0, 0, 0, 1.0, 0.5, 0.0, 2.0};
+        std::vector<unsigned char> nd(7 * 32, 0); for (int k = 1; k < 7; k++) for (int b = 0; b < 32; b++) nd[(size_t)k * 32 + b] = (unsigned char)(k * 37 + b * (k & 1 ? 255 : 1));
+        viorb_vocabulary* voc = nullptr;
+        EXPECT(viorb_vocabulary_create(7, 2, cs, ci, nd.data(), wid, wt, &voc) == VIORB_OK);
+        viorb_shim::compute_bow(F, voc, true, L1);
+        std::vector<int32_t> word(F.N), node(F.N); std::vector<double> wgt(F.N);
+        EXPECT(viorb_bow_transform(voc, F.mDescriptors.data, F.N, 4, word.data(), wgt.data(), node.data()) == VIORB_OK);
+        double sum = 0; size_t nfeat = 0; for (auto& e : F.mBowVec) sum += e.second; for (auto& e : F.mFeatVec) nfeat += e.second.size();
+        size_t want = 0; for (int i = 0; i < F.N; i++) want += wgt[i] > 0;
+        EXPECT(std::fabs(sum - 1.0) < 1e-12 && nfeat == want && want > 0 && want < (size_t)F.N);      // the zero-weight word is stopped
+        viorb_vocabulary_destroy(voc);
+    } else {
+        Frame F; F.N = 4; F.mDescriptors.create(4, 32, CV_8U);
+        EXPECT(throws([&] { viorb_shim::compute_bow(F, (const viorb_vocabulary*)nullptr, true, L1); }));
+    }
+    // ---------------------------------------------------------------- Optimizer: vision-only pose, both window solves
+    {   // 6. PoseOptimization(Frame*): mono and stereo edges of points seen from a slightly wrong pose
+        Frame F = Cur; F.mvpMapPoints.assign(N, nullptr);
+        for (int i = 0; i < N; i++) if (Last.mvpMapPoints[i]) { F.mvpMapPoints[i] = &pts[i]; F.mvKeysUn[i].pt.x = Last.mvKeys[i].pt.x + R.uni(-0.7f, 0.7f); F.mvKeysUn[i].pt.y = Last.mvKeys[i].pt.y + R.uni(-0.7f, 0.7f);
+            if (i % 4 == 0) F.mvuRight[i] = F.mvKeysUn[i].pt.x - F.mbf / pts[i].Pw.at<float>(2); if (i % 17 == 0) F.mvKeysUn[i].pt.x += 25.f; }
+        F.mTcw.at<float>(0, 3) = 0.03f; F.mTcw.at<float>(2, 3) = -0.02f;
+        Frame G = F; int got = -1;
+        const bool th = throws([&] { got = viorb_shim::pose_optimization(&F); });
+        if (!gpu) EXPECT(th);
+        else {
+            std::vector<double> o7; std::vector<int> idx;
+            for (int i = 0; i < N; i++) if (G.mvpMapPoints[i]) { const cv::Mat X = G.mvpMapPoints[i]->GetWorldPos(); const double o[7] = {X.at<float>(0), X.at<float>(1), X.at<float>(2), G.mvKeysUn[i].pt.x, G.mvKeysUn[i].pt.y, G.mvuRight[i], G.mvInvLevelSigma2[G.mvKeysUn[i].octave]}; o7.insert(o7.end(), o, o + 7); idx.push_back(i); }
+            float pose[12], out[12]; viorb_shim::flatten_pose(G.mTcw, pose); const float intr5[5] = {G.fx, G.fy, G.cx, G.cy, G.mbf};
+            std::vector<unsigned char> ol(idx.size()); double info[4];
+            EXPECT(viorb_pose_opt_se3(pose, intr5, o7.data(), (int)idx.size(), out, ol.data(), info) == VIORB_OK);
+            int bad = 0; for (size_t k = 0; k < idx.size(); k++) { bad += ol[k] != 0; EXPECT(F.mvbOutlier[idx[k]] == (ol[k] != 0)); }
+            EXPECT(!th && got == (int)idx.size() - bad && got == (int)info[0] && bad >= 20 && F.pose_sets == 1);
+            for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) EXPECT(F.mTcw.at<float>(r, c) == out[3 * r + c]); EXPECT(F.mTcw.at<float>(r, 3) == out[9 + r]); }
+            EXPECT(std::fabs(F.mTcw.at<float>(0, 3)) < 5e-3f);                    // the solve pulled the pose back towards the identity
+        }
+    }
+    {   // 7. + 8. the two local window solves on a small static scene: 3 local key frames, the key frame before the window, one covisible key frame
+        const int NK = 5, NP = 120; std::vector<KeyFrame> kf(NK); std::vector<MapPoint> mp(NP); Map map;
+        const double dt = 0.15, g[3] = {0.0, 9.81, 0.0};
+        for (int k = 0; k < NK; k++) {
+            KeyFrame& K = kf[k]; K.mnId = 10 + k; K.N = NP; K.mvScaleFactors = sf; K.mvLevelSigma2 = s2; K.mvInvLevelSigma2 = is2; K.Tcw = eye4(); K.mvuRight.assign(NP, -1.f); K.mps.assign(NP, nullptr); K.mvKeysUn.resize(NP);
+            K.ns.P = Vec3(0.02 * k, 0, 0); K.Tcw.at<float>(0, 3) = (float)(-0.02 * k);            // Tbc = I: the camera moves with the body
+            for (int d = 0; d < 3; d++) { K.preint.dR(d, d) = 1; K.preint.dP = Vec3(0.02 - 0.5 * g[0] * dt * dt, -0.5 * g[1] * dt * dt, 0); K.preint.dV = Vec3(0, -g[1] * dt, 0); }
+            for (int d = 0; d < 9; d++) K.preint.cov(d, d) = 1e-4; K.preint.dt = dt;
+        }
+        for (int k = 1; k < 4; k++) kf[k].prev = &kf[k - 1];
+        for (int p = 0; p < NP; p++) {
+            MapPoint& P = mp[p]; P.mnId = p; const float z = R.uni(3, 9), X = R.uni(-2, 2), Y = R.uni(-1.2f, 1.2f);
+            P.Pw.at<float>(0) = X + R.uni(-0.03f, 0.03f); P.Pw.at<float>(1) = Y + R.uni(-0.03f, 0.03f); P.Pw.at<float>(2) = z;
+            for (int k = 0; k < NK; k++) {
+                if ((p + k) % 4 == 3) continue;
+                const float xc = X - 0.02f * k; float u = kf[k].fx * xc / z + kf[k].cx + R.uni(-0.5f, 0.5f), v = kf[k].fy * Y / z + kf[k].cy + R.uni(-0.5f, 0.5f);
+                if (p % 23 == 0 && k == 2) u += 30.f;                               // an outlier observation: must come back erased
+                kf[k].mvKeysUn[p] = cv::KeyPoint(u, v, 31.f, 0.f, 50.f, p % 3, -1); kf[k].mps[p] = &P; P.obs[&kf[k]] = p;
+            }
+        }
+        std::list<KeyFrame*> local = {&kf[1], &kf[2], &kf[3]};
+        Mat<4, 4> Tbc; for (int d = 0; d < 4; d++) Tbc(d, d) = 1;
+        cv::Mat MatTbc; volatile int stop = 0; bool bstop = false;
+        const bool th = throws([&] { viorb_shim::local_bundle_adjustment_navstate<Vec3, Quat, SO3, MapPoint>(&kf[3], local, &bstop, &stop, &map, g, Tbc, MatTbc); });
+        if (!gpu) EXPECT(th);
+        else {
+            int erased = 0, upd = 0; for (auto& K : kf) erased += K.erased; for (auto& P : mp) upd += P.updates;
+            EXPECT(!th && kf[1].pose_updates == 1 && kf[2].pose_updates == 1 && kf[3].pose_updates == 1 && kf[0].pose_updates == 0 && kf[4].pose_updates == 0);
+            EXPECT(upd == NP && erased >= 4 && erased <= 12);
+            EXPECT(kf[0].mnBAFixedForKF == kf[3].mnId && kf[4].mnBAFixedForKF == kf[3].mnId && kf[2].mnBALocalForKF == kf[3].mnId);
+            EXPECT(std::fabs(kf[2].ns.P[0] - 0.04) < 0.02 && std::fabs(kf[2].ns.P[1]) < 0.02);
+        }
+        // vision only: the current key frame + its covisible ones
+        for (auto& K : kf) { K.mnBALocalForKF = K.mnBAFixedForKF = 0; K.erased = 0; } for (auto& P : mp) { P.mnBALocalForKF = 0; P.updates = 0; }
+        kf[3].covisible = {&kf[2], &kf[1]};
+        auto pose_to_qt = [](const cv::Mat& T, double* qt) { qt[0] = qt[1] = qt[2] = 0; qt[3] = 1; for (int d = 0; d < 3; d++) qt[4 + d] = T.at<float>(d, 3); };      // identity rotations in this scene
+        auto qt_to_pose = [](const double* qt) { cv::Mat T = eye4(); const double x = qt[0], y = qt[1], z = qt[2], w = qt[3];
+            const double Rm[9] = {1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w), 2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w), 2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)};
+            for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) T.at<float>(r, c) = (float)Rm[3 * r + c]; T.at<float>(r, 3) = (float)qt[4 + r]; } return T; };
+        const bool th2 = throws([&] { viorb_shim::local_bundle_adjustment<MapPoint>(&kf[3], &bstop, &stop, &map, pose_to_qt, qt_to_pose); });
+        if (!gpu) EXPECT(th2);
+        else {
+            int upd = 0; for (auto& P : mp) upd += P.updates;
+            EXPECT(!th2 && kf[1].pose_sets == 1 && kf[2].pose_sets == 1 && kf[3].pose_sets == 1 && kf[0].pose_sets == 0 && kf[4].pose_sets == 0 && upd == NP);
+            EXPECT(kf[0].mnBAFixedForKF == kf[3].mnId && kf[4].mnBAFixedForKF == kf[3].mnId);
+            EXPECT(std::fabs(kf[2].Tcw.at<float>(0, 3) + 0.04f) < 0.02f);
+        }
+    }
+    if (g_fail) { std::printf("FAILED %d checks\n", g_fail); return 1; }
+    std::printf(gpu ? "OK all nine call-site templates equal the direct C-ABI calls\n" : "OK (no device: every call-site template threw, none fell back)\n");
+    return 0;
+}

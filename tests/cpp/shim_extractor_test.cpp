@@ -18,6 +18,7 @@ int main(int argc, char** argv) {
     unsigned s = 12345;
     for (int y = 0; y < h; y++) for (int x = 0; x < w; x++) { s = s * 1664525u + 1013904223u; im.data[(size_t)y * w + x] = (unsigned char)(((x / 16 + y / 16) % 2) * 120 + 60 + (s >> 28)); }
     ex(im, mask, kps, desc);
+    if (ex.mvImagePyramid.downloads() != 0) { std::printf("FAIL: pyramid downloaded without being read\n"); return 1; }     // lazy: the mono path never pays for it
     std::printf("OK %zu keypoints, descriptors %dx%d, pyramid[7] %dx%d\n", kps.size(), desc.rows, desc.cols, ex.mvImagePyramid[7].cols, ex.mvImagePyramid[7].rows);
     return kps.size() > 100 && desc.rows == (int)kps.size() ? 0 : 1;
 }

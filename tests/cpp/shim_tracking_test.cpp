@@ -2,7 +2,8 @@
 // from Optimizer::PoseOptimization(Frame*, Frame* | KeyFrame*, ...). The reference's Frame / KeyFrame / MapPoint / NavState /
 // IMUPreintegrator and Eigen / Sophus are absent from this image, so minimal stand-ins WITH THE REFERENCE'S MEMBER NAMES (the ones
 // the shim touches: include/Frame.h, include/IMU/NavState.h, include/IMU/IMUPreintegrator.h) are defined here — test scaffolding only.
-//   shim_tracking_test                      no device needed: runs both overloads on a tiny problem, expects a clean return
+//   shim_tracking_test                      no device needed: runs both overloads on a tiny problem; without a device both must THROW
+//                                           (viorb_shim::check surfaces viorb_last_error(); a GPU failure is never "0 inliers")
 //   shim_tracking_test problem.bin out.bin  reads a problem written by tests/test_gpu_shims.py, writes what the shim stored in the frame
 #include <cstdio>
 #include <cstdlib>
@@ -97,8 +98,17 @@ int main(int argc, char** argv) {
         fill_frame(F, pc, cam, cur, oc, nc); fill_frame(L, pl, cam, last, ol, nl);
         unpack(prior, L.mNavStatePrior);
         for (int r = 0; r < 12; r++) for (int c = 0; c < 12; c++) L.mMargCovInv(r, c) = mci[12 * r + c];
-        const int inl = variant ? viorb_shim::pose_optimization_frame<Vec3, Quat, SO3>(&F, &L, M, gw, Tbc, MatTbc, true)
-                                : viorb_shim::pose_optimization_keyframe<Vec3, Quat, SO3>(&F, static_cast<KeyFrame*>(&L), M, gw, Tbc, MatTbc, true);
+        int inl = 0;
+        try {
+            inl = variant ? viorb_shim::pose_optimization_frame<Vec3, Quat, SO3>(&F, &L, M, gw, Tbc, MatTbc, true)
+                          : viorb_shim::pose_optimization_keyframe<Vec3, Quat, SO3>(&F, static_cast<KeyFrame*>(&L), M, gw, Tbc, MatTbc, true);
+            if (viorb_device_count() < 1) { printf("FAIL: no device, but the shim returned %d instead of throwing\n", inl); return 1; }
+        } catch (const std::runtime_error& e) {
+            if (viorb_device_count() >= 1) { printf("FAIL: %s\n", e.what()); return 1; }
+            if (F.pose_updates != 0) { printf("FAIL: frame touched before the error\n"); return 1; }
+            if (variant == 0) { printf("OK (no device: both overloads threw \"%s\", frame untouched)\n", e.what()); return 0; }
+            continue;
+        }
         double ns[22]; viorb_shim::pack_navstate(F.GetNavState(), ns);
         out.push_back((double)inl); out.push_back((double)F.pose_updates);
         out.insert(out.end(), ns, ns + 22);

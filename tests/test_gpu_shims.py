@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import viorb_amd
 from viorb_amd.synth import make_vio_problem
-from test_host_hooks import _build_tracking_shim_test
+from test_host_hooks import _build_tracking_shim_test, _build_callsites_shim_test
 
 pytestmark = pytest.mark.gpu
 
@@ -50,3 +50,14 @@ def test_tracking_shim_equals_direct_calls(tmp_path, oracle, seed):
         if variant:
             np.testing.assert_array_equal(blk[24 + len(oc):24 + len(oc) + len(ol)].astype(np.uint8), g["outlier_last"])
         np.testing.assert_array_equal(blk[per - 144:].reshape(12, 12), g["marg_cov_inv"])
+
+
+def test_callsite_shims_equal_direct_calls(tmp_path):
+    """The nine call-site templates (viorb_amd/shim/{ORBmatcher,Frame,Optimizer}_shim.h) driven from C++ with stand-in Frame / KeyFrame /
+    MapPoint / Map types: what each writes into the objects equals a direct C-ABI call on independently flattened arrays
+    (tests/cpp/shim_callsites_test.cpp)."""
+    if viorb_amd.lib().viorb_device_count() < 1:
+        pytest.fail("no HIP device visible: -m gpu tests need the MI355X (and never fall back)")
+    exe = _build_callsites_shim_test(tmp_path)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and out.stdout.strip().endswith("OK all nine call-site templates equal the direct C-ABI calls"), out.stdout + out.stderr

@@ -239,10 +239,31 @@ def _build_tracking_shim_test(tmp_path):
     return exe
 
 
+def _build_callsites_shim_test(tmp_path):
+    import subprocess
+    exe = str(tmp_path / "shim_callsites_test")
+    lib_dir = os.path.join(ROOT, "viorb_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "viorb_amd", "shim"),
+                           "-I", os.path.join(ROOT, "tests", "cpp"), os.path.join(ROOT, "tests", "cpp", "shim_callsites_test.cpp"),
+                           "-L", lib_dir, "-lviorb_hip", "-Wl,-rpath," + lib_dir, "-o", exe])
+    return exe
+
+
+def test_cpp_callsite_shims_compile_link_and_refuse_without_a_device(tmp_path):
+    """viorb_amd/shim/{ORBmatcher,Frame,Optimizer}_shim.h — the nine call-site templates of INTEGRATION.md (both SearchByProjection forms,
+    SearchByBoW, SearchForTriangulation, Fuse, UndistortKeyPoints / ComputeImageBounds, ComputeStereoMatches, ComputeBoW,
+    PoseOptimization(Frame*), both local window solves) compile against stand-ins that carry the reference's member names and link
+    libviorb_hip.so; without a device every one of them throws (the error is surfaced, nothing falls back to the CPU)."""
+    import subprocess
+    exe = _build_callsites_shim_test(tmp_path)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.startswith("OK"), out.stdout + out.stderr
+
+
 def test_cpp_tracking_shim_compiles_links_and_runs(tmp_path):
     """viorb_amd/shim/viorb_tracking_shim.h (the templates behind Optimizer::PoseOptimization(Frame*, Frame* | KeyFrame*, ...) in
-    INTEGRATION.md) compiles against stand-ins that carry the reference's member names, links libviorb_hip.so and returns cleanly
-    (0 inliers, frame untouched) when there is no device — no CPU fallback."""
+    INTEGRATION.md) compiles against stand-ins that carry the reference's member names, links libviorb_hip.so and, when there is no
+    device, throws with the library's error text and leaves the frame untouched — no CPU fallback, no silent "0 inliers"."""
     import subprocess
     exe = _build_tracking_shim_test(tmp_path)
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)

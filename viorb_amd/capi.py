@@ -66,7 +66,7 @@ class TrackerInputs(C.Structure):
     """viorb_tracker_inputs (include/viorb.h)."""
     _fields_ = [("d_images", C.c_void_p), ("image_stride", C.c_int32), ("image_pitch_bytes", C.c_size_t), ("d_imu", C.c_void_p), ("n_imu", C.c_int32),
                 ("d_t_cur", C.c_void_p), ("d_map_updated", C.c_void_p), ("d_recent_reloc", C.c_void_p), ("d_t_next_last", C.c_void_p),
-                ("d_reset_ns", C.c_void_p), ("d_reset_marg", C.c_void_p), ("d_synth_pose12", C.c_void_p)]
+                ("d_reset_ns", C.c_void_p), ("d_reset_marg", C.c_void_p), ("d_synth_pose12", C.c_void_p), ("h_images", C.c_void_p)]
 
 
 class TrackerResults(C.Structure):

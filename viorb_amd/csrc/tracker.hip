@@ -153,6 +153,8 @@ struct viorb_tracker {
     int *n_cur, *n_last, *n_cur2; double *out_ns, *out_last_ns, *out_ns2, *ns1, *final_ns, *final_marg, *marg_out, *info, *info2;
     uint8_t *outlier_cur, *outlier_last, *outlier_cur2, *owner_obs, *skip1, *skip2, *variant; int *n_map, *loc_match, *n_loc, *state, *inliers;
     bool undistort = false; viorb_keypoint* kps_un = nullptr;      // mvKeysUn of the frame in flight (Frame::UndistortKeyPoints)
+    // live feed: host images -> ring of device buffers on a copy stream (the third stream of the tracker)
+    hipStream_t s_cp = nullptr; std::vector<uint8_t*> stage; std::vector<hipEvent_t> ev_cp; size_t stage_bytes = 0; double upload_bytes = 0;
     // host statistics
     double enqueue_s = 0, throttle_s = 0; long long steps = 0;
 };
@@ -251,6 +253,9 @@ int viorb_tracker_destroy(viorb_tracker* h) {
     for (int i = 0; i < 2; i++) { if (h->ev_ex[i]) (void)hipEventDestroy(h->ev_ex[i]); if (h->ev_tr[i]) (void)hipEventDestroy(h->ev_tr[i]); }
     if (h->s_ex) (void)hipStreamDestroy(h->s_ex);
     if (h->s_tr) (void)hipStreamDestroy(h->s_tr);
+    if (h->s_cp) { (void)hipStreamSynchronize(h->s_cp); (void)hipStreamDestroy(h->s_cp); }
+    for (uint8_t* p : h->stage) if (p) (void)hipFree(p);
+    for (hipEvent_t e : h->ev_cp) if (e) (void)hipEventDestroy(e);
     for (int i = 0; i < 2; i++) viorb_extractor_destroy(h->ex[i]);
     viorb_frontend_destroy(h->fe);
     h->mem.release();
@@ -296,10 +301,33 @@ int viorb_tracker_set_last_points_device(viorb_tracker* h, const float* d_Pw, co
 }
 
 int viorb_tracker_step(viorb_tracker* h, const viorb_tracker_inputs* in, void* caller_stream) {
-    VIORB_REQUIRE(h && in && in->d_images && in->d_imu && in->d_t_cur && in->n_imu >= 1, "null argument");
+    VIORB_REQUIRE(h && in && (in->d_images || in->h_images) && in->d_imu && in->d_t_cur && in->n_imu >= 1, "null argument");
     VIORB_HIP_TRY(hipSetDevice(h->device));
     const auto t_begin = std::chrono::steady_clock::now();
     const int B = h->B, slot = (int)(h->k & 1);
+    const uint8_t* d_images = in->d_images;
+    hipEvent_t ev_upload = nullptr;
+    if (in->h_images) {
+        // Host -> device staging of a live feed (the reference's Frame constructor takes a host cv::Mat, src/Frame.cc:427-433): one
+        // asynchronous copy per step on its own stream; buffer k % n is free again because the throttle below keeps the host at most
+        // max_steps_ahead steps in front of the device.
+        const int ahead_ = h->cfg.max_steps_ahead > 0 ? h->cfg.max_steps_ahead : 8;
+        const size_t bytes = (size_t)B * in->image_pitch_bytes;
+        if (h->stage.empty() || h->stage_bytes < bytes) {
+            VIORB_HIP_TRY(hipDeviceSynchronize());
+            for (uint8_t* p : h->stage) if (p) (void)hipFree(p);
+            h->stage.assign((size_t)ahead_ + 2, nullptr); h->stage_bytes = 0;
+            for (auto& p : h->stage) VIORB_HIP_TRY(hipMalloc(&p, bytes));
+            h->stage_bytes = bytes;
+            if (h->ev_cp.empty()) { h->ev_cp.assign(h->stage.size(), nullptr); for (auto& e : h->ev_cp) VIORB_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming)); }
+            if (!h->s_cp) VIORB_HIP_TRY(hipStreamCreateWithFlags(&h->s_cp, hipStreamNonBlocking));
+        }
+        const size_t sl = (size_t)(h->k % (long long)h->stage.size());
+        VIORB_HIP_TRY(hipMemcpyAsync(h->stage[sl], in->h_images, bytes, hipMemcpyHostToDevice, h->s_cp));
+        VIORB_HIP_TRY(hipEventRecord(h->ev_cp[sl], h->s_cp));
+        d_images = h->stage[sl]; ev_upload = h->ev_cp[sl];
+        h->upload_bytes += (double)bytes;
+    }
     const bool tlm = h->cfg.track_local_map != 0;
     const int marg = h->cfg.compute_marg != 0;
     viorb_extractor* ex = h->ex[slot];
@@ -308,7 +336,8 @@ int viorb_tracker_step(viorb_tracker* h, const viorb_tracker_inputs* in, void* c
     VIORB_HIP_TRY(hipStreamWaitEvent(h->s_ex, h->ev_in, 0));
     VIORB_HIP_TRY(hipStreamWaitEvent(h->s_tr, h->ev_in, 0));
     if (h->ev_tr_valid[slot]) VIORB_HIP_TRY(hipStreamWaitEvent(h->s_ex, h->ev_tr[slot], 0));     // this handle's previous results have been consumed
-    TR_TRY(viorb_extract_batch_device(ex, in->d_images, B, h->cfg.width, h->cfg.height, in->image_stride, in->image_pitch_bytes, h->s_ex));
+    if (ev_upload) VIORB_HIP_TRY(hipStreamWaitEvent(h->s_ex, ev_upload, 0));
+    TR_TRY(viorb_extract_batch_device(ex, d_images, B, h->cfg.width, h->cfg.height, in->image_stride, in->image_pitch_bytes, h->s_ex));
     VIORB_HIP_TRY(hipEventRecord(h->ev_ex[slot], h->s_ex));
     hipStream_t st = h->s_tr;
     // ---- what does not need the new frame's keypoints: IMU pre-integration + prediction, the last frame's own observations
@@ -380,6 +409,7 @@ int viorb_tracker_step(viorb_tracker* h, const viorb_tracker_inputs* in, void* c
 int viorb_tracker_sync(viorb_tracker* h) {
     VIORB_REQUIRE(h, "null handle");
     VIORB_HIP_TRY(hipSetDevice(h->device));
+    if (h->s_cp) VIORB_HIP_TRY(hipStreamSynchronize(h->s_cp));
     VIORB_HIP_TRY(hipStreamSynchronize(h->s_ex));
     VIORB_HIP_TRY(hipStreamSynchronize(h->s_tr));
     while (!h->in_flight.empty()) { h->ev_pool.push_back(h->in_flight.front()); h->in_flight.pop_front(); }

@@ -37,7 +37,7 @@ public:
         mnFeaturesPerLevel.resize(nlevels);
         viorb_extractor_tables(mHandle, &mvScaleFactor[0], &mvInvScaleFactor[0], &mvLevelSigma2[0], &mvInvLevelSigma2[0], &mnFeaturesPerLevel[0]);
         viorb_extractor_max_keypoints(mHandle, &mCap);
-        mvImagePyramid.resize(nlevels);
+        mvImagePyramid.bind(mHandle, nlevels);
     }
     ~ORBextractor() { viorb_extractor_destroy(mHandle); }
 
@@ -50,21 +50,18 @@ public:
         std::vector<viorb_keypoint> k(mCap);
         cv::Mat desc(mCap, 32, CV_8U);
         int n = 0;
+        // Every failure is surfaced: the reference has no error channel here (it cannot fail), so a GPU-side error — VIORB_ERR_CAPACITY
+        // included: a truncated keypoint set must never flow into Frame unnoticed — becomes an exception with viorb_last_error().
         const int rc = viorb_extract(mHandle, image.data, image.cols, image.rows, (int)image.step, &k[0], desc.data, mCap, &n);
-        if (rc != VIORB_OK && rc != VIORB_ERR_CAPACITY) throw std::runtime_error(std::string("viorb_extract: ") + viorb_last_error());
-        if (n > mCap) n = mCap;
+        if (rc != VIORB_OK) throw std::runtime_error(std::string("viorb_extract: ") + viorb_last_error());
         _keypoints.clear(); _keypoints.reserve(n);
         for (int i = 0; i < n; i++)                                    // viorb_keypoint is layout-identical to cv::KeyPoint
             _keypoints.push_back(cv::KeyPoint(k[i].x, k[i].y, k[i].size, k[i].angle, k[i].response, k[i].octave, k[i].class_id));
         if (n == 0) _descriptors.release();
         else desc.rowRange(0, n).copyTo(_descriptors);
-        // mvImagePyramid is public in the reference and read by Frame::ComputeStereoMatches (src/Frame.cc:653,743-760)
-        for (int l = 0; l < nlevels; l++) {
-            int w = 0, h = 0;
-            viorb_extractor_level_download(mHandle, 0, l, 0, 0, &w, &h);
-            mvImagePyramid[l].create(h, w, CV_8U);
-            viorb_extractor_level_download(mHandle, 0, l, 0, mvImagePyramid[l].data, &w, &h);
-        }
+        // mvImagePyramid is public in the reference and read by Frame::ComputeStereoMatches (src/Frame.cc:653,743-760) only: the levels
+        // stay on the device and a level is downloaded when (if) somebody indexes it (the mono-inertial path never does)
+        mvImagePyramid.invalidate();
     }
 
     int inline GetLevels(){ return nlevels;}
@@ -77,7 +74,29 @@ public:
     // not in the reference: the device handle, for Frame::ComputeStereoMatches -> viorb_stereo_match
     viorb_extractor* handle() { return mHandle; }
 
-    std::vector<cv::Mat> mvImagePyramid;          // un-padded levels (the reference's 19-px border is never read)
+    // Stands in for the reference's public `std::vector<cv::Mat> mvImagePyramid` (include/ORBextractor.h:86): operator[] / size() as
+    // Frame::ComputeStereoMatches uses them, a level is copied from the device the first time it is indexed after an extraction.
+    class LazyPyramid {
+    public:
+        LazyPyramid() : mHandle(0) {}
+        void bind(viorb_extractor* h, int nlevels) { mHandle = h; mLevels.assign(nlevels, cv::Mat()); mFresh.assign(nlevels, 0); }
+        void invalidate() { for (size_t l = 0; l < mFresh.size(); l++) mFresh[l] = 0; }
+        size_t size() const { return mLevels.size(); }
+        int downloads() const { return mDownloads; }
+        cv::Mat& operator[](size_t l) {
+            if (!mFresh[l]) {
+                int w = 0, h = 0;
+                if (viorb_extractor_level_download(mHandle, 0, (int)l, 0, 0, &w, &h) != VIORB_OK) throw std::runtime_error(std::string("mvImagePyramid: ") + viorb_last_error());
+                mLevels[l].create(h, w, CV_8U);
+                if (viorb_extractor_level_download(mHandle, 0, (int)l, 0, mLevels[l].data, &w, &h) != VIORB_OK) throw std::runtime_error(std::string("mvImagePyramid: ") + viorb_last_error());
+                mFresh[l] = 1; mDownloads++;
+            }
+            return mLevels[l];
+        }
+    private:
+        viorb_extractor* mHandle; std::vector<cv::Mat> mLevels; std::vector<char> mFresh; int mDownloads = 0;
+    };
+    LazyPyramid mvImagePyramid;                   // un-padded levels (the reference's 19-px border is never read)
 
 protected:
     int nfeatures;

@@ -1,0 +1,207 @@
+// viorb_amd/shim/ORBmatcher_shim.h — bodies for the ORBmatcher member functions on the SURVEY §8 path, as function templates over
+// the reference's own Frame / KeyFrame / MapPoint (reference include/ORBmatcher.h:41-89, src/ORBmatcher.cc). Included in
+// src/ORBmatcher.cc AFTER the reference's headers (this header includes none of them); each reference function keeps its signature
+// and becomes a one-line call. A template only flattens the pointer-rich objects into the arrays of the
+// C ABI (include/viorb.h), calls it, and writes the result back where the reference keeps it. A failure of the GPU library throws
+// (viorb_shim::check) — it is never reported as "0 matches".
+//
+//   search_by_projection_frame       ORBmatcher::SearchByProjection(Frame&, const Frame&, th, bMono)            src/ORBmatcher.cc:1328-1471
+//   search_by_projection_points      Frame::isInFrustum loop + ORBmatcher::SearchByProjection(Frame&, vpMapPoints, th)
+//                                                                               src/Tracking.cc:1904-1958, src/ORBmatcher.cc:45-129
+//   search_by_bow                    ORBmatcher::SearchByBoW(KeyFrame*, Frame&, vpMapPointMatches)              src/ORBmatcher.cc:159-288
+//   search_for_triangulation         ORBmatcher::SearchForTriangulation(pKF1, pKF2, F12, vMatchedPairs, bOnlyStereo)   :657-823
+//   fuse                             ORBmatcher::Fuse(KeyFrame*, vpMapPoints, th)                               :825-975
+//
+// Two accessors the reference does not have are needed on MapPoint (its mfMinDistance / mfMaxDistance are protected and the existing
+// getters return them scaled by 0.8 / 1.2): `float GetMinDistance()` and `float GetMaxDistance()`, returning the raw members under
+// mMutexPos — a two-line addition to include/MapPoint.h.
+#ifndef VIORB_ORBMATCHER_SHIM_H
+#define VIORB_ORBMATCHER_SHIM_H
+
+#include <vector>
+#include <utility>
+#include <cstring>
+#include "viorb_tracking_shim.h"
+
+namespace viorb_shim {
+
+inline viorb_keypoint to_viorb(const cv::KeyPoint& k) {
+    viorb_keypoint v; v.x = k.pt.x; v.y = k.pt.y; v.size = k.size; v.angle = k.angle; v.response = k.response; v.octave = k.octave; v.class_id = k.class_id;
+    return v;
+}
+template <class KeyVec> inline void flatten_keys(const KeyVec& keys, int n, std::vector<viorb_keypoint>& out) {
+    out.resize(n > 0 ? n : 1);
+    for (int i = 0; i < n; i++) out[i] = to_viorb(keys[i]);
+}
+// pose12 = Rcw (row-major) tcw of a 4x4 CV_32F Tcw
+inline void flatten_pose(const cv::Mat& Tcw, float* pose12) {
+    for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) pose12[3 * r + c] = Tcw.at<float>(r, c); pose12[9 + r] = Tcw.at<float>(r, 3); }
+}
+// pts_f[p][8] = Pw3 normal3 mfMinDistance mfMaxDistance, descriptor of a map point
+template <class MapPointT> inline void flatten_point(MapPointT* pMP, float* f8, unsigned char* d32) {
+    const cv::Mat Pw = pMP->GetWorldPos(), Pn = pMP->GetNormal();
+    for (int c = 0; c < 3; c++) { f8[c] = Pw.at<float>(c); f8[3 + c] = Pn.at<float>(c); }
+    f8[6] = pMP->GetMinDistance(); f8[7] = pMP->GetMaxDistance();
+    const cv::Mat d = pMP->GetDescriptor();
+    std::memcpy(d32, d.data, 32);
+}
+
+// ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, const float th, const bool bMono): fills
+// CurrentFrame.mvpMapPoints, returns nmatches. check_ori = mbCheckOrientation.
+template <class FrameT>
+inline int search_by_projection_frame(FrameT& Cur, const FrameT& Last, float th, bool bMono, bool check_ori) {
+    std::vector<viorb_keypoint> ck, lk;
+    flatten_keys(Cur.mvKeysUn, Cur.N, ck); flatten_keys(Last.mvKeysUn, Last.N, lk);
+    std::vector<unsigned char> lflags(Last.N + 1, 0), ldesc((size_t)(Last.N + 1) * 32, 0);
+    std::vector<float> lPw((size_t)(Last.N + 1) * 3, 0.f);
+    for (int i = 0; i < Last.N; i++) {
+        lk[i].octave = Last.mvKeys[i].octave;                              // "int nLastOctave = LastFrame.mvKeys[i].octave" (:1379)
+        if (!Last.mvpMapPoints[i]) continue;
+        lflags[i] = (unsigned char)(1 | (Last.mvbOutlier[i] ? 2 : 0) | (Last.mvpMapPoints[i]->Observations() > 0 ? 4 : 0));
+        const cv::Mat Pw = Last.mvpMapPoints[i]->GetWorldPos();
+        for (int c = 0; c < 3; c++) lPw[3 * i + c] = Pw.at<float>(c);
+        const cv::Mat d = Last.mvpMapPoints[i]->GetDescriptor();
+        std::memcpy(&ldesc[(size_t)i * 32], d.data, 32);
+    }
+    float pose[12]; flatten_pose(Cur.mTcw, pose);
+    const float bounds[4] = {Cur.mnMinX, Cur.mnMaxX, Cur.mnMinY, Cur.mnMaxY}, intr[4] = {Cur.fx, Cur.fy, Cur.cx, Cur.cy};
+    std::vector<int32_t> match(Cur.N + 1, -1); int nmatches = 0;
+    if (bMono)
+        check(viorb_search_by_projection_frame(&ck[0], Cur.mDescriptors.data, Cur.N, bounds, pose, intr, &Cur.mvScaleFactors[0], Cur.mnScaleLevels,
+                                               &lk[0], Last.N, &lflags[0], &lPw[0], &ldesc[0], th, check_ori ? 1 : 0, &match[0], &nmatches),
+              "SearchByProjection(Frame, Frame)");
+    else {                                                                 // forward / backward octave windows, mvuRight gate (:1346-1349, 1385-1410)
+        float lpose[12]; flatten_pose(Last.mTcw, lpose);
+        check(viorb_search_by_projection_frame_stereo(&ck[0], Cur.mDescriptors.data, &Cur.mvuRight[0], Cur.N, bounds, pose, lpose, intr, Cur.mbf, Cur.mb,
+                                                      &Cur.mvScaleFactors[0], Cur.mnScaleLevels, &lk[0], Last.N, &lflags[0], &lPw[0], &ldesc[0], th,
+                                                      check_ori ? 1 : 0, &match[0], &nmatches),
+              "SearchByProjection(Frame, Frame, stereo)");
+    }
+    for (int i2 = 0; i2 < Cur.N; i2++) if (match[i2] >= 0) Cur.mvpMapPoints[i2] = Last.mvpMapPoints[match[i2]];
+    return nmatches;
+}
+
+// Tracking::SearchLocalPoints' two loops (src/Tracking.cc:1922-1957): Frame::isInFrustum(pMP, 0.5) over the local map points that
+// are not already matched in this frame — which sets mbTrackInView, mTrackProjX, mTrackProjY, mTrackProjXR, mnTrackScaleLevel,
+// mTrackViewCos and calls IncreaseVisible() — followed by ORBmatcher(0.8).SearchByProjection(F, vpMapPoints, th). The caller keeps
+// the first loop of SearchLocalPoints (marking mnLastFrameSeen of the points the frame already holds). Returns the matcher's nmatches.
+// Monocular frames only (VIORB's mono-inertial path): the mvuRight gate of :91-97 (stereo / RGB-D keypoints against mTrackProjXR) is
+// not in the device search, so a frame with right coordinates is refused instead of being matched differently.
+template <class FrameT, class MapPointT>
+inline int search_by_projection_points(FrameT& F, const std::vector<MapPointT*>& vpMapPoints, float th, float nnratio) {
+    const int np = (int)vpMapPoints.size();
+    for (int i = 0; i < F.N; i++) if (F.mvuRight[i] > 0) throw std::runtime_error("SearchByProjection(Frame, MapPoints): stereo keypoints are not supported by the device search");
+    std::vector<viorb_keypoint> ck; flatten_keys(F.mvKeysUn, F.N, ck);
+    std::vector<float> pts_f((size_t)(np + 1) * 8, 0.f), frustum((size_t)(np + 1) * 5, 0.f);
+    std::vector<unsigned char> flags(np + 1, 0), pdesc((size_t)(np + 1) * 32, 0), owner(F.N + 1, 0);
+    for (int p = 0; p < np; p++) {
+        MapPointT* pMP = vpMapPoints[p];
+        if (!pMP || pMP->isBad()) continue;
+        flags[p] = (unsigned char)(1 | (pMP->mnLastFrameSeen == F.mnId ? 2 : 0) | (pMP->Observations() > 0 ? 4 : 0));
+        flatten_point(pMP, &pts_f[(size_t)p * 8], &pdesc[(size_t)p * 32]);
+    }
+    for (int i = 0; i < F.N; i++) owner[i] = (F.mvpMapPoints[i] && F.mvpMapPoints[i]->Observations() > 0) ? 1 : 0;   // "if(F.mvpMapPoints[idx]) if(...->Observations()>0) continue" (:86-88)
+    float pose[12]; flatten_pose(F.mTcw, pose);
+    const float bounds[4] = {F.mnMinX, F.mnMaxX, F.mnMinY, F.mnMaxY}, intr[4] = {F.fx, F.fy, F.cx, F.cy};
+    std::vector<int32_t> match(F.N + 1, -1); int nmatches = 0;
+    check(viorb_search_by_projection_points(&ck[0], F.mDescriptors.data, F.N, bounds, pose, intr, &F.mvScaleFactors[0], F.mnScaleLevels, &pts_f[0], &flags[0],
+                                            &pdesc[0], np, th, nnratio, &owner[0], &match[0], &nmatches, &frustum[0]), "SearchByProjection(Frame, MapPoints)");
+    for (int p = 0; p < np; p++) {
+        MapPointT* pMP = vpMapPoints[p];
+        if (!(flags[p] & 1) || (flags[p] & 2)) continue;                    // isInFrustum is not called for these (:1929-1932)
+        const float* f = &frustum[(size_t)p * 5];
+        pMP->mbTrackInView = f[0] != 0.f;
+        if (pMP->mbTrackInView) {
+            pMP->mTrackProjX = f[1]; pMP->mTrackProjY = f[2]; pMP->mTrackViewCos = f[3]; pMP->mnTrackScaleLevel = (int)f[4];
+            pMP->IncreaseVisible();
+        }
+    }
+    for (int i = 0; i < F.N; i++) if (match[i] >= 0) F.mvpMapPoints[i] = vpMapPoints[match[i]];
+    return nmatches;
+}
+
+// Per-feature FeatureVector node (-1: the feature is in no node) from a DBoW2::FeatureVector (map<NodeId, vector<unsigned int>>)
+template <class FeatVecT> inline void flatten_featvec(const FeatVecT& fv, int n, std::vector<int32_t>& node) {
+    node.assign(n + 1, -1);
+    for (typename FeatVecT::const_iterator it = fv.begin(); it != fv.end(); ++it)
+        for (size_t k = 0; k < it->second.size(); k++) node[it->second[k]] = (int32_t)it->first;
+}
+
+// ORBmatcher::SearchByBoW(KeyFrame* pKF, Frame &F, vector<MapPoint*> &vpMapPointMatches): nnratio = mfNNratio, check_ori = mbCheckOrientation
+template <class KeyFrameT, class FrameT, class MapPointT>
+inline int search_by_bow(KeyFrameT* pKF, FrameT& F, std::vector<MapPointT*>& vpMapPointMatches, float nnratio, bool check_ori) {
+    const std::vector<MapPointT*> vpMapPointsKF = pKF->GetMapPointMatches();
+    vpMapPointMatches = std::vector<MapPointT*>(F.N, static_cast<MapPointT*>(0));
+    std::vector<viorb_keypoint> kk, fk; flatten_keys(pKF->mvKeysUn, pKF->N, kk); flatten_keys(F.mvKeys, F.N, fk);
+    std::vector<int32_t> knode, fnode; flatten_featvec(pKF->mFeatVec, pKF->N, knode); flatten_featvec(F.mFeatVec, F.N, fnode);
+    std::vector<unsigned char> has(pKF->N + 1, 0);
+    for (int i = 0; i < pKF->N; i++) has[i] = (vpMapPointsKF[i] && !vpMapPointsKF[i]->isBad()) ? 1 : 0;
+    std::vector<int32_t> match(F.N + 1, -1); int nmatches = 0;
+    check(viorb_search_by_bow(&kk[0], pKF->mDescriptors.data, &knode[0], &has[0], pKF->N, &fk[0], F.mDescriptors.data, &fnode[0], F.N, nnratio,
+                              check_ori ? 1 : 0, &match[0], &nmatches), "SearchByBoW");
+    for (int iF = 0; iF < F.N; iF++) if (match[iF] >= 0) vpMapPointMatches[iF] = vpMapPointsKF[match[iF]];
+    return nmatches;
+}
+
+// ORBmatcher::SearchForTriangulation(KeyFrame *pKF1, KeyFrame *pKF2, cv::Mat F12, vector<pair<size_t,size_t>> &vMatchedPairs, bOnlyStereo)
+template <class KeyFrameT>
+inline int search_for_triangulation(KeyFrameT* pKF1, KeyFrameT* pKF2, const cv::Mat& F12, std::vector<std::pair<size_t, size_t> >& vMatchedPairs,
+                                    bool bOnlyStereo, bool check_ori) {
+    std::vector<viorb_keypoint> k1, k2; flatten_keys(pKF1->mvKeysUn, pKF1->N, k1); flatten_keys(pKF2->mvKeysUn, pKF2->N, k2);
+    std::vector<int32_t> n1, n2; flatten_featvec(pKF1->mFeatVec, pKF1->N, n1); flatten_featvec(pKF2->mFeatVec, pKF2->N, n2);
+    std::vector<unsigned char> h1(pKF1->N + 1, 0), h2(pKF2->N + 1, 0);
+    for (int i = 0; i < pKF1->N; i++) h1[i] = pKF1->GetMapPoint(i) ? 1 : 0;
+    for (int i = 0; i < pKF2->N; i++) h2[i] = pKF2->GetMapPoint(i) ? 1 : 0;
+    float F[9], Cw[3], pose2[12];
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) F[3 * r + c] = F12.at<float>(r, c);
+    const cv::Mat C1 = pKF1->GetCameraCenter();
+    for (int c = 0; c < 3; c++) Cw[c] = C1.at<float>(c);
+    flatten_pose(pKF2->GetPose(), pose2);
+    const float intr[4] = {pKF2->fx, pKF2->fy, pKF2->cx, pKF2->cy};
+    std::vector<int32_t> match12(pKF1->N + 1, -1); int nmatches = 0;
+    check(viorb_search_for_triangulation(&k1[0], pKF1->mDescriptors.data, &h1[0], &pKF1->mvuRight[0], &n1[0], pKF1->N, &k2[0], pKF2->mDescriptors.data, &h2[0],
+                                         &pKF2->mvuRight[0], &n2[0], pKF2->N, F, Cw, pose2, intr, &pKF2->mvScaleFactors[0], &pKF2->mvLevelSigma2[0],
+                                         pKF2->mnScaleLevels, bOnlyStereo ? 1 : 0, check_ori ? 1 : 0, &match12[0], &nmatches), "SearchForTriangulation");
+    vMatchedPairs.clear(); vMatchedPairs.reserve(nmatches);
+    for (int i = 0; i < pKF1->N; i++) if (match12[i] >= 0) vMatchedPairs.push_back(std::make_pair((size_t)i, (size_t)match12[i]));   // (:812-819)
+    return nmatches;
+}
+
+// ORBmatcher::Fuse(KeyFrame *pKF, const vector<MapPoint *> &vpMapPoints, const float th): the search runs on the device, the
+// reference's own Replace / AddObservation / AddMapPoint block (:956-972) runs here over best_idx in point order. Returns nFused.
+template <class KeyFrameT, class MapPointT>
+inline int fuse(KeyFrameT* pKF, const std::vector<MapPointT*>& vpMapPoints, float th) {
+    const int np = (int)vpMapPoints.size();
+    std::vector<viorb_keypoint> kk; flatten_keys(pKF->mvKeysUn, pKF->N, kk);
+    std::vector<float> pts_f((size_t)(np + 1) * 8, 0.f);
+    std::vector<unsigned char> valid(np + 1, 0), pdesc((size_t)(np + 1) * 32, 0);
+    for (int p = 0; p < np; p++) {
+        MapPointT* pMP = vpMapPoints[p];
+        if (!pMP || pMP->isBad() || pMP->IsInKeyFrame(pKF)) continue;      // (:847-851)
+        valid[p] = 1;
+        flatten_point(pMP, &pts_f[(size_t)p * 8], &pdesc[(size_t)p * 32]);
+    }
+    float pose[12]; flatten_pose(pKF->GetPose(), pose);
+    const float bounds[4] = {pKF->mnMinX, pKF->mnMaxX, pKF->mnMinY, pKF->mnMaxY}, intr5[5] = {pKF->fx, pKF->fy, pKF->cx, pKF->cy, pKF->mbf};
+    std::vector<int32_t> best(np + 1, -1); int nFused = 0;
+    check(viorb_fuse(&kk[0], pKF->mDescriptors.data, &pKF->mvuRight[0], pKF->N, bounds, pose, intr5, &pKF->mvScaleFactors[0], &pKF->mvInvLevelSigma2[0],
+                     pKF->mnScaleLevels, &pts_f[0], &valid[0], &pdesc[0], np, th, &best[0], &nFused), "Fuse");
+    for (int p = 0; p < np; p++) {
+        if (best[p] < 0) continue;
+        MapPointT* pMP = vpMapPoints[p];
+        MapPointT* pMPinKF = pKF->GetMapPoint(best[p]);
+        if (pMPinKF) {
+            if (!pMPinKF->isBad()) {
+                if (pMPinKF->Observations() > pMP->Observations()) pMP->Replace(pMPinKF);
+                else pMPinKF->Replace(pMP);
+            }
+        } else {
+            pMP->AddObservation(pKF, best[p]);
+            pKF->AddMapPoint(pMP, best[p]);
+        }
+    }
+    return nFused;
+}
+
+} // namespace viorb_shim
+#endif

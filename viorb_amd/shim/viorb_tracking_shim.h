@@ -12,10 +12,18 @@
 
 #include <vector>
 #include <cstring>
+#include <string>
+#include <stdexcept>
 #include <type_traits>
 #include "viorb.h"
 
 namespace viorb_shim {
+
+// The reference's functions have no error channel (an int count or void): a failure of the GPU library is therefore surfaced as an
+// exception carrying viorb_last_error() — never as "0 matches" / "0 inliers", which Tracking would read as a lost track.
+inline void check(int rc, const char* what) {
+    if (rc != VIORB_OK) throw std::runtime_error(std::string(what) + ": " + viorb_last_error());
+}
 
 // ---- NavState / IMUPreintegrator <-> flat doubles (layouts documented in include/viorb.h) ---------------------
 template <class NavStateT> inline void pack_navstate(const NavStateT& ns, double* o) {
@@ -74,8 +82,8 @@ inline int pose_optimization_frame(FrameT* pFrame, FrameT* pLast, const Preint& 
     std::vector<double> oc, ol; std::vector<int> ic, il;
     gather_observations(*pFrame, oc, ic); gather_observations(*pLast, ol, il);
     std::vector<unsigned char> fc(ic.size() + 1), fl(il.size() + 1);
-    if (viorb_pose_opt_vi(1, bComputeMarg, cur, last, prior, mci, pre, gw, cam, oc.empty() ? 0 : &oc[0], (int)ic.size(),
-                          ol.empty() ? 0 : &ol[0], (int)il.size(), out, outl, &fc[0], &fl[0], marg, info) != VIORB_OK) return 0;
+    check(viorb_pose_opt_vi(1, bComputeMarg, cur, last, prior, mci, pre, gw, cam, oc.empty() ? 0 : &oc[0], (int)ic.size(),
+                            ol.empty() ? 0 : &ol[0], (int)il.size(), out, outl, &fc[0], &fl[0], marg, info), "PoseOptimization(Frame, Frame)");
     if (ic.size() < 3) return 0;                                              // reference returns before touching the frame
     for (size_t k = 0; k < ic.size(); k++) pFrame->mvbOutlier[ic[k]] = fc[k] != 0;
     for (size_t k = 0; k < il.size(); k++) pLast->mvbOutlier[il[k]] = fl[k] != 0;
@@ -100,8 +108,8 @@ inline int pose_optimization_keyframe(FrameT* pFrame, KeyFrameT* pLastKF, const 
     std::vector<double> oc; std::vector<int> ic;
     gather_observations(*pFrame, oc, ic);
     std::vector<unsigned char> fc(ic.size() + 1);
-    if (viorb_pose_opt_vi(0, bComputeMarg, cur, last, 0, 0, pre, gw, cam, oc.empty() ? 0 : &oc[0], (int)ic.size(), 0, 0, out, 0,
-                          &fc[0], 0, marg, info) != VIORB_OK) return 0;
+    check(viorb_pose_opt_vi(0, bComputeMarg, cur, last, 0, 0, pre, gw, cam, oc.empty() ? 0 : &oc[0], (int)ic.size(), 0, 0, out, 0,
+                            &fc[0], 0, marg, info), "PoseOptimization(Frame, KeyFrame)");
     if (ic.size() < 3) return 0;
     for (size_t k = 0; k < ic.size(); k++) pFrame->mvbOutlier[ic[k]] = fc[k] != 0;
     typename std::remove_reference<decltype(pFrame->mNavStatePrior)>::type ns;

@@ -303,9 +303,14 @@ class NativeTracker:
 
     def step(self, images, imu, t_cur, true_pose12=None, map_updated=None, recent_reloc=None, t_next_last=None, reset_ns=None, reset_marg=None):
         """images [B,h,w] u8, imu [B,n,7] f64, t_cur [B] f64 — CUDA tensors. true_pose12 [B,12] f64: map points of the new last frame from
-        the synthetic plane world (None: call set_last_points before the next step). map_updated / recent_reloc: [B] u8 flags."""
+        the synthetic plane world (None: call set_last_points before the next step). map_updated / recent_reloc: [B] u8 flags.
+        `images` may also be a HOST tensor (page-locked: torch.Tensor.pin_memory()): the live-feed path, uploaded by the tracker's copy stream."""
         inp = capi_mod.TrackerInputs()
-        inp.d_images = images.data_ptr(); inp.image_stride = images.stride(1); inp.image_pitch_bytes = images.stride(0)
+        if images.is_cuda:
+            inp.d_images = images.data_ptr()
+        else:
+            inp.h_images = images.data_ptr()
+        inp.image_stride = images.stride(1); inp.image_pitch_bytes = images.stride(0)
         inp.d_imu = imu.data_ptr(); inp.n_imu = imu.shape[1]; inp.d_t_cur = t_cur.data_ptr()
         opt = lambda t: t.data_ptr() if t is not None else None
         inp.d_map_updated = opt(map_updated); inp.d_recent_reloc = opt(recent_reloc); inp.d_t_next_last = opt(t_next_last)
