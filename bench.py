@@ -36,6 +36,8 @@ CONFIGS = {
     "synth720p": dict(w=1280, h=720, nfeat=1500, streams=8, baseline_config=4),
     "kitti_stereo": dict(w=1241, h=376, nfeat=2000, streams=256, baseline_config=2),
     "local_ba": dict(w=752, h=480, nfeat=1000, streams=64, baseline_config=3),
+    # one stream through the host-buffer drop-ins, call by call: the reference's own calling pattern (a Tracking thread built with viorb_amd/shim/)
+    "dropin": dict(w=752, h=480, nfeat=1000, streams=1, baseline_config=1),
 }
 EXTRACT_KERNELS = ("k_copy_level0", "k_resize", "k_fast_cells", "k_octree", "k_octree_large", "k_blur", "k_orient_describe")
 
@@ -364,6 +366,57 @@ def run_tracking(args, cfg, rank, dev_index, dev, world):
 
 
 # ------------------------------------------------------------------------------------------------------------------------------
+# dropin: ONE stream, every library call a host-buffer drop-in with its own upload / launch / synchronise / download (what a single VIORB
+# process pays per frame through the shims) — a latency figure, per call and per frame; never the headline
+# ------------------------------------------------------------------------------------------------------------------------------
+def run_dropin(args, cfg, rank, dev_index, dev, world):
+    import torch
+    from viorb_amd.distributed import stream_seeds
+    from viorb_amd.tracker import DropinTracker
+    s = generate_streams(stream_seeds(rank, 1), cfg["w"], cfg["h"], 1)[0]
+    tr = DropinTracker(s["cam"], s["gw"], cfg["w"], cfg["h"], cfg["nfeat"])
+    mci = np.eye(12) * 1e3
+    tr.bootstrap(s["frames"][0], s["pose_true"][0], s["t"][0], s["ns_true"][0], mci)
+    states = []
+
+    def run_step(k):
+        j = k % N_FRAMES
+        if j == 0:
+            r = tr.step(s["frames"][0], s["imu"][0], s["period"], s["pose_true"][0], t_next_last=0.0, reset_ns=s["ns_true"][0], reset_marg=mci)
+        else:
+            r = tr.step(s["frames"][j], s["imu"][j], s["t"][j], s["pose_true"][j], map_updated=(j == 1 and k > 1))
+        states.append(r["state"])
+    k = 1
+    for _ in range(args.warmup):
+        run_step(k); k += 1
+    tr.times.clear(); del states[:]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run_step(k); k += 1
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    out = dict(units=args.steps, elapsed=elapsed)
+    if rank == 0:
+        per_call = {name: {"ms_per_call": round(v[0] / v[1] * 1e3, 4), "calls_per_frame": round(v[1] / args.steps, 2)} for name, v in sorted(tr.times.items())}
+        in_calls = sum(v[0] for v in tr.times.values())
+        out["config"] = {"workload": "ONE EuRoC-shaped synthetic stream %dx%d / %d features through the host-buffer drop-ins call by call (viorb_extract, "
+                                     "viorb_preintegrate, viorb_search_by_projection_frame, viorb_pose_opt_vi, viorb_search_by_projection_points, viorb_pose_opt_vi), "
+                                     "host buffers in and out of every call; Python caller (numpy glue between the calls = %.2f ms per frame)"
+                                     % (cfg["w"], cfg["h"], cfg["nfeat"], (elapsed - in_calls) / args.steps * 1e3),
+                         "baseline_config": cfg["baseline_config"], "streams_per_gpu": 1, "per_call": per_call,
+                         "ms_per_frame_inside_the_calls": round(in_calls / args.steps * 1e3, 4),
+                         "frames_per_s_inside_the_calls": round(args.steps / in_calls, 1),
+                         "tracked_frames": int(sum(1 for x in states if x == 0)), "frames": len(states)}
+        out["roofline"] = None
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline_tracking([s], cfg["w"], cfg["h"], cfg["nfeat"], 100, 10)
+    out["metric"] = "frames/sec ORB extract+match+pose-opt, EuRoC 752x480, single stream through the host-buffer drop-ins"
+    out["unit"] = "frames/s"; out["dtype"] = "u8"
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
 # kitti_stereo: extraction of both images + Frame::ComputeStereoMatches (reference src/Frame.cc:241-262, :646-820)
 # ------------------------------------------------------------------------------------------------------------------------------
 def run_stereo(args, cfg, rank, dev_index, dev, world):
@@ -527,9 +580,9 @@ def main():
     if args.streams is None:
         args.streams = cfg["streams"]
     if args.steps is None:
-        args.steps = {"euroc": 200, "synth720p": 200, "kitti_stereo": 50, "local_ba": 4}[args.config]
+        args.steps = {"euroc": 200, "synth720p": 200, "kitti_stereo": 50, "local_ba": 4, "dropin": 200}[args.config]
     if args.warmup is None:
-        args.warmup = {"euroc": 16, "synth720p": 16, "kitti_stereo": 5, "local_ba": 1}[args.config]
+        args.warmup = {"euroc": 16, "synth720p": 16, "kitti_stereo": 5, "local_ba": 1, "dropin": 16}[args.config]
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -568,7 +621,7 @@ def main():
     dev = torch.device("cuda", dev_index)
     if world > 1:
         dist_init("gloo" if rehearsal else "nccl", None if rehearsal else dev)       # "nccl" is RCCL on ROCm
-    runner = {"euroc": run_tracking, "synth720p": run_tracking, "kitti_stereo": run_stereo, "local_ba": run_local_ba}[args.config]
+    runner = {"euroc": run_tracking, "synth720p": run_tracking, "kitti_stereo": run_stereo, "local_ba": run_local_ba, "dropin": run_dropin}[args.config]
     r = runner(args, cfg, rank, dev_index, dev, world)
     units, elapsed = reduce_throughput(r["units"], r["elapsed"], None if rehearsal else dev)
     if rank == 0:

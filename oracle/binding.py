@@ -102,6 +102,9 @@ class Extractor:
     def level_keypoints(self, l, candidates=False):
         buf = np.zeros(self.nfeatures * 40 + 1024, KP_DTYPE)
         n = self.L.ora_level_keypoints(self.h, l, 0 if candidates else 1, _p(buf), len(buf))
+        if n > len(buf):                     # an image of noise: more candidates than the usual buffer
+            buf = np.zeros(n, KP_DTYPE)
+            n = self.L.ora_level_keypoints(self.h, l, 0 if candidates else 1, _p(buf), len(buf))
         assert 0 <= n <= len(buf)
         return buf[:n].copy()
 

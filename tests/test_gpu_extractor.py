@@ -233,3 +233,25 @@ def test_dense_corner_images(gpu, oracle, kind):
         want = np.stack([oc["x"], oc["y"], oc["response"]], 1).astype(np.int32).reshape(-1, 3)
         np.testing.assert_array_equal(ex.debug_level_points(l, kept=False), want, err_msg="%s: FAST candidates level %d" % (kind, l))
     assert len(kps) == len(okps) and (kps == okps).all() and (desc == odesc).all()
+
+
+@pytest.mark.parametrize("w,h,nf", [(752, 480, 1000), (1280, 720, 1500)])
+def test_uniform_noise_images_have_no_candidate_cap(gpu, oracle, w, h, nf):
+    """Uniform noise at the two bench sizes: tens of thousands of FAST candidates per level (the reference has no limit: its
+    vToDistributeKeys.reserve(nfeatures * 10) is only a reserve, src/ORBextractor.cc:779) — far beyond the 8192 the LDS quadtree
+    holds, so the over-size levels take the global-scratch instantiation of the same kernel. Everything must still equal the oracle."""
+    img = np.random.default_rng(w).integers(0, 256, (h, w), dtype=np.uint8)
+    ex = viorb_amd.ORBextractor(nf, 1.2, 8, 20, 7)
+    kps, desc = ex(img)
+    ox = oracle.Extractor(nf, 1.2, 8, 20, 7)
+    okps, odesc = ox(img)
+    ncand = [len(ox.level_keypoints(l, candidates=True)) for l in range(8)]
+    assert max(ncand) > 20000 and sum(n > 8192 for n in ncand) >= 2, ncand
+    for l in range(8):
+        oc = ox.level_keypoints(l, candidates=True)
+        want = np.stack([oc["x"], oc["y"], oc["response"]], 1).astype(np.int32).reshape(-1, 3)
+        np.testing.assert_array_equal(ex.debug_level_points(l, kept=False), want, err_msg="FAST candidates level %d" % l)
+        ok = ox.level_keypoints(l)
+        wantk = np.stack([ok["x"], ok["y"], ok["response"]], 1).astype(np.int32).reshape(-1, 3)
+        np.testing.assert_array_equal(ex.debug_level_points(l, kept=True), wantk, err_msg="quadtree level %d" % l)
+    assert len(kps) == len(okps) and (kps == okps).all() and (desc == odesc).all()

@@ -10,7 +10,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="--streams $S --steps 4 --warmup 2 --no-cpu-baseline --no-kernel-events --distinct 16 --gen-procs 1"
+ARGS="--streams $S --steps 4 --warmup 2 --no-cpu-baseline --no-kernel-events --no-host-input-pass --distinct 16 --gen-procs 1"
 date
 timeout -k 10 400 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_sq_step -- python3 $R/bench.py $ARGS > $OUT/${TAG}_pmc_sq_step.json 2> $OUT/${TAG}_pmc_sq_step.err || { echo "sq pass failed rc=$?"; tail -5 $OUT/${TAG}_pmc_sq_step.err; exit 1; }
 python3 $R/tools/pmc_summary.py $OUT/${TAG}_pmc_sq_step > $OUT/${TAG}_pmc_sq_step${S}.txt

@@ -992,8 +992,16 @@ __global__ __launch_bounds__(64) void k_fast_cells3(const uint8_t* __restrict__ 
 // single-wavefront workgroups: a workgroup barrier is one s_barrier and also orders LDS traffic
 #define WAVE_SYNC() __syncthreads()
 #define OCT_NCAP_SMALL 2048
-struct OctLds {
-    uint32_t* keys; uint16_t* perm0; uint16_t* perm1; OctNode* nd; uint32_t* sortb;
+// Two instantiations of the same code: BIG = false keeps candidates (keys + two u16 permutation buffers) in LDS — up to oct_ncap of
+// them — and BIG = true takes a level with MORE candidates than that (an image of noise: the reference has no limit, src/ORBextractor.cc:779
+// is only a reserve) with u32 permutations in a global scratch slot, 32-bit node ranges and 64-bit sort keys; nodes and the sort buffer
+// stay in LDS either way. Same decisions, same output.
+struct OctNodeBig { int16_t x0, x1, y0, y1; uint32_t begin, count; uint16_t flags, pad; };
+template <bool BIG> struct OctT;
+template <> struct OctT<false> { typedef uint16_t Perm; typedef OctNode Node; typedef uint32_t SortKey; enum { KEY_SHIFT = 16 }; };
+template <> struct OctT<true> { typedef uint32_t Perm; typedef OctNodeBig Node; typedef unsigned long long SortKey; enum { KEY_SHIFT = 32 }; };
+template <bool BIG> struct OctLdsT {
+    uint32_t* keys; typename OctT<BIG>::Perm* perm0; typename OctT<BIG>::Perm* perm1; typename OctT<BIG>::Node* nd; typename OctT<BIG>::SortKey* sortb;
 };
 
 __device__ __forceinline__ unsigned long long lanemask_lt(int lane) { return (1ull << lane) - 1ull; }
@@ -1005,14 +1013,14 @@ __device__ __forceinline__ unsigned long long lanemask_lt(int lane) { return (1u
 #define OCT_LANE_LIMIT 64                     // points a lane-local expansion handles (child codes live in two 64-bit registers)
 struct OctExpandResult { int off, nexp; };    // non-empty children, children with more than one point
 
-__device__ __forceinline__ void oct_write_children(const OctLds& S, const OctNode& p, int i, int slot, int mx, int my, int sb,
+template <bool BIG> __device__ __forceinline__ void oct_write_children(const OctLdsT<BIG>& S, const typename OctT<BIG>::Node& p, int i, int slot, int mx, int my, int sb,
                                                    const int tc[4], const int sc4[4]) {
 #pragma unroll
     for (int c = 0; c < 4; c++) {
-        OctNode o;
+        typename OctT<BIG>::Node o;
         o.x0 = (c & 1) ? (int16_t)mx : p.x0; o.x1 = (c & 1) ? p.x1 : (int16_t)mx;
         o.y0 = (c & 2) ? (int16_t)my : p.y0; o.y1 = (c & 2) ? p.y1 : (int16_t)my;
-        o.begin = (uint16_t)sc4[c]; o.count = (uint16_t)tc[c];
+        o.begin = (decltype(o.begin))sc4[c]; o.count = (decltype(o.count))tc[c];
         o.flags = tc[c] > 0 ? (uint16_t)((sb ^ 1) | (tc[c] == 1 ? OCT_NOMORE : 0)) : (uint16_t)OCT_DEAD; o.pad = 0;
         S.nd[slot + c] = o;
     }
@@ -1020,13 +1028,13 @@ __device__ __forceinline__ void oct_write_children(const OctLds& S, const OctNod
 }
 
 // whole wave on one node: stable 4-way partition of its key segment with ballots
-__device__ __forceinline__ OctExpandResult oct_expand_wave(const OctLds& S, int i, int slot, int lane) {
-    const OctNode p = S.nd[i];
+template <bool BIG> __device__ __forceinline__ OctExpandResult oct_expand_wave(const OctLdsT<BIG>& S, int i, int slot, int lane) {
+    const typename OctT<BIG>::Node p = S.nd[i];
     const int mx = p.x0 + ((p.x1 - p.x0 + 1) >> 1), my = p.y0 + ((p.y1 - p.y0 + 1) >> 1);
     const int sb = p.flags & OCT_BUF;
-    const uint16_t* src = sb ? S.perm1 : S.perm0;
-    uint16_t* dst = sb ? S.perm0 : S.perm1;
-    const int cnt = p.count, beg = p.begin;
+    const typename OctT<BIG>::Perm* src = sb ? S.perm1 : S.perm0;
+    typename OctT<BIG>::Perm* dst = sb ? S.perm0 : S.perm1;
+    const int cnt = (int)p.count, beg = (int)p.begin;
     int t0 = 0, t1 = 0, t2 = 0, t3 = 0;
     for (int o = 0; o < cnt; o += 64) {
         const int idx = o + lane;
@@ -1043,7 +1051,7 @@ __device__ __forceinline__ OctExpandResult oct_expand_wave(const OctLds& S, int 
     for (int o = 0; o < cnt; o += 64) {
         const int idx = o + lane;
         int c = -1;
-        uint16_t id = 0;
+        typename OctT<BIG>::Perm id = 0;
         if (idx < cnt) {
             id = src[beg + idx];
             const uint32_t key = S.keys[id];
@@ -1064,8 +1072,8 @@ __device__ __forceinline__ OctExpandResult oct_expand_wave(const OctLds& S, int 
 }
 
 // one lane on one node (count <= OCT_LANE_LIMIT): counting pass (child codes kept in registers), then the stable scatter
-__device__ __forceinline__ void oct_lane_count(const OctLds& S, const OctNode& p, int mx, int my, unsigned long long& lo, unsigned long long& hi, int tc[4]) {
-    const uint16_t* src = (p.flags & OCT_BUF) ? S.perm1 : S.perm0;
+template <bool BIG> __device__ __forceinline__ void oct_lane_count(const OctLdsT<BIG>& S, const typename OctT<BIG>::Node& p, int mx, int my, unsigned long long& lo, unsigned long long& hi, int tc[4]) {
+    const typename OctT<BIG>::Perm* src = (p.flags & OCT_BUF) ? S.perm1 : S.perm0;
     lo = 0; hi = 0; tc[0] = tc[1] = tc[2] = tc[3] = 0;
     for (int k = 0; k < (int)p.count; k++) {
         const uint32_t key = S.keys[src[p.begin + k]];
@@ -1075,15 +1083,15 @@ __device__ __forceinline__ void oct_lane_count(const OctLds& S, const OctNode& p
         tc[0] += c == 0; tc[1] += c == 1; tc[2] += c == 2; tc[3] += c == 3;
     }
 }
-__device__ __forceinline__ void oct_lane_scatter(const OctLds& S, const OctNode& p, int i, int slot, int mx, int my, unsigned long long lo,
+template <bool BIG> __device__ __forceinline__ void oct_lane_scatter(const OctLdsT<BIG>& S, const typename OctT<BIG>::Node& p, int i, int slot, int mx, int my, unsigned long long lo,
                                                  unsigned long long hi, const int tc[4]) {
     const int sb = p.flags & OCT_BUF;
-    const uint16_t* src = sb ? S.perm1 : S.perm0;
-    uint16_t* dst = sb ? S.perm0 : S.perm1;
-    const int sc4[4] = {p.begin, p.begin + tc[0], p.begin + tc[0] + tc[1], p.begin + tc[0] + tc[1] + tc[2]};
+    const typename OctT<BIG>::Perm* src = sb ? S.perm1 : S.perm0;
+    typename OctT<BIG>::Perm* dst = sb ? S.perm0 : S.perm1;
+    const int sc4[4] = {(int)p.begin, (int)p.begin + tc[0], (int)p.begin + tc[0] + tc[1], (int)p.begin + tc[0] + tc[1] + tc[2]};
     int w0 = sc4[0], w1 = sc4[1], w2 = sc4[2], w3 = sc4[3];
     for (int k = 0; k < (int)p.count; k++) {
-        const uint16_t id = src[p.begin + k];
+        const typename OctT<BIG>::Perm id = src[p.begin + k];
         const int c = (int)((lo >> k) & 1) | ((int)((hi >> k) & 1) << 1);
         const int pos = c == 0 ? w0 : (c == 1 ? w1 : (c == 2 ? w2 : w3));
         dst[pos] = id;
@@ -1093,12 +1101,12 @@ __device__ __forceinline__ void oct_lane_scatter(const OctLds& S, const OctNode&
 }
 
 // Stable in-place removal of dead nodes; returns the new node count; first_new = new index of `upto`.
-__device__ __forceinline__ int oct_compact(const OctLds& S, int nn, int upto, int lane, int& first_new) {
+template <bool BIG> __device__ __forceinline__ int oct_compact(const OctLdsT<BIG>& S, int nn, int upto, int lane, int& first_new) {
     int w = 0;
     first_new = -1;
     for (int base = 0; base < nn; base += 64) {
         const int i = base + lane;
-        OctNode o; o.flags = OCT_DEAD;
+        typename OctT<BIG>::Node o; o.flags = OCT_DEAD;
         if (i < nn) o = S.nd[i];
         const bool alive = (i < nn) && !(o.flags & OCT_DEAD);
         const unsigned long long m = __ballot(alive);
@@ -1113,32 +1121,41 @@ __device__ __forceinline__ int oct_compact(const OctLds& S, int nn, int upto, in
 }
 
 // Ascending bitonic sort of m (power of two) u32 keys in LDS by one wavefront.
-__device__ __forceinline__ void oct_sort(uint32_t* a, int m, int lane) {
+template <class K> __device__ __forceinline__ void oct_sort(K* a, int m, int lane) {
     for (int k = 2; k <= m; k <<= 1)
         for (int j = k >> 1; j > 0; j >>= 1) {
             for (int t = lane; t < (m >> 1); t += 64) {
                 const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));   // index with bit j clear
                 const int hi = lo | j;
                 const bool up = (lo & k) == 0;
-                const uint32_t x = a[lo], y = a[hi];
+                const K x = a[lo], y = a[hi];
                 if ((x > y) == up) { a[lo] = y; a[hi] = x; }
             }
             WAVE_SYNC();
         }
 }
 
+template <bool BIG>
 __global__ __launch_bounds__(64) void k_octree(const LevelDev* __restrict__ lv, const uint32_t* __restrict__ slots,
                                                int slot_cap, const int* __restrict__ cell_cnt, int ncells_total,
                                                uint32_t* __restrict__ lvl_kp, int kp_pitch, int* __restrict__ lvl_cnt,
                                                int* __restrict__ lvl_ncand, int nlevels, int* __restrict__ status,
-                                               int ncap, int nodecap, int sortcap, int n_above, int n_upto) {
+                                               int ncap, int nodecap, int sortcap, int n_above, int n_upto,
+                                               uint32_t* __restrict__ big_scratch, int* __restrict__ big_next, int big_slots, int* __restrict__ lvl_tot) {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_oct[];
-    OctLds S;
-    S.keys = s_oct;
-    S.perm0 = reinterpret_cast<uint16_t*>(s_oct + ncap);
-    S.perm1 = S.perm0 + ncap;
-    S.nd = reinterpret_cast<OctNode*>(S.perm1 + ncap);
-    S.sortb = reinterpret_cast<uint32_t*>(S.nd + nodecap);
+    typedef typename OctT<BIG>::Perm Perm; typedef typename OctT<BIG>::Node Node; typedef typename OctT<BIG>::SortKey SortKey;
+    OctLdsT<BIG> S;
+    if (BIG) {                                                          // nodes + sort keys in LDS; keys / permutations in a scratch slot claimed below
+        S.sortb = reinterpret_cast<SortKey*>(s_oct);
+        S.nd = reinterpret_cast<Node*>(S.sortb + sortcap);
+        S.keys = nullptr; S.perm0 = S.perm1 = nullptr;
+    } else {
+        S.keys = s_oct;
+        S.perm0 = reinterpret_cast<Perm*>(s_oct + ncap);
+        S.perm1 = S.perm0 + ncap;
+        S.nd = reinterpret_cast<Node*>(S.perm1 + ncap);
+        S.sortb = reinterpret_cast<SortKey*>(S.nd + nodecap);
+    }
     // grid = (image, level): with the level in x and 8 levels, the round-robin deal of workgroups to the 8 XCDs would send every
     // level-0 quadtree (the longest) to XCD 0 and every level-7 one to XCD 7; image-major order spreads each level over all XCDs
     // and starts the long ones first
@@ -1150,16 +1167,29 @@ __global__ __launch_bounds__(64) void k_octree(const LevelDev* __restrict__ lv, 
     const int* cc = cell_cnt + (size_t)b * ncells_total + L.cell_base;
     {
         int tot = 0;
-        for (int c0 = 0; c0 < L.ncells; c0 += 512) {                 // eight independent loads in flight per lane
-            int part[8];
+        if (n_above < 0) {                                               // the first launch counts the level's candidates, the later ones read the count
+            for (int c0 = 0; c0 < L.ncells; c0 += 512) {                 // eight independent loads in flight per lane
+                int part[8];
 #pragma unroll
-            for (int j = 0; j < 8; j++) { const int ci = c0 + 64 * j + lane; part[j] = cc[min(ci, L.ncells - 1)]; if (ci >= L.ncells) part[j] = 0; }
+                for (int j = 0; j < 8; j++) { const int ci = c0 + 64 * j + lane; part[j] = cc[min(ci, L.ncells - 1)]; if (ci >= L.ncells) part[j] = 0; }
 #pragma unroll
-            for (int j = 0; j < 8; j++) tot += part[j];
-        }
+                for (int j = 0; j < 8; j++) tot += part[j];
+            }
 #pragma unroll
-        for (int d = 32; d > 0; d >>= 1) tot += __shfl_xor(tot, d);
+            for (int d = 32; d > 0; d >>= 1) tot += __shfl_xor(tot, d);
+            if (lane == 0) lvl_tot[b * nlevels + level] = tot;
+        } else tot = lvl_tot[b * nlevels + level];
         if (tot <= n_above || tot > n_upto) return;
+        if (BIG) {
+            // one scratch slot of 3 * ncap words per over-size (image, level); when more levels than slots overflow in one call the rest
+            // report VIORB_ERR_CAPACITY (big_slots = min(batch * levels, 64): every level of a small batch of pure-noise images fits)
+            int slot = 0;
+            if (lane == 0) slot = atomicAdd(big_next, 1);
+            slot = __shfl(slot, 0);
+            if (slot >= big_slots) { if (lane == 0) { lvl_cnt[b * nlevels + level] = 0; lvl_ncand[b * nlevels + level] = tot; status[b] = VIORB_ERR_CAPACITY; } return; }
+            uint32_t* base = big_scratch + (size_t)slot * 3 * (size_t)ncap;
+            S.keys = base; S.perm0 = reinterpret_cast<Perm*>(base + ncap); S.perm1 = reinterpret_cast<Perm*>(base + 2 * (size_t)ncap);
+        }
     }
     // ---- 1. gather candidates in the reference's push order (cell-major, row-major inside a cell): one cell per lane, eight of its
     //         slots requested before the first is stored (the slot loop used to be one L2 round trip per slot)
@@ -1206,15 +1236,15 @@ __global__ __launch_bounds__(64) void k_octree(const LevelDev* __restrict__ lv, 
                 bool mine = false;
                 if (idx < n) mine = ((int)((float)(S.keys[idx] & 0xfff) / L.hx)) == r;
                 const unsigned long long m = __ballot(mine);
-                if (mine) S.perm0[begin + cnt + __popcll(m & lanemask_lt(lane))] = (uint16_t)idx;
+                if (mine) S.perm0[begin + cnt + __popcll(m & lanemask_lt(lane))] = (Perm)idx;
                 cnt += __popcll(m);
             }
             if (cnt > 0) {
                 if (lane == 0) {
-                    OctNode o;
+                    Node o;
                     o.x0 = (int16_t)(int)(L.hx * (float)r); o.x1 = (int16_t)(int)(L.hx * (float)(r + 1));
                     o.y0 = 0; o.y1 = (int16_t)L.oct_h;
-                    o.begin = (uint16_t)begin; o.count = (uint16_t)cnt;
+                    o.begin = (decltype(o.begin))begin; o.count = (decltype(o.count))cnt;
                     o.flags = (uint16_t)(cnt == 1 ? OCT_NOMORE : 0); o.pad = 0;
                     S.nd[nn] = o;
                 }
@@ -1225,7 +1255,7 @@ __global__ __launch_bounds__(64) void k_octree(const LevelDev* __restrict__ lv, 
         WAVE_SYNC();
         // reverse the root array (list front = root 0 must be the LAST array element)
         for (int i = lane; i < (nn >> 1); i += 64) {
-            const OctNode a = S.nd[i], z = S.nd[nn - 1 - i];
+            const Node a = S.nd[i], z = S.nd[nn - 1 - i];
             S.nd[i] = z; S.nd[nn - 1 - i] = a;
         }
         WAVE_SYNC();
@@ -1246,7 +1276,7 @@ __global__ __launch_bounds__(64) void k_octree(const LevelDev* __restrict__ lv, 
         int n_to_expand = 0, e_base = 0;
         for (int base = 0; base < nn0; base += 64) {
             const int i = nn0 - 1 - (base + lane);
-            OctNode p; p.flags = OCT_DEAD; p.count = 0;
+            Node p; p.flags = OCT_DEAD; p.count = 0;
             if (i >= 0) p = S.nd[i];
             const bool ex = i >= 0 && !(p.flags & (OCT_NOMORE | OCT_DEAD));
             const unsigned long long m = __ballot(ex);
@@ -1288,8 +1318,8 @@ __global__ __launch_bounds__(64) void k_octree(const LevelDev* __restrict__ lv, 
                 int m = 0;
                 for (int base = first_new; base < nn; base += 64) {
                     const int i = base + lane;
-                    bool want = false; uint32_t key = 0;
-                    if (i < nn) { const OctNode o = S.nd[i]; want = o.count > 1; key = ((uint32_t)o.count << 16) | (uint32_t)i; }
+                    bool want = false; SortKey key = 0;
+                    if (i < nn) { const Node o = S.nd[i]; want = o.count > 1; key = ((SortKey)o.count << OctT<BIG>::KEY_SHIFT) | (SortKey)i; }
                     const unsigned long long bm = __ballot(want);
                     if (want) { const int pos = m + __popcll(bm & lanemask_lt(lane)); if (pos < sortcap) S.sortb[pos] = key; }
                     m += __popcll(bm);
@@ -1307,7 +1337,7 @@ __global__ __launch_bounds__(64) void k_octree(const LevelDev* __restrict__ lv, 
                     const int q = base + lane;
                     const bool valid = q < m;
                     const int i = valid ? (int)(S.sortb[mp - 1 - q] & 0xffff) : 0;
-                    OctNode p; p.flags = OCT_DEAD; p.count = 0;
+                    Node p; p.flags = OCT_DEAD; p.count = 0;
                     if (valid) p = S.nd[i];
                     if (__any(valid && p.count > OCT_LANE_LIMIT)) {           // rare: big nodes this late -> one at a time on the whole wave
                         for (int l = 0; l < 64 && base + l < m; l++) {
@@ -1344,10 +1374,10 @@ __global__ __launch_bounds__(64) void k_octree(const LevelDev* __restrict__ lv, 
     for (int base = 0; base < nn; base += 64) {
         const int i = base + lane;
         if (i < nn) {
-            const OctNode o = S.nd[i];
-            const uint16_t* pm = (o.flags & OCT_BUF) ? S.perm1 : S.perm0;
+            const Node o = S.nd[i];
+            const Perm* pm = (o.flags & OCT_BUF) ? S.perm1 : S.perm0;
             uint32_t best = S.keys[pm[o.begin]];
-            for (int k = 1; k < o.count; k++) {
+            for (int k = 1; k < (int)o.count; k++) {
                 const uint32_t key = S.keys[pm[o.begin + k]];
                 if ((key >> 24) > (best >> 24)) best = key;
             }
@@ -1776,6 +1806,7 @@ struct viorb_extractor {
     bool fast_v3 = false;            // every cell fits k_fast_cells3's compile-time LDS geometry
     int fast3_tile_bytes = 0, fast3_score_bytes = 0;
     int oct_ncap = 0, oct_nodecap = 0, oct_sortcap = 0;
+    int oct_big_cap = 0, oct_big_slots = 0; uint32_t* d_oct_big = nullptr; int* d_oct_big_next = nullptr; int* d_lvl_tot = nullptr;   // over-size levels (k_octree<true>)
     std::vector<int> rs_pitch_dw, rs_rows;
     // second resize form (k_resize2): per-level tile table, LDS pitch, whether the level qualifies; whether level 1's kernel may also write level 0
     std::vector<int4> rs2_tiles; std::vector<int> rs2_off, rs2_pitch_dw, rs2_ok; bool rs2_copy_ok = false;
@@ -1802,9 +1833,9 @@ struct viorb_extractor {
 static void free_device(viorb_extractor* h) {
     void* ptrs[] = {h->d_planes, h->d_blur, h->d_desc, h->d_stage, h->d_lv, h->d_cells, h->d_blur_tiles, h->d_xtab,
                     h->d_ytab, h->d_slots, h->d_lvl_kp, h->d_cell_cnt, h->d_lvl_cnt, h->d_lvl_ncand, h->d_count,
-                    h->d_status, h->d_kps, h->d_rs2_tiles, h->d_rss_items, h->d_rss_etab};
+                    h->d_status, h->d_kps, h->d_rs2_tiles, h->d_rss_items, h->d_rss_etab, h->d_oct_big, h->d_oct_big_next, h->d_lvl_tot};
     for (void* p : ptrs) if (p) (void)hipFree(p);
-    h->d_rs2_tiles = nullptr; h->d_rss_items = nullptr; h->d_rss_etab = nullptr;
+    h->d_rs2_tiles = nullptr; h->d_rss_items = nullptr; h->d_rss_etab = nullptr; h->d_oct_big = nullptr; h->d_oct_big_next = nullptr; h->d_lvl_tot = nullptr;
     h->d_planes = h->d_blur = h->d_desc = h->d_stage = nullptr; h->d_lv = nullptr; h->d_cells = nullptr;
     h->d_blur_tiles = nullptr; h->d_xtab = h->d_ytab = nullptr; h->d_slots = h->d_lvl_kp = nullptr;
     h->d_cell_cnt = h->d_lvl_cnt = h->d_lvl_ncand = h->d_count = h->d_status = nullptr; h->d_kps = nullptr;
@@ -2017,7 +2048,7 @@ static int configure(viorb_extractor* h, int w, int hgt) {
     size_t oct_lds = (size_t)h->oct_ncap * 8 + (size_t)h->oct_nodecap * sizeof(OctNode) + (size_t)sc * 4;
     if (oct_lds > 160 * 1024 || h->oct_nodecap > 65535) { set_error("nfeatures too large for the LDS quadtree (%zu B)", oct_lds); return VIORB_ERR_UNSUPPORTED; }
     if (oct_lds > 64 * 1024 &&
-        raise_dynamic_lds(reinterpret_cast<const void*>(k_octree), oct_lds) != hipSuccess) {
+        raise_dynamic_lds(reinterpret_cast<const void*>(k_octree<false>), oct_lds) != hipSuccess) {
         (void)hipGetLastError();
         h->oct_ncap = 4096;                              // stay inside the default 64 KiB dynamic-LDS window
         oct_lds = (size_t)h->oct_ncap * 8 + (size_t)h->oct_nodecap * sizeof(OctNode) + (size_t)sc * 4;
@@ -2040,6 +2071,16 @@ static int configure(viorb_extractor* h, int w, int hgt) {
     VIORB_HIP_TRY(hipMalloc(&h->d_lvl_kp, B * h->kp_pitch * sizeof(uint32_t)));
     VIORB_HIP_TRY(hipMalloc(&h->d_lvl_cnt, B * nl * sizeof(int)));
     VIORB_HIP_TRY(hipMalloc(&h->d_lvl_ncand, B * nl * sizeof(int)));
+    VIORB_HIP_TRY(hipMalloc(&h->d_lvl_tot, B * nl * sizeof(int)));
+    {   // scratch of the over-size quadtree levels: a level's candidates are bounded by its cells' slots (strict 3x3 NMS keeps at most every
+        // other pixel of every other row); up to 64 such levels per call
+        int big = 1;
+        for (int l = 0; l < nl; l++) big = std::max(big, h->lv[l].ncells * h->slot_cap);
+        h->oct_big_cap = (int)align_up((size_t)big, 64);
+        h->oct_big_slots = (int)std::min<size_t>(B * nl, 64);
+        VIORB_HIP_TRY(hipMalloc(&h->d_oct_big, (size_t)h->oct_big_slots * 3 * h->oct_big_cap * sizeof(uint32_t)));
+        VIORB_HIP_TRY(hipMalloc(&h->d_oct_big_next, sizeof(int)));
+    }
     VIORB_HIP_TRY(hipMalloc(&h->d_kps, B * h->out_cap * sizeof(viorb_keypoint)));
     VIORB_HIP_TRY(hipMalloc(&h->d_desc, B * h->out_cap * 32));
     VIORB_HIP_TRY(hipMalloc(&h->d_count, B * sizeof(int)));
@@ -2207,15 +2248,23 @@ static int launch_all(viorb_extractor* h, const uint8_t* d_images, int batch, in
         const int small = std::min(h->oct_ncap, (int)OCT_NCAP_SMALL);
         {
             ProfScope ps("k_octree", st);
-            hipLaunchKernelGGL(k_octree, dim3(batch, nl), dim3(64), (size_t)small * 8 + fixed, st, h->d_lv, h->d_slots, h->slot_cap, h->d_cell_cnt,
+            hipLaunchKernelGGL(k_octree<false>, dim3(batch, nl), dim3(64), (size_t)small * 8 + fixed, st, h->d_lv, h->d_slots, h->slot_cap, h->d_cell_cnt,
                                ncells, h->d_lvl_kp, h->kp_pitch, h->d_lvl_cnt, h->d_lvl_ncand, nl, h->d_status, small, h->oct_nodecap,
-                               h->oct_sortcap, -1, small);
+                               h->oct_sortcap, -1, small, nullptr, nullptr, 0, h->d_lvl_tot);
         }
         if (small < h->oct_ncap) {
             ProfScope ps("k_octree_large", st);
-            hipLaunchKernelGGL(k_octree, dim3(batch, nl), dim3(64), (size_t)h->oct_ncap * 8 + fixed, st, h->d_lv, h->d_slots, h->slot_cap,
+            hipLaunchKernelGGL(k_octree<false>, dim3(batch, nl), dim3(64), (size_t)h->oct_ncap * 8 + fixed, st, h->d_lv, h->d_slots, h->slot_cap,
                                h->d_cell_cnt, ncells, h->d_lvl_kp, h->kp_pitch, h->d_lvl_cnt, h->d_lvl_ncand, nl, h->d_status, h->oct_ncap,
-                               h->oct_nodecap, h->oct_sortcap, small, 0x7fffffff);
+                               h->oct_nodecap, h->oct_sortcap, small, h->oct_ncap, nullptr, nullptr, 0, h->d_lvl_tot);
+        }
+        {   // levels with more candidates than the LDS form holds (none on camera images; their workgroups read one count and return)
+            const size_t lds_big = (size_t)h->oct_sortcap * 8 + (size_t)h->oct_nodecap * sizeof(OctNodeBig);
+            VIORB_HIP_TRY(hipMemsetAsync(h->d_oct_big_next, 0, sizeof(int), st));
+            ProfScope ps("k_octree_big", st);
+            hipLaunchKernelGGL(k_octree<true>, dim3(batch, nl), dim3(64), lds_big, st, h->d_lv, h->d_slots, h->slot_cap, h->d_cell_cnt, ncells, h->d_lvl_kp,
+                               h->kp_pitch, h->d_lvl_cnt, h->d_lvl_ncand, nl, h->d_status, h->oct_big_cap, h->oct_nodecap, h->oct_sortcap,
+                               std::max(h->oct_ncap, (int)small), 0x7fffffff, h->d_oct_big, h->d_oct_big_next, h->oct_big_slots, h->d_lvl_tot);
         }
     }
     if (bst != st) VIORB_HIP_TRY(hipStreamWaitEvent(st, h->ev_join, 0));

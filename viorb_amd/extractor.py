@@ -104,7 +104,7 @@ class ORBextractor:
         return out
 
     def debug_level_points(self, l, b=0, kept=False):
-        buf = np.zeros((20000, 3), np.int32)
+        buf = np.zeros((131072, 3), np.int32)
         n = C.c_int()
         check(self.L.viorb_extractor_debug_level_points(self.h, b, l, int(kept), ptr(buf), len(buf), C.byref(n)))
         return buf[:min(n.value, len(buf))].copy()
