@@ -62,11 +62,12 @@ def algo_bytes(w, h, nfeat):
 def load_traffic_table():
     """HBM bytes per launch of the extractor / solver kernels from the PMC counters (rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE in
     separate passes, 2 x FETCH_SIZE + WRITE_SIZE as calibrated by tools/ubench/fetch_calib.hip), recorded per round under profiles/."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
-    try:
-        return json.load(open(path))
-    except Exception:
-        return None
+    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json"):         # the newest round's table that exists
+        try:
+            return json.load(open(os.path.join(ROOT, "profiles", name)))
+        except Exception:
+            pass
+    return None
 
 
 def _gen_stream(args):
