@@ -71,13 +71,13 @@ def load_traffic_table():
 
 
 def _gen_stream(args):
-    seed, w, h = args
+    seed, w, h, dist = args
     from viorb_amd.synth import make_periodic_stream
-    s = make_periodic_stream(seed, N_FRAMES, w, h)
+    s = make_periodic_stream(seed, N_FRAMES, w, h, dist=dist)
     return dict(frames=s["frames"], imu=s["imu"], t=s["t"], ns_true=s["ns_true"], pose_true=s["pose_true"], period=s["period"], cam=s["cam"], gw=s["gw"])
 
 
-def generate_streams(seeds, w=752, h=480, procs=None):
+def generate_streams(seeds, w=752, h=480, procs=None, dist=None):
     """CPU-side synthetic data (before anything touches the GPU). `procs=1` generates in-process: under `rocprofv3 --pmc` the profiler's
     preloaded library has initialised the GPU before Python starts, and forked pool workers of such a process never exit (that, not a
     kernel-ordering bug, is why the round-2 bench "did not finish" under --pmc: profiles/README.md, round 3)."""
@@ -85,7 +85,7 @@ def generate_streams(seeds, w=752, h=480, procs=None):
     nproc = max(1, min(len(seeds), (os.cpu_count() or 2) // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1"))), 16))
     if procs:
         nproc = max(1, min(nproc, procs))
-    jobs = [(s, w, h) for s in seeds]
+    jobs = [(s, w, h, dist) for s in seeds]
     if nproc == 1:
         return [_gen_stream(j) for j in jobs]
     with mp.get_context("fork").Pool(nproc) as pool:
@@ -108,9 +108,10 @@ def cpu_model():
 def _oracle_track_frames(args):
     """One oracle stream: per-frame wall times of `n` frames after `warm` warm-up frames (the example mains' convention,
     reference Examples/Stereo/stereo_kitti.cc:80-124)."""
-    s, w, h, nfeat, warm, n = args
+    s, w, h, nfeat, warm, n = args[:6]
+    dist = args[6] if len(args) > 6 else None
     from oracle.harness import OracleTracker
-    tr = OracleTracker(s["cam"], s["gw"], w, h, nfeat, track_local_map=True)
+    tr = OracleTracker(s["cam"], s["gw"], w, h, nfeat, track_local_map=True, dist_coef=dist)
     mci = np.eye(12) * 1e3
     tr.bootstrap(s["frames"][0], s["pose_true"][0], s["t"][0], s["ns_true"][0], mci)
     times = []
@@ -127,17 +128,17 @@ def _oracle_track_frames(args):
     return times
 
 
-def cpu_baseline_tracking(streams, w, h, nfeat, frames_1core, warm):
+def cpu_baseline_tracking(streams, w, h, nfeat, frames_1core, warm, dist=None):
     import multiprocessing as mp
     hw = os.cpu_count() or 1
-    t1 = _oracle_track_frames((streams[0], w, h, nfeat, warm, frames_1core))
+    t1 = _oracle_track_frames((streams[0], w, h, nfeat, warm, frames_1core, dist))
     one = dict(value=round(len(t1) / sum(t1), 3), median_ms=round(float(np.median(t1)) * 1e3, 3), mean_ms=round(float(np.mean(t1)) * 1e3, 3), frames=len(t1))
     # all cores: one oracle stream per hardware thread (the batched counterpart), each frames_1core / 4 frames after the warm-up
     per = max(10, frames_1core // 4)
     nproc = min(hw, len(streams))
     t0 = time.perf_counter()
     with mp.get_context("fork").Pool(nproc) as pool:
-        res = pool.map(_oracle_track_frames, [(streams[i], w, h, nfeat, min(warm, 4), per) for i in range(nproc)])
+        res = pool.map(_oracle_track_frames, [(streams[i], w, h, nfeat, min(warm, 4), per, dist) for i in range(nproc)])
     wall = time.perf_counter() - t0
     busy = sum(sum(r) for r in res)
     allc = dict(value=round(nproc * per / (busy / nproc), 3), cores=nproc, frames=nproc * per, wall_s=round(wall, 2),
@@ -164,7 +165,11 @@ def run_tracking(args, cfg, rank, dev_index, dev, world):
     # at most 256 distinct synthetic streams are generated per rank (CPU time); beyond that the streams repeat (own copy of the images, independent
     # tracker state each)
     distinct = min(S, args.distinct or 256)
-    base = generate_streams(stream_seeds(rank, distinct), W_IMG, H_IMG, args.gen_procs)
+    # the EuRoC camera of the reference's settings file is distorted (Examples/ROS/ORB_VIO/launch/euroc.yaml:64-67): the synthetic frames are rendered
+    # through that lens and the tracker undistorts the keypoints ahead of the grid (Frame::UndistortKeyPoints) with bounds from the undistorted corners
+    from viorb_amd.synth import EUROC_DIST
+    lens = EUROC_DIST if (args.config == "euroc" and not args.no_distortion) else None
+    base = generate_streams(stream_seeds(rank, distinct), W_IMG, H_IMG, args.gen_procs, lens)
     streams = [base[i % distinct] for i in range(S)]
     up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     frames = up(np.stack([s["frames"] for s in streams], 1))                   # [F, S, h, w] u8
@@ -177,7 +182,7 @@ def run_tracking(args, cfg, rank, dev_index, dev, world):
     mci0 = up(np.stack([np.eye(12).ravel() * 1e3] * S))
     ones_u8 = torch.ones(S, dtype=torch.uint8, device=dev)
     cam, gw = streams[0]["cam"], streams[0]["gw"]
-    tr = NativeTracker(cam, gw, S, W_IMG, H_IMG, NFEAT, th=15.0, device=dev_index, compute_marg=True, track_local_map=TLM)
+    tr = NativeTracker(cam, gw, S, W_IMG, H_IMG, NFEAT, th=15.0, device=dev_index, compute_marg=True, track_local_map=TLM, dist_coef=lens)
     tr.bootstrap(frames[0], pose_true[0], t_frames[0], ns_true[0], mci0)
 
     # live feed: the same frames in page-locked host memory, uploaded by the tracker's copy stream inside the step (viorb_tracker_inputs.h_images)
@@ -338,6 +343,8 @@ def run_tracking(args, cfg, rank, dev_index, dev, world):
                         ("EuRoC" if args.config == "euroc" else "1280x720", W_IMG, H_IMG, NFEAT,
                          " + SearchLocalPoints(~2000 local points) + PoseOptimization(marg)  [TrackWithIMU + TrackLocalMapWithIMU]" if TLM else " [TrackWithIMU only]"),
             "baseline_config": cfg["baseline_config"], "keyframe_boundary_every_frames": N_FRAMES,
+            "camera_model": ("EuRoC radial-tangential distortion k1 k2 p1 p2 = %s (euroc.yaml:64-67): frames rendered through the lens, keypoints undistorted on the "
+                             "device (Frame::UndistortKeyPoints), image bounds from the undistorted corners" % (list(lens[:4]),)) if lens else "pinhole (no distortion)",
             "keyframe_variant": "PoseOptimization(Frame, KeyFrame) on the frame after every boundary (mbMapUpdated), (Frame, Frame) otherwise",
             "input": ("page-locked host memory, uploaded inside the timed region by the tracker's copy stream (live feed)" if args.host_input
                       else "HBM-resident frames (uploaded before the timed region)"),
@@ -359,7 +366,7 @@ def run_tracking(args, cfg, rank, dev_index, dev, world):
         if not (res["status"] == 0).all():
             raise SystemExit("a stream reported a capacity / status error: %s" % res["status"])
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline_tracking(base, W_IMG, H_IMG, NFEAT, 200 if args.config == "euroc" else 60, 20 if args.config == "euroc" else 8)
+            out["cpu_baseline"] = cpu_baseline_tracking(base, W_IMG, H_IMG, NFEAT, 200 if args.config == "euroc" else 60, 20 if args.config == "euroc" else 8, lens)
     out["metric"] = "frames/sec ORB extract+match+pose-opt, EuRoC 752x480, 1/2/4/8 GPUs" if args.config == "euroc" else \
         "frames/sec ORB extract+match+pose-opt, synthetic 1280x720 / 1500 features, batched streams"
     out["unit"] = "frames/s"; out["dtype"] = "u8"
@@ -374,8 +381,10 @@ def run_dropin(args, cfg, rank, dev_index, dev, world):
     import torch
     from viorb_amd.distributed import stream_seeds
     from viorb_amd.tracker import DropinTracker
-    s = generate_streams(stream_seeds(rank, 1), cfg["w"], cfg["h"], 1)[0]
-    tr = DropinTracker(s["cam"], s["gw"], cfg["w"], cfg["h"], cfg["nfeat"])
+    from viorb_amd.synth import EUROC_DIST
+    dist = None if args.no_distortion else EUROC_DIST
+    s = generate_streams(stream_seeds(rank, 1), cfg["w"], cfg["h"], 1, dist)[0]
+    tr = DropinTracker(s["cam"], s["gw"], cfg["w"], cfg["h"], cfg["nfeat"], dist_coef=dist)
     mci = np.eye(12) * 1e3
     tr.bootstrap(s["frames"][0], s["pose_true"][0], s["t"][0], s["ns_true"][0], mci)
     states = []
@@ -403,15 +412,16 @@ def run_dropin(args, cfg, rank, dev_index, dev, world):
         in_calls = sum(v[0] for v in tr.times.values())
         out["config"] = {"workload": "ONE EuRoC-shaped synthetic stream %dx%d / %d features through the host-buffer drop-ins call by call (viorb_extract, "
                                      "viorb_preintegrate, viorb_search_by_projection_frame, viorb_pose_opt_vi, viorb_search_by_projection_points, viorb_pose_opt_vi), "
-                                     "host buffers in and out of every call; Python caller (numpy glue between the calls = %.2f ms per frame)"
-                                     % (cfg["w"], cfg["h"], cfg["nfeat"], (elapsed - in_calls) / args.steps * 1e3),
+                                     "host buffers in and out of every call; %s; Python caller (numpy glue between the calls = %.2f ms per frame)"
+                                     % (cfg["w"], cfg["h"], cfg["nfeat"], "EuRoC lens, keypoints undistorted by viorb_undistort_points" if dist else "pinhole camera",
+                                        (elapsed - in_calls) / args.steps * 1e3),
                          "baseline_config": cfg["baseline_config"], "streams_per_gpu": 1, "per_call": per_call,
                          "ms_per_frame_inside_the_calls": round(in_calls / args.steps * 1e3, 4),
                          "frames_per_s_inside_the_calls": round(args.steps / in_calls, 1),
                          "tracked_frames": int(sum(1 for x in states if x == 0)), "frames": len(states)}
         out["roofline"] = None
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline_tracking([s], cfg["w"], cfg["h"], cfg["nfeat"], 100, 10)
+            out["cpu_baseline"] = cpu_baseline_tracking([s], cfg["w"], cfg["h"], cfg["nfeat"], 100, 10, dist)
     out["metric"] = "frames/sec ORB extract+match+pose-opt, EuRoC 752x480, single stream through the host-buffer drop-ins"
     out["unit"] = "frames/s"; out["dtype"] = "u8"
     return out
@@ -571,7 +581,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--host-input", action="store_true", help="tracking configs: frames come from page-locked HOST memory and are uploaded inside the "
                     "timed region (live feed); default: HBM-resident frames, with the live-feed rate reported as config.host_input_frames_per_s")
-    ap.add_argument("--no-host-input-pass", action="store_true", help="skip the extra pass that measures the other input mode")
+    ap.add_argument("--no-distortion", action="store_true", help="euroc: pinhole camera instead of the EuRoC lens (the round-1/2 workload)")
+    ap.add_argument("--no-host-input-pass", "--no-extra-passes", action="store_true", help="skip the extra passes after the timed region (the other input mode; euroc at N=1: the pinhole-camera rendering)")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip the per-kernel HIP events (rooflines become null); dev aid")
     ap.add_argument("--timeline", default=None, help="dev aid (with --all-kernel-events): write start / end / duration (us) of the last kernels to this file")
     ap.add_argument("--timeline-rows", type=int, default=120)
@@ -624,6 +635,16 @@ def main():
         dist_init("gloo" if rehearsal else "nccl", None if rehearsal else dev)       # "nccl" is RCCL on ROCm
     runner = {"euroc": run_tracking, "synth720p": run_tracking, "kitti_stereo": run_stereo, "local_ba": run_local_ba, "dropin": run_dropin}[args.config]
     r = runner(args, cfg, rank, dev_index, dev, world)
+    if args.config == "euroc" and world == 1 and not args.no_distortion and not args.no_host_input_pass:
+        # continuity with rounds 1-2, outside the timed region: the same step on the pinhole rendering of the same scenes (those rounds' workload,
+        # `--no-distortion`); the lens compresses the periphery, so its frames hold ~30 % more FAST candidates (DESIGN.md "Round 3 measurements")
+        import copy
+        a2 = copy.copy(args)
+        a2.no_distortion = a2.no_cpu_baseline = a2.no_host_input_pass = a2.no_kernel_events = True
+        a2.steps = max(8, min(args.steps, 64)); a2.timeline = None
+        r2 = run_tracking(a2, cfg, rank, dev_index, dev, 1)
+        r["config"]["pinhole_camera_frames_per_s"] = round(r2["units"] / r2["elapsed"], 1)
+        r["config"]["pinhole_camera_note"] = "same scenes and step without the lens (--no-distortion, the round-1/2 workload), %d steps after the timed region" % a2.steps
     units, elapsed = reduce_throughput(r["units"], r["elapsed"], None if rehearsal else dev)
     if rank == 0:
         out = {"metric": r["metric"], "value": round(units / elapsed, 2), "unit": r["unit"], "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

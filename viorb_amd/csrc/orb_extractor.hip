@@ -991,7 +991,7 @@ __global__ __launch_bounds__(64) void k_fast_cells3(const uint8_t* __restrict__ 
 // ---------------------------------------------------------------------------------------------
 // single-wavefront workgroups: a workgroup barrier is one s_barrier and also orders LDS traffic
 #define WAVE_SYNC() __syncthreads()
-#define OCT_NCAP_SMALL 2048
+#define OCT_NCAP_SMALL 4096
 // Two instantiations of the same code: BIG = false keeps candidates (keys + two u16 permutation buffers) in LDS — up to oct_ncap of
 // them — and BIG = true takes a level with MORE candidates than that (an image of noise: the reference has no limit, src/ORBextractor.cc:779
 // is only a reserve) with u32 permutations in a global scratch slot, 32-bit node ranges and 64-bit sort keys; nodes and the sort buffer
@@ -1027,75 +1027,105 @@ template <bool BIG> __device__ __forceinline__ void oct_write_children(const Oct
     S.nd[i].flags = p.flags | OCT_DEAD;
 }
 
-// whole wave on one node: stable 4-way partition of its key segment with ballots
+// whole wave on one node: stable 4-way partition of its key segment with ballots. A single wavefront per tree has nothing to hide
+// LDS latency behind but its own instruction stream, so four 64-point chunks are in flight at a time: their four index loads, then
+// their four key loads, then the sixteen ballots. Nodes of <= 256 points (all but the first rounds) keep indices and child codes
+// in registers between the counting and the scatter pass.
+#define OCT_CODE(key) (((int)((key) & 0xfff) < mx ? 0 : 1) | ((int)(((key) >> 12) & 0xfff) < my ? 0 : 2))
 template <bool BIG> __device__ __forceinline__ OctExpandResult oct_expand_wave(const OctLdsT<BIG>& S, int i, int slot, int lane) {
+    typedef typename OctT<BIG>::Perm Perm;
     const typename OctT<BIG>::Node p = S.nd[i];
     const int mx = p.x0 + ((p.x1 - p.x0 + 1) >> 1), my = p.y0 + ((p.y1 - p.y0 + 1) >> 1);
     const int sb = p.flags & OCT_BUF;
-    const typename OctT<BIG>::Perm* src = sb ? S.perm1 : S.perm0;
-    typename OctT<BIG>::Perm* dst = sb ? S.perm0 : S.perm1;
+    const Perm* src = (sb ? S.perm1 : S.perm0) + (int)p.begin;
+    Perm* dst = sb ? S.perm0 : S.perm1;
     const int cnt = (int)p.count, beg = (int)p.begin;
-    int t0 = 0, t1 = 0, t2 = 0, t3 = 0;
-    for (int o = 0; o < cnt; o += 64) {
-        const int idx = o + lane;
-        int c = -1;
-        if (idx < cnt) {
-            const uint32_t key = S.keys[src[beg + idx]];
-            c = ((int)(key & 0xfff) < mx ? 0 : 1) | ((int)((key >> 12) & 0xfff) < my ? 0 : 2);
+    const unsigned long long lt = lanemask_lt(lane);
+    int t[4] = {0, 0, 0, 0};
+    Perm id[4]; int c[4];
+    auto load4 = [&](int o) {                                    // chunks o, o + 64, o + 128, o + 192 (a chunk past the end costs one clamped load)
+#pragma unroll
+        for (int u = 0; u < 4; u++) id[u] = src[min(o + 64 * u + lane, cnt - 1)];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const uint32_t key = S.keys[id[u]]; c[u] = o + 64 * u + lane < cnt ? OCT_CODE(key) : -1; }
+    };
+    int w0, w1, w2, w3;                                          // running write positions of the four children
+    auto scatter4 = [&]() {
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const unsigned long long m0 = __ballot(c[u] == 0), m1 = __ballot(c[u] == 1), m2 = __ballot(c[u] == 2), m3 = __ballot(c[u] == 3);
+            const unsigned long long mm = c[u] == 0 ? m0 : (c[u] == 1 ? m1 : (c[u] == 2 ? m2 : m3));
+            int at = w3;
+            at = c[u] == 2 ? w2 : at; at = c[u] == 1 ? w1 : at; at = c[u] == 0 ? w0 : at;
+            if (c[u] >= 0) dst[at + __popcll(mm & lt)] = id[u];
+            w0 += __popcll(m0); w1 += __popcll(m1); w2 += __popcll(m2); w3 += __popcll(m3);
         }
-        t0 += __popcll(__ballot(c == 0)); t1 += __popcll(__ballot(c == 1));
-        t2 += __popcll(__ballot(c == 2)); t3 += __popcll(__ballot(c == 3));
-    }
-    const int s0 = beg, s1 = s0 + t0, s2 = s1 + t1, s3 = s2 + t2;
-    int r0 = 0, r1 = 0, r2 = 0, r3 = 0;
-    for (int o = 0; o < cnt; o += 64) {
-        const int idx = o + lane;
-        int c = -1;
-        typename OctT<BIG>::Perm id = 0;
-        if (idx < cnt) {
-            id = src[beg + idx];
-            const uint32_t key = S.keys[id];
-            c = ((int)(key & 0xfff) < mx ? 0 : 1) | ((int)((key >> 12) & 0xfff) < my ? 0 : 2);
+    };
+    auto count4 = [&]() {
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            t[0] += __popcll(__ballot(c[u] == 0)); t[1] += __popcll(__ballot(c[u] == 1));
+            t[2] += __popcll(__ballot(c[u] == 2)); t[3] += __popcll(__ballot(c[u] == 3));
         }
-        const unsigned long long m0 = __ballot(c == 0), m1 = __ballot(c == 1), m2 = __ballot(c == 2), m3 = __ballot(c == 3);
-        const unsigned long long lt = lanemask_lt(lane);
-        if (c == 0) dst[s0 + r0 + __popcll(m0 & lt)] = id;
-        else if (c == 1) dst[s1 + r1 + __popcll(m1 & lt)] = id;
-        else if (c == 2) dst[s2 + r2 + __popcll(m2 & lt)] = id;
-        else if (c == 3) dst[s3 + r3 + __popcll(m3 & lt)] = id;
-        r0 += __popcll(m0); r1 += __popcll(m1); r2 += __popcll(m2); r3 += __popcll(m3);
+    };
+    if (cnt <= 256) {
+        load4(0); count4();
+        w0 = beg; w1 = w0 + t[0]; w2 = w1 + t[1]; w3 = w2 + t[2];
+        scatter4();
+    } else {
+        for (int o = 0; o < cnt; o += 256) { load4(o); count4(); }
+        w0 = beg; w1 = w0 + t[0]; w2 = w1 + t[1]; w3 = w2 + t[2];
+        for (int o = 0; o < cnt; o += 256) { load4(o); scatter4(); }
     }
-    const int tc[4] = {t0, t1, t2, t3}, sc4[4] = {s0, s1, s2, s3};
-    if (lane == 0) oct_write_children(S, p, i, slot, mx, my, sb, tc, sc4);
-    OctExpandResult r; r.off = (t0 > 0) + (t1 > 0) + (t2 > 0) + (t3 > 0); r.nexp = (t0 > 1) + (t1 > 1) + (t2 > 1) + (t3 > 1);
+    const int sc4[4] = {beg, beg + t[0], beg + t[0] + t[1], beg + t[0] + t[1] + t[2]};
+    if (lane == 0) oct_write_children(S, p, i, slot, mx, my, sb, t, sc4);
+    OctExpandResult r; r.off = (t[0] > 0) + (t[1] > 0) + (t[2] > 0) + (t[3] > 0); r.nexp = (t[0] > 1) + (t[1] > 1) + (t[2] > 1) + (t[3] > 1);
     return r;
 }
 
-// one lane on one node (count <= OCT_LANE_LIMIT): counting pass (child codes kept in registers), then the stable scatter
+// one lane on one node (count <= OCT_LANE_LIMIT): counting pass (child codes kept in registers), then the stable scatter; four
+// points in flight per trip for the same reason as above
 template <bool BIG> __device__ __forceinline__ void oct_lane_count(const OctLdsT<BIG>& S, const typename OctT<BIG>::Node& p, int mx, int my, unsigned long long& lo, unsigned long long& hi, int tc[4]) {
-    const typename OctT<BIG>::Perm* src = (p.flags & OCT_BUF) ? S.perm1 : S.perm0;
+    const typename OctT<BIG>::Perm* src = ((p.flags & OCT_BUF) ? S.perm1 : S.perm0) + (int)p.begin;
     lo = 0; hi = 0; tc[0] = tc[1] = tc[2] = tc[3] = 0;
-    for (int k = 0; k < (int)p.count; k++) {
-        const uint32_t key = S.keys[src[p.begin + k]];
-        const int cx = (int)(key & 0xfff) < mx ? 0 : 1, cy = (int)((key >> 12) & 0xfff) < my ? 0 : 1;
-        lo |= (unsigned long long)cx << k; hi |= (unsigned long long)cy << k;
-        const int c = cx | (cy << 1);
-        tc[0] += c == 0; tc[1] += c == 1; tc[2] += c == 2; tc[3] += c == 3;
+    const int cnt = (int)p.count;
+    for (int k = 0; k < cnt; k += 4) {
+        typename OctT<BIG>::Perm id[4]; uint32_t key[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) id[u] = src[min(k + u, cnt - 1)];
+#pragma unroll
+        for (int u = 0; u < 4; u++) key[u] = S.keys[id[u]];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const bool in = k + u < cnt;
+            const int cx = (int)(key[u] & 0xfff) < mx ? 0 : 1, cy = (int)((key[u] >> 12) & 0xfff) < my ? 0 : 1;
+            lo |= (unsigned long long)(in ? cx : 0) << ((k + u) & 63); hi |= (unsigned long long)(in ? cy : 0) << ((k + u) & 63);
+            const int c = in ? (cx | (cy << 1)) : -1;
+            tc[0] += c == 0; tc[1] += c == 1; tc[2] += c == 2; tc[3] += c == 3;
+        }
     }
 }
 template <bool BIG> __device__ __forceinline__ void oct_lane_scatter(const OctLdsT<BIG>& S, const typename OctT<BIG>::Node& p, int i, int slot, int mx, int my, unsigned long long lo,
                                                  unsigned long long hi, const int tc[4]) {
     const int sb = p.flags & OCT_BUF;
-    const typename OctT<BIG>::Perm* src = sb ? S.perm1 : S.perm0;
+    const typename OctT<BIG>::Perm* src = (sb ? S.perm1 : S.perm0) + (int)p.begin;
     typename OctT<BIG>::Perm* dst = sb ? S.perm0 : S.perm1;
     const int sc4[4] = {(int)p.begin, (int)p.begin + tc[0], (int)p.begin + tc[0] + tc[1], (int)p.begin + tc[0] + tc[1] + tc[2]};
     int w0 = sc4[0], w1 = sc4[1], w2 = sc4[2], w3 = sc4[3];
-    for (int k = 0; k < (int)p.count; k++) {
-        const typename OctT<BIG>::Perm id = src[p.begin + k];
-        const int c = (int)((lo >> k) & 1) | ((int)((hi >> k) & 1) << 1);
-        const int pos = c == 0 ? w0 : (c == 1 ? w1 : (c == 2 ? w2 : w3));
-        dst[pos] = id;
-        w0 += c == 0; w1 += c == 1; w2 += c == 2; w3 += c == 3;
+    const int cnt = (int)p.count;
+    for (int k = 0; k < cnt; k += 4) {
+        typename OctT<BIG>::Perm id[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) id[u] = src[min(k + u, cnt - 1)];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (k + u < cnt) {
+                const int c = (int)((lo >> (k + u)) & 1) | ((int)((hi >> (k + u)) & 1) << 1);
+                const int pos = c == 0 ? w0 : (c == 1 ? w1 : (c == 2 ? w2 : w3));
+                dst[pos] = id[u];
+                w0 += c == 0; w1 += c == 1; w2 += c == 2; w3 += c == 3;
+            }
+        }
     }
     oct_write_children(S, p, i, slot, mx, my, sb, tc, sc4);
 }
@@ -1106,13 +1136,21 @@ template <bool BIG> __device__ __forceinline__ int oct_compact(const OctLdsT<BIG
     first_new = -1;
     for (int base = 0; base < nn; base += 64) {
         const int i = base + lane;
-        typename OctT<BIG>::Node o; o.flags = OCT_DEAD;
-        if (i < nn) o = S.nd[i];
-        const bool alive = (i < nn) && !(o.flags & OCT_DEAD);
+        typedef typename OctT<BIG>::Node Node;
+        enum { NW = sizeof(Node) / 4, FW = offsetof(Node, flags) / 4, FS = 8 * (offsetof(Node, flags) % 4) };
+        uint32_t wd[NW];                                         // the node as words: a struct copy across the barrier went through scratch
+        const uint32_t* from = reinterpret_cast<const uint32_t*>(S.nd + min(i, nn - 1));
+#pragma unroll
+        for (int k = 0; k < NW; k++) wd[k] = from[k];
+        const bool alive = (i < nn) && !((wd[FW] >> FS) & OCT_DEAD);
         const unsigned long long m = __ballot(alive);
         if (upto >= base && upto < base + 64) first_new = w + __popcll(m & lanemask_lt(upto - base));
         WAVE_SYNC();
-        if (alive) S.nd[w + __popcll(m & lanemask_lt(lane))] = o;
+        if (alive) {
+            uint32_t* to = reinterpret_cast<uint32_t*>(S.nd + w + __popcll(m & lanemask_lt(lane)));
+#pragma unroll
+            for (int k = 0; k < NW; k++) to[k] = wd[k];
+        }
         w += __popcll(m);
         WAVE_SYNC();
     }
@@ -1163,7 +1201,7 @@ __global__ __launch_bounds__(64) void k_octree(const LevelDev* __restrict__ lv, 
     const LevelDev L = lv[level];
     const int N = L.quota;
     // ---- 0. this launch only takes the (image, level) pairs with n_above < candidates <= n_upto: the common case runs
-    //         with a small LDS footprint (4 workgroups per CU), a second launch with the full capacity takes the rest
+    //         with a smaller LDS footprint (3 workgroups per CU), a second launch with the full capacity takes the rest
     const int* cc = cell_cnt + (size_t)b * ncells_total + L.cell_base;
     {
         int tot = 0;
@@ -2242,8 +2280,11 @@ static int launch_all(viorb_extractor* h, const uint8_t* d_images, int batch, in
     }
     if (bst != st) VIORB_HIP_TRY(hipEventRecord(h->ev_join, bst));
     {
-        // common case first: <= OCT_NCAP_SMALL candidates per level fit a ~35 KB footprint (4 single-wave workgroups per CU);
-        // the second launch covers the rest with the full capacity (its workgroups return at once when they have no work)
+        // common case first: <= OCT_NCAP_SMALL candidates per level fit a ~51 KB footprint (3 single-wave workgroups per CU); the second
+        // launch covers the rest with the full capacity (its workgroups return at once when they have no work). Every launch lasts about as
+        // long as its longest tree (a level 0: the launch is latency-bound, not slot-bound), so the first one is sized to take every level
+        // of a feature-rich frame: with 2048 (4 per CU) the level-0 trees of EuRoC-lens frames (~2400 candidates) all fell to the second
+        // launch and the pair took twice as long (DESIGN.md "Round 3 measurements")
         const size_t fixed = (size_t)h->oct_nodecap * sizeof(OctNode) + (size_t)h->oct_sortcap * 4;
         const int small = std::min(h->oct_ncap, (int)OCT_NCAP_SMALL);
         {

@@ -179,7 +179,27 @@ PLANE_Z0 = 5.0
 GRAVITY_CAM_WORLD = np.array([0.0, 9.81, 0.0])       # world = reference camera frame, y points down
 
 
-def undistort_normalized(xd, yd, dist, iters=30):
+_RAY_CACHE = {}
+
+
+def pixel_rays(w, h, cam4, dist=None):
+    """Normalised ray (x, y, 1) of every pixel of a w x h image for the pinhole intrinsics cam4 and, when given, the lens distortion
+    (the inverse model run to convergence); cached per camera — every frame of a stream shares it."""
+    key = (w, h, tuple(float(v) for v in cam4), None if dist is None else tuple(float(v) for v in dist))
+    r = _RAY_CACHE.get(key)
+    if r is None:
+        fx, fy, cx, cy = cam4
+        v, u = np.mgrid[0:h, 0:w].astype(np.float64)
+        xn, yn = (u - cx) / fx, (v - cy) / fy
+        if dist is not None and dist[0] != 0:
+            xn, yn = undistort_normalized(xn, yn, dist)
+        if len(_RAY_CACHE) > 8:
+            _RAY_CACHE.clear()
+        r = _RAY_CACHE[key] = (xn, yn)
+    return r
+
+
+def undistort_normalized(xd, yd, dist, iters=20):
     """Inverse of the radial-tangential model by fixed-point iteration run to convergence (the TRUE camera of the synthetic world;
     the reference's cv::undistortPoints stops after five iterations)."""
     k1, k2, p1, p2, k3 = [float(v) for v in dist]
@@ -197,11 +217,8 @@ def render_view(base, cam, Rcw, tcw, seed=0, noise=1.0, dist=None):
     camera has that lens distortion (pixel -> ray through the inverse model), as the EuRoC camera of the reference's settings file."""
     h, w = base.shape
     fx, fy, cx, cy = cam[:4]
-    v, u = np.mgrid[0:h, 0:w].astype(np.float64)
-    xn, yn = (u - cx) / fx, (v - cy) / fy
-    if dist is not None and dist[0] != 0:
-        xn, yn = undistort_normalized(xn, yn, dist)
-    d = np.stack([xn, yn, np.ones_like(u)], -1) @ Rcw          # Rcw^T d, row-vector form
+    xn, yn = pixel_rays(w, h, cam[:4], dist)
+    d = np.stack([xn, yn, np.ones_like(xn)], -1) @ Rcw          # Rcw^T d, row-vector form
     O = -Rcw.T @ tcw
     s = (PLANE_Z0 - O[2]) / d[..., 2]
     X = O[0] + s * d[..., 0]

@@ -376,17 +376,27 @@ class DropinTracker:
     time spent inside each drop-in call."""
     LOCAL_FRAMES = 2
 
-    def __init__(self, cam, gw, width=752, height=480, nfeatures=1000, th=15.0):
+    def __init__(self, cam, gw, width=752, height=480, nfeatures=1000, th=15.0, dist_coef=None):
         from . import frontend as fe_mod
         from .extractor import ORBextractor
         self.fe = fe_mod
         self.ex = ORBextractor(nfeatures, 1.2, 8, 20, 7)
         self.tab = self.ex.tables()
         self.cam, self.gw, self.th = np.asarray(cam, np.float64), np.asarray(gw, np.float64), float(th)
-        self.bounds = (0.0, float(width), 0.0, float(height))
+        self.K4 = np.asarray(cam[:4], np.float32)
+        self.dist = np.zeros(5, np.float32) if dist_coef is None else np.asarray(dist_coef, np.float32)
+        self.bounds = tuple(float(v) for v in fe_mod.ComputeImageBounds(width, height, self.K4, self.dist))      # Frame::ComputeImageBounds, once
         self.matcher = fe_mod.ORBmatcher(0.9, True)
         self.local = []
         self.times = {}
+
+    def _extract(self, image):
+        """Frame::ExtractORB + Frame::UndistortKeyPoints: everything downstream reads mvKeysUn."""
+        k, d = self._timed("viorb_extract", self.ex, image)
+        if self.dist[0] != 0 and len(k):
+            un = self._timed("viorb_undistort_points", self.fe.UndistortKeyPoints, np.stack([k["x"], k["y"]], 1), self.K4, self.dist)
+            k = k.copy(); k["x"] = un[:, 0]; k["y"] = un[:, 1]
+        return k, d
 
     def _timed(self, name, f, *a, **kw):
         t0 = time.perf_counter()
@@ -432,13 +442,13 @@ class DropinTracker:
         self.last_pts_f = synth.local_points_f32(kps["octave"], pose_true, self.last_Pw, self.tab["scale"])
 
     def bootstrap(self, image, pose_true, t0, ns0, marg_cov_inv):
-        k, d = self.ex(image)
+        k, d = self._extract(image)
         self.marg_cov_inv = np.asarray(marg_cov_inv, np.float64).reshape(12, 12).copy()
         self._adopt(k, d, pose_true, np.asarray(ns0, np.float64), t0)
 
     def step(self, image, imu, t_cur, pose_true, t_next_last=None, reset_ns=None, reset_marg=None, map_updated=False):
         fe = self.fe
-        kps, desc = self._timed("viorb_extract", self.ex, image)
+        kps, desc = self._extract(image)
         last = self.last_ns
         pre = self._timed("viorb_preintegrate", fe.preintegrate, imu, last[10:13], last[13:16], self.t_last, t_cur)
         cur_ns = self._predict(last, pre)
