@@ -35,7 +35,7 @@ CONFIGS = {
     "euroc": dict(w=752, h=480, nfeat=1000, streams=512, baseline_config=1),
     "synth720p": dict(w=1280, h=720, nfeat=1500, streams=8, baseline_config=4),
     "kitti_stereo": dict(w=1241, h=376, nfeat=2000, streams=256, baseline_config=2),
-    "local_ba": dict(w=752, h=480, nfeat=1000, streams=64, baseline_config=3),
+    "local_ba": dict(w=752, h=480, nfeat=1000, streams=256, baseline_config=3),
     # one stream through the host-buffer drop-ins, call by call: the reference's own calling pattern (a Tracking thread built with viorb_amd/shim/)
     "dropin": dict(w=752, h=480, nfeat=1000, streams=1, baseline_config=1),
 }
@@ -576,7 +576,7 @@ def main():
     ap.add_argument("--distinct", type=int, default=None, help="tracking configs: distinct synthetic streams generated per rank (default min(streams, 256))")
     ap.add_argument("--gen-procs", type=int, default=None, help="worker processes of the synthetic-stream generator; 1 = in-process, no fork (needed under "
                     "rocprofv3 --pmc, whose preloaded library initialises the GPU before Python starts)")
-    ap.add_argument("--in-flight", type=int, default=32, help="local_ba: windows kept in flight by the batch driver")
+    ap.add_argument("--in-flight", type=int, default=128, help="local_ba: windows advanced together by the lock-step batch driver (one launch per solver step for the group)")
     ap.add_argument("--no-track-local-map", action="store_true", help="stop after TrackWithIMU's pose solve")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--host-input", action="store_true", help="tracking configs: frames come from page-locked HOST memory and are uploaded inside the "

@@ -475,12 +475,13 @@ int viorb_local_ba_navstate(const double* kfs, int nk, int n_local, int prev_kf,
 
 /* Several windows at once (one per camera stream in a multi-stream deployment; the reference runs one LocalMapping thread per system):
  * each entry carries the arguments of one viorb_local_ba_navstate call and receives its return code in `status`. All windows advance in
- * LOCK STEP, 128 at a time: one launch per solver step covers every window of the group (blockIdx.y = window) and each window's
- * Levenberg / two-phase state machine lives in its control block on the device — a single window is a chain of small latency-bound
- * launches that leaves most of the GPU idle. max_in_flight only applies to the per-stream driver kept behind VIORB_LBA_STREAMS=1
- * (one HIP stream and host LM loop per window, <= 0: 16). When a group fails (a HIP error), every window of it that has no result
- * yet and every later window gets that error in `status`. Results are those of the individual calls (to rounding: the Schur
- * accumulation uses LDS atomics, whose order is not fixed from run to run). */
+ * LOCK STEP, max_in_flight at a time (<= 0: 128; at most 512): one launch per solver step covers every window of the group and each
+ * window's Levenberg / two-phase state machine lives in its control block on the device — a single window is a chain of small
+ * latency-bound launches that leaves most of the GPU idle. The windows of a group are prepared (checks, graph bookkeeping, upload) by a
+ * few host threads. With VIORB_LBA_STREAMS=1 the round-1 driver runs instead (one HIP stream and host LM loop per window, max_in_flight
+ * of them, <= 0: 16). When a group fails (a HIP error), every window of it that has no result yet and every later window gets that
+ * error in `status`. Results are those of the individual calls (to rounding: the order of the terms of a Schur block's sum is not
+ * fixed from run to run). */
 typedef struct viorb_lba_window {
     const double* kfs; int32_t nk, n_local, prev_kf; const double* preint; const double* points; int32_t np;
     const int32_t* edge_idx; const double* edge_obs; int32_t ne; const double* gw; const double* cam; const volatile int* stop;

@@ -8,8 +8,8 @@
 //
 // Kernels (all FP64): k_ba_errors (per edge residuals + robust chi2), k_ba_lin_points (one thread per point: Jacobians,
 // weights, Hll, bl), k_ba_hpp (one workgroup per local key frame: its 6x6 (P,Phi) block), k_ba_imu (one workgroup per IMU
-// factor), k_ba_dinv (one thread per point: (Hll + lambda I)^-1), k_ba_schur (workgroups per key frame: the -W D^-1 W^T block row in
-// LDS with FP64 atomics, W blocks precomputed with the linearisation), k_ba_chol_solve (dense Cholesky of the <= 240x240 reduced system by
+// factor), k_ba_dinv (one thread per point: (Hll + lambda I)^-1), k_ba_schur (one wavefront per key-frame pair: its 6x6 block of
+// -W D^-1 W^T gathered over the points both key frames observe, W blocks precomputed with the linearisation, no atomics), k_ba_chol_solve (dense Cholesky of the <= 240x240 reduced system by
 // one 512-thread workgroup, register tiles + v_mfma_f64_16x16x4), k_ba_backsub, k_ba_update. The LM control flow (accept / reject, lambda
 // schedule, stop rule) runs on the device (k_ba_decide / the lock-step batch's control block); the host polls a few scalars per chunk.
 #include <hip/hip_runtime.h>
@@ -38,6 +38,7 @@ struct BaDev {
     uint8_t* level;                 // [NE]
     double *err, *Jp, *Jk, *wgt;    // [NE][2], [NE][6], [NE][12], [NE]
     double *We;                     // [NE][6][3] = wgt * Jk^T Jp, the edge's block of W (block_solver.hpp's Hpl), written with the linearisation
+    int *pr_start, *pr_ent;         // CSR over the key-frame pairs (a >= b, pair a (a + 1) / 2 + b): (edge of a, edge of b) of every point both observe (k_ba_pairs_*)
     const int *pt_start;            // [NP+1]
     const int *kf_start, *kf_list;  // CSR of the edges of each local key frame
     double *Hll, *bl, *Dinv, *db;   // [NP][9], [NP][3], [NP][9], [NP][3] = Dinv bl
@@ -280,59 +281,69 @@ __device__ __forceinline__ void k_ba_dinv_body(const BaDev& D, double lambda_arg
     const double b0 = D.bl[3 * p], b1 = D.bl[3 * p + 1], b2 = D.bl[3 * p + 2];
     D.db[3 * p] = i00 * b0 + i01 * b1 + i02 * b2; D.db[3 * p + 1] = i01 * b0 + i11 * b1 + i12 * b2; D.db[3 * p + 2] = i02 * b0 + i12 * b1 + i22 * b2;
 }
-// Schur complement of the point block (block_solver.hpp:381-432): the workgroups (a, part) of local key frame a accumulate the block row
-// [a][0..a] of -sum_p W_pa Dinv_p W_pb^T (6 x 12(a+1) values; the Cholesky never reads above the diagonal) and -W_pa Dinv_p bl_p in
-// LDS with ds_add_f64, each walking every nparts-th observation of a and, for each, the other observations of that point; the partial
-// row is then added to S and bs (plain adds with one part, global_atomic_add_f64 with several). W_e = wgt Jk^T Jp comes precomputed with
-// the linearisation (D.We): a trial only changes Dinv. One window alone spreads a key frame over BA_SCHUR_PARTS workgroups — with one
-// per key frame the kernel was 20 workgroups of dependent global loads (102 us of a 365 us trial); a batch has workgroups enough.
-#define BA_SCHUR_PARTS 8
-__device__ __forceinline__ void k_ba_schur_body(const BaDev& D, int ka, int part, int nparts) {
+// Schur complement of the point block (block_solver.hpp:381-432), gathered per key-frame PAIR: wavefront (a, b), a >= b, owns the 6 x 6 block
+// S[a][b] -= sum_p (W_pa Dinv_p) W_pb^T over the points p both observe (W = wgt Jk^T Jp from the linearisation, Dinv from k_ba_dinv; the
+// Cholesky never reads above the diagonal) and, on the diagonal pairs, bs[a] -= sum_p W_pa Dinv_p bl_p. The pair's list of (edge of a,
+// edge of b) comes from the host (ba_build_pairs: the graph is fixed over the solve; an edge gated out after the first phase is skipped by
+// its level). One lane per list entry: both W blocks and Dinv as 16-byte loads, 162 FMA, 36 (+ 6) running sums in registers; the lanes' sums
+// meet through an LDS transpose (row k = the 64 lanes' k-th sums, padded against bank conflicts), lane k adds row k and updates its
+// element. One writer per block: no atomics, neither in LDS nor on S. (The round-2 form walked a key frame's observations with one thread
+// each and added every product to an LDS block row by ds_add_f64 — 256 threads on the 36 addresses of each partner block: 0.6 atomics
+// per cycle and CU, 475 us for 128 windows.)
+#define BA_SCHUR_VALS 42
+__device__ __forceinline__ void k_ba_schur_body(const BaDev& D, int pid) {
     if (ba_skip(D)) return;
-    __shared__ double s_row[6][240], s_b[6];
-    const int t = threadIdx.x, ld = D.ld, pd = D.pose_dim, ncol = pd * (ka + 1);
-    for (int q = t; q < 6 * 240; q += blockDim.x) (&s_row[0][0])[q] = 0.0;
-    if (t < 6) s_b[t] = 0.0;
-    __syncthreads();
-    for (int q = D.kf_start[ka] + part * (int)blockDim.x + t; q < D.kf_start[ka + 1]; q += nparts * (int)blockDim.x) {
-        const int ea = D.kf_list[q];
-        if (D.level[ea] != 0) continue;
+    __shared__ double s_t[BA_SCHUR_VALS][65];
+    const int lane = threadIdx.x;
+    int a = (int)((sqrt(8.0 * (double)pid + 1.0) - 1.0) * 0.5);
+    while (a * (a + 1) / 2 > pid) a--;
+    while ((a + 1) * (a + 2) / 2 <= pid) a++;
+    const int b = pid - a * (a + 1) / 2;
+    const int e0 = D.pr_start[pid], e1 = D.pr_start[pid + 1];
+    double acc[BA_SCHUR_VALS];
+#pragma unroll
+    for (int k = 0; k < BA_SCHUR_VALS; k++) acc[k] = 0.0;
+    for (int i = e0 + lane; i < e1; i += 64) {
+        const int2 ent = reinterpret_cast<const int2*>(D.pr_ent)[i];
+        const int ea = ent.x, eb = ent.y;
+        if (D.level[ea] != 0 || D.level[eb] != 0) continue;
         const int p = D.e_pt[ea];
-        const int eb0 = D.pt_start[p], eb1 = D.pt_start[p + 1];
-        const double* Di = D.Dinv + (size_t)p * 9;
-        const double* Wa = D.We + (size_t)18 * ea;
-        const double db0 = D.db[3 * p], db1 = D.db[3 * p + 1], db2 = D.db[3 * p + 2];
-        double BD[18];
+        double wa[18], wb[18], di[9];
+        {
+            const double2* A2 = reinterpret_cast<const double2*>(D.We + (size_t)18 * ea); const double2* B2 = reinterpret_cast<const double2*>(D.We + (size_t)18 * eb);
 #pragma unroll
-        for (int r = 0; r < 6; r++) {
-            const double w0 = Wa[3 * r], w1 = Wa[3 * r + 1], w2 = Wa[3 * r + 2];
-            BD[r * 3] = w0 * Di[0] + w1 * Di[1] + w2 * Di[2]; BD[r * 3 + 1] = w0 * Di[3] + w1 * Di[4] + w2 * Di[5]; BD[r * 3 + 2] = w0 * Di[6] + w1 * Di[7] + w2 * Di[8];
-            atomicAdd(&s_b[r], -(w0 * db0 + w1 * db1 + w2 * db2));
+            for (int k = 0; k < 9; k++) { const double2 u = A2[k], v = B2[k]; wa[2 * k] = u.x; wa[2 * k + 1] = u.y; wb[2 * k] = v.x; wb[2 * k + 1] = v.y; }
+            const double* Dp = D.Dinv + (size_t)9 * p;
+#pragma unroll
+            for (int k = 0; k < 9; k++) di[k] = Dp[k];
         }
-        for (int eb = eb0; eb < eb1; eb++) {
-            const int kb = D.e_kf[eb];
-            if (D.level[eb] != 0 || kb > ka) continue;                   // kb > ka: the transposed block, accumulated by key frame kb's workgroups
-            const double* Wb = D.We + (size_t)18 * eb;
+        double y[18];
 #pragma unroll
-            for (int cc = 0; cc < 6; cc++) {
-                const double w0 = Wb[3 * cc], w1 = Wb[3 * cc + 1], w2 = Wb[3 * cc + 2];
-                const int col = pd * kb + ba_loc(D, cc);
+        for (int r = 0; r < 6; r++)
 #pragma unroll
-                for (int r = 0; r < 6; r++) atomicAdd(&s_row[r][col], -(BD[r * 3] * w0 + BD[r * 3 + 1] * w1 + BD[r * 3 + 2] * w2));
-            }
+            for (int c = 0; c < 3; c++) y[3 * r + c] = wa[3 * r] * di[3 * c] + wa[3 * r + 1] * di[3 * c + 1] + wa[3 * r + 2] * di[3 * c + 2];
+#pragma unroll
+        for (int r = 0; r < 6; r++)
+#pragma unroll
+            for (int c = 0; c < 6; c++) acc[6 * r + c] += y[3 * r] * wb[3 * c] + y[3 * r + 1] * wb[3 * c + 1] + y[3 * r + 2] * wb[3 * c + 2];
+        if (ea == eb) {                                              // once per observation of a: W_pa (Dinv_p bl_p)
+            const double d0 = D.db[3 * p], d1 = D.db[3 * p + 1], d2 = D.db[3 * p + 2];
+#pragma unroll
+            for (int r = 0; r < 6; r++) acc[36 + r] += wa[3 * r] * d0 + wa[3 * r + 1] * d1 + wa[3 * r + 2] * d2;
         }
     }
+#pragma unroll
+    for (int k = 0; k < BA_SCHUR_VALS; k++) s_t[k][lane] = acc[k];
     __syncthreads();
-    for (int q = t; q < 6 * ncol; q += blockDim.x) {
-        const int r = q / ncol, c = q - r * ncol, row = pd * ka + ba_loc(D, r);
-        if (c <= row) {
-            if (nparts == 1) D.S[(size_t)row * ld + c] += s_row[r][c];
-            else if (s_row[r][c] != 0.0) unsafeAtomicAdd(&D.S[(size_t)row * ld + c], s_row[r][c]);
-        }
-    }
-    if (t < 6) {
-        if (nparts == 1) D.bs[pd * ka + ba_loc(D, t)] += s_b[t];
-        else unsafeAtomicAdd(&D.bs[pd * ka + ba_loc(D, t)], s_b[t]);
+    if (lane < BA_SCHUR_VALS) {
+        double v = 0.0;
+#pragma unroll 16
+        for (int l = 0; l < 64; l++) v += s_t[lane][l];
+        const int pd = D.pose_dim;
+        if (lane < 36) {
+            const int row = pd * a + ba_loc(D, lane / 6), col = pd * b + ba_loc(D, lane % 6);
+            if (col <= row && v != 0.0) D.S[(size_t)row * D.ld + col] -= v;
+        } else if (a == b) D.bs[pd * a + ba_loc(D, lane - 36)] -= v;
     }
 }
 
@@ -707,7 +718,7 @@ __global__ __launch_bounds__(256) void k_ba_imu(BaDev D) { k_ba_imu_body(D); }
 __global__ void k_ba_init_reduced(BaDev D, double lambda_arg) { k_ba_init_reduced_body(D, lambda_arg); }
 __global__ void k_ba_max_diag(BaDev D) { k_ba_max_diag_body(D); }
 __global__ void k_ba_dinv(BaDev D, double lambda_arg) { k_ba_dinv_body(D, lambda_arg); }
-__global__ __launch_bounds__(256) void k_ba_schur(BaDev D) { k_ba_schur_body(D, blockIdx.x / BA_SCHUR_PARTS, blockIdx.x % BA_SCHUR_PARTS, BA_SCHUR_PARTS); }
+__global__ __launch_bounds__(64) void k_ba_schur(BaDev D) { k_ba_schur_body(D, blockIdx.x); }
 __global__ __launch_bounds__(BA_CHOL_THREADS) void k_ba_chol_solve(BaDev D) { extern __shared__ __attribute__((aligned(16))) double s_chol[]; k_ba_chol_solve_body(D, s_chol); }
 __global__ void k_ba_backsub(BaDev D, double lambda_arg) { k_ba_backsub_body(D, lambda_arg); }
 __global__ void k_ba_update(BaDev D) { k_ba_update_body(D); }
@@ -756,7 +767,17 @@ __global__ void k_bab_lambda0(const BaDev* __restrict__ Dv, int nwin) {
 }
 __global__ void k_bab_init_reduced(const BaDev* __restrict__ Dv) { BA_B_WINDOW(); k_ba_init_reduced_body(D, 0.0); }
 __global__ void k_bab_dinv(const BaDev* __restrict__ Dv) { BA_B_WINDOW(); k_ba_dinv_body(D, 0.0); }
-__global__ __launch_bounds__(256) void k_bab_schur(const BaDev* __restrict__ Dv) { BA_B_WINDOW(); if ((int)blockIdx.x >= D.W) return; k_ba_schur_body(D, blockIdx.x, 0, 1); }
+// The batch's grid is (pairs, windows) linearised and dealt so that all pairs of a window run on ONE XCD (workgroup ids go round-robin over the
+// eight XCDs): a window's W blocks (1.6 MB at 10.9 k edges) are read by ~5 pairs each and stay in that XCD's L2 meanwhile.
+__global__ __launch_bounds__(64) void k_bab_schur(const BaDev* __restrict__ Dv, int npairs, int nwin) {
+    const int L = blockIdx.x, xcd = L & 7, s = L >> 3;
+    const int win = (s / npairs) * 8 + xcd, pid = s - (s / npairs) * npairs;
+    if (win >= nwin) return;
+    const BaDev& D = Dv[win]; const double* c = D.ctl;
+    if (c[BA_B_DONE] != 0.0 || c[BA_B_ABORT] != 0.0) return;
+    if (pid >= D.W * (D.W + 1) / 2) return;
+    k_ba_schur_body(D, pid);
+}
 __global__ __launch_bounds__(BA_CHOL_THREADS) void k_bab_chol_solve(const BaDev* __restrict__ Dv) { extern __shared__ __attribute__((aligned(16))) double s_chol[]; BA_B_WINDOW(); k_ba_chol_solve_body(D, s_chol); }
 __global__ void k_bab_backsub(const BaDev* __restrict__ Dv) { BA_B_WINDOW(); k_ba_backsub_body(D, 0.0); }
 // the Levenberg decisions of one trial, per window (:129-161), and the end of an optimize() call
@@ -934,6 +955,27 @@ __global__ void k_bab_errors(const BaDev* __restrict__ Dv) {
     BA_B_WINDOW();
     if (D.pose_dim == 12) k_ba_errors_body(D, c[BA_B_MONO] != 0.0); else k_ba_se3_errors_body(D, c[BA_B_MONO] != 0.0);
 }
+// control blocks of a group's windows at the start of the solve (one launch instead of one small copy per window)
+__global__ void k_bab_ctl_init(const BaDev* __restrict__ Dv) {
+    double* c = Dv[blockIdx.x].ctl;
+    const int t = threadIdx.x;
+    if (t < BA_B_N) c[t] = (t == BA_B_NEED_CHI || t == BA_B_NEED_LIN || t == BA_B_FIRST || t == BA_B_MONO) ? 1.0 : (t == BA_B_ITERS ? 5.0 : 0.0);
+}
+// results of a group's windows into one device buffer (one copy back for the group instead of four per window): per window, at offs[4 w ..],
+// key frames | points | erase flags | control block
+__global__ void k_bab_pack(const BaDev* __restrict__ Dv, uint8_t* const* __restrict__ erase, uint8_t* __restrict__ out, const unsigned long long* __restrict__ offs) {
+    const BaDev& D = Dv[blockIdx.y];
+    const unsigned long long* o = offs + 4 * (size_t)blockIdx.y;
+    const size_t nkf = (size_t)D.W * D.kf_stride, npt = (size_t)D.NP * 3, ner = (size_t)D.NE;
+    double* okf = reinterpret_cast<double*>(out + o[0]); double* opt = reinterpret_cast<double*>(out + o[1]); uint8_t* oer = out + o[2]; double* oct = reinterpret_cast<double*>(out + o[3]);
+    size_t n = ner > npt ? ner : npt; n = n > nkf ? n : nkf; n = n > (size_t)BA_B_N ? n : (size_t)BA_B_N;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        if (i < ner) oer[i] = erase[blockIdx.y][i];
+        if (i < nkf) okf[i] = D.kf[i];
+        if (i < npt) opt[i] = D.pt[i];
+        if (i < BA_B_N) oct[i] = D.ctl[i];
+    }
+}
 __global__ void k_bab_gate(const BaDev* __restrict__ Dv, uint8_t* const* __restrict__ erase) {
     const BaDev& D = Dv[blockIdx.y]; const double* c = D.ctl;
     if (c[BA_B_DONE] != 0.0 || c[BA_B_GATE] == 0.0) return;
@@ -1059,6 +1101,7 @@ bool host_inverse9(const double* a_in, double* inv) {
 // The LM driver reads three scalars per trial: it polls the stream instead of blocking in hipStreamSynchronize (whose wake-up costs more
 // than the kernels of a trial take).
 struct BaSolve;
+static int ba_launch_pairs(const BaDev& D, hipStream_t st);      // the Schur complement's gather lists (k_ba_pairs_build, below)
 static void ba_mirror_stop_flags(BaSolve* const* S, int n);
 // Waits for the stream; meanwhile mirrors the callers' stop flags into the page-locked words the device-side LM control polls.
 static hipError_t ba_wait(hipStream_t st, BaSolve* const* S = nullptr, int n = 0) {
@@ -1133,7 +1176,7 @@ struct BaSolve {
                     }
                     hipLaunchKernelGGL(k_ba_init_reduced, dim3((unsigned)((nl2 + TB - 1) / TB)), dim3(TB), 0, st, D, 0.0);
                     hipLaunchKernelGGL(k_ba_dinv, dim3(gP), dim3(TB), 0, st, D, 0.0);
-                    hipLaunchKernelGGL(k_ba_schur, dim3(n_local * BA_SCHUR_PARTS), dim3(256), 0, st, D);
+                    hipLaunchKernelGGL(k_ba_schur, dim3(n_local * (n_local + 1) / 2), dim3(64), 0, st, D);
                     (void)raise_dynamic_lds(reinterpret_cast<const void*>(k_ba_chol_solve), BA_CHOL_LDS_BYTES);
                     hipLaunchKernelGGL(k_ba_chol_solve, dim3(1), dim3(BA_CHOL_THREADS), BA_CHOL_LDS_BYTES, st, D);
                     hipLaunchKernelGGL(k_ba_backsub, dim3(gP), dim3(TB), 0, st, D, 0.0);
@@ -1189,7 +1232,7 @@ struct BaSolve {
             case ST_TRIAL_ENQ:
                 hipLaunchKernelGGL(k_ba_init_reduced, dim3((unsigned)((nl2 + TB - 1) / TB)), dim3(TB), 0, st, D, lambda);
                 hipLaunchKernelGGL(k_ba_dinv, dim3(gP), dim3(TB), 0, st, D, lambda);
-                hipLaunchKernelGGL(k_ba_schur, dim3(n_local * BA_SCHUR_PARTS), dim3(256), 0, st, D);
+                hipLaunchKernelGGL(k_ba_schur, dim3(n_local * (n_local + 1) / 2), dim3(64), 0, st, D);
                 (void)raise_dynamic_lds(reinterpret_cast<const void*>(k_ba_chol_solve), BA_CHOL_LDS_BYTES);
                     hipLaunchKernelGGL(k_ba_chol_solve, dim3(1), dim3(BA_CHOL_THREADS), BA_CHOL_LDS_BYTES, st, D);
                 hipLaunchKernelGGL(k_ba_backsub, dim3(gP), dim3(TB), 0, st, D, lambda);
@@ -1248,6 +1291,7 @@ struct BaSolve {
     }
     // one window: block on the stream between the steps
     int run() {
+        if (state != ST_DONE) { const int rc = ba_launch_pairs(D, st); if (rc != VIORB_OK) return rc; }
         for (;;) {
             const int r = advance();
             if (r < 0 || r == BA_DONE) return r < 0 ? r : VIORB_OK;
@@ -1273,6 +1317,60 @@ static hipError_t ba_map_stop_flag(BaSolve& S) {
     return e;
 }
 
+
+// The gather lists of k_ba_schur, built on the device when a window is prepared (the graph is fixed over the solve): (edge of a, edge of b)
+// for every pair of local key frames a >= b and every point both observe; the diagonal pairs list every local observation once. One
+// 1024-thread workgroup per window on the window's stream: histogram of the pairs in LDS, exclusive scan, fill through LDS cursors (the
+// order inside a pair's list is not fixed: it only permutes the terms of that block's sum). Building the lists on the host cost 0.1-0.2 ms
+// per window, counting with global atomics 0.1 ms (30 k increments of 210 counters) — more than a batched solve gains from them.
+#define BA_MAX_PAIRS 820                                               // 40 local key frames (the SE3 window's limit)
+template <class F> __device__ __forceinline__ void ba_pairs_walk(const BaDev& D, F f) {
+    for (int p = threadIdx.x; p < D.NP; p += blockDim.x) {
+        const int k0 = D.pt_start[p], k1 = D.pt_start[p + 1];
+        for (int i = k0; i < k1; i++) {
+            const int a = D.e_kf[i];
+            if (a >= D.W) continue;
+            for (int j = k0; j < k1; j++) {
+                const int b = D.e_kf[j];
+                if (b <= a) f(a * (a + 1) / 2 + b, i, j);            // (i, j) with kf(i) >= kf(j); i == j once
+            }
+        }
+    }
+}
+__device__ __forceinline__ void k_ba_pairs_build_body(const BaDev& D) {
+    __shared__ int s_h[BA_MAX_PAIRS + 1];
+    const int npairs = D.W * (D.W + 1) / 2, t = threadIdx.x;
+    for (int q = t; q <= npairs; q += blockDim.x) s_h[q] = 0;
+    __syncthreads();
+    ba_pairs_walk(D, [&](int q, int, int) { atomicAdd(&s_h[q], 1); });
+    __syncthreads();
+    if (t < 64) {                                                      // exclusive scan; the counters become the fill cursors
+        int run = 0;
+        for (int base = 0; base <= npairs; base += 64) {
+            const int q = base + t, c = q < npairs ? s_h[q] : 0;
+            int incl = c;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d); if (t >= d) incl += o; }
+            if (q <= npairs) { D.pr_start[q] = run + incl - c; s_h[q] = run + incl - c; }
+            run += __shfl(incl, 63);
+        }
+    }
+    __syncthreads();
+    ba_pairs_walk(D, [&](int q, int i, int j) { const int at = atomicAdd(&s_h[q], 1); D.pr_ent[2 * (size_t)at] = i; D.pr_ent[2 * (size_t)at + 1] = j; });
+}
+__global__ __launch_bounds__(1024) void k_ba_pairs_build(BaDev D) { k_ba_pairs_build_body(D); }
+__global__ __launch_bounds__(1024) void k_bab_pairs_build(const BaDev* __restrict__ Dv) { k_ba_pairs_build_body(Dv[blockIdx.x]); }   // a lock-step group's windows in one launch
+static int ba_launch_pairs(const BaDev& D, hipStream_t st) {
+    hipLaunchKernelGGL(k_ba_pairs_build, dim3(1), dim3(1024), 0, st, D);
+    VIORB_HIP_TRY(hipGetLastError());
+    return VIORB_OK;
+}
+// upper bound of the pair lists' length: every ordered pair of a point's local observations
+static size_t ba_pairs_bound(const std::vector<int>& e_kf, const std::vector<int>& pt_start, int npts, int n_local) {
+    size_t tot = 0;
+    for (int p = 0; p < npts; p++) { size_t k = 0; for (int i = pt_start[p]; i < pt_start[p + 1]; i++) k += e_kf[i] < n_local; tot += k * k; }
+    return tot;
+}
 
 // Argument checks, host-side graph bookkeeping and the upload of one NavState window; leaves `S` ready for advance() (or already done
 // when the stop flag was set on entry).
@@ -1303,6 +1401,7 @@ static int ba_prepare_navstate(BaSolve& S, const double* kfs, int nk, int n_loca
     for (int i = 0; i < n_local; i++) kf_start[i + 1] += kf_start[i];
     kf_list.resize(kf_start[n_local]);
     { std::vector<int> pos(kf_start.begin(), kf_start.end() - 1); for (int k = 0; k < ne; k++) if (e_kf[k] < n_local) kf_list[pos[e_kf[k]]++] = k; }
+    const size_t pr_bound = ba_pairs_bound(e_kf, pt_start, npts, n_local);
     std::vector<double> info_pvr((size_t)n_local * 81);
     for (int i = 0; i < n_local; i++) if (!host_inverse9(preint + (size_t)i * 142 + 60, &info_pvr[(size_t)i * 81])) { set_error("singular IMU covariance"); return VIORB_ERR_INVALID_ARG; }
 
@@ -1320,6 +1419,7 @@ static int ba_prepare_navstate(BaSolve& S, const double* kfs, int nk, int n_loca
     bool ok = B.alloc(&D.kf, (size_t)nk * 22, kfs) && B.alloc(&D.kf_bak, (size_t)nk * 22) && B.alloc(&D.pt, (size_t)npts * 3, points) && B.alloc(&D.pt_bak, (size_t)npts * 3) &&
               B.alloc(&d_ept, ne, e_pt.data()) && B.alloc(&d_ekf, ne, e_kf.data()) && B.alloc(&d_obs, (size_t)ne * 3, edge_obs) && B.alloc(&D.level, ne) &&
               B.alloc(&D.err, (size_t)ne * 2) && B.alloc(&D.Jp, (size_t)ne * 6) && B.alloc(&D.Jk, (size_t)ne * 12) && B.alloc(&D.wgt, ne) && B.alloc(&D.We, (size_t)ne * 18) &&
+              B.alloc(&D.pr_start, (size_t)n_local * (n_local + 1) / 2 + 1) && B.alloc(&D.pr_ent, 2 * pr_bound + 2) &&
               B.alloc(&d_pts, npts + 1, pt_start.data()) && B.alloc(&d_kfs, n_local + 1, kf_start.data()) && B.alloc(&d_kfl, kf_list.size(), kf_list.data()) &&
               B.alloc(&D.Hll, (size_t)npts * 9) && B.alloc(&D.bl, (size_t)npts * 3) && B.alloc(&D.Dinv, (size_t)npts * 9) &&
               B.alloc(&D.Hpp, n2) && B.alloc(&D.bp, D.np) && B.alloc(&D.S, nl2 + (size_t)16 * D.ld + (size_t)(D.ld / 16) * 256) && B.alloc(&D.bs, D.ld) && B.alloc(&D.xp, D.ld) && B.alloc(&D.db, (size_t)npts * 3) && B.alloc(&D.xl, (size_t)npts * 3) &&
@@ -1363,6 +1463,7 @@ static int ba_run_batch(int n, int max_in_flight, Prepare prepare, SetStatus set
             const int i = next++;
             auto S = std::make_unique<BaSolve>();
             int status = prepare(i, *S);
+            if (status == VIORB_OK && S->state != BaSolve::ST_DONE) status = ba_launch_pairs(S->D, S->st);
             if (status == VIORB_OK && S->state != BaSolve::ST_DONE) {
                 const int r = S->advance();                      // first batch of work
                 if (r == BA_WAIT) { live[slot] = std::move(S); which[slot] = i; return; }
@@ -1397,23 +1498,40 @@ static int ba_run_batch(int n, int max_in_flight, Prepare prepare, SetStatus set
 
 // Lock-step batch of NavState windows (kernels k_bab_*): returns the first error; every window's status through set_status.
 template <class Win, class Prepare>
-static int ba_run_lockstep(Win* w, int n, Prepare prepare) {
+static int ba_run_lockstep(Win* w, int n, int max_in_flight, Prepare prepare) {
     if (viorb_device_count() < 1) { set_error("no HIP device: libviorb_hip has no CPU fallback"); return VIORB_ERR_NO_DEVICE; }
     VIORB_HIP_TRY(hipSetDevice(lba_device()));
     int first_error = VIORB_OK;
-    const int GROUP = 128, TB = 256, ROUNDS_PER_CHECK = 4, MAX_ROUNDS = 600;
+    // windows advanced together (max_in_flight of the batch entry points; default 128): every solver step is one launch over the group
+    const int GROUP = max_in_flight > 0 ? std::min(max_in_flight, 512) : 128, TB = 256, ROUNDS_PER_CHECK = 4, MAX_ROUNDS = 600;
     for (int g0 = 0; g0 < n; g0 += GROUP) {
         const int ng = std::min(GROUP, n - g0);
         std::vector<std::unique_ptr<BaSolve>> S(ng);
         std::vector<int> act;
-        for (int i = 0; i < ng; i++) {
-            Win& q = w[g0 + i];
-            S[i] = std::make_unique<BaSolve>();
-            const int rc = prepare(*S[i], q);
-            q.status = rc;
-            if (rc != VIORB_OK) { if (first_error == VIORB_OK) first_error = rc; continue; }
-            if (S[i]->state == BaSolve::ST_DONE) continue;               // stop flag already set: inputs copied to the outputs
-            act.push_back(i);
+        {   // argument checks, graph bookkeeping, input mirror and upload of every window: independent per window (own context, stream and
+            // arena), ~0.1 ms of host time each — spread over a few host threads so that the device does not wait for them
+            const int dev = lba_device();
+            const int nthr = std::max(1, std::min(std::min(8, (int)std::thread::hardware_concurrency()), ng / 4));
+            std::vector<std::string> errs(ng);
+            auto work = [&](int t0) {
+                (void)hipSetDevice(dev);
+                for (int i = t0; i < ng; i += nthr) {
+                    Win& q = w[g0 + i];
+                    S[i] = std::make_unique<BaSolve>();
+                    q.status = prepare(*S[i], q);
+                    if (q.status != VIORB_OK) errs[i] = viorb_last_error();      // the error text is per thread
+                }
+            };
+            std::vector<std::thread> pool;
+            for (int t0 = 1; t0 < nthr; t0++) pool.emplace_back(work, t0);
+            work(0);
+            for (std::thread& th : pool) th.join();
+            for (int i = 0; i < ng; i++) {
+                const int rc = w[g0 + i].status;
+                if (rc != VIORB_OK) { if (first_error == VIORB_OK) { first_error = rc; set_error("%s", errs[i].c_str()); } continue; }
+                if (S[i]->state == BaSolve::ST_DONE) continue;           // stop flag already set: inputs copied to the outputs
+                act.push_back(i);
+            }
         }
         const int na = (int)act.size();
         if (na == 0) continue;
@@ -1422,15 +1540,12 @@ static int ba_run_lockstep(Win* w, int n, Prepare prepare) {
         hipStream_t st = S[act[0]]->st;
         std::vector<BaDev> Dh(na); std::vector<uint8_t*> Eh(na);
         int gE = 1, gP = 1, Wmax = 1; size_t nl2 = 1, n2 = 1;
-        std::vector<double> c0(BA_B_N, 0.0);
-        c0[BA_B_NEED_CHI] = 1; c0[BA_B_NEED_LIN] = 1; c0[BA_B_FIRST] = 1; c0[BA_B_MONO] = 1; c0[BA_B_ITERS] = 5;
         for (int a = 0; a < na; a++) {
             BaSolve& B = *S[act[a]];
             VIORB_HIP_TRY(hipStreamSynchronize(B.st));                   // the window's inputs are uploaded
             Dh[a] = B.D; Dh[a].use_ctl = 1; Eh[a] = B.d_erase;
             gE = std::max(gE, (B.D.NE + TB - 1) / TB); gP = std::max(gP, (B.D.NP + TB - 1) / TB); Wmax = std::max(Wmax, B.D.W);
             nl2 = std::max(nl2, (size_t)B.D.ld * B.D.ld); n2 = std::max(n2, (size_t)B.D.np * B.D.np);
-            VIORB_HIP_TRY(hipMemcpyAsync(B.D.ctl, c0.data(), sizeof(double) * BA_B_N, hipMemcpyHostToDevice, st));
         }
         BaDev* Dv = nullptr; uint8_t** Ev = nullptr; int* d_done = nullptr;
         struct Free { void* p[3]; ~Free() { for (void* q : p) if (q) (void)hipFree(q); } } fr{{nullptr, nullptr, nullptr}};
@@ -1439,6 +1554,8 @@ static int ba_run_lockstep(Win* w, int n, Prepare prepare) {
         VIORB_HIP_TRY(hipMemcpyAsync(Dv, Dh.data(), sizeof(BaDev) * na, hipMemcpyHostToDevice, st));
         VIORB_HIP_TRY(hipMemcpyAsync(Ev, Eh.data(), sizeof(uint8_t*) * na, hipMemcpyHostToDevice, st));
         VIORB_HIP_TRY(hipMemsetAsync(d_done, 0, sizeof(int), st));
+        hipLaunchKernelGGL(k_bab_ctl_init, dim3(na), dim3(64), 0, st, Dv);
+        hipLaunchKernelGGL(k_bab_pairs_build, dim3(na), dim3(1024), 0, st, Dv);            // the Schur complement's gather lists of every window
         double* pin = S[act[0]]->h;                                      // page-locked scratch of the first window's context
         int* h_done = reinterpret_cast<int*>(pin + 48);
         const unsigned gw = (unsigned)((na + 63) / 64), gR = (unsigned)((nl2 + TB - 1) / TB), gC = (unsigned)std::min<size_t>((n2 + TB - 1) / TB, 64);
@@ -1460,7 +1577,7 @@ static int ba_run_lockstep(Win* w, int n, Prepare prepare) {
                 hipLaunchKernelGGL(k_bab_lambda0, dim3(gw), dim3(64), 0, st, Dv, na);
                 hipLaunchKernelGGL(k_bab_init_reduced, dim3(gR, na), dim3(TB), 0, st, Dv);
                 hipLaunchKernelGGL(k_bab_dinv, YP, dim3(TB), 0, st, Dv);
-                hipLaunchKernelGGL(k_bab_schur, YW, dim3(256), 0, st, Dv);
+                hipLaunchKernelGGL(k_bab_schur, dim3((unsigned)(Wmax * (Wmax + 1) / 2) * 8u * (unsigned)((na + 7) / 8)), dim3(64), 0, st, Dv, Wmax * (Wmax + 1) / 2, na);
                 (void)raise_dynamic_lds(reinterpret_cast<const void*>(k_bab_chol_solve), BA_CHOL_LDS_BYTES);
                 hipLaunchKernelGGL(k_bab_chol_solve, Y1, dim3(BA_CHOL_THREADS), BA_CHOL_LDS_BYTES, st, Dv);
                 hipLaunchKernelGGL(k_bab_backsub, YP, dim3(TB), 0, st, Dv);
@@ -1487,34 +1604,49 @@ static int ba_run_lockstep(Win* w, int n, Prepare prepare) {
             }
         }
         if (done < na) { set_error("window solve did not finish in %d rounds", MAX_ROUNDS); return VIORB_ERR_HIP; }
-        // results come back through every window's page-locked staging buffer (its inputs are long consumed): asynchronous copies, one
-        // synchronisation for the group, then plain memcpy into the callers' (pageable) arrays
-        for (int a = 0; a < na; a++) {
-            BaSolve& B = *S[act[a]];
-            BaCtx* c = B.lease.c;
-            const size_t nkf = (size_t)B.D.W * B.D.kf_stride * sizeof(double), npt = (size_t)B.D.NP * 3 * sizeof(double), ner = (size_t)B.D.NE, nct = sizeof(double) * BA_B_N;
-            const size_t o1 = (nkf + 255) & ~(size_t)255, o2 = o1 + ((npt + 255) & ~(size_t)255), o3 = o2 + ((ner + 255) & ~(size_t)255), need = o3 + nct;
-            if (c->stage_bytes < need) {
-                if (c->stage) (void)hipHostFree(c->stage);
-                c->stage = nullptr; c->stage_bytes = 0;
-                VIORB_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->stage), need));
-                c->stage_bytes = need;
+        // results: packed by one kernel into a group buffer on the device, ONE copy into page-locked memory, then plain memcpy into the callers'
+        // (pageable) arrays
+        {
+            std::vector<unsigned long long> offs(4 * (size_t)na);
+            size_t total = 0, max_ne = 1;
+            auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+            for (int a = 0; a < na; a++) {
+                const BaDev& Da = S[act[a]]->D;
+                offs[4 * a] = total; total += up((size_t)Da.W * Da.kf_stride * sizeof(double));
+                offs[4 * a + 1] = total; total += up((size_t)Da.NP * 3 * sizeof(double));
+                offs[4 * a + 2] = total; total += up((size_t)Da.NE);
+                offs[4 * a + 3] = total; total += up(sizeof(double) * BA_B_N);
+                max_ne = std::max(max_ne, (size_t)std::max(Da.NE, std::max(Da.NP * 3, Da.W * Da.kf_stride)));
             }
-            VIORB_HIP_TRY(hipMemcpyAsync(c->stage, B.D.kf, nkf, hipMemcpyDeviceToHost, st));
-            VIORB_HIP_TRY(hipMemcpyAsync(c->stage + o1, B.D.pt, npt, hipMemcpyDeviceToHost, st));
-            VIORB_HIP_TRY(hipMemcpyAsync(c->stage + o2, B.d_erase, ner, hipMemcpyDeviceToHost, st));
-            VIORB_HIP_TRY(hipMemcpyAsync(c->stage + o3, B.D.ctl, nct, hipMemcpyDeviceToHost, st));
-        }
-        VIORB_HIP_TRY(hipStreamSynchronize(st));
-        for (int a = 0; a < na; a++) {
-            BaSolve& B = *S[act[a]];
-            const uint8_t* sg = B.lease.c->stage;
-            const size_t nkf = (size_t)B.D.W * B.D.kf_stride * sizeof(double), npt = (size_t)B.D.NP * 3 * sizeof(double), ner = (size_t)B.D.NE;
-            const size_t o1 = (nkf + 255) & ~(size_t)255, o2 = o1 + ((npt + 255) & ~(size_t)255), o3 = o2 + ((ner + 255) & ~(size_t)255);
-            memcpy(B.kfs_out, sg, nkf); memcpy(B.points_out, sg + o1, npt); memcpy(B.erase, sg + o2, ner);
-            const double* c = reinterpret_cast<const double*>(sg + o3);
-            double* info = B.info;
-            info[0] = c[BA_B_CHI0]; info[1] = c[BA_B_CHI1]; info[2] = c[BA_B_ITS0]; info[3] = c[BA_B_ITS1];
+            // grow-only buffers of the calling thread (hipMalloc / hipHostMalloc synchronise the device and take longer than a round)
+            struct Bufs {
+                void* dev = nullptr; void* host = nullptr; void* doffs = nullptr; size_t bytes = 0, noffs = 0; int device = -1;
+                void drop() { if (dev) (void)hipFree(dev); if (host) (void)hipHostFree(host); if (doffs) (void)hipFree(doffs); dev = host = doffs = nullptr; bytes = noffs = 0; }
+                ~Bufs() { drop(); }
+            };
+            static thread_local Bufs bufs;
+            if (bufs.device != lba_device() || bufs.bytes < total || bufs.noffs < offs.size()) {
+                bufs.drop(); bufs.device = lba_device();
+                const size_t want = total + total / 4, wo = offs.size() + 64;
+                VIORB_HIP_TRY(hipMalloc(&bufs.dev, want)); VIORB_HIP_TRY(hipHostMalloc(&bufs.host, want)); VIORB_HIP_TRY(hipMalloc(&bufs.doffs, wo * sizeof(unsigned long long)));
+                bufs.bytes = want; bufs.noffs = wo;
+            }
+            VIORB_HIP_TRY(hipMemcpyAsync(bufs.doffs, offs.data(), offs.size() * sizeof(unsigned long long), hipMemcpyHostToDevice, st));
+            hipLaunchKernelGGL(k_bab_pack, dim3((unsigned)std::min<size_t>((max_ne + TB - 1) / TB, 64), na), dim3(TB), 0, st, Dv, Ev, static_cast<uint8_t*>(bufs.dev),
+                               static_cast<const unsigned long long*>(bufs.doffs));
+            VIORB_HIP_TRY(hipGetLastError());
+            VIORB_HIP_TRY(hipMemcpyAsync(bufs.host, bufs.dev, total, hipMemcpyDeviceToHost, st));
+            VIORB_HIP_TRY(hipStreamSynchronize(st));
+            const uint8_t* hb = static_cast<const uint8_t*>(bufs.host);
+            for (int a = 0; a < na; a++) {
+                BaSolve& B = *S[act[a]];
+                memcpy(B.kfs_out, hb + offs[4 * a], (size_t)B.D.W * B.D.kf_stride * sizeof(double));
+                memcpy(B.points_out, hb + offs[4 * a + 1], (size_t)B.D.NP * 3 * sizeof(double));
+                memcpy(B.erase, hb + offs[4 * a + 2], (size_t)B.D.NE);
+                const double* c = reinterpret_cast<const double*>(hb + offs[4 * a + 3]);
+                double* info = B.info;
+                info[0] = c[BA_B_CHI0]; info[1] = c[BA_B_CHI1]; info[2] = c[BA_B_ITS0]; info[3] = c[BA_B_ITS1];
+            }
         }
         return VIORB_OK;
         };
@@ -1531,7 +1663,7 @@ static int ba_run_lockstep(Win* w, int n, Prepare prepare) {
 extern "C" int viorb_local_ba_navstate_batch(viorb_lba_window* w, int n, int max_in_flight) {
     VIORB_REQUIRE(w && n >= 0, "null windows");
     static const bool per_stream = getenv("VIORB_LBA_STREAMS") != nullptr;      // the round-1 driver: one stream and host LM loop per window
-    if (!per_stream) return ba_run_lockstep(w, n, [](BaSolve& S, viorb_lba_window& q) {
+    if (!per_stream) return ba_run_lockstep(w, n, max_in_flight, [](BaSolve& S, viorb_lba_window& q) {
         return ba_prepare_navstate(S, q.kfs, q.nk, q.n_local, q.prev_kf, q.preint, q.points, q.np, q.edge_idx, q.edge_obs, q.ne, q.gw, q.cam, q.stop,
                                    q.kfs_out, q.points_out, q.erase, q.info);
     });
@@ -1568,6 +1700,7 @@ static int ba_prepare_se3(BaSolve& S, const double* kfs, int nk, int n_local, co
     for (int i = 0; i < n_local; i++) kf_start[i + 1] += kf_start[i];
     kf_list.resize(kf_start[n_local]);
     { std::vector<int> pos(kf_start.begin(), kf_start.end() - 1); for (int k = 0; k < ne; k++) if (e_kf[k] < n_local) kf_list[pos[e_kf[k]]++] = k; }
+    const size_t pr_bound = ba_pairs_bound(e_kf, pt_start, npts, n_local);
     VIORB_HIP_TRY(hipSetDevice(lba_device()));
     BaCtxLease& lease = S.lease;
     if (!lease.ready()) { set_error("could not create a HIP stream"); return VIORB_ERR_HIP; }
@@ -1583,6 +1716,7 @@ static int ba_prepare_se3(BaSolve& S, const double* kfs, int nk, int n_local, co
     bool ok = B.alloc(&D.kf, (size_t)nk * 7, kfs) && B.alloc(&D.kf_bak, (size_t)nk * 7) && B.alloc(&D.pt, (size_t)npts * 3, points) && B.alloc(&D.pt_bak, (size_t)npts * 3) &&
               B.alloc(&d_ept, ne, e_pt.data()) && B.alloc(&d_ekf, ne, e_kf.data()) && B.alloc(&d_obs, (size_t)ne * 4, edge_obs) && B.alloc(&D.level, ne) &&
               B.alloc(&D.err, (size_t)ne * 3) && B.alloc(&D.Jp, (size_t)ne * 9) && B.alloc(&D.Jk, (size_t)ne * 18) && B.alloc(&D.wgt, ne) && B.alloc(&D.We, (size_t)ne * 18) &&
+              B.alloc(&D.pr_start, (size_t)n_local * (n_local + 1) / 2 + 1) && B.alloc(&D.pr_ent, 2 * pr_bound + 2) &&
               B.alloc(&d_pts, npts + 1, pt_start.data()) && B.alloc(&d_kfs, n_local + 1, kf_start.data()) && B.alloc(&d_kfl, kf_list.size(), kf_list.data()) &&
               B.alloc(&D.Hll, (size_t)npts * 9) && B.alloc(&D.bl, (size_t)npts * 3) && B.alloc(&D.Dinv, (size_t)npts * 9) &&
               B.alloc(&D.Hpp, n2) && B.alloc(&D.bp, D.np) && B.alloc(&D.S, nl2 + (size_t)16 * D.ld + (size_t)(D.ld / 16) * 256) && B.alloc(&D.bs, D.ld) && B.alloc(&D.xp, D.ld) &&
@@ -1606,7 +1740,7 @@ extern "C" int viorb_local_ba_se3(const double* kfs, int nk, int n_local, const 
 extern "C" int viorb_local_ba_se3_batch(viorb_lba_se3_window* w, int n, int max_in_flight) {
     VIORB_REQUIRE(w && n >= 0, "null windows");
     static const bool per_stream = getenv("VIORB_LBA_STREAMS") != nullptr;      // the round-1 driver: one stream and host LM loop per window
-    if (!per_stream) return ba_run_lockstep(w, n, [](BaSolve& S, viorb_lba_se3_window& q) {
+    if (!per_stream) return ba_run_lockstep(w, n, max_in_flight, [](BaSolve& S, viorb_lba_se3_window& q) {
         return ba_prepare_se3(S, q.kfs, q.nk, q.n_local, q.points, q.np, q.edge_idx, q.edge_obs, q.ne, q.intr5, q.stop, q.kfs_out, q.points_out, q.erase, q.info);
     });
     return ba_run_batch(n, max_in_flight,

@@ -148,7 +148,7 @@ def LocalBundleAdjustmentNavState(kfs, n_local, prev_kf, preint, points, edge_id
     return dict(kfs=ko, points=po, erase=er[:len(ei)], chi2_first=info[0], chi2_final=info[1], its_first=int(info[2]), its_second=int(info[3]))
 
 
-def LocalBundleAdjustmentNavStateBatch(problems, max_in_flight=16):
+def LocalBundleAdjustmentNavStateBatch(problems, max_in_flight=128):
     """Several LocalBundleAdjustmentNavState windows solved concurrently (viorb_local_ba_navstate_batch): `problems` is a list of dicts
     with the keyword arguments of LocalBundleAdjustmentNavState (kfs, n_local, prev_kf, preint, points, edge_idx, edge_obs, gw, cam);
     returns the list of result dicts, each identical to what the single call returns."""
@@ -185,7 +185,7 @@ def LocalBundleAdjustment(kfs, n_local, points, edge_idx, edge_obs, intr5, stop=
     return dict(kfs=ko, points=po, erase=er[:len(ei)], chi2_first=info[0], chi2_final=info[1], its_first=int(info[2]), its_second=int(info[3]))
 
 
-def LocalBundleAdjustmentBatch(problems, max_in_flight=16):
+def LocalBundleAdjustmentBatch(problems, max_in_flight=128):
     """Several vision-only LocalBundleAdjustment windows kept in flight together (viorb_local_ba_se3_batch): `problems` is a list of
     dicts with the keyword arguments of LocalBundleAdjustment (kfs, n_local, points, edge_idx, edge_obs, intr5)."""
     n = len(problems)
