@@ -135,7 +135,7 @@ struct viorb_tracker {
     int B = 0, cap = 0, device = 0, nlevels = 0;
     viorb_extractor* ex[2] = {nullptr, nullptr};
     viorb_frontend* fe = nullptr;
-    hipStream_t s_ex = nullptr, s_tr = nullptr;
+    hipStream_t s_ex = nullptr, s_ex2 = nullptr, s_tr = nullptr;       // s_ex2: the second extractor handle's stream (VIORB_TRACKER_EX_STREAMS=2)
     hipEvent_t ev_in = nullptr, ev_ex[2] = {nullptr, nullptr}, ev_tr[2] = {nullptr, nullptr};
     bool ev_tr_valid[2] = {false, false};
     std::deque<hipEvent_t> in_flight; std::vector<hipEvent_t> ev_pool;
@@ -209,6 +209,7 @@ int viorb_tracker_create(const viorb_tracker_config* cfg, viorb_tracker** out) {
         const char* pr = getenv("VIORB_TRACK_PRIORITY");                  // experiment switch: 1 = tracking stream above extraction, 2 = below
         const int p_tr = pr && pr[0] == '1' ? hi : (pr && pr[0] == '2' ? lo : 0), p_ex = pr && pr[0] == '1' ? lo : (pr && pr[0] == '2' ? hi : 0);
         VIORB_HIP_TRY(hipStreamCreateWithPriority(&h->s_ex, hipStreamNonBlocking, p_ex));
+        { const char* e2 = getenv("VIORB_TRACKER_EX_STREAMS"); if (e2 && atoi(e2) == 2) VIORB_HIP_TRY(hipStreamCreateWithPriority(&h->s_ex2, hipStreamNonBlocking, p_ex)); }
         VIORB_HIP_TRY(hipStreamCreateWithPriority(&h->s_tr, hipStreamNonBlocking, p_tr));
     }
     VIORB_HIP_TRY(hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming));
@@ -246,12 +247,14 @@ int viorb_tracker_destroy(viorb_tracker* h) {
     if (!h) return VIORB_OK;
     (void)hipSetDevice(h->device);
     if (h->s_ex) (void)hipStreamSynchronize(h->s_ex);
+    if (h->s_ex2) (void)hipStreamSynchronize(h->s_ex2);
     if (h->s_tr) (void)hipStreamSynchronize(h->s_tr);
     for (hipEvent_t e : h->in_flight) (void)hipEventDestroy(e);
     for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
     if (h->ev_in) (void)hipEventDestroy(h->ev_in);
     for (int i = 0; i < 2; i++) { if (h->ev_ex[i]) (void)hipEventDestroy(h->ev_ex[i]); if (h->ev_tr[i]) (void)hipEventDestroy(h->ev_tr[i]); }
     if (h->s_ex) (void)hipStreamDestroy(h->s_ex);
+    if (h->s_ex2) (void)hipStreamDestroy(h->s_ex2);
     if (h->s_tr) (void)hipStreamDestroy(h->s_tr);
     if (h->s_cp) { (void)hipStreamSynchronize(h->s_cp); (void)hipStreamDestroy(h->s_cp); }
     for (uint8_t* p : h->stage) if (p) (void)hipFree(p);
@@ -274,7 +277,7 @@ int viorb_tracker_bootstrap(viorb_tracker* h, const uint8_t* d_images, int strid
     VIORB_REQUIRE(h && d_images && d_ns0 && d_t0 && d_marg_cov_inv, "null argument");
     VIORB_HIP_TRY(hipSetDevice(h->device));
     VIORB_HIP_TRY(hipStreamSynchronize((hipStream_t)caller_stream));
-    VIORB_HIP_TRY(hipStreamSynchronize(h->s_ex)); VIORB_HIP_TRY(hipStreamSynchronize(h->s_tr));
+    VIORB_HIP_TRY(hipStreamSynchronize(h->s_ex)); if (h->s_ex2) VIORB_HIP_TRY(hipStreamSynchronize(h->s_ex2)); VIORB_HIP_TRY(hipStreamSynchronize(h->s_tr));
     h->rolls = 0; h->k = 0; h->ev_tr_valid[0] = h->ev_tr_valid[1] = false; h->cur_slot = 0;
     TR_TRY(viorb_extract_batch_device(h->ex[0], d_images, h->B, h->cfg.width, h->cfg.height, stride, image_pitch_bytes, h->s_tr));
     const viorb_keypoint* kps; const uint8_t* desc; const int32_t* count; const int32_t* st; int cap;
@@ -333,12 +336,13 @@ int viorb_tracker_step(viorb_tracker* h, const viorb_tracker_inputs* in, void* c
     viorb_extractor* ex = h->ex[slot];
     // inputs were produced on the caller's stream
     VIORB_HIP_TRY(hipEventRecord(h->ev_in, (hipStream_t)caller_stream));
-    VIORB_HIP_TRY(hipStreamWaitEvent(h->s_ex, h->ev_in, 0));
+    hipStream_t sx = (slot && h->s_ex2) ? h->s_ex2 : h->s_ex;
+    VIORB_HIP_TRY(hipStreamWaitEvent(sx, h->ev_in, 0));
     VIORB_HIP_TRY(hipStreamWaitEvent(h->s_tr, h->ev_in, 0));
-    if (h->ev_tr_valid[slot]) VIORB_HIP_TRY(hipStreamWaitEvent(h->s_ex, h->ev_tr[slot], 0));     // this handle's previous results have been consumed
-    if (ev_upload) VIORB_HIP_TRY(hipStreamWaitEvent(h->s_ex, ev_upload, 0));
-    TR_TRY(viorb_extract_batch_device(ex, d_images, B, h->cfg.width, h->cfg.height, in->image_stride, in->image_pitch_bytes, h->s_ex));
-    VIORB_HIP_TRY(hipEventRecord(h->ev_ex[slot], h->s_ex));
+    if (h->ev_tr_valid[slot]) VIORB_HIP_TRY(hipStreamWaitEvent(sx, h->ev_tr[slot], 0));     // this handle's previous results have been consumed
+    if (ev_upload) VIORB_HIP_TRY(hipStreamWaitEvent(sx, ev_upload, 0));
+    TR_TRY(viorb_extract_batch_device(ex, d_images, B, h->cfg.width, h->cfg.height, in->image_stride, in->image_pitch_bytes, sx));
+    VIORB_HIP_TRY(hipEventRecord(h->ev_ex[slot], sx));
     hipStream_t st = h->s_tr;
     // ---- what does not need the new frame's keypoints: IMU pre-integration + prediction, the last frame's own observations
     TR_TRY(viorb_frontend_imu_predict_device(h->fe, in->d_imu, in->n_imu, h->t_last, in->d_t_cur, h->last_ns, B, h->preint, h->cur_ns, h->pose12, st));
@@ -411,6 +415,7 @@ int viorb_tracker_sync(viorb_tracker* h) {
     VIORB_HIP_TRY(hipSetDevice(h->device));
     if (h->s_cp) VIORB_HIP_TRY(hipStreamSynchronize(h->s_cp));
     VIORB_HIP_TRY(hipStreamSynchronize(h->s_ex));
+    if (h->s_ex2) VIORB_HIP_TRY(hipStreamSynchronize(h->s_ex2));
     VIORB_HIP_TRY(hipStreamSynchronize(h->s_tr));
     while (!h->in_flight.empty()) { h->ev_pool.push_back(h->in_flight.front()); h->in_flight.pop_front(); }
     return VIORB_OK;
