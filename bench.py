@@ -169,7 +169,8 @@ def run_tracking(args, cfg, rank, dev_index, dev, world):
     # through that lens and the tracker undistorts the keypoints ahead of the grid (Frame::UndistortKeyPoints) with bounds from the undistorted corners
     from viorb_amd.synth import EUROC_DIST
     lens = EUROC_DIST if (args.config == "euroc" and not args.no_distortion) else None
-    base = generate_streams(stream_seeds(rank, distinct), W_IMG, H_IMG, args.gen_procs, lens)
+    pre = getattr(args, "pregenerated", None)               # the pinhole pass's streams, generated before anything touched the GPU (main)
+    base = pre if (pre is not None and lens is None) else generate_streams(stream_seeds(rank, distinct), W_IMG, H_IMG, args.gen_procs, lens)
     streams = [base[i % distinct] for i in range(S)]
     up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     frames = up(np.stack([s["frames"] for s in streams], 1))                   # [F, S, h, w] u8
@@ -623,6 +624,11 @@ def main():
         if world > 1:
             dist.barrier(); dist.destroy_process_group()
         return
+    pinhole_pass = args.config == "euroc" and world == 1 and not args.no_distortion and not args.no_host_input_pass
+    if pinhole_pass:
+        # the streams of the pinhole-camera pass (after the timed region) are generated here, before anything touches the GPU: a process pool
+        # forked from a process that has initialised HIP is not something to rely on (under rocprofv3 its workers have been seen not to exit)
+        args.pregenerated = generate_streams(stream_seeds(rank, min(args.streams, args.distinct or 256)), cfg["w"], cfg["h"], args.gen_procs, None)
     if viorb_amd.lib().viorb_device_count() < 1:
         raise SystemExit("bench.py needs a HIP device (viorb_amd has no CPU fallback)")
     # VIORB_BENCH_REHEARSAL=1: run the N > 1 code path on a box with fewer GPUs than ranks (ranks share devices, gloo instead of
@@ -635,7 +641,7 @@ def main():
         dist_init("gloo" if rehearsal else "nccl", None if rehearsal else dev)       # "nccl" is RCCL on ROCm
     runner = {"euroc": run_tracking, "synth720p": run_tracking, "kitti_stereo": run_stereo, "local_ba": run_local_ba, "dropin": run_dropin}[args.config]
     r = runner(args, cfg, rank, dev_index, dev, world)
-    if args.config == "euroc" and world == 1 and not args.no_distortion and not args.no_host_input_pass:
+    if pinhole_pass:
         # continuity with rounds 1-2, outside the timed region: the same step on the pinhole rendering of the same scenes (those rounds' workload,
         # `--no-distortion`); the lens compresses the periphery, so its frames hold ~30 % more FAST candidates (DESIGN.md "Round 3 measurements")
         import copy

@@ -10,7 +10,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 500 python3 $R/bench.py > $OUT/${TAG}_bench256.json 2> $OUT/${TAG}_bench256.err
 echo "bench done"; date
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats -- python3 $R/bench.py --no-cpu-baseline > $OUT/${TAG}_bench256_under_rocprof.json 2> /dev/null
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats -- python3 $R/bench.py --no-cpu-baseline --no-extra-passes > $OUT/${TAG}_bench256_under_rocprof.json 2> /dev/null
 find $OUT/${TAG}_stats -name "*kernel_stats.csv" -exec cp {} $OUT/${TAG}_bench256_kernel_stats.csv \;
 echo "kernel stats done"; date
 for C in FETCH_SIZE WRITE_SIZE; do
