@@ -1548,9 +1548,20 @@ static int ba_run_lockstep(Win* w, int n, int max_in_flight, Prepare prepare) {
             nl2 = std::max(nl2, (size_t)B.D.ld * B.D.ld); n2 = std::max(n2, (size_t)B.D.np * B.D.np);
         }
         BaDev* Dv = nullptr; uint8_t** Ev = nullptr; int* d_done = nullptr;
-        struct Free { void* p[3]; ~Free() { for (void* q : p) if (q) (void)hipFree(q); } } fr{{nullptr, nullptr, nullptr}};
-        VIORB_HIP_TRY(hipMalloc(&fr.p[0], sizeof(BaDev) * na)); VIORB_HIP_TRY(hipMalloc(&fr.p[1], sizeof(uint8_t*) * na)); VIORB_HIP_TRY(hipMalloc(&fr.p[2], sizeof(int)));
-        Dv = (BaDev*)fr.p[0]; Ev = (uint8_t**)fr.p[1]; d_done = (int*)fr.p[2];
+        // the group's descriptor arrays: grow-only buffers of the calling thread (hipMalloc / hipFree synchronise the whole device)
+        struct GroupBufs {
+            void* p[3] = {nullptr, nullptr, nullptr}; int cap = 0, device = -1;
+            void drop() { for (void*& q : p) { if (q) (void)hipFree(q); q = nullptr; } cap = 0; }
+            ~GroupBufs() { drop(); }
+        };
+        static thread_local GroupBufs gb;
+        if (gb.device != lba_device() || gb.cap < na) {
+            gb.drop(); gb.device = lba_device();
+            const int want = std::max(na, 128);
+            VIORB_HIP_TRY(hipMalloc(&gb.p[0], sizeof(BaDev) * want)); VIORB_HIP_TRY(hipMalloc(&gb.p[1], sizeof(uint8_t*) * want)); VIORB_HIP_TRY(hipMalloc(&gb.p[2], sizeof(int)));
+            gb.cap = want;
+        }
+        Dv = (BaDev*)gb.p[0]; Ev = (uint8_t**)gb.p[1]; d_done = (int*)gb.p[2];
         VIORB_HIP_TRY(hipMemcpyAsync(Dv, Dh.data(), sizeof(BaDev) * na, hipMemcpyHostToDevice, st));
         VIORB_HIP_TRY(hipMemcpyAsync(Ev, Eh.data(), sizeof(uint8_t*) * na, hipMemcpyHostToDevice, st));
         VIORB_HIP_TRY(hipMemsetAsync(d_done, 0, sizeof(int), st));
