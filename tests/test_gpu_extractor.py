@@ -145,6 +145,24 @@ def test_batch_of_21_takes_the_sub_launch_and_side_stream_paths(gpu, oracle):
             np.testing.assert_array_equal(d, od, err_msg="image %d" % b)
 
 
+def test_batch_of_72_images(gpu, oracle):
+    """A batch with more (image, level) quadtrees than one round of workgroup slots and more FAST cells than one sub-launch: every image
+    must come out as the oracle's, whatever ran beside it."""
+    import torch
+    B, D = 72, 6
+    base = [make_image(500 + b, 320, 240) for b in range(D)]
+    imgs = np.stack([base[b % D] for b in range(B)])
+    ex = viorb_amd.ORBextractor(500, 1.2, 8, 20, 7, max_batch=B)
+    ox = oracle.Extractor(500, 1.2, 8, 20, 7)
+    ex.extract_batch_device(torch.from_numpy(imgs).cuda())
+    torch.cuda.synchronize()
+    ref = [ox(base[b]) for b in range(D)]
+    for b in range(B):
+        k, d = ex.download(b)
+        np.testing.assert_array_equal(k, ref[b % D][0], err_msg="image %d" % b)
+        np.testing.assert_array_equal(d, ref[b % D][1], err_msg="image %d" % b)
+
+
 def test_edge_inputs(gpu, oracle):
     ex = viorb_amd.ORBextractor(300, 1.2, 8, 20, 7)
     k, d = ex(np.full((120, 160), 77, np.uint8))               # textureless: zero keypoints everywhere
