@@ -47,6 +47,7 @@ struct BaDev {
     double *e_pvr, *e_b;            // [W][9], [W][3]
     double *scal;                   // [8]: 0 chi2, 1 scale, 2 ok, 3 max diag
     double *ctl;                    // device-side LM control (BA_CTL_*), used when use_ctl != 0: kernels return at once while ctl[HALT] != 0
+    int *ticket;                    // block counter of k_ba_f_errors_decide (the last block to add its chi2 takes the trial's decision)
     int use_ctl;                    // and take lambda from ctl[LAMBDA] instead of their argument
     const unsigned long long* abort_host;   // page-locked word the waiting host thread sets when the caller's pbStopFlag goes up (nullptr: no flag)
     double cam[16], gw[3];
@@ -158,11 +159,61 @@ __device__ __forceinline__ void k_ba_lin_points_body(const BaDev& D, int mono_ke
     for (int a = 0; a < 3; a++) D.bl[(size_t)p * 3 + a] = b[a];
 }
 
+// The same linearisation with one thread per EDGE (Jacobians, weight, W block) and the point blocks summed afterwards by one thread per
+// point from the stored Jacobians (k_ba_hll_body: same terms in the same order as k_ba_lin_points_body, bit for bit): a single window
+// has 2000 points = 8 workgroups for the version above but 43 for this one.
+__device__ __forceinline__ void k_ba_lin_edges_body(const BaDev& D, int mono_kernel) {
+    if (ba_skip(D)) return;
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= D.NE || D.level[k] != 0) return;
+    const double d_mono = (double)(float)sqrt(5.991);
+    d3 Pc, Paux; m33 RT; cam_t K;
+    ba_edge_geom(D, k, D.kf, D.pt, Pc, RT, Paux, K);
+    const double x = Pc.x, y = Pc.y, z = Pc.z;
+    const double j00 = K.fx / z, j02 = -x / z * K.fx / z, j11 = K.fy / z, j12 = -y / z * K.fy / z;
+    const m33 RR = mul(K.Rcb, RT), HR = mul(hat3(Paux), K.Rcb);
+    double Jp[6], Jk[12];
+    Jp[0] = -(j00 * RR.a00 + j02 * RR.a20); Jp[1] = -(j00 * RR.a01 + j02 * RR.a21); Jp[2] = -(j00 * RR.a02 + j02 * RR.a22);
+    Jp[3] = -(j11 * RR.a10 + j12 * RR.a20); Jp[4] = -(j11 * RR.a11 + j12 * RR.a21); Jp[5] = -(j11 * RR.a12 + j12 * RR.a22);
+    Jk[0] = j00 * K.Rcb.a00 + j02 * K.Rcb.a20; Jk[1] = j00 * K.Rcb.a01 + j02 * K.Rcb.a21; Jk[2] = j00 * K.Rcb.a02 + j02 * K.Rcb.a22;
+    Jk[3] = -(j00 * HR.a00 + j02 * HR.a20); Jk[4] = -(j00 * HR.a01 + j02 * HR.a21); Jk[5] = -(j00 * HR.a02 + j02 * HR.a22);
+    Jk[6] = j11 * K.Rcb.a10 + j12 * K.Rcb.a20; Jk[7] = j11 * K.Rcb.a11 + j12 * K.Rcb.a21; Jk[8] = j11 * K.Rcb.a12 + j12 * K.Rcb.a22;
+    Jk[9] = -(j11 * HR.a10 + j12 * HR.a20); Jk[10] = -(j11 * HR.a11 + j12 * HR.a21); Jk[11] = -(j11 * HR.a12 + j12 * HR.a22);
+    const double e0 = D.err[2 * k], e1 = D.err[2 * k + 1], is2 = D.e_obs[3 * k + 2];
+    double r0, r1 = 1;
+    if (mono_kernel) huber(is2 * (e0 * e0 + e1 * e1), d_mono, &r0, &r1);
+    const double w = r1 * is2;
+    D.wgt[k] = w;
+    for (int a = 0; a < 6; a++) D.Jp[6 * k + a] = Jp[a];
+    for (int a = 0; a < 12; a++) D.Jk[12 * k + a] = Jk[a];
+#pragma unroll
+    for (int r = 0; r < 6; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) D.We[18 * (size_t)k + 3 * r + c] = w * (Jk[r] * Jp[c] + Jk[6 + r] * Jp[3 + c]);
+}
+__device__ __forceinline__ void k_ba_hll_body(const BaDev& D, int bid) {
+    if (ba_skip(D)) return;
+    const int p = bid * blockDim.x + threadIdx.x;
+    if (p >= D.NP) return;
+    double H[6] = {0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};
+    for (int k = D.pt_start[p]; k < D.pt_start[p + 1]; k++) {
+        if (D.level[k] != 0) continue;
+        const double* Jp = D.Jp + 6 * (size_t)k;
+        const double w = D.wgt[k], e0 = D.err[2 * k], e1 = D.err[2 * k + 1];
+        H[0] += w * (Jp[0] * Jp[0] + Jp[3] * Jp[3]); H[1] += w * (Jp[0] * Jp[1] + Jp[3] * Jp[4]); H[2] += w * (Jp[0] * Jp[2] + Jp[3] * Jp[5]);
+        H[3] += w * (Jp[1] * Jp[1] + Jp[4] * Jp[4]); H[4] += w * (Jp[1] * Jp[2] + Jp[4] * Jp[5]); H[5] += w * (Jp[2] * Jp[2] + Jp[5] * Jp[5]);
+        for (int a = 0; a < 3; a++) b[a] -= w * (Jp[a] * e0 + Jp[3 + a] * e1);
+    }
+    double* Ho = D.Hll + (size_t)p * 9;
+    Ho[0] = H[0]; Ho[1] = H[1]; Ho[2] = H[2]; Ho[3] = H[1]; Ho[4] = H[3]; Ho[5] = H[4]; Ho[6] = H[2]; Ho[7] = H[4]; Ho[8] = H[5];
+    for (int a = 0; a < 3; a++) D.bl[(size_t)p * 3 + a] = b[a];
+}
+
 // one workgroup per local key frame: sum of Jk^T w Jk / Jk^T w e over its active edges -> the 6x6 reprojection block of Hpp, bp
-__device__ __forceinline__ void k_ba_hpp_body(const BaDev& D) {
+__device__ __forceinline__ void k_ba_hpp_body(const BaDev& D, int i = blockIdx.x) {
     if (ba_skip(D)) return;
     __shared__ double s_red[4][27];
-    const int i = blockIdx.x, t = threadIdx.x, rows = D.rows;
+    const int t = threadIdx.x, rows = D.rows;
     double a[27];
 #pragma unroll
     for (int k = 0; k < 27; k++) a[k] = 0;
@@ -202,12 +253,12 @@ __device__ __forceinline__ void k_ba_hpp_body(const BaDev& D) {
 }
 
 // one workgroup per local key frame i: IMU factor (pred(i) -> i) and bias factor
-__device__ __forceinline__ void k_ba_imu_body(const BaDev& D) {
+__device__ __forceinline__ void k_ba_imu_body(const BaDev& D, int i = blockIdx.x) {
     if (ba_skip(D)) return;
     __shared__ double J[9 * 21], OJ[9 * 21], e[9];
     __shared__ int map[21];
     __shared__ double s_w;
-    const int i = blockIdx.x, t = threadIdx.x, j = ba_pred(D, i), n = D.np;
+    const int t = threadIdx.x, j = ba_pred(D, i), n = D.np;
     if (j < 0) return;
     const double* ki = D.kf + (size_t)i * 22; const double* kj = D.kf + (size_t)j * 22;
     if (t == 0) {
@@ -267,10 +318,10 @@ __device__ __forceinline__ void k_ba_max_diag_body(const BaDev& D) {
 }
 
 // one thread per point: Dinv = (Hll + lambda I)^-1 and Dinv * bl
-__device__ __forceinline__ void k_ba_dinv_body(const BaDev& D, double lambda_arg) {
+__device__ __forceinline__ void k_ba_dinv_body(const BaDev& D, double lambda_arg, int bid = blockIdx.x) {
     if (ba_skip(D)) return;
     const double lambda = ba_lambda(D, lambda_arg);
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    const int p = bid * blockDim.x + threadIdx.x;
     if (p >= D.NP) return;
     const double* H = D.Hll + (size_t)p * 9;
     const double a = H[0] + lambda, b = H[1], c = H[2], d = H[4] + lambda, e = H[5], f = H[8] + lambda;
@@ -665,11 +716,11 @@ __device__ __forceinline__ void k_ba_gate_body(const BaDev& D, uint8_t* out, int
 }
 
 // zero Hpp / bp (and the max-diagonal accumulator) for the linearisation of an iteration; first = 1 on the first iteration of a phase
-__device__ __forceinline__ void k_ba_clear_body(const BaDev& D, int first) {
+__device__ __forceinline__ void k_ba_clear_body(const BaDev& D, int first, int bid = blockIdx.x, int nblk = gridDim.x) {
     if (ba_skip(D)) return;
     const size_t n2 = (size_t)D.np * D.np;
-    for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < n2; q += (size_t)gridDim.x * blockDim.x) D.Hpp[q] = 0.0;
-    if (blockIdx.x == 0) {
+    for (size_t q = (size_t)bid * blockDim.x + threadIdx.x; q < n2; q += (size_t)nblk * blockDim.x) D.Hpp[q] = 0.0;
+    if (bid == 0) {
         for (int q = threadIdx.x; q < D.np; q += blockDim.x) D.bp[q] = 0.0;
         if (threadIdx.x == 0) {
             if (first) { D.scal[3] = 0.0; D.ctl[BA_CTL_CHI] = D.scal[0]; D.ctl[BA_CTL_NBAD] = 0.0; }   // chi2 of the phase's first computeActiveErrors
@@ -684,11 +735,10 @@ __device__ __forceinline__ void k_ba_lambda0_body(const BaDev& D) {
 }
 // after the trial's k_ba_*_errors: rho = (chi - chi_trial) / (sum x (lambda x + b) + 1e-3) (:129-132); accepted -> lambda update, stop
 // tests; rejected -> HALT = 1 and nothing else changes (the host takes over from ST_AFTER_TRIAL with the scalars as they are)
-__global__ void k_ba_decide(BaDev D, int last_of_phase) {
+__device__ __forceinline__ void k_ba_decide_body(const BaDev& D, int last_of_phase) {     // one thread
     if (ba_skip(D)) return;
-    if (blockIdx.x != 0 || threadIdx.x != 0) return;
     double* c = D.ctl;
-    double tempChi = D.scal[0];
+    double tempChi = __hip_atomic_load(&D.scal[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const bool ok2 = D.scal[2] > 0.5;
     if (!ok2) tempChi = 1.7976931348623157e308;
     const double scale = (ok2 ? D.scal[1] : 0.0) + 1e-3;
@@ -708,6 +758,7 @@ __global__ void k_ba_decide(BaDev D, int last_of_phase) {
     c[BA_CTL_NBAD] = nBad;
     if (nBad >= 3.0 || last_of_phase || ba_abort_requested(D)) c[BA_CTL_HALT] = 2.0;      // this optimize() call is over (or "!terminate()" failed)
 }
+__global__ void k_ba_decide(BaDev D, int last_of_phase) { if (blockIdx.x == 0 && threadIdx.x == 0) k_ba_decide_body(D, last_of_phase); }
 
 
 // ---- by-value kernels of the single-window driver ---------------------------------------------------------------------------------
@@ -941,6 +992,93 @@ __global__ void k_ba_se3_errors(BaDev D, int kernels) { k_ba_se3_errors_body(D, 
 __global__ void k_ba_se3_lin_points(BaDev D, int kernels) { k_ba_se3_lin_points_body(D, kernels); }
 __global__ void k_ba_se3_update(BaDev D) { k_ba_se3_update_body(D); }
 __global__ void k_ba_se3_gate(BaDev D, uint8_t* out, int set_level) { k_ba_se3_gate_body(D, out, set_level); }
+
+// ---- fused launches of the single window's device-side LM chunk (BaSolve::advance, ST_FAST_CHUNK): kernels with no dependency between
+// them share a launch (by block range), the per-point back-substitution applies its own update, and the last block of the error pass
+// takes the trial's decision — 8 launches per LM iteration instead of 13. A single window is a chain of latency-bound launches of
+// 5-25 us each: every launch removed is ~7 us of the ~230 us a trial takes.
+__global__ __launch_bounds__(256) void k_ba_f_lin_clear(BaDev D, int mono_kernel, int first, int gP, int gC) {
+    if ((int)blockIdx.x < gP) { if (D.pose_dim == 12) k_ba_lin_points_body(D, mono_kernel); else k_ba_se3_lin_points_body(D, mono_kernel); }
+    else k_ba_clear_body(D, first, (int)blockIdx.x - gP, gC);
+}
+__global__ __launch_bounds__(256) void k_ba_f_line_clear(BaDev D, int mono_kernel, int first, int gE, int gC) {      // NavState window: one thread per edge
+    if ((int)blockIdx.x < gE) k_ba_lin_edges_body(D, mono_kernel); else k_ba_clear_body(D, first, (int)blockIdx.x - gE, gC);
+}
+__global__ __launch_bounds__(256) void k_ba_f_hpp_imu_hll(BaDev D) {
+    const int b = blockIdx.x;
+    if (b < D.W) k_ba_hpp_body(D, b); else if (b < 2 * D.W) k_ba_imu_body(D, b - D.W); else k_ba_hll_body(D, b - 2 * D.W);
+}
+__global__ __launch_bounds__(256) void k_ba_f_hpp_imu(BaDev D) {
+    if ((int)blockIdx.x < D.W) k_ba_hpp_body(D, blockIdx.x); else k_ba_imu_body(D, (int)blockIdx.x - D.W);
+}
+__global__ __launch_bounds__(256) void k_ba_f_init_dinv(BaDev D, int gR) {
+    if ((int)blockIdx.x < gR) k_ba_init_reduced_body(D, 0.0); else k_ba_dinv_body(D, 0.0, (int)blockIdx.x - gR);
+}
+__global__ __launch_bounds__(256) void k_ba_f_backsub_update(BaDev D) {
+    k_ba_backsub_body(D, 0.0);                                           // xl of this thread's point (and the scale of rho) ...
+    if (D.pose_dim == 12) k_ba_update_body(D); else k_ba_se3_update_body(D);      // ... applied by the same thread; key frames from xp
+}
+// back-substitution of the point block with EIGHT lanes per point (one observation each per trip, shuffle reduction) + the update: the
+// thread-per-point form (k_ba_backsub_body + k_ba_*_update_body) is 8 workgroups for a 2000-point window and the latency of a lane
+// walking its point's observations one after the other
+__global__ __launch_bounds__(256) void k_ba_f_backsub8_update(BaDev D) {
+    if (ba_skip(D)) return;
+    const double lambda = ba_lambda(D, 0.0);
+    __shared__ double s_red[4];
+    const int g = blockIdx.x * blockDim.x + threadIdx.x, p = g >> 3, sub = g & 7;
+    double a0 = 0, a1 = 0, a2 = 0;
+    if (p < D.NP)
+        for (int k = D.pt_start[p] + sub; k < D.pt_start[p + 1]; k += 8) {
+            if (D.level[k] != 0 || D.e_kf[k] >= D.W) continue;
+            const double* Wk = D.We + (size_t)18 * k;
+            const int ba = D.pose_dim * D.e_kf[k];
+#pragma unroll
+            for (int r = 0; r < 6; r++) {
+                const double x = D.xp[ba + ba_loc(D, r)];
+                a0 += Wk[3 * r] * x; a1 += Wk[3 * r + 1] * x; a2 += Wk[3 * r + 2] * x;
+            }
+        }
+#pragma unroll
+    for (int d = 1; d < 8; d <<= 1) { a0 += __shfl_xor(a0, d); a1 += __shfl_xor(a1, d); a2 += __shfl_xor(a2, d); }
+    double sc = 0;
+    if (p < D.NP && sub == 0) {
+        const double b0 = D.bl[3 * p], b1 = D.bl[3 * p + 1], b2 = D.bl[3 * p + 2];
+        const double c0 = b0 - a0, c1 = b1 - a1, c2 = b2 - a2;
+        const double* Di = D.Dinv + (size_t)p * 9;
+        const double x0 = Di[0] * c0 + Di[1] * c1 + Di[2] * c2, x1 = Di[3] * c0 + Di[4] * c1 + Di[5] * c2, x2 = Di[6] * c0 + Di[7] * c1 + Di[8] * c2;
+        D.xl[3 * p] = x0; D.xl[3 * p + 1] = x1; D.xl[3 * p + 2] = x2;
+        sc = x0 * (lambda * x0 + b0) + x1 * (lambda * x1 + b1) + x2 * (lambda * x2 + b2);
+        const double xs[3] = {x0, x1, x2};
+        for (int c = 0; c < 3; c++) { D.pt_bak[3 * p + c] = D.pt[3 * p + c]; D.pt[3 * p + c] += xs[c]; }      // k_ba_*_update_body's point part
+    }
+    if (blockIdx.x == 0) for (int q = threadIdx.x; q < D.np; q += blockDim.x) sc += D.xp[q] * (lambda * D.xp[q] + D.bp[q]);
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) sc += __shfl_xor(sc, d);
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = sc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(&D.scal[1], s_red[0] + s_red[1] + s_red[2] + s_red[3]);
+    if (g < D.W) {                                                       // the key frames (k_ba_update_body / k_ba_se3_update_body)
+        if (D.pose_dim == 12) {
+            double* k = D.kf + (size_t)g * 22;
+            for (int c = 0; c < 22; c++) D.kf_bak[(size_t)g * 22 + c] = k[c];
+            const pvr s = inc_small_pvr(ld_pvr(k), D.xp + 12 * g);
+            st_pvr(k, s);
+            for (int c = 0; c < 3; c++) k[19 + c] += D.xp[12 * g + 9 + c];
+        } else {
+            double* k = D.kf + (size_t)g * 7;
+            for (int c = 0; c < 7; c++) D.kf_bak[(size_t)g * 7 + c] = k[c];
+            const se3q s = se3_mul(se3_exp(D.xp + 6 * g), ba_ld_se3(k));
+            k[0] = s.r.x; k[1] = s.r.y; k[2] = s.r.z; k[3] = s.r.w; k[4] = s.t.x; k[5] = s.t.y; k[6] = s.t.z;
+        }
+    }
+}
+__global__ __launch_bounds__(256) void k_ba_f_errors_decide(BaDev D, int mono_kernel, int last_of_phase) {
+    if (D.pose_dim == 12) k_ba_errors_body(D, mono_kernel); else k_ba_se3_errors_body(D, mono_kernel);
+    __shared__ int s_last;
+    if (threadIdx.x == 0) { __threadfence(); s_last = atomicAdd(D.ticket, 1) == (int)gridDim.x - 1; }
+    __syncthreads();
+    if (s_last && threadIdx.x == 0) { *D.ticket = 0; __threadfence(); k_ba_decide_body(D, last_of_phase); }
+}
 // lock-step batch, the launches whose body depends on the kind of window (pose_dim 12: NavState, 6: vision-only SE3)
 __global__ void k_bab_errors_chi(const BaDev* __restrict__ Dv) {
     BA_B_WINDOW(); if (c[BA_B_NEED_CHI] == 0.0) return;
@@ -1124,10 +1262,11 @@ struct BaSolve {
     // LM state
     enum State { ST_OPT_BEGIN, ST_ITER_BEGIN, ST_AFTER_CHI, ST_AFTER_DIAG, ST_TRIAL_ENQ, ST_AFTER_TRIAL, ST_FINISH, ST_AFTER_FINAL, ST_DONE,
                  ST_FAST_CHUNK, ST_FAST_WAIT } state = ST_OPT_BEGIN;
-    // Device-side LM control (k_ba_decide): iterations are enqueued FAST_CHUNK at a time with no host round trip in between; the host
-    // looks at the control block (and at the caller's stop flag, which g2o polls once per iteration) once per chunk and only takes the
-    // per-trial path below after a trial was rejected. VIORB_LBA_HOST_LM=1 forces the per-trial path (tests compare both).
-    enum { FAST_CHUNK = 5 };
+    // Device-side LM control (k_ba_decide_body): iterations are enqueued FAST_CHUNK at a time with no host round trip in between (8 launches
+    // each, k_ba_f_*); the host looks at the control block once per chunk and only takes the per-trial path below after a trial was
+    // rejected. The caller's stop flag, which g2o polls once per iteration, is polled on the device through its page-locked mirror.
+    // VIORB_LBA_HOST_LM=1 forces the per-trial path (tests compare both).
+    enum { FAST_CHUNK = 10 };          // a whole optimize() call per round trip (5 and 10 iterations); the stop flag is polled on the device (k_ba_decide_body)
     bool fast_phase = false; int fast_enq = 0;
     int phase = 0, iterations = 5, it = 0, nBad = 0, qmax = 0, mono_kernel = 1;
     int its[2] = {0, 0}; double chi[2] = {0, 0};
@@ -1165,26 +1304,24 @@ struct BaSolve {
                 const unsigned gC = (unsigned)std::min<size_t>((n2 + TB - 1) / TB, 256);
                 for (int i = 0; i < n; i++, fast_enq++) {
                     const int first = fast_enq == 0;
-                    hipLaunchKernelGGL(k_ba_clear, dim3(gC), dim3(TB), 0, st, D, first);
-                    if (model == 0) hipLaunchKernelGGL(k_ba_lin_points, dim3(gP), dim3(TB), 0, st, D, mono_kernel);
-                    else hipLaunchKernelGGL(k_ba_se3_lin_points, dim3(gP), dim3(TB), 0, st, D, mono_kernel);
-                    hipLaunchKernelGGL(k_ba_hpp, dim3(n_local), dim3(256), 0, st, D);
-                    if (model == 0) hipLaunchKernelGGL(k_ba_imu, dim3(n_local), dim3(256), 0, st, D);
+                    const unsigned gR = (unsigned)((nl2 + TB - 1) / TB);
+                    if (model == 0) {
+                        hipLaunchKernelGGL(k_ba_f_line_clear, dim3(gE + gC), dim3(TB), 0, st, D, mono_kernel, first, (int)gE, (int)gC);
+                        hipLaunchKernelGGL(k_ba_f_hpp_imu_hll, dim3(2 * n_local + gP), dim3(256), 0, st, D);
+                    } else {
+                        hipLaunchKernelGGL(k_ba_f_lin_clear, dim3(gP + gC), dim3(TB), 0, st, D, mono_kernel, first, (int)gP, (int)gC);
+                        hipLaunchKernelGGL(k_ba_f_hpp_imu, dim3(n_local), dim3(256), 0, st, D);
+                    }
                     if (first) {
                         hipLaunchKernelGGL(k_ba_max_diag, dim3(32), dim3(256), 0, st, D);
                         hipLaunchKernelGGL(k_ba_lambda0, dim3(1), dim3(64), 0, st, D);
                     }
-                    hipLaunchKernelGGL(k_ba_init_reduced, dim3((unsigned)((nl2 + TB - 1) / TB)), dim3(TB), 0, st, D, 0.0);
-                    hipLaunchKernelGGL(k_ba_dinv, dim3(gP), dim3(TB), 0, st, D, 0.0);
+                    hipLaunchKernelGGL(k_ba_f_init_dinv, dim3(gR + gP), dim3(TB), 0, st, D, (int)gR);
                     hipLaunchKernelGGL(k_ba_schur, dim3(n_local * (n_local + 1) / 2), dim3(64), 0, st, D);
                     (void)raise_dynamic_lds(reinterpret_cast<const void*>(k_ba_chol_solve), BA_CHOL_LDS_BYTES);
                     hipLaunchKernelGGL(k_ba_chol_solve, dim3(1), dim3(BA_CHOL_THREADS), BA_CHOL_LDS_BYTES, st, D);
-                    hipLaunchKernelGGL(k_ba_backsub, dim3(gP), dim3(TB), 0, st, D, 0.0);
-                    if (model == 0) hipLaunchKernelGGL(k_ba_update, dim3(std::max(gP, 1)), dim3(TB), 0, st, D);
-                    else hipLaunchKernelGGL(k_ba_se3_update, dim3(std::max(gP, 1)), dim3(TB), 0, st, D);
-                    if (model == 0) hipLaunchKernelGGL(k_ba_errors, dim3(gE), dim3(TB), 0, st, D, mono_kernel);
-                    else hipLaunchKernelGGL(k_ba_se3_errors, dim3(gE), dim3(TB), 0, st, D, mono_kernel);
-                    hipLaunchKernelGGL(k_ba_decide, dim3(1), dim3(64), 0, st, D, 0);
+                    hipLaunchKernelGGL(k_ba_f_backsub8_update, dim3((unsigned)std::max((8 * npts + TB - 1) / TB, 1)), dim3(TB), 0, st, D);
+                    hipLaunchKernelGGL(k_ba_f_errors_decide, dim3(gE), dim3(TB), 0, st, D, mono_kernel, 0);
                 }
                 D.use_ctl = 0;
                 VIORB_HIP_TRY(hipMemcpyAsync(h, D.scal, 8 * sizeof(double), hipMemcpyDeviceToHost, st));
@@ -1424,7 +1561,7 @@ static int ba_prepare_navstate(BaSolve& S, const double* kfs, int nk, int n_loca
               B.alloc(&D.Hll, (size_t)npts * 9) && B.alloc(&D.bl, (size_t)npts * 3) && B.alloc(&D.Dinv, (size_t)npts * 9) &&
               B.alloc(&D.Hpp, n2) && B.alloc(&D.bp, D.np) && B.alloc(&D.S, nl2 + (size_t)16 * D.ld + (size_t)(D.ld / 16) * 256) && B.alloc(&D.bs, D.ld) && B.alloc(&D.xp, D.ld) && B.alloc(&D.db, (size_t)npts * 3) && B.alloc(&D.xl, (size_t)npts * 3) &&
               B.alloc(&d_pre, (size_t)n_local * 142, preint) && B.alloc(&d_info, info_pvr.size(), info_pvr.data()) &&
-              B.alloc(&D.e_pvr, (size_t)n_local * 9) && B.alloc(&D.e_b, (size_t)n_local * 3) && B.alloc(&D.scal, 8) && B.alloc(&D.ctl, (size_t)BA_CTL_N) && B.alloc(&d_erase, ne) && B.commit(lease.c);
+              B.alloc(&D.e_pvr, (size_t)n_local * 9) && B.alloc(&D.e_b, (size_t)n_local * 3) && B.alloc(&D.scal, 8) && B.alloc(&D.ctl, (size_t)BA_CTL_N) && B.alloc(&D.ticket, 1) && B.alloc(&d_erase, ne) && B.commit(lease.c);
     if (!ok) { set_error("device allocation / upload failed"); return VIORB_ERR_HIP; }
     D.e_pt = d_ept; D.e_kf = d_ekf; D.e_obs = d_obs; D.pt_start = d_pts; D.kf_start = d_kfs; D.kf_list = d_kfl; D.preint = d_pre; D.info_pvr = d_info;
     S.st = lease.c->st; S.h = lease.c->pinned; S.model = 0; S.stop = stop; S.d_erase = d_erase;
@@ -1731,7 +1868,7 @@ static int ba_prepare_se3(BaSolve& S, const double* kfs, int nk, int n_local, co
               B.alloc(&d_pts, npts + 1, pt_start.data()) && B.alloc(&d_kfs, n_local + 1, kf_start.data()) && B.alloc(&d_kfl, kf_list.size(), kf_list.data()) &&
               B.alloc(&D.Hll, (size_t)npts * 9) && B.alloc(&D.bl, (size_t)npts * 3) && B.alloc(&D.Dinv, (size_t)npts * 9) &&
               B.alloc(&D.Hpp, n2) && B.alloc(&D.bp, D.np) && B.alloc(&D.S, nl2 + (size_t)16 * D.ld + (size_t)(D.ld / 16) * 256) && B.alloc(&D.bs, D.ld) && B.alloc(&D.xp, D.ld) &&
-              B.alloc(&D.db, (size_t)npts * 3) && B.alloc(&D.xl, (size_t)npts * 3) && B.alloc(&D.scal, 8) && B.alloc(&D.ctl, (size_t)BA_CTL_N) && B.alloc(&d_erase, ne) && B.commit(lease.c);
+              B.alloc(&D.db, (size_t)npts * 3) && B.alloc(&D.xl, (size_t)npts * 3) && B.alloc(&D.scal, 8) && B.alloc(&D.ctl, (size_t)BA_CTL_N) && B.alloc(&D.ticket, 1) && B.alloc(&d_erase, ne) && B.commit(lease.c);
     if (!ok) { set_error("device allocation / upload failed"); return VIORB_ERR_HIP; }
     D.e_pt = d_ept; D.e_kf = d_ekf; D.e_obs = d_obs; D.pt_start = d_pts; D.kf_start = d_kfs; D.kf_list = d_kfl;
     S.st = lease.c->st; S.h = lease.c->pinned; S.model = 1; S.stop = stop; S.d_erase = d_erase;
