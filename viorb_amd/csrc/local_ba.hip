@@ -784,7 +784,7 @@ __global__ void k_ba_lambda0(BaDev D) { k_ba_lambda0_body(D); }
 // same ROUND of launches — [chi2 of a new phase] [linearise if the last trial was accepted] [lambda_0 on a phase's first iteration]
 // [one LM trial] [decide] [restore a rejected trial] [phase gate] — and the per-window state machine of g2o's Levenberg loop
 // (optimization_algorithm_levenberg.cpp:61-164) plus LocalBundleAdjustmentNavState's two optimize() calls (src/Optimizer.cc:2026-2099)
-// lives in the window's control block on the device. A round is 20 launches for the whole batch; the host only counts finished windows
+// lives in the window's control block on the device. A round is 15 launches for the whole batch (the k_bab_f_* ones cover several solver steps by block range); the host only counts finished windows
 // every few rounds.
 enum { BA_B_DONE = 16, BA_B_NEED_CHI, BA_B_NEED_LIN, BA_B_FIRST, BA_B_PHASE, BA_B_MONO, BA_B_QMAX, BA_B_GATE, BA_B_RESTORE, BA_B_ITERS,
        BA_B_ITS0, BA_B_ITS1, BA_B_CHI0, BA_B_CHI1, BA_B_ABORT, BA_B_N = 32 };
@@ -804,9 +804,6 @@ __global__ void k_bab_take_chi(const BaDev* __restrict__ Dv, int nwin) {
     if (c[BA_B_DONE] != 0.0 || c[BA_B_ABORT] != 0.0 || c[BA_B_NEED_CHI] == 0.0) return;
     c[BA_CTL_CHI] = D.scal[0]; c[BA_B_NEED_CHI] = 0.0;
 }
-__global__ void k_bab_clear(const BaDev* __restrict__ Dv) { BA_B_WINDOW(); if (c[BA_B_NEED_LIN] == 0.0) return; k_ba_clear_body(D, 0); }
-__global__ __launch_bounds__(256) void k_bab_hpp(const BaDev* __restrict__ Dv) { BA_B_WINDOW(); if (c[BA_B_NEED_LIN] == 0.0 || (int)blockIdx.x >= D.W) return; k_ba_hpp_body(D); }
-__global__ __launch_bounds__(256) void k_bab_imu(const BaDev* __restrict__ Dv) { BA_B_WINDOW(); if (c[BA_B_NEED_LIN] == 0.0 || (int)blockIdx.x >= D.W || D.pose_dim != 12) return; k_ba_imu_body(D); }
 __global__ void k_bab_max_diag(const BaDev* __restrict__ Dv) { BA_B_WINDOW(); if (c[BA_B_NEED_LIN] == 0.0 || c[BA_B_FIRST] == 0.0) return; k_ba_max_diag_body(D); }
 __global__ void k_bab_lambda0(const BaDev* __restrict__ Dv, int nwin) {
     const int w = blockIdx.x * blockDim.x + threadIdx.x;
@@ -816,8 +813,6 @@ __global__ void k_bab_lambda0(const BaDev* __restrict__ Dv, int nwin) {
     if (c[BA_B_FIRST] != 0.0) { c[BA_CTL_LAMBDA] = 1e-5 * D.scal[3]; c[BA_CTL_NI] = 2.0; c[BA_CTL_NBAD] = 0.0; c[BA_B_FIRST] = 0.0; }
     c[BA_B_NEED_LIN] = 0.0;
 }
-__global__ void k_bab_init_reduced(const BaDev* __restrict__ Dv) { BA_B_WINDOW(); k_ba_init_reduced_body(D, 0.0); }
-__global__ void k_bab_dinv(const BaDev* __restrict__ Dv) { BA_B_WINDOW(); k_ba_dinv_body(D, 0.0); }
 // The batch's grid is (pairs, windows) linearised and dealt so that all pairs of a window run on ONE XCD (workgroup ids go round-robin over the
 // eight XCDs): a window's W blocks (1.6 MB at 10.9 k edges) are read by ~5 pairs each and stay in that XCD's L2 meanwhile.
 __global__ __launch_bounds__(64) void k_bab_schur(const BaDev* __restrict__ Dv, int npairs, int nwin) {
@@ -830,7 +825,6 @@ __global__ __launch_bounds__(64) void k_bab_schur(const BaDev* __restrict__ Dv, 
     k_ba_schur_body(D, pid);
 }
 __global__ __launch_bounds__(BA_CHOL_THREADS) void k_bab_chol_solve(const BaDev* __restrict__ Dv) { extern __shared__ __attribute__((aligned(16))) double s_chol[]; BA_B_WINDOW(); k_ba_chol_solve_body(D, s_chol); }
-__global__ void k_bab_backsub(const BaDev* __restrict__ Dv) { BA_B_WINDOW(); k_ba_backsub_body(D, 0.0); }
 // the Levenberg decisions of one trial, per window (:129-161), and the end of an optimize() call
 __global__ void k_bab_decide(const BaDev* __restrict__ Dv, int nwin) {
     const int w = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1014,14 +1008,10 @@ __global__ __launch_bounds__(256) void k_ba_f_hpp_imu(BaDev D) {
 __global__ __launch_bounds__(256) void k_ba_f_init_dinv(BaDev D, int gR) {
     if ((int)blockIdx.x < gR) k_ba_init_reduced_body(D, 0.0); else k_ba_dinv_body(D, 0.0, (int)blockIdx.x - gR);
 }
-__global__ __launch_bounds__(256) void k_ba_f_backsub_update(BaDev D) {
-    k_ba_backsub_body(D, 0.0);                                           // xl of this thread's point (and the scale of rho) ...
-    if (D.pose_dim == 12) k_ba_update_body(D); else k_ba_se3_update_body(D);      // ... applied by the same thread; key frames from xp
-}
 // back-substitution of the point block with EIGHT lanes per point (one observation each per trip, shuffle reduction) + the update: the
 // thread-per-point form (k_ba_backsub_body + k_ba_*_update_body) is 8 workgroups for a 2000-point window and the latency of a lane
 // walking its point's observations one after the other
-__global__ __launch_bounds__(256) void k_ba_f_backsub8_update(BaDev D) {
+__device__ __forceinline__ void k_ba_backsub8_update_body(const BaDev& D) {
     if (ba_skip(D)) return;
     const double lambda = ba_lambda(D, 0.0);
     __shared__ double s_red[4];
@@ -1072,6 +1062,25 @@ __global__ __launch_bounds__(256) void k_ba_f_backsub8_update(BaDev D) {
         }
     }
 }
+__global__ __launch_bounds__(256) void k_ba_f_backsub8_update(BaDev D) { k_ba_backsub8_update_body(D); }
+// ---- the lock-step batch's fused launches (blockIdx.y = window; the same bodies, gated by the window's control block) ----
+__global__ __launch_bounds__(256) void k_bab_f_lin_clear(const BaDev* __restrict__ Dv, int gL, int gC) {   // gL = blocks of the linearisation: edges (NavState) or points (SE3)
+    BA_B_WINDOW(); if (c[BA_B_NEED_LIN] == 0.0) return;
+    if ((int)blockIdx.x < gL) { if (D.pose_dim == 12) k_ba_lin_edges_body(D, c[BA_B_MONO] != 0.0); else k_ba_se3_lin_points_body(D, c[BA_B_MONO] != 0.0); }
+    else k_ba_clear_body(D, 0, (int)blockIdx.x - gL, gC);
+}
+__global__ __launch_bounds__(256) void k_bab_f_hpp_imu_hll(const BaDev* __restrict__ Dv, int Wmax) {
+    BA_B_WINDOW(); if (c[BA_B_NEED_LIN] == 0.0) return;
+    const int b = blockIdx.x;
+    if (b < Wmax) { if (b < D.W) k_ba_hpp_body(D, b); }
+    else if (b < 2 * Wmax) { if (b - Wmax < D.W && D.pose_dim == 12) k_ba_imu_body(D, b - Wmax); }
+    else if (D.pose_dim == 12) k_ba_hll_body(D, b - 2 * Wmax);           // the SE3 linearisation (one thread per point) wrote its point blocks itself
+}
+__global__ __launch_bounds__(256) void k_bab_f_init_dinv(const BaDev* __restrict__ Dv, int gR) {
+    BA_B_WINDOW();
+    if ((int)blockIdx.x < gR) k_ba_init_reduced_body(D, 0.0); else k_ba_dinv_body(D, 0.0, (int)blockIdx.x - gR);
+}
+__global__ __launch_bounds__(256) void k_bab_f_backsub8_update(const BaDev* __restrict__ Dv) { BA_B_WINDOW(); k_ba_backsub8_update_body(D); }
 __global__ __launch_bounds__(256) void k_ba_f_errors_decide(BaDev D, int mono_kernel, int last_of_phase) {
     if (D.pose_dim == 12) k_ba_errors_body(D, mono_kernel); else k_ba_se3_errors_body(D, mono_kernel);
     __shared__ int s_last;
@@ -1084,11 +1093,6 @@ __global__ void k_bab_errors_chi(const BaDev* __restrict__ Dv) {
     BA_B_WINDOW(); if (c[BA_B_NEED_CHI] == 0.0) return;
     if (D.pose_dim == 12) k_ba_errors_body(D, c[BA_B_MONO] != 0.0); else k_ba_se3_errors_body(D, c[BA_B_MONO] != 0.0);
 }
-__global__ void k_bab_lin_points(const BaDev* __restrict__ Dv) {
-    BA_B_WINDOW(); if (c[BA_B_NEED_LIN] == 0.0) return;
-    if (D.pose_dim == 12) k_ba_lin_points_body(D, c[BA_B_MONO] != 0.0); else k_ba_se3_lin_points_body(D, c[BA_B_MONO] != 0.0);
-}
-__global__ void k_bab_update(const BaDev* __restrict__ Dv) { BA_B_WINDOW(); if (D.pose_dim == 12) k_ba_update_body(D); else k_ba_se3_update_body(D); }
 __global__ void k_bab_errors(const BaDev* __restrict__ Dv) {
     BA_B_WINDOW();
     if (D.pose_dim == 12) k_ba_errors_body(D, c[BA_B_MONO] != 0.0); else k_ba_se3_errors_body(D, c[BA_B_MONO] != 0.0);
@@ -1171,27 +1175,36 @@ struct BaCtxLease {
 struct BaBuf {
     // Inputs are laid out in a host mirror and uploaded in one copy; work arrays follow them in the arena and are only zeroed on the
     // device (uploading their zeros from the host was most of the per-window host time of a batch).
-    struct Item { void** slot; size_t off; bool work; };
+    struct Item { void** slot; size_t off; int kind; };            // 0 input, 1 zeroed work array, 2 work array that is written before it is read
     std::vector<Item> items;
     std::vector<uint8_t> mirror;
-    size_t work_bytes = 0;
+    size_t work_bytes = 0, raw_bytes = 0;
     template <class T> bool alloc(T** d, size_t n, const T* src = nullptr) {
         const size_t bytes = std::max<size_t>(n, 1) * sizeof(T);
         if (src) {
             const size_t off = (mirror.size() + 255) & ~(size_t)255;
             mirror.resize(off + bytes, 0);
             if (n) memcpy(mirror.data() + off, src, n * sizeof(T));
-            items.push_back({reinterpret_cast<void**>(d), off, false});
+            items.push_back({reinterpret_cast<void**>(d), off, 0});
         } else {
             const size_t off = (work_bytes + 255) & ~(size_t)255;
             work_bytes = off + bytes;
-            items.push_back({reinterpret_cast<void**>(d), off, true});
+            items.push_back({reinterpret_cast<void**>(d), off, 1});
         }
         *d = nullptr;
         return true;
     }
+    // the large per-edge / per-point work arrays: every element a kernel reads has been written by an earlier kernel of the same solve
+    // (zeroing them was 4 MB of memset per window, 8 % of a batch's stream time)
+    template <class T> bool alloc_raw(T** d, size_t n) {
+        const size_t off = (raw_bytes + 255) & ~(size_t)255;
+        raw_bytes = off + std::max<size_t>(n, 1) * sizeof(T);
+        items.push_back({reinterpret_cast<void**>(d), off, 2});
+        *d = nullptr;
+        return true;
+    }
     bool commit(BaCtx* c) {
-        const size_t in_bytes = (mirror.size() + 255) & ~(size_t)255, total = in_bytes + work_bytes;
+        const size_t in_bytes = (mirror.size() + 255) & ~(size_t)255, zero_bytes = (work_bytes + 255) & ~(size_t)255, total = in_bytes + zero_bytes + raw_bytes;
         if (c->bytes < total) {
             if (c->arena) (void)hipFree(c->arena);
             c->arena = nullptr; c->bytes = 0;
@@ -1215,7 +1228,7 @@ struct BaBuf {
             if (hipMemcpyAsync(base, c->stage, mirror.size(), hipMemcpyHostToDevice, c->st) != hipSuccess) return false;
         }
         if (work_bytes && hipMemsetAsync(base + in_bytes, 0, work_bytes, c->st) != hipSuccess) return false;
-        for (const Item& it : items) *it.slot = base + (it.work ? in_bytes + it.off : it.off);
+        for (const Item& it : items) *it.slot = base + (it.kind == 0 ? it.off : (it.kind == 1 ? in_bytes + it.off : in_bytes + zero_bytes + it.off));
         return true;
     }
 };
@@ -1553,13 +1566,13 @@ static int ba_prepare_navstate(BaSolve& S, const double* kfs, int nk, int n_loca
     int *d_ept, *d_ekf, *d_pts, *d_kfs, *d_kfl; double *d_obs, *d_pre, *d_info; uint8_t* d_erase;
     D.ld = (D.np + 15) & ~15;
     const size_t n2 = (size_t)D.np * D.np, nl2 = (size_t)D.ld * D.ld;
-    bool ok = B.alloc(&D.kf, (size_t)nk * 22, kfs) && B.alloc(&D.kf_bak, (size_t)nk * 22) && B.alloc(&D.pt, (size_t)npts * 3, points) && B.alloc(&D.pt_bak, (size_t)npts * 3) &&
+    bool ok = B.alloc(&D.kf, (size_t)nk * 22, kfs) && B.alloc_raw(&D.kf_bak, (size_t)nk * 22) && B.alloc(&D.pt, (size_t)npts * 3, points) && B.alloc_raw(&D.pt_bak, (size_t)npts * 3) &&
               B.alloc(&d_ept, ne, e_pt.data()) && B.alloc(&d_ekf, ne, e_kf.data()) && B.alloc(&d_obs, (size_t)ne * 3, edge_obs) && B.alloc(&D.level, ne) &&
-              B.alloc(&D.err, (size_t)ne * 2) && B.alloc(&D.Jp, (size_t)ne * 6) && B.alloc(&D.Jk, (size_t)ne * 12) && B.alloc(&D.wgt, ne) && B.alloc(&D.We, (size_t)ne * 18) &&
-              B.alloc(&D.pr_start, (size_t)n_local * (n_local + 1) / 2 + 1) && B.alloc(&D.pr_ent, 2 * pr_bound + 2) &&
+              B.alloc_raw(&D.err, (size_t)ne * 2) && B.alloc_raw(&D.Jp, (size_t)ne * 6) && B.alloc_raw(&D.Jk, (size_t)ne * 12) && B.alloc_raw(&D.wgt, ne) && B.alloc_raw(&D.We, (size_t)ne * 18) &&
+              B.alloc(&D.pr_start, (size_t)n_local * (n_local + 1) / 2 + 1) && B.alloc_raw(&D.pr_ent, 2 * pr_bound + 2) &&
               B.alloc(&d_pts, npts + 1, pt_start.data()) && B.alloc(&d_kfs, n_local + 1, kf_start.data()) && B.alloc(&d_kfl, kf_list.size(), kf_list.data()) &&
-              B.alloc(&D.Hll, (size_t)npts * 9) && B.alloc(&D.bl, (size_t)npts * 3) && B.alloc(&D.Dinv, (size_t)npts * 9) &&
-              B.alloc(&D.Hpp, n2) && B.alloc(&D.bp, D.np) && B.alloc(&D.S, nl2 + (size_t)16 * D.ld + (size_t)(D.ld / 16) * 256) && B.alloc(&D.bs, D.ld) && B.alloc(&D.xp, D.ld) && B.alloc(&D.db, (size_t)npts * 3) && B.alloc(&D.xl, (size_t)npts * 3) &&
+              B.alloc_raw(&D.Hll, (size_t)npts * 9) && B.alloc_raw(&D.bl, (size_t)npts * 3) && B.alloc_raw(&D.Dinv, (size_t)npts * 9) &&
+              B.alloc_raw(&D.Hpp, n2) && B.alloc(&D.bp, D.np) && B.alloc(&D.S, nl2 + (size_t)16 * D.ld + (size_t)(D.ld / 16) * 256) && B.alloc(&D.bs, D.ld) && B.alloc(&D.xp, D.ld) && B.alloc_raw(&D.db, (size_t)npts * 3) && B.alloc_raw(&D.xl, (size_t)npts * 3) &&
               B.alloc(&d_pre, (size_t)n_local * 142, preint) && B.alloc(&d_info, info_pvr.size(), info_pvr.data()) &&
               B.alloc(&D.e_pvr, (size_t)n_local * 9) && B.alloc(&D.e_b, (size_t)n_local * 3) && B.alloc(&D.scal, 8) && B.alloc(&D.ctl, (size_t)BA_CTL_N) && B.alloc(&D.ticket, 1) && B.alloc(&d_erase, ne) && B.commit(lease.c);
     if (!ok) { set_error("device allocation / upload failed"); return VIORB_ERR_HIP; }
@@ -1707,7 +1720,8 @@ static int ba_run_lockstep(Win* w, int n, int max_in_flight, Prepare prepare) {
         double* pin = S[act[0]]->h;                                      // page-locked scratch of the first window's context
         int* h_done = reinterpret_cast<int*>(pin + 48);
         const unsigned gw = (unsigned)((na + 63) / 64), gR = (unsigned)((nl2 + TB - 1) / TB), gC = (unsigned)std::min<size_t>((n2 + TB - 1) / TB, 64);
-        const dim3 Y1(1, na), YE(gE, na), YP(std::max(gP, 1), na), YW(Wmax, na);
+        const dim3 Y1(1, na), YE(gE, na), YP(std::max(gP, 1), na);
+        const int gL = std::max(gE, gP), g8 = std::max(8 * gP, 1);      // blocks of the linearisation (edges or points, by the kind of window) and of the 8-lane back-substitution
         int rounds = 0, done = 0;
         std::vector<char> aborted(na, 0);
         std::vector<BaSolve*> Sp(na);
@@ -1717,19 +1731,15 @@ static int ba_run_lockstep(Win* w, int n, int max_in_flight, Prepare prepare) {
                 hipLaunchKernelGGL(k_bab_round_begin, dim3(gw), dim3(64), 0, st, Dv, na);
                 hipLaunchKernelGGL(k_bab_errors_chi, YE, dim3(TB), 0, st, Dv);
                 hipLaunchKernelGGL(k_bab_take_chi, dim3(gw), dim3(64), 0, st, Dv, na);
-                hipLaunchKernelGGL(k_bab_clear, dim3(gC, na), dim3(TB), 0, st, Dv);
-                hipLaunchKernelGGL(k_bab_lin_points, YP, dim3(TB), 0, st, Dv);
-                hipLaunchKernelGGL(k_bab_hpp, YW, dim3(256), 0, st, Dv);
-                hipLaunchKernelGGL(k_bab_imu, YW, dim3(256), 0, st, Dv);
+                hipLaunchKernelGGL(k_bab_f_lin_clear, dim3((unsigned)gL + gC, na), dim3(TB), 0, st, Dv, gL, (int)gC);
+                hipLaunchKernelGGL(k_bab_f_hpp_imu_hll, dim3((unsigned)(2 * Wmax + gP), na), dim3(256), 0, st, Dv, Wmax);
                 hipLaunchKernelGGL(k_bab_max_diag, dim3(8, na), dim3(256), 0, st, Dv);
                 hipLaunchKernelGGL(k_bab_lambda0, dim3(gw), dim3(64), 0, st, Dv, na);
-                hipLaunchKernelGGL(k_bab_init_reduced, dim3(gR, na), dim3(TB), 0, st, Dv);
-                hipLaunchKernelGGL(k_bab_dinv, YP, dim3(TB), 0, st, Dv);
+                hipLaunchKernelGGL(k_bab_f_init_dinv, dim3(gR + (unsigned)gP, na), dim3(TB), 0, st, Dv, (int)gR);
                 hipLaunchKernelGGL(k_bab_schur, dim3((unsigned)(Wmax * (Wmax + 1) / 2) * 8u * (unsigned)((na + 7) / 8)), dim3(64), 0, st, Dv, Wmax * (Wmax + 1) / 2, na);
                 (void)raise_dynamic_lds(reinterpret_cast<const void*>(k_bab_chol_solve), BA_CHOL_LDS_BYTES);
                 hipLaunchKernelGGL(k_bab_chol_solve, Y1, dim3(BA_CHOL_THREADS), BA_CHOL_LDS_BYTES, st, Dv);
-                hipLaunchKernelGGL(k_bab_backsub, YP, dim3(TB), 0, st, Dv);
-                hipLaunchKernelGGL(k_bab_update, YP, dim3(TB), 0, st, Dv);
+                hipLaunchKernelGGL(k_bab_f_backsub8_update, dim3((unsigned)g8, na), dim3(TB), 0, st, Dv);
                 hipLaunchKernelGGL(k_bab_errors, YE, dim3(TB), 0, st, Dv);
                 hipLaunchKernelGGL(k_bab_decide, dim3(gw), dim3(64), 0, st, Dv, na);
                 hipLaunchKernelGGL(k_bab_restore, YP, dim3(TB), 0, st, Dv);
@@ -1861,14 +1871,14 @@ static int ba_prepare_se3(BaSolve& S, const double* kfs, int nk, int n_local, co
     const size_t n2 = (size_t)D.np * D.np, nl2 = (size_t)D.ld * D.ld;
     int *d_ept, *d_ekf, *d_pts, *d_kfs, *d_kfl; double* d_obs; uint8_t* d_erase;
     D.preint = nullptr; D.info_pvr = nullptr; D.e_pvr = nullptr; D.e_b = nullptr;
-    bool ok = B.alloc(&D.kf, (size_t)nk * 7, kfs) && B.alloc(&D.kf_bak, (size_t)nk * 7) && B.alloc(&D.pt, (size_t)npts * 3, points) && B.alloc(&D.pt_bak, (size_t)npts * 3) &&
+    bool ok = B.alloc(&D.kf, (size_t)nk * 7, kfs) && B.alloc_raw(&D.kf_bak, (size_t)nk * 7) && B.alloc(&D.pt, (size_t)npts * 3, points) && B.alloc_raw(&D.pt_bak, (size_t)npts * 3) &&
               B.alloc(&d_ept, ne, e_pt.data()) && B.alloc(&d_ekf, ne, e_kf.data()) && B.alloc(&d_obs, (size_t)ne * 4, edge_obs) && B.alloc(&D.level, ne) &&
-              B.alloc(&D.err, (size_t)ne * 3) && B.alloc(&D.Jp, (size_t)ne * 9) && B.alloc(&D.Jk, (size_t)ne * 18) && B.alloc(&D.wgt, ne) && B.alloc(&D.We, (size_t)ne * 18) &&
-              B.alloc(&D.pr_start, (size_t)n_local * (n_local + 1) / 2 + 1) && B.alloc(&D.pr_ent, 2 * pr_bound + 2) &&
+              B.alloc_raw(&D.err, (size_t)ne * 3) && B.alloc_raw(&D.Jp, (size_t)ne * 9) && B.alloc_raw(&D.Jk, (size_t)ne * 18) && B.alloc_raw(&D.wgt, ne) && B.alloc_raw(&D.We, (size_t)ne * 18) &&
+              B.alloc(&D.pr_start, (size_t)n_local * (n_local + 1) / 2 + 1) && B.alloc_raw(&D.pr_ent, 2 * pr_bound + 2) &&
               B.alloc(&d_pts, npts + 1, pt_start.data()) && B.alloc(&d_kfs, n_local + 1, kf_start.data()) && B.alloc(&d_kfl, kf_list.size(), kf_list.data()) &&
-              B.alloc(&D.Hll, (size_t)npts * 9) && B.alloc(&D.bl, (size_t)npts * 3) && B.alloc(&D.Dinv, (size_t)npts * 9) &&
-              B.alloc(&D.Hpp, n2) && B.alloc(&D.bp, D.np) && B.alloc(&D.S, nl2 + (size_t)16 * D.ld + (size_t)(D.ld / 16) * 256) && B.alloc(&D.bs, D.ld) && B.alloc(&D.xp, D.ld) &&
-              B.alloc(&D.db, (size_t)npts * 3) && B.alloc(&D.xl, (size_t)npts * 3) && B.alloc(&D.scal, 8) && B.alloc(&D.ctl, (size_t)BA_CTL_N) && B.alloc(&D.ticket, 1) && B.alloc(&d_erase, ne) && B.commit(lease.c);
+              B.alloc_raw(&D.Hll, (size_t)npts * 9) && B.alloc_raw(&D.bl, (size_t)npts * 3) && B.alloc_raw(&D.Dinv, (size_t)npts * 9) &&
+              B.alloc_raw(&D.Hpp, n2) && B.alloc(&D.bp, D.np) && B.alloc(&D.S, nl2 + (size_t)16 * D.ld + (size_t)(D.ld / 16) * 256) && B.alloc(&D.bs, D.ld) && B.alloc(&D.xp, D.ld) &&
+              B.alloc_raw(&D.db, (size_t)npts * 3) && B.alloc_raw(&D.xl, (size_t)npts * 3) && B.alloc(&D.scal, 8) && B.alloc(&D.ctl, (size_t)BA_CTL_N) && B.alloc(&D.ticket, 1) && B.alloc(&d_erase, ne) && B.commit(lease.c);
     if (!ok) { set_error("device allocation / upload failed"); return VIORB_ERR_HIP; }
     D.e_pt = d_ept; D.e_kf = d_ekf; D.e_obs = d_obs; D.pt_start = d_pts; D.kf_start = d_kfs; D.kf_list = d_kfl;
     S.st = lease.c->st; S.h = lease.c->pinned; S.model = 1; S.stop = stop; S.d_erase = d_erase;
