@@ -68,7 +68,11 @@ typedef struct viorb_extractor viorb_extractor;   /* opaque */
 
 /* Create an extractor able to process up to max_batch same-sized images per call on HIP device
  * `device`. Device buffers are sized lazily for the first image size seen and re-sized when it
- * changes. max_batch = 1 gives the literal per-camera object of the reference. */
+ * changes. max_batch = 1 gives the literal per-camera object of the reference.
+ * Limits (each refused with an error, never served with a wrong result): the node list of a level's quadtree lives in LDS, which holds
+ * a per-level quota (mnFeaturesPerLevel) of up to ~1100 — any nfeatures up to ~5000 with the reference's 8 levels of 1.2, but e.g. not
+ * 1700 features on ONE level (VIORB_ERR_UNSUPPORTED at the first image); a FAST cell wider or taller than 255 px; see also
+ * viorb_extractor_max_keypoints. There is no limit on the candidates of a level. */
 int viorb_extractor_create(const viorb_extractor_params* params, int max_batch, int device,
                            viorb_extractor** out);
 int viorb_extractor_destroy(viorb_extractor* h);
@@ -79,7 +83,11 @@ int viorb_extractor_destroy(viorb_extractor* h);
 int viorb_extractor_tables(const viorb_extractor* h, float* scale, float* inv_scale, float* sigma2,
                            float* inv_sigma2, int32_t* features_per_level);
 
-/* Upper bound on keypoints per image (sum of per-level quota + 2): size output buffers with it. */
+/* Keypoints per image that every buffer of the path is sized for (sum of per-level quota + 2): size output buffers with it. The quadtree
+ * keeps at most quota + 2 keypoints on a level — except on a level whose roots (round(width / height) of the bordered level) outnumber a
+ * quarter of its quota, where the unchecked first round keeps up to 4 x roots (src/ORBextractor.cc:514-552): a panorama-shaped image with
+ * a very small nfeatures. Such an image makes the extraction return VIORB_ERR_CAPACITY (never a silently shortened list); no camera
+ * configuration of the reference's settings files comes near it (roots <= 3, quotas >= 60). */
 int viorb_extractor_max_keypoints(const viorb_extractor* h, int* cap);
 /* Images per k_fast_cells launch of a batched call (the FAST stage of a batch goes out as several launches over sub-ranges of the
  * batch; with a kernel selection the profiler times one of them per call, in rotation). For bench.py's bytes-per-launch figure. */

@@ -163,6 +163,21 @@ def test_batch_of_72_images(gpu, oracle):
         np.testing.assert_array_equal(d, ref[b % D][1], err_msg="image %d" % b)
 
 
+def test_more_kept_keypoints_than_the_buffers_hold_is_an_error_not_a_truncation(gpu, oracle):
+    """592x158 with 172 features over 8 levels of 1.1: level 7 is 304x81 with 6 quadtree roots and a quota of 15; the unchecked first
+    round keeps 24 (the oracle returns 191 keypoints, the buffers hold sum(quota + 2) = 188). The library must say so."""
+    from viorb_amd.capi import ViorbError
+    img = make_image(7023, 592, 158)
+    ok, _ = oracle.Extractor(172, 1.1, 8, 12, 7)(img)
+    ex = viorb_amd.ORBextractor(172, 1.1, 8, 12, 7)
+    assert len(ok) > ex.cap
+    with pytest.raises(ViorbError):
+        ex(img)
+    k, d = ex(make_image(7023, 320, 240))                    # the handle stays usable
+    ok2, od2 = oracle.Extractor(172, 1.1, 8, 12, 7)(make_image(7023, 320, 240))
+    np.testing.assert_array_equal(k, ok2); np.testing.assert_array_equal(d, od2)
+
+
 def test_edge_inputs(gpu, oracle):
     ex = viorb_amd.ORBextractor(300, 1.2, 8, 20, 7)
     k, d = ex(np.full((120, 160), 77, np.uint8))               # textureless: zero keypoints everywhere

@@ -1561,7 +1561,7 @@ __global__ __launch_bounds__(256) void k_orient_describe(const uint8_t* __restri
                                                          const int* __restrict__ lvl_cnt,
                                                          viorb_keypoint* __restrict__ out_kp,
                                                          uint8_t* __restrict__ out_desc, int out_cap,
-                                                         int* __restrict__ out_cnt, XcdPlace PL) {
+                                                         int* __restrict__ out_cnt, int* __restrict__ status, XcdPlace PL) {
     const int lane = threadIdx.x & 63;
     int b, item;
     if (!xcd_place(PL, b, item)) return;
@@ -1573,7 +1573,10 @@ __global__ __launch_bounds__(256) void k_orient_describe(const uint8_t* __restri
         if (level < 0 && k < total + c) { level = l; local = k - total; }
         total += c;
     }
-    if (k == 0 && lane == 0) out_cnt[b] = min(total, out_cap);
+    // out_cap = sum over the levels of quota + 2 (viorb_extractor_max_keypoints, the pitch of every per-keypoint array downstream). A level
+    // can keep more than that only when its roots outnumber a quarter of its quota (the first round splits all n_ini roots unchecked:
+    // 592x158 with 172 features over 8 levels of 1.1 keeps 24 where the quota is 15): reported, never truncated silently
+    if (k == 0 && lane == 0) { out_cnt[b] = min(total, out_cap); if (total > out_cap) status[b] = VIORB_ERR_CAPACITY; }
     if (level < 0 || k >= out_cap) return;
     const LevelDev L = lv[level];
     const uint32_t key = lvl_kp[(size_t)b * kp_pitch + L.kp_off + local];
@@ -2313,7 +2316,7 @@ static int launch_all(viorb_extractor* h, const uint8_t* d_images, int batch, in
         ProfScope ps("k_orient_describe", st);
         const XcdPlace PL = make_place((h->out_cap + 3) / 4, batch);
         hipLaunchKernelGGL(k_orient_describe, dim3(place_blocks(PL)), dim3(256), 0, st, h->d_planes, h->d_blur, h->frame_bytes,
-                           h->d_lv, nl, h->d_lvl_kp, h->kp_pitch, h->d_lvl_cnt, h->d_kps, h->d_desc, h->out_cap, h->d_count, PL);
+                           h->d_lv, nl, h->d_lvl_kp, h->kp_pitch, h->d_lvl_cnt, h->d_kps, h->d_desc, h->out_cap, h->d_count, h->d_status, PL);
     }
     VIORB_HIP_TRY(hipGetLastError());
     h->last_stream = st; h->last_batch = batch;
@@ -2489,7 +2492,7 @@ int viorb_extractor_download(viorb_extractor* h, int b, viorb_keypoint* kps, uin
     const int m = std::min(cnt, cap);
     if (m > 0 && kps) VIORB_HIP_TRY(hipMemcpy(kps, h->d_kps + (size_t)b * h->out_cap, sizeof(viorb_keypoint) * m, hipMemcpyDeviceToHost));
     if (m > 0 && desc) VIORB_HIP_TRY(hipMemcpy(desc, h->d_desc + (size_t)b * h->out_cap * 32, (size_t)32 * m, hipMemcpyDeviceToHost));
-    if (st != VIORB_OK) { set_error("internal candidate/node capacity exceeded for image %d", b); return st; }
+    if (st != VIORB_OK) { set_error("image %d: a capacity of the extractor was exceeded (quadtree nodes / scratch slots, or more keypoints kept than viorb_extractor_max_keypoints: a level whose quadtree roots outnumber a quarter of its quota)", b); return st; }
     if (cnt > cap) { set_error("caller capacity %d < %d keypoints", cap, cnt); return VIORB_ERR_CAPACITY; }
     return VIORB_OK;
 }
