@@ -69,10 +69,10 @@ typedef struct viorb_extractor viorb_extractor;   /* opaque */
 /* Create an extractor able to process up to max_batch same-sized images per call on HIP device
  * `device`. Device buffers are sized lazily for the first image size seen and re-sized when it
  * changes. max_batch = 1 gives the literal per-camera object of the reference.
- * Limits (each refused with an error, never served with a wrong result): the node list of a level's quadtree lives in LDS, which holds
- * a per-level quota (mnFeaturesPerLevel) of up to ~1100 — any nfeatures up to ~5000 with the reference's 8 levels of 1.2, but e.g. not
- * 1700 features on ONE level (VIORB_ERR_UNSUPPORTED at the first image); a FAST cell wider or taller than 255 px; see also
- * viorb_extractor_max_keypoints. There is no limit on the candidates of a level. */
+ * Limits (each refused with an error, never served with a wrong result): a per-level quota (mnFeaturesPerLevel) above 13 000; a FAST
+ * cell wider or taller than 255 px; see also viorb_extractor_max_keypoints. There is no limit on the candidates of a level. A
+ * per-level quota above ~1100 (e.g. 1700 features on ONE level; any nfeatures up to ~5000 with the reference's 8 levels of 1.2 stays
+ * below) moves the quadtree's node lists from LDS to global memory: same output, a slower quadtree. */
 int viorb_extractor_create(const viorb_extractor_params* params, int max_batch, int device,
                            viorb_extractor** out);
 int viorb_extractor_destroy(viorb_extractor* h);

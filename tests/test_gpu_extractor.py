@@ -229,7 +229,10 @@ def test_properties_full_size(gpu):
 
 
 @pytest.mark.parametrize("w,h,nf,sf,nl,ini,mn", [(640, 480, 800, 1.2, 1, 20, 7), (640, 480, 1200, 1.1, 12, 20, 7), (500, 375, 600, 1.5, 4, 30, 10),
-                                                 (96, 80, 100, 1.2, 3, 20, 7), (131, 97, 150, 1.2, 8, 12, 5), (1280, 720, 1500, 1.2, 8, 20, 7)])
+                                                 (96, 80, 100, 1.2, 3, 20, 7), (131, 97, 150, 1.2, 8, 12, 5), (1280, 720, 1500, 1.2, 8, 20, 7),
+                                                 # per-level quotas beyond what LDS holds: 3000 features over 8 levels (the global-scratch launch needs > 64 KB of LDS),
+                                                 # 1728 on ONE level and 2393 on three (node list and sort keys in global scratch, every level through that launch)
+                                                 (752, 480, 3000, 1.2, 8, 20, 7), (741, 663, 1728, 1.5, 1, 20, 7), (680, 567, 2393, 1.5, 3, 30, 5)])
 def test_constructor_parameter_variations(gpu, oracle, w, h, nf, sf, nl, ini, mn):
     """Other pyramid depths / scale factors / thresholds / tiny images (one or two large FAST cells per level, vanishing upper
     levels) and the 1280x720 / 1500-feature configuration of BASELINE.json: keypoints and descriptors bit-exact."""

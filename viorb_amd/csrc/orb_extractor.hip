@@ -1179,7 +1179,8 @@ __global__ __launch_bounds__(64) void k_octree(const LevelDev* __restrict__ lv, 
                                                uint32_t* __restrict__ lvl_kp, int kp_pitch, int* __restrict__ lvl_cnt,
                                                int* __restrict__ lvl_ncand, int nlevels, int* __restrict__ status,
                                                int ncap, int nodecap, int sortcap, int n_above, int n_upto,
-                                               uint32_t* __restrict__ big_scratch, int* __restrict__ big_next, int big_slots, int* __restrict__ lvl_tot) {
+                                               uint32_t* __restrict__ big_scratch, int* __restrict__ big_next, int big_slots, int* __restrict__ lvl_tot,
+                                               uint8_t* __restrict__ node_scratch = nullptr, size_t node_bytes = 0) {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_oct[];
     typedef typename OctT<BIG>::Perm Perm; typedef typename OctT<BIG>::Node Node; typedef typename OctT<BIG>::SortKey SortKey;
     OctLdsT<BIG> S;
@@ -1227,6 +1228,10 @@ __global__ __launch_bounds__(64) void k_octree(const LevelDev* __restrict__ lv, 
             if (slot >= big_slots) { if (lane == 0) { lvl_cnt[b * nlevels + level] = 0; lvl_ncand[b * nlevels + level] = tot; status[b] = VIORB_ERR_CAPACITY; } return; }
             uint32_t* base = big_scratch + (size_t)slot * 3 * (size_t)ncap;
             S.keys = base; S.perm0 = reinterpret_cast<Perm*>(base + ncap); S.perm1 = reinterpret_cast<Perm*>(base + 2 * (size_t)ncap);
+            if (node_scratch) {                                          // a quota whose node list does not fit LDS: nodes + sort keys in the slot as well
+                S.sortb = reinterpret_cast<SortKey*>(node_scratch + (size_t)slot * node_bytes);
+                S.nd = reinterpret_cast<Node*>(S.sortb + sortcap);
+            }
         }
     }
     // ---- 1. gather candidates in the reference's push order (cell-major, row-major inside a cell): one cell per lane, eight of its
@@ -1848,6 +1853,7 @@ struct viorb_extractor {
     int fast3_tile_bytes = 0, fast3_score_bytes = 0;
     int oct_ncap = 0, oct_nodecap = 0, oct_sortcap = 0;
     int oct_big_cap = 0, oct_big_slots = 0; uint32_t* d_oct_big = nullptr; int* d_oct_big_next = nullptr; int* d_lvl_tot = nullptr;   // over-size levels (k_octree<true>)
+    bool oct_huge = false; uint8_t* d_oct_nodes = nullptr; size_t oct_node_bytes = 0;     // a per-level quota whose node list does not fit LDS: nodes + sort keys in global scratch too
     std::vector<int> rs_pitch_dw, rs_rows;
     // second resize form (k_resize2): per-level tile table, LDS pitch, whether the level qualifies; whether level 1's kernel may also write level 0
     std::vector<int4> rs2_tiles; std::vector<int> rs2_off, rs2_pitch_dw, rs2_ok; bool rs2_copy_ok = false;
@@ -1874,9 +1880,9 @@ struct viorb_extractor {
 static void free_device(viorb_extractor* h) {
     void* ptrs[] = {h->d_planes, h->d_blur, h->d_desc, h->d_stage, h->d_lv, h->d_cells, h->d_blur_tiles, h->d_xtab,
                     h->d_ytab, h->d_slots, h->d_lvl_kp, h->d_cell_cnt, h->d_lvl_cnt, h->d_lvl_ncand, h->d_count,
-                    h->d_status, h->d_kps, h->d_rs2_tiles, h->d_rss_items, h->d_rss_etab, h->d_oct_big, h->d_oct_big_next, h->d_lvl_tot};
+                    h->d_status, h->d_kps, h->d_rs2_tiles, h->d_rss_items, h->d_rss_etab, h->d_oct_big, h->d_oct_big_next, h->d_lvl_tot, h->d_oct_nodes};
     for (void* p : ptrs) if (p) (void)hipFree(p);
-    h->d_rs2_tiles = nullptr; h->d_rss_items = nullptr; h->d_rss_etab = nullptr; h->d_oct_big = nullptr; h->d_oct_big_next = nullptr; h->d_lvl_tot = nullptr;
+    h->d_rs2_tiles = nullptr; h->d_rss_items = nullptr; h->d_rss_etab = nullptr; h->d_oct_big = nullptr; h->d_oct_big_next = nullptr; h->d_lvl_tot = nullptr; h->d_oct_nodes = nullptr;
     h->d_planes = h->d_blur = h->d_desc = h->d_stage = nullptr; h->d_lv = nullptr; h->d_cells = nullptr;
     h->d_blur_tiles = nullptr; h->d_xtab = h->d_ytab = nullptr; h->d_slots = h->d_lvl_kp = nullptr;
     h->d_cell_cnt = h->d_lvl_cnt = h->d_lvl_ncand = h->d_count = h->d_status = nullptr; h->d_kps = nullptr;
@@ -2087,8 +2093,12 @@ static int configure(viorb_extractor* h, int w, int hgt) {
     int sc = 1; while (sc < maxq + 8) sc <<= 1;
     h->oct_sortcap = sc;
     size_t oct_lds = (size_t)h->oct_ncap * 8 + (size_t)h->oct_nodecap * sizeof(OctNode) + (size_t)sc * 4;
-    if (oct_lds > 160 * 1024 || h->oct_nodecap > 65535) { set_error("nfeatures too large for the LDS quadtree (%zu B)", oct_lds); return VIORB_ERR_UNSUPPORTED; }
-    if (oct_lds > 64 * 1024 &&
+    if (h->oct_nodecap > 65535) { set_error("per-level quota %d too large for the quadtree's 16-bit node indices", maxq); return VIORB_ERR_UNSUPPORTED; }
+    // A per-level quota above ~1100 (many features on one to three levels): the node list (5 x quota nodes) does not fit LDS beside the
+    // candidates. Every level then takes the global-scratch instantiation with its nodes and sort keys in global memory as well —
+    // slower (the serial phases walk global memory), but the same decisions and the same output; the reference has no such limit.
+    h->oct_huge = oct_lds > 160 * 1024;
+    if (!h->oct_huge && oct_lds > 64 * 1024 &&
         raise_dynamic_lds(reinterpret_cast<const void*>(k_octree<false>), oct_lds) != hipSuccess) {
         (void)hipGetLastError();
         h->oct_ncap = 4096;                              // stay inside the default 64 KiB dynamic-LDS window
@@ -2096,6 +2106,11 @@ static int configure(viorb_extractor* h, int w, int hgt) {
         if (oct_lds > 64 * 1024) { set_error("quadtree LDS (%zu B) exceeds the dynamic-LDS limit", oct_lds); return VIORB_ERR_UNSUPPORTED; }
     }
 
+    if (!h->oct_huge) {                                  // the global-scratch instantiation keeps nodes and sort keys in LDS (its launch is part of every call)
+        const size_t lds_big = (size_t)h->oct_sortcap * 8 + (size_t)h->oct_nodecap * sizeof(OctNodeBig);
+        if (lds_big > 160 * 1024) h->oct_huge = true;
+        else if (lds_big > 64 * 1024) VIORB_HIP_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(k_octree<true>), lds_big));
+    }
     const size_t B = (size_t)h->max_batch;
     VIORB_HIP_TRY(hipMalloc(&h->d_planes, B * h->frame_bytes));
     VIORB_HIP_TRY(hipMalloc(&h->d_blur, B * h->frame_bytes));
@@ -2118,9 +2133,13 @@ static int configure(viorb_extractor* h, int w, int hgt) {
         int big = 1;
         for (int l = 0; l < nl; l++) big = std::max(big, h->lv[l].ncells * h->slot_cap);
         h->oct_big_cap = (int)align_up((size_t)big, 64);
-        h->oct_big_slots = (int)std::min<size_t>(B * nl, 64);
+        h->oct_big_slots = h->oct_huge ? (int)(B * nl) : (int)std::min<size_t>(B * nl, 64);
         VIORB_HIP_TRY(hipMalloc(&h->d_oct_big, (size_t)h->oct_big_slots * 3 * h->oct_big_cap * sizeof(uint32_t)));
         VIORB_HIP_TRY(hipMalloc(&h->d_oct_big_next, sizeof(int)));
+        if (h->oct_huge) {
+            h->oct_node_bytes = align_up((size_t)h->oct_sortcap * 8 + (size_t)h->oct_nodecap * sizeof(OctNodeBig), 256);
+            VIORB_HIP_TRY(hipMalloc(&h->d_oct_nodes, (size_t)h->oct_big_slots * h->oct_node_bytes));
+        }
     }
     VIORB_HIP_TRY(hipMalloc(&h->d_kps, B * h->out_cap * sizeof(viorb_keypoint)));
     VIORB_HIP_TRY(hipMalloc(&h->d_desc, B * h->out_cap * 32));
@@ -2290,25 +2309,27 @@ static int launch_all(viorb_extractor* h, const uint8_t* d_images, int batch, in
         // launch and the pair took twice as long (DESIGN.md "Round 3 measurements")
         const size_t fixed = (size_t)h->oct_nodecap * sizeof(OctNode) + (size_t)h->oct_sortcap * 4;
         const int small = std::min(h->oct_ncap, (int)OCT_NCAP_SMALL);
-        {
+        if (!h->oct_huge) {
             ProfScope ps("k_octree", st);
             hipLaunchKernelGGL(k_octree<false>, dim3(batch, nl), dim3(64), (size_t)small * 8 + fixed, st, h->d_lv, h->d_slots, h->slot_cap, h->d_cell_cnt,
                                ncells, h->d_lvl_kp, h->kp_pitch, h->d_lvl_cnt, h->d_lvl_ncand, nl, h->d_status, small, h->oct_nodecap,
                                h->oct_sortcap, -1, small, nullptr, nullptr, 0, h->d_lvl_tot);
         }
-        if (small < h->oct_ncap) {
+        if (!h->oct_huge && small < h->oct_ncap) {
             ProfScope ps("k_octree_large", st);
             hipLaunchKernelGGL(k_octree<false>, dim3(batch, nl), dim3(64), (size_t)h->oct_ncap * 8 + fixed, st, h->d_lv, h->d_slots, h->slot_cap,
                                h->d_cell_cnt, ncells, h->d_lvl_kp, h->kp_pitch, h->d_lvl_cnt, h->d_lvl_ncand, nl, h->d_status, h->oct_ncap,
                                h->oct_nodecap, h->oct_sortcap, small, h->oct_ncap, nullptr, nullptr, 0, h->d_lvl_tot);
         }
         {   // levels with more candidates than the LDS form holds (none on camera images; their workgroups read one count and return)
-            const size_t lds_big = (size_t)h->oct_sortcap * 8 + (size_t)h->oct_nodecap * sizeof(OctNodeBig);
+            const size_t lds_big = h->oct_huge ? 0 : (size_t)h->oct_sortcap * 8 + (size_t)h->oct_nodecap * sizeof(OctNodeBig);
             VIORB_HIP_TRY(hipMemsetAsync(h->d_oct_big_next, 0, sizeof(int), st));
             ProfScope ps("k_octree_big", st);
+            // huge quota: this launch takes EVERY level (n_above = -1: it counts the candidates itself), one scratch slot per (image, level)
             hipLaunchKernelGGL(k_octree<true>, dim3(batch, nl), dim3(64), lds_big, st, h->d_lv, h->d_slots, h->slot_cap, h->d_cell_cnt, ncells, h->d_lvl_kp,
                                h->kp_pitch, h->d_lvl_cnt, h->d_lvl_ncand, nl, h->d_status, h->oct_big_cap, h->oct_nodecap, h->oct_sortcap,
-                               std::max(h->oct_ncap, (int)small), 0x7fffffff, h->d_oct_big, h->d_oct_big_next, h->oct_big_slots, h->d_lvl_tot);
+                               h->oct_huge ? -1 : std::max(h->oct_ncap, (int)small), 0x7fffffff, h->d_oct_big, h->d_oct_big_next, h->oct_big_slots, h->d_lvl_tot,
+                               h->oct_huge ? h->d_oct_nodes : (uint8_t*)nullptr, h->oct_node_bytes);
         }
     }
     if (bst != st) VIORB_HIP_TRY(hipStreamWaitEvent(st, h->ev_join, 0));
