@@ -125,6 +125,15 @@ def test_native_tracker_1280x720_1500_features_equals_twin():
     assert seen == {0}, seen
 
 
+def test_native_tracker_3000_features_equals_twin():
+    """More keypoints per frame than the projection and local-point searches can cache candidate slots for in LDS (2400): above that the
+    searches take every candidate from the global list; same matches, same solves."""
+    plan = dict(B=2, image=lambda b, j, streams: streams[b]["frames"][j], last_points=lambda b, j: None,
+                map_updated=lambda b, j: b == 0 and j == 2, recent_reloc=lambda b, j: False)
+    seen = _run(1280, 720, 3000, 4, plan)
+    assert seen == {0}, seen
+
+
 def test_native_tracker_euroc_lens_distortion_equals_twin():
     """Row x2: Frame::UndistortKeyPoints + ComputeImageBounds (reference src/Frame.cc:584-644) on the device path. The EuRoC camera of the
     reference's settings file (Examples/ROS/ORB_VIO/launch/euroc.yaml:64-67, k1 = -0.283) — images rendered through that lens, keypoints

@@ -120,6 +120,7 @@ struct SearchArgs {
     uint32_t* cand;           // [B][cap][CAND_CAP] = dist<<16 | idx
     int* cand_n;              // [B][cap]
     int cap;
+    int slot_n;               // candidates per point cached in LDS: SEARCH_SLOT, or 0 when the frame's arrays leave no room (cap > ~2400)
     float minX, maxX, minY, maxY, wInv, hInv, fx, fy, cx, cy, th;
     float scale[16];
     int check_ori;
@@ -136,9 +137,11 @@ struct SearchArgs {
 #ifndef SEARCH_SLOT
 #define SEARCH_SLOT 8
 #endif
-__host__ __device__ inline size_t search_lds_bytes(int cap) {
-    return (size_t)(GRID_CELLS + 1) * 2 + 2 /*pad*/ + (size_t)cap * (2 + 8 + 4 + 1 + 3 /*pad to 4*/) + (size_t)cap * SEARCH_SLOT * 4 + (size_t)cap * 4 * 4 + 64;
+__host__ __device__ inline size_t search_lds_bytes(int cap, int slot_n = SEARCH_SLOT) {
+    return (size_t)(GRID_CELLS + 1) * 2 + 2 /*pad*/ + (size_t)cap * (2 + 8 + 4 + 1 + 3 /*pad to 4*/) + (size_t)cap * slot_n * 4 + (size_t)cap * 4 * 4 + 64;
 }
+// the slot cache is dropped (every candidate goes through the global list) when the arrays would not fit LDS with it
+__host__ inline int search_slot_n(int cap) { return search_lds_bytes(cap, SEARCH_SLOT) <= 160 * 1024 ? SEARCH_SLOT : 0; }
 
 // 1024 threads per stream: the kernel is a chain of LDS / L2 latencies per point (grid walk, descriptor fetch), so it wants every
 // point of a ~1000-point frame on its own thread and 16 waves per CU to hide them (256 threads: 0.32 ms per 256 streams)
@@ -149,8 +152,9 @@ __global__ __launch_bounds__(SEARCH_THREADS) void k_search_projection(SearchArgs
     if (A.skip_if_at_least > 0 && A.nmatches[b] >= A.skip_if_at_least) return;       // uniform per workgroup, before any barrier
     const int ncur = min(A.cur_count[b], cap), nlast = min(A.last_count[b], cap);
     // carve LDS (4-byte aligned sections first)
-    uint32_t* slot = reinterpret_cast<uint32_t*>(s_raw);                 // [cap][SLOT] dist<<16 | idx
-    int* choice = reinterpret_cast<int*>(slot + (size_t)cap * SEARCH_SLOT);   // [cap] chosen current keypoint of last point i, or -1
+    const int slot_n = A.slot_n;
+    uint32_t* slot = reinterpret_cast<uint32_t*>(s_raw);                 // [cap][slot_n] dist<<16 | idx
+    int* choice = reinterpret_cast<int*>(slot + (size_t)cap * slot_n);   // [cap] chosen current keypoint of last point i, or -1
     int* taken = choice + cap;            // [cap] per current keypoint: smallest i (with observations) that chose it
     int* owner = taken + cap;             // [cap] per current keypoint: largest i that chose it
     int* rej = owner + cap;               // [cap] scratch / per current keypoint: chosen by a point of a rejected bin
@@ -245,7 +249,7 @@ __global__ __launch_bounds__(SEARCH_THREADS) void k_search_projection(SearchArgs
     // ---- phase A
     for (int i = t; i < nlast; i += blockDim.x) {
         cand_n[i] = enumerate(i, [&](int k, uint32_t e) {
-            if (k < SEARCH_SLOT) slot[(size_t)i * SEARCH_SLOT + k] = e;
+            if (k < slot_n) slot[(size_t)i * slot_n + k] = e;
             else if (k < CAND_CAP) cand[(size_t)i * CAND_CAP + k] = e;
         });                                                            // the true count, also beyond CAND_CAP
         choice[i] = -1;
@@ -269,7 +273,7 @@ __global__ __launch_bounds__(SEARCH_THREADS) void k_search_projection(SearchArgs
                 if (dist < best) { best = dist; bidx = i2; }
             };
             if (nc <= CAND_CAP) {
-                for (int k = 0; k < nc; k++) consider(k, k < SEARCH_SLOT ? slot[(size_t)i * SEARCH_SLOT + k] : cand[(size_t)i * CAND_CAP + k]);
+                for (int k = 0; k < nc; k++) consider(k, k < slot_n ? slot[(size_t)i * slot_n + k] : cand[(size_t)i * CAND_CAP + k]);
             } else enumerate(i, consider);                        // more candidates than the stored list holds: walk the grid again
             const int nw = best <= TH_HIGH ? bidx : -1;
             changed = changed || (nw != choice[i]);
@@ -356,21 +360,22 @@ struct LocalSearchArgs {
     const uint8_t* cur_owner_obs;
     int* match; int* nmatches; int* status; float* frustum;
     uint32_t* cand; int* cand_n;
-    int cap, pcap;
+    int cap, pcap, slot_n;    // slot_n: candidates per point cached in LDS (LOCAL_SLOT or 0)
     float minX, maxX, minY, maxY, wInv, hInv, fx, fy, cx, cy, th, nnratio, log_sf;
     float scale[16];
     int nlevels;
 };
-__host__ __device__ inline size_t local_search_lds_bytes(int cap, int pcap) {
-    return (size_t)pcap * (LOCAL_SLOT * 4 + 4 + 4) + (size_t)cap * (4 + 8 + 2 + 1 + 1) + (size_t)(GRID_CELLS + 2) * 2 + 64;
+__host__ __device__ inline size_t local_search_lds_bytes(int cap, int pcap, int slot_n = LOCAL_SLOT) {
+    return (size_t)pcap * (slot_n * 4 + 4 + 4) + (size_t)cap * (4 + 8 + 2 + 1 + 1) + (size_t)(GRID_CELLS + 2) * 2 + 64;
 }
 
 __global__ __launch_bounds__(SEARCH_THREADS) void k_search_local_points(LocalSearchArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
     const int b = blockIdx.x, cap = A.cap, pcap = A.pcap, t = threadIdx.x, lane = t & 63;
     const int ncur = min(A.cur_count[b], cap), npts = min(A.pts_count[b], pcap);
-    uint32_t* slot = reinterpret_cast<uint32_t*>(s_raw);                       // [pcap][LOCAL_SLOT]
-    int* choice = reinterpret_cast<int*>(slot + (size_t)pcap * LOCAL_SLOT);     // [pcap]
+    const int slot_n = A.slot_n;
+    uint32_t* slot = reinterpret_cast<uint32_t*>(s_raw);                       // [pcap][slot_n]
+    int* choice = reinterpret_cast<int*>(slot + (size_t)pcap * slot_n);         // [pcap]
     int* nchoice = choice + pcap;                                                // [pcap]
     int* taken = nchoice + pcap;                                                 // [cap]
     float2* cxy = reinterpret_cast<float2*>(taken + cap);                        // [cap]
@@ -467,7 +472,7 @@ __global__ __launch_bounds__(SEARCH_THREADS) void k_search_local_points(LocalSea
     // ---- phase A: frustum + candidates
     for (int i = t; i < npts; i += blockDim.x) {
         cand_n[i] = enumerate(i, A.frustum ? A.frustum + ((size_t)b * pcap + i) * 5 : nullptr, [&](int k, uint32_t e) {
-            if (k < LOCAL_SLOT) slot[(size_t)i * LOCAL_SLOT + k] = e;
+            if (k < slot_n) slot[(size_t)i * slot_n + k] = e;
             else if (k < CAND_CAP) cand[(size_t)i * CAND_CAP + k] = e;
         });                                                            // the true count, also beyond CAND_CAP
         choice[i] = -1;
@@ -492,7 +497,7 @@ __global__ __launch_bounds__(SEARCH_THREADS) void k_search_local_points(LocalSea
                 else if (dist < bestDist2) { bestLevel2 = coct[i2]; bestDist2 = dist; }
             };
             if (nc <= CAND_CAP) {
-                for (int k = 0; k < nc; k++) consider(k, k < LOCAL_SLOT ? slot[(size_t)i * LOCAL_SLOT + k] : cand[(size_t)i * CAND_CAP + k]);
+                for (int k = 0; k < nc; k++) consider(k, k < slot_n ? slot[(size_t)i * slot_n + k] : cand[(size_t)i * CAND_CAP + k]);
             } else enumerate(i, nullptr, consider);               // more candidates than the stored list holds: walk the grid again
             int nw = -1;
             if (bestDist <= TH_HIGH && !(bestLevel == bestLevel2 && (float)bestDist > A.nnratio * (float)bestDist2)) nw = bestIdx;
@@ -2018,9 +2023,11 @@ int viorb_frontend_create(const viorb_frontend_config* cfg, int max_batch, int c
     h->hInv = static_cast<float>(GRID_ROWS) / static_cast<float>(cfg->max_y - cfg->min_y);
     int s = 64; while (s < cap) s <<= 1;
     h->sort_n = s;
-    if (search_lds_bytes(cap) > 160 * 1024) { delete h; set_error("cap %d needs %zu B of LDS for the projection search", cap, search_lds_bytes(cap)); return VIORB_ERR_UNSUPPORTED; }
-    if (search_lds_bytes(cap) > 64 * 1024)
-        VIORB_HIP_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(k_search_projection), search_lds_bytes(cap)));
+    {
+        const size_t lds = search_lds_bytes(cap, search_slot_n(cap));
+        if (lds > 160 * 1024) { delete h; set_error("cap %d needs %zu B of LDS for the projection search", cap, lds); return VIORB_ERR_UNSUPPORTED; }
+        if (lds > 64 * 1024) VIORB_HIP_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(k_search_projection), lds));
+    }
     VIORB_HIP_TRY(hipMalloc(&h->d_cand, (size_t)max_batch * cap * CAND_CAP * sizeof(uint32_t)));
     VIORB_HIP_TRY(hipMalloc(&h->d_cand_n, (size_t)max_batch * cap * sizeof(int)));
     VIORB_HIP_TRY(hipMalloc(&h->d_cam, 16 * sizeof(double)));
@@ -2155,7 +2162,8 @@ int viorb_frontend_search_projection_retry_device(viorb_frontend* h, const viorb
     A.skip_if_at_least = retry_below > 0 ? retry_below : 0;
     A.cur_uright = g_stereo_args.cur_uright; A.last_pose12 = g_stereo_args.last_pose12; A.bf = g_stereo_args.bf; A.mb = g_stereo_args.mb;
     ProfScope ps("k_search_projection", (hipStream_t)stream);
-    hipLaunchKernelGGL(k_search_projection, dim3(batch), dim3(SEARCH_THREADS), search_lds_bytes(h->cap), (hipStream_t)stream, A);
+    A.slot_n = search_slot_n(h->cap);
+    hipLaunchKernelGGL(k_search_projection, dim3(batch), dim3(SEARCH_THREADS), search_lds_bytes(h->cap, A.slot_n), (hipStream_t)stream, A);
     VIORB_HIP_TRY(hipGetLastError());
     return VIORB_OK;
 }
@@ -2193,7 +2201,8 @@ int viorb_frontend_search_local_points_device(viorb_frontend* h, const viorb_key
     VIORB_REQUIRE(cur_kps && cur_desc && cur_count && cell_start && cell_idx && pose12 && pts_f && pts_flags && pts_desc && pts_count &&
                   cur_owner_obs && match && nmatches && status, "null array");
     VIORB_REQUIRE(pcap >= 1 && pcap <= 65535, "1 <= pcap <= 65535");
-    const size_t lds = local_search_lds_bytes(h->cap, pcap);
+    const int lslot = local_search_lds_bytes(h->cap, pcap, LOCAL_SLOT) <= 160 * 1024 ? LOCAL_SLOT : 0;      // the slot cache only while it fits
+    const size_t lds = local_search_lds_bytes(h->cap, pcap, lslot);
     if (lds > 160 * 1024) { set_error("%d local points x %d keypoints need %zu B of LDS", pcap, h->cap, lds); return VIORB_ERR_UNSUPPORTED; }
     if (h->lcand_pcap < pcap) {
         if (h->d_lcand) (void)hipFree(h->d_lcand);
@@ -2209,7 +2218,7 @@ int viorb_frontend_search_local_points_device(viorb_frontend* h, const viorb_key
     A.cur_kps = cur_kps; A.cur_desc = cur_desc; A.cur_count = cur_count; A.cell_start = cell_start; A.cell_idx = cell_idx; A.pose12 = pose12;
     A.pts_f = pts_f; A.pts_flags = pts_flags; A.pts_desc = pts_desc; A.pts_count = pts_count; A.cur_owner_obs = cur_owner_obs;
     A.match = match; A.nmatches = nmatches; A.status = status; A.frustum = frustum; A.cand = h->d_lcand; A.cand_n = h->d_lcand_n;
-    A.cap = h->cap; A.pcap = pcap;
+    A.cap = h->cap; A.pcap = pcap; A.slot_n = lslot;
     A.minX = h->cfg.min_x; A.maxX = h->cfg.max_x; A.minY = h->cfg.min_y; A.maxY = h->cfg.max_y; A.wInv = h->wInv; A.hInv = h->hInv;
     A.fx = h->cfg.fx; A.fy = h->cfg.fy; A.cx = h->cfg.cx; A.cy = h->cfg.cy; A.th = th; A.nnratio = nnratio;
     A.log_sf = (float)log((double)h->cfg.scale_factors[h->cfg.nlevels > 1 ? 1 : 0]);   // Frame::mfLogScaleFactor = log(mfScaleFactor), rounded once
