@@ -175,6 +175,19 @@ def test_pose_optimisation_edge_counts_around_the_thread_count(torch_cuda, oracl
     np.testing.assert_allclose(g["ns"], o["ns"], rtol=0, atol=1e-7)
 
 
+@pytest.mark.parametrize("n_points,variant", [(4700, 0), (9000, 1)])
+def test_pose_optimisation_more_edges_than_the_searches_hold_keypoints(torch_cuda, oracle, n_points, variant):
+    """The host drop-in builds its handle for the number of edges; the keypoint limit of the projection search (LDS plan,
+    viorb_frontend_search_capacity) must not apply to a handle that only solves."""
+    assert n_points > viorb_amd.lib().viorb_frontend_search_capacity()
+    p = make_vio_problem(n_points, n_points=n_points)
+    o, g = _gpu_pose_opt(p, oracle, variant, True)
+    assert abs(g["final_chi2"] - o["final_chi2"]) <= 1e-5 * abs(o["final_chi2"]) and g["n_inliers"] == o["n_inliers"]
+    np.testing.assert_array_equal(g["outlier_cur"], o["outlier_cur"])
+    assert g["lm_iterations"] == o["lm_iterations"]
+    np.testing.assert_allclose(g["ns"], o["ns"], rtol=0, atol=1e-7)
+
+
 def test_pose_optimisation_random_sweep(torch_cuda, oracle):
     """Forty random problems per overload: the discrete outcomes (inliers, outlier flags, LM iterations) never differ from the oracle's."""
     for variant in (0, 1):

@@ -99,6 +99,7 @@ SIGNATURES = {
     "viorb_stereo_match": (i32, [vp, vp, f32, f32, vp, vp, i32, PP(i32)]),
     "viorb_extractor_debug_level_points": (i32, [vp, i32, i32, i32, vp, i32, PP(i32)]),
     "viorb_frontend_create": (i32, [PP(FrontendConfig), i32, i32, i32, PP(vp)]),
+    "viorb_frontend_search_capacity": (i32, []),
     "viorb_frontend_destroy": (i32, [vp]),
     "viorb_frontend_grid_device": (i32, [vp, vp, vp, i32, vp, vp, vp]),
     "viorb_frontend_undistort_device": (i32, [vp, vp, vp, i32, vp, vp]),

@@ -2023,10 +2023,10 @@ int viorb_frontend_create(const viorb_frontend_config* cfg, int max_batch, int c
     h->hInv = static_cast<float>(GRID_ROWS) / static_cast<float>(cfg->max_y - cfg->min_y);
     int s = 64; while (s < cap) s <<= 1;
     h->sort_n = s;
-    {
+    {   // the projection search's LDS plan limits cap to ~4600 — checked where it is launched: the other calls of the handle (grid, IMU
+        // prediction, pose solves: the host drop-in of PoseOptimization builds its handle for the number of edges) have no such limit
         const size_t lds = search_lds_bytes(cap, search_slot_n(cap));
-        if (lds > 160 * 1024) { delete h; set_error("cap %d needs %zu B of LDS for the projection search", cap, lds); return VIORB_ERR_UNSUPPORTED; }
-        if (lds > 64 * 1024) VIORB_HIP_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(k_search_projection), lds));
+        if (lds > 64 * 1024 && lds <= 160 * 1024) VIORB_HIP_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(k_search_projection), lds));
     }
     VIORB_HIP_TRY(hipMalloc(&h->d_cand, (size_t)max_batch * cap * CAND_CAP * sizeof(uint32_t)));
     VIORB_HIP_TRY(hipMalloc(&h->d_cand_n, (size_t)max_batch * cap * sizeof(int)));
@@ -2038,6 +2038,12 @@ int viorb_frontend_create(const viorb_frontend_config* cfg, int max_batch, int c
     VIORB_HIP_TRY(hipMemcpy(h->d_inv_sigma2, cfg->inv_level_sigma2, 16 * sizeof(float), hipMemcpyHostToDevice));
     *out = h;
     return VIORB_OK;
+}
+
+int viorb_frontend_search_capacity(void) {                                 // largest cap the projection search's LDS plan holds
+    int lo = 1, hi = 65535;
+    while (lo < hi) { const int mid = (lo + hi + 1) / 2; if (search_lds_bytes(mid, search_slot_n(mid)) <= 160 * 1024) lo = mid; else hi = mid - 1; }
+    return lo;
 }
 
 int viorb_frontend_destroy(viorb_frontend* h) {
@@ -2163,6 +2169,7 @@ int viorb_frontend_search_projection_retry_device(viorb_frontend* h, const viorb
     A.cur_uright = g_stereo_args.cur_uright; A.last_pose12 = g_stereo_args.last_pose12; A.bf = g_stereo_args.bf; A.mb = g_stereo_args.mb;
     ProfScope ps("k_search_projection", (hipStream_t)stream);
     A.slot_n = search_slot_n(h->cap);
+    if (search_lds_bytes(h->cap, A.slot_n) > 160 * 1024) { set_error("cap %d needs %zu B of LDS for the projection search", h->cap, search_lds_bytes(h->cap, A.slot_n)); return VIORB_ERR_UNSUPPORTED; }
     hipLaunchKernelGGL(k_search_projection, dim3(batch), dim3(SEARCH_THREADS), search_lds_bytes(h->cap, A.slot_n), (hipStream_t)stream, A);
     VIORB_HIP_TRY(hipGetLastError());
     return VIORB_OK;
@@ -2512,13 +2519,17 @@ int current_device() { int d = 0; if (hipGetDevice(&d) != hipSuccess) d = 0; ret
 // tables change, re-created when a call needs more keypoint capacity or runs on another device.
 struct HostFrontend { viorb_frontend* h = nullptr; ~HostFrontend() { if (h) viorb_frontend_destroy(h); } };
 static thread_local HostFrontend g_host_fe;
-static int host_frontend(const viorb_frontend_config& c, int cap, viorb_frontend** out) {
+static int host_frontend(const viorb_frontend_config& c, int cap, viorb_frontend** out, bool for_search = false) {
     const int dev = current_device();
     viorb_frontend*& h = g_host_fe.h;
-    if (h && (h->cap < cap || h->device != dev)) { viorb_frontend_destroy(h); h = nullptr; }
+    // the searches' LDS plan is sized by the handle's pitch: a handle grown for a pose solve with more edges than the searches hold
+    // keypoints (viorb_frontend_search_capacity) is replaced by one of the caller's size when a search comes
+    const int lim = viorb_frontend_search_capacity();
+    if (h && (h->cap < cap || h->device != dev || (for_search && h->cap > lim && cap <= lim))) { viorb_frontend_destroy(h); h = nullptr; }
     if (!h) {
         int want = 1024; while (want < cap) want *= 2;
         want = std::min(want, 32768);
+        if (cap <= lim) want = std::min(want, lim);                   // growth in powers of two, but not past what the searches hold
         const int rc = viorb_frontend_create(&c, 1, std::max(cap, want), dev, &h);
         if (rc != VIORB_OK) { h = nullptr; return rc; }
     } else {
@@ -2568,7 +2579,7 @@ static int search_by_projection_frame_host(const viorb_keypoint* cur_kps, const 
     for (int i = 0; i < 16; i++) c.scale_factors[i] = scale_factors[i < nlevels ? i : nlevels - 1];
     const int cap = std::max(ncur, nlast);
     viorb_frontend* h = nullptr;
-    FE_TRY(host_frontend(c, cap, &h));
+    FE_TRY(host_frontend(c, cap, &h, true));
     const int hc = h->cap;                                 // staging arrays are pitched by the (cached, possibly larger) handle capacity
     DevBuf B; viorb_keypoint *d_ck, *d_lk; uint8_t *d_cd, *d_ld, *d_lf; float *d_lp, *d_pose; int *d_cc, *d_lc, *d_cs, *d_ci, *d_m, *d_nm, *d_st;
     FE_TRY(B.up(&d_ck, (const viorb_keypoint*)nullptr, (size_t)hc)); FE_TRY(B.up(&d_lk, (const viorb_keypoint*)nullptr, (size_t)hc));
@@ -2631,7 +2642,7 @@ int viorb_fuse(const viorb_keypoint* kps, const uint8_t* desc, const float* urig
     c.nlevels = nlevels;
     for (int i = 0; i < 16; i++) { c.scale_factors[i] = scale_factors[i < nlevels ? i : nlevels - 1]; c.inv_level_sigma2[i] = inv_level_sigma2[i < nlevels ? i : nlevels - 1]; }
     viorb_frontend* h = nullptr;
-    FE_TRY(host_frontend(c, n, &h));
+    FE_TRY(host_frontend(c, n, &h, true));
     const size_t hc = (size_t)h->cap;
     DevBuf B; viorb_keypoint* d_k; uint8_t *d_d, *d_pv, *d_pd; float *d_ur, *d_pose, *d_pf; int *d_c, *d_cs, *d_ci, *d_pc, *d_bi, *d_nf;
     FE_TRY(B.up(&d_k, (const viorb_keypoint*)nullptr, hc)); FE_TRY(B.up(&d_d, (const uint8_t*)nullptr, hc * 32)); FE_TRY(B.up(&d_ur, (const float*)nullptr, hc));
@@ -2665,7 +2676,7 @@ int viorb_search_by_projection_points(const viorb_keypoint* cur_kps, const uint8
     c.nlevels = nlevels;
     for (int i = 0; i < 16; i++) c.scale_factors[i] = scale_factors[i < nlevels ? i : nlevels - 1];
     viorb_frontend* h = nullptr;
-    FE_TRY(host_frontend(c, ncur, &h));
+    FE_TRY(host_frontend(c, ncur, &h, true));
     const size_t hc = (size_t)h->cap;
     DevBuf B; viorb_keypoint* d_k; uint8_t *d_d, *d_pfl, *d_pd, *d_own; float *d_pose, *d_pf, *d_fr = nullptr; int *d_c, *d_cs, *d_ci, *d_pc, *d_m, *d_nm, *d_st;
     FE_TRY(B.up(&d_k, (const viorb_keypoint*)nullptr, hc)); FE_TRY(B.up(&d_d, (const uint8_t*)nullptr, hc * 32)); FE_TRY(B.up(&d_own, (const uint8_t*)nullptr, hc));
