@@ -85,8 +85,32 @@ def lba(seed, W, npts, extra):
     np.testing.assert_allclose(got["points"], ref["points"], rtol=0, atol=1e-6)
 
 
+def lba_se3(seed, W, nfix, npts, stereo):
+    from viorb_amd import LocalBundleAdjustment
+    from viorb_amd.synth import make_local_ba_se3_problem
+    p = make_local_ba_se3_problem(seed, W=W, n_fixed=nfix, n_points=npts, stereo_frac=stereo)
+    a = (p["kfs"], p["n_local"], p["points"], p["edge_idx"], p["edge_obs"], p["intr5"])
+    ref = oracle.local_ba_se3(*a); got = LocalBundleAdjustment(*a)
+    assert (got["its_first"], got["its_second"]) == (ref["its_first"], ref["its_second"])
+    assert abs(got["chi2_final"] - ref["chi2_final"]) <= 1e-5 * ref["chi2_final"] and np.array_equal(got["erase"], ref["erase"])
+    np.testing.assert_allclose(got["kfs"], ref["kfs"], rtol=0, atol=1e-7)
+
+
+def undistort(seed):
+    r = np.random.default_rng(seed)
+    K = np.float32([r.uniform(200, 900), r.uniform(200, 900), r.uniform(300, 700), r.uniform(200, 400)])
+    D = np.float32([r.uniform(-0.4, 0.3), r.uniform(-0.2, 0.2), r.uniform(-3e-3, 3e-3), r.uniform(-3e-3, 3e-3), r.choice([0.0, r.uniform(-0.05, 0.05)])])
+    if D[0] == 0: D[0] = np.float32(0.01)
+    xy = r.uniform([-200, -200], [1500, 1000], (int(r.integers(1, 30000)), 2)).astype(np.float32)
+    assert np.array_equal(viorb_amd.UndistortKeyPoints(xy, K, D).view(np.uint32), oracle.undistort_points(xy, K, D).view(np.uint32))
+    w, h = int(r.integers(100, 2000)), int(r.integers(100, 1200))
+    assert np.array_equal(viorb_amd.ComputeImageBounds(w, h, K, D), oracle.image_bounds(w, h, K, D))
+
+
 for i in range(N):
     s = int(rng.integers(100, 100000))
+    run("local_ba_se3", lba_se3, s, int(rng.integers(1, 41)), int(rng.integers(1, 4)), int(rng.integers(30, 1200)), float(rng.choice([0.0, 0.5, 1.0])))
+    run("undistort", undistort, s)
     n1, n2 = int(rng.integers(2, 2500)), int(rng.integers(2, 2500)); nc = int(rng.integers(1, min(n1, n2) + 1))
     run("triangulation", tri, s, n1, n2, nc, float(rng.choice([0.0, 0.3, 1.0])), bool(rng.integers(0, 2)), bool(rng.integers(0, 2)))
     k, L = int(rng.integers(2, 18)), int(rng.integers(2, 7))
