@@ -184,12 +184,20 @@ __device__ __forceinline__ void k_ba_lin_edges_body(const BaDev& D, int mono_ker
     if (mono_kernel) huber(is2 * (e0 * e0 + e1 * e1), d_mono, &r0, &r1);
     const double w = r1 * is2;
     D.wgt[k] = w;
-    for (int a = 0; a < 6; a++) D.Jp[6 * k + a] = Jp[a];
-    for (int a = 0; a < 12; a++) D.Jk[12 * k + a] = Jk[a];
+    // 16-byte stores (the blocks are 48, 96 and 144 bytes: 16-byte aligned): the kernel is bound by the number of per-lane memory operations
+    double2* Jpo = reinterpret_cast<double2*>(D.Jp + 6 * (size_t)k); double2* Jko = reinterpret_cast<double2*>(D.Jk + 12 * (size_t)k);
+    double2* Wo = reinterpret_cast<double2*>(D.We + 18 * (size_t)k);
+#pragma unroll
+    for (int a = 0; a < 3; a++) Jpo[a] = make_double2(Jp[2 * a], Jp[2 * a + 1]);
+#pragma unroll
+    for (int a = 0; a < 6; a++) Jko[a] = make_double2(Jk[2 * a], Jk[2 * a + 1]);
+    double We[18];
 #pragma unroll
     for (int r = 0; r < 6; r++)
 #pragma unroll
-        for (int c = 0; c < 3; c++) D.We[18 * (size_t)k + 3 * r + c] = w * (Jk[r] * Jp[c] + Jk[6 + r] * Jp[3 + c]);
+        for (int c = 0; c < 3; c++) We[3 * r + c] = w * (Jk[r] * Jp[c] + Jk[6 + r] * Jp[3 + c]);
+#pragma unroll
+    for (int a = 0; a < 9; a++) Wo[a] = make_double2(We[2 * a], We[2 * a + 1]);
 }
 __device__ __forceinline__ void k_ba_hll_body(const BaDev& D, int bid) {
     if (ba_skip(D)) return;
