@@ -83,12 +83,15 @@ int viorb_extractor_destroy(viorb_extractor* h);
 int viorb_extractor_tables(const viorb_extractor* h, float* scale, float* inv_scale, float* sigma2,
                            float* inv_sigma2, int32_t* features_per_level);
 
-/* Keypoints per image that every buffer of the path is sized for (sum of per-level quota + 2): size output buffers with it. The quadtree
- * keeps at most quota + 2 keypoints on a level — except on a level whose roots (round(width / height) of the bordered level) outnumber a
- * quarter of its quota, where the unchecked first round keeps up to 4 x roots (src/ORBextractor.cc:514-552): a panorama-shaped image with
- * a very small nfeatures. Such an image makes the extraction return VIORB_ERR_CAPACITY (never a silently shortened list); no camera
- * configuration of the reference's settings files comes near it (roots <= 3, quotas >= 60). */
+/* Upper bound on the keypoints of one image: size output buffers with it. The quadtree keeps at most quota + 2 keypoints on a level —
+ * except on a level whose roots (round(width / height) of the bordered level) outnumber a quarter of its quota, where the unchecked first
+ * round keeps up to 4 x roots (src/ORBextractor.cc:514-552): a panorama-shaped image with a very small nfeatures (no camera configuration
+ * of the reference's settings files comes near it: roots <= 3, quotas >= 60). viorb_extractor_max_keypoints is the sum of quota + 2, what
+ * holds for every ordinary size; viorb_extractor_max_keypoints_for(width, height) is the exact bound for that image size (the same number
+ * unless the image is of that kind) and the pitch of the handle's device results for it. A caller buffer that is too small makes the
+ * extraction return VIORB_ERR_CAPACITY (never a silently shortened list). */
 int viorb_extractor_max_keypoints(const viorb_extractor* h, int* cap);
+int viorb_extractor_max_keypoints_for(const viorb_extractor* h, int width, int height, int* cap);
 /* Images per k_fast_cells launch of a batched call (the FAST stage of a batch goes out as several launches over sub-ranges of the
  * batch; with a kernel selection the profiler times one of them per call, in rotation). For bench.py's bytes-per-launch figure. */
 int viorb_extractor_fast_launch_images(int batch);

@@ -163,19 +163,24 @@ def test_batch_of_72_images(gpu, oracle):
         np.testing.assert_array_equal(d, ref[b % D][1], err_msg="image %d" % b)
 
 
-def test_more_kept_keypoints_than_the_buffers_hold_is_an_error_not_a_truncation(gpu, oracle):
+def test_level_with_more_quadtree_roots_than_a_quarter_of_its_quota(gpu, oracle):
     """592x158 with 172 features over 8 levels of 1.1: level 7 is 304x81 with 6 quadtree roots and a quota of 15; the unchecked first
-    round keeps 24 (the oracle returns 191 keypoints, the buffers hold sum(quota + 2) = 188). The library must say so."""
-    from viorb_amd.capi import ViorbError
+    round keeps 24, the image returns 191 keypoints where sum(quota + 2) = 188 — the size-aware bound (viorb_extractor_max_keypoints_for)
+    sizes the buffers, the result is the oracle's; a caller buffer of the generic size is an error, never a truncation."""
+    import ctypes as C
+    from viorb_amd.capi import ViorbError, KP_DTYPE, ptr, check
     img = make_image(7023, 592, 158)
-    ok, _ = oracle.Extractor(172, 1.1, 8, 12, 7)(img)
+    ok, od = oracle.Extractor(172, 1.1, 8, 12, 7)(img)
     ex = viorb_amd.ORBextractor(172, 1.1, 8, 12, 7)
-    assert len(ok) > ex.cap
+    generic = ex.cap
+    assert len(ok) > generic
+    k, d = ex(img)
+    np.testing.assert_array_equal(k, ok); np.testing.assert_array_equal(d, od)
+    assert ex.cap >= len(ok) > generic
+    kb, db, n = np.zeros(generic, KP_DTYPE), np.zeros((generic, 32), np.uint8), C.c_int()
     with pytest.raises(ViorbError):
-        ex(img)
-    k, d = ex(make_image(7023, 320, 240))                    # the handle stays usable
-    ok2, od2 = oracle.Extractor(172, 1.1, 8, 12, 7)(make_image(7023, 320, 240))
-    np.testing.assert_array_equal(k, ok2); np.testing.assert_array_equal(d, od2)
+        check(ex.L.viorb_extract(ex.h, ptr(img), 592, 158, img.strides[0], ptr(kb), ptr(db), generic, C.byref(n)))
+    assert ex.capacity_for(752, 480) == generic                 # an ordinary size: the two bounds agree
 
 
 def test_edge_inputs(gpu, oracle):

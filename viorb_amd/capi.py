@@ -88,6 +88,7 @@ SIGNATURES = {
     "viorb_extractor_destroy": (i32, [vp]),
     "viorb_extractor_tables": (i32, [vp, vp, vp, vp, vp, vp]),
     "viorb_extractor_max_keypoints": (i32, [vp, PP(i32)]),
+    "viorb_extractor_max_keypoints_for": (i32, [vp, i32, i32, PP(i32)]),
     "viorb_extractor_fast_launch_images": (i32, [i32]),
     "viorb_extract": (i32, [vp, vp, i32, i32, i32, vp, vp, i32, PP(i32)]),
     "viorb_extract_batch_device": (i32, [vp, vp, i32, i32, i32, i32, sz, vp]),

@@ -1578,9 +1578,9 @@ __global__ __launch_bounds__(256) void k_orient_describe(const uint8_t* __restri
         if (level < 0 && k < total + c) { level = l; local = k - total; }
         total += c;
     }
-    // out_cap = sum over the levels of quota + 2 (viorb_extractor_max_keypoints, the pitch of every per-keypoint array downstream). A level
-    // can keep more than that only when its roots outnumber a quarter of its quota (the first round splits all n_ini roots unchecked:
-    // 592x158 with 172 features over 8 levels of 1.1 keeps 24 where the quota is 15): reported, never truncated silently
+    // out_cap = viorb_extractor_max_keypoints_for(image size): per level quota + 2, or 4 x roots where the unchecked first round keeps more
+    // (592x158 with 172 features over 8 levels of 1.1 keeps 24 on a level whose quota is 15); the pitch of every per-keypoint array
+    // downstream. Exceeding it would be a bug: reported, never truncated silently
     if (k == 0 && lane == 0) { out_cnt[b] = min(total, out_cap); if (total > out_cap) status[b] = VIORB_ERR_CAPACITY; }
     if (level < 0 || k >= out_cap) return;
     const LevelDev L = lv[level];
@@ -1889,6 +1889,20 @@ static void free_device(viorb_extractor* h) {
     h->stage_bytes = 0;
 }
 
+// Keypoints an image of w x h can return: per level what the quadtree keeps at most — quota + 2 after a checked round, or every child of the
+// unchecked first round (4 per root, roots = round(width / height) of the bordered level, reference :514-552) where that is more.
+static int max_keypoints_for_size(const viorb_extractor* h, int w, int hgt) {
+    int cap = 0;
+    for (int l = 0; l < h->p.nlevels; l++) {
+        const float s = h->inv_scale[l];
+        const int lw = host_cv_round((double)((float)w * s)), lh = host_cv_round((double)((float)hgt * s));
+        const int ow = lw - 2 * MINB, oh = lh - 2 * MINB;
+        const int n_ini = (oh > 0 && ow > 0) ? (int)roundf((float)ow / (float)oh) : 0;
+        cap += std::max(h->quota[l] + 2, 4 * n_ini);
+    }
+    return cap;
+}
+
 // Build level geometry, FAST cell table, resize tables and buffers for a w x h image.
 static int configure(viorb_extractor* h, int w, int hgt) {
     const int nl = h->p.nlevels;
@@ -2062,8 +2076,7 @@ static int configure(viorb_extractor* h, int w, int hgt) {
     }
     h->frame_bytes = align_up(off, 256);
     h->kp_pitch = kp_off;
-    int cap = 0; for (int l = 0; l < nl; l++) cap += h->quota[l] + 2;
-    h->out_cap = cap;
+    h->out_cap = max_keypoints_for_size(h, w, hgt);                       // == viorb_extractor_max_keypoints except on levels with more roots than a quarter of their quota
     const int ncells = (int)h->cells.size();
     if (ncells == 0) { set_error("image %dx%d too small for a FAST cell grid", w, hgt); return VIORB_ERR_UNSUPPORTED; }
     // FAST LDS: tile rows x pitch (dword aligned start => up to 3 extra bytes) + score map
@@ -2467,6 +2480,12 @@ int viorb_extractor_max_keypoints(const viorb_extractor* h, int* cap) {
     VIORB_REQUIRE(h && cap, "null handle/cap");
     int c = 0; for (int l = 0; l < h->p.nlevels; l++) c += h->quota[l] + 2;
     *cap = c;
+    return VIORB_OK;
+}
+
+int viorb_extractor_max_keypoints_for(const viorb_extractor* h, int width, int height, int* cap) {
+    VIORB_REQUIRE(h && cap && width > 0 && height > 0, "null handle/cap or empty size");
+    *cap = max_keypoints_for_size(h, width, height);
     return VIORB_OK;
 }
 

@@ -189,7 +189,7 @@ int viorb_tracker_create(const viorb_tracker_config* cfg, viorb_tracker** out) {
     struct Guard { viorb_tracker* h; ~Guard() { if (h) viorb_tracker_destroy(h); } } guard{h};
     h->cfg = *cfg; h->B = cfg->batch; h->device = cfg->device; h->nlevels = cfg->extractor.nlevels;
     for (int i = 0; i < 2; i++) TR_TRY(viorb_extractor_create(&cfg->extractor, cfg->batch, cfg->device, &h->ex[i]));
-    TR_TRY(viorb_extractor_max_keypoints(h->ex[0], &h->cap));
+    TR_TRY(viorb_extractor_max_keypoints_for(h->ex[0], cfg->width, cfg->height, &h->cap));      // the pitch of the extractor's results for this image size
     viorb_frontend_config fc = cfg->frontend;
     float sf[16], is2[16];
     TR_TRY(viorb_extractor_tables(h->ex[0], sf, nullptr, nullptr, is2, nullptr));

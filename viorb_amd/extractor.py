@@ -62,11 +62,20 @@ class ORBextractor:
         assert image.dtype == np.uint8 and image.ndim == 2          # reference asserts CV_8UC1
         image = np.ascontiguousarray(image)
         h, w = image.shape
-        kps = np.zeros(self.cap, KP_DTYPE)
-        desc = np.zeros((self.cap, 32), np.uint8)
+        cap = self.capacity_for(w, h)
+        kps = np.zeros(cap, KP_DTYPE)
+        desc = np.zeros((cap, 32), np.uint8)
         n = C.c_int()
-        check(self.L.viorb_extract(self.h, ptr(image), w, h, image.strides[0], ptr(kps), ptr(desc), self.cap, C.byref(n)))
+        check(self.L.viorb_extract(self.h, ptr(image), w, h, image.strides[0], ptr(kps), ptr(desc), cap, C.byref(n)))
         return kps[:n.value].copy(), desc[:n.value].copy()
+
+    def capacity_for(self, width, height):
+        """Exact keypoint bound for an image size (== self.cap unless a level has more quadtree roots than a quarter of its quota); also the
+        pitch of the handle's device results for images of that size. self.cap follows the last size asked for."""
+        cap = C.c_int()
+        check(self.L.viorb_extractor_max_keypoints_for(self.h, int(width), int(height), C.byref(cap)))
+        self.cap = cap.value
+        return cap.value
 
     # ---- batched, device-resident ---------------------------------------------------------------
     def extract_batch_device(self, images, stream=None):
@@ -80,6 +89,7 @@ class ORBextractor:
         check(self.L.viorb_extract_batch_device(self.h, ptr(images), B, w, h, images.stride(1), images.stride(0),
                                                 C.c_void_p(st.cuda_stream)))
         self._last_batch = B
+        self.capacity_for(w, h)                                  # self.cap = the pitch of the device results for this size
 
     def download(self, b):
         kps = np.zeros(self.cap, KP_DTYPE)

@@ -47,12 +47,14 @@ public:
         if (_image.empty()) return;                                   // reference src/ORBextractor.cc:1046-1047
         cv::Mat image = _image.getMat();
         assert(image.type() == CV_8UC1);
-        std::vector<viorb_keypoint> k(mCap);
-        cv::Mat desc(mCap, 32, CV_8U);
+        int cap = mCap;                                               // exact bound for this image size (== mCap for every ordinary camera)
+        viorb_extractor_max_keypoints_for(mHandle, image.cols, image.rows, &cap);
+        std::vector<viorb_keypoint> k(cap);
+        cv::Mat desc(cap, 32, CV_8U);
         int n = 0;
         // Every failure is surfaced: the reference has no error channel here (it cannot fail), so a GPU-side error — VIORB_ERR_CAPACITY
         // included: a truncated keypoint set must never flow into Frame unnoticed — becomes an exception with viorb_last_error().
-        const int rc = viorb_extract(mHandle, image.data, image.cols, image.rows, (int)image.step, &k[0], desc.data, mCap, &n);
+        const int rc = viorb_extract(mHandle, image.data, image.cols, image.rows, (int)image.step, &k[0], desc.data, cap, &n);
         if (rc != VIORB_OK) throw std::runtime_error(std::string("viorb_extract: ") + viorb_last_error());
         _keypoints.clear(); _keypoints.reserve(n);
         for (int i = 0; i < n; i++)                                    // viorb_keypoint is layout-identical to cv::KeyPoint

@@ -39,7 +39,7 @@ class BatchedTracker:
         self.exs = [ORBextractor(nfeatures, 1.2, 8, 20, 7, max_batch=batch, device=device) for _ in range(2 if overlap else 1)]
         self.ex = self.exs[0]
         t = self.ex.tables()
-        self.cap = self.ex.cap
+        self.cap = self.ex.capacity_for(width, height)
         self.overlap = overlap
         self.s_ex = torch.cuda.Stream(device=self.dev) if overlap else None
         self.s_tr = torch.cuda.Stream(device=self.dev) if overlap else None
