@@ -184,12 +184,12 @@ typedef struct viorb_frontend_config {
 } viorb_frontend_config;
 
 /* cap = keypoints per frame the handle's arrays are pitched for (viorb_extractor_max_keypoints of the extractor that feeds it). The
- * projection and local-point searches keep a frame's keypoints in LDS: cap <= viorb_frontend_search_capacity() (~4600; the reference's
- * settings files use 1000-2000 features), beyond that the searches return VIORB_ERR_UNSUPPORTED and viorb_tracker_create refuses; above
- * 2400 they give up their LDS cache of the first candidates of every point and take all candidates from the global list (same result,
- * slower). The other calls of a handle (grid, IMU prediction, pose solves) and the extractor have no such limit. */
+ * projection and local-point searches keep a frame's keypoints and their work arrays in LDS up to cap = viorb_frontend_search_capacity()
+ * (~4600; the reference's settings files use 1000-2000 features): above 2400 they give up their LDS cache of the first candidates of every
+ * point and take all candidates from the global list, above the capacity they keep the work arrays in global memory as well — same
+ * result, slower each time. cap <= 65535 (16-bit keypoint indices). */
 int viorb_frontend_create(const viorb_frontend_config* cfg, int max_batch, int cap, int device, viorb_frontend** out);
-int viorb_frontend_search_capacity(void);      /* largest cap the projection / local-point searches accept (their LDS plan) */
+int viorb_frontend_search_capacity(void);      /* largest cap whose search work arrays fit LDS (beyond it: global memory, slower) */
 int viorb_frontend_destroy(viorb_frontend* h);
 
 /* Frame::UndistortKeyPoints (reference src/Frame.cc:584-614) for a batch: kps_un[b][i] = kps[b][i] with pt replaced by

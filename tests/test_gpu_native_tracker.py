@@ -134,6 +134,17 @@ def test_native_tracker_3000_features_equals_twin():
     assert seen == {0}, seen
 
 
+def test_native_tracker_5000_features_equals_twin():
+    """More keypoints per frame than the searches' work arrays fit in LDS (viorb_frontend_search_capacity, ~4600): they then live in global
+    memory (k_search_projection<true>, k_search_local_points<true>); same matches, same solves."""
+    import viorb_amd
+    assert 5000 > viorb_amd.lib().viorb_frontend_search_capacity()
+    plan = dict(B=2, image=lambda b, j, streams: streams[b]["frames"][j], last_points=lambda b, j: None,
+                map_updated=lambda b, j: b == 1 and j == 2, recent_reloc=lambda b, j: False)
+    seen = _run(1280, 720, 5000, 4, plan)
+    assert seen == {0}, seen
+
+
 def test_native_tracker_euroc_lens_distortion_equals_twin():
     """Row x2: Frame::UndistortKeyPoints + ComputeImageBounds (reference src/Frame.cc:584-644) on the device path. The EuRoC camera of the
     reference's settings file (Examples/ROS/ORB_VIO/launch/euroc.yaml:64-67, k1 = -0.283) — images rendered through that lens, keypoints

@@ -121,6 +121,7 @@ struct SearchArgs {
     int* cand_n;              // [B][cap]
     int cap;
     int slot_n;               // candidates per point cached in LDS: SEARCH_SLOT, or 0 when the frame's arrays leave no room (cap > ~2400)
+    unsigned char* work; size_t work_bytes;   // k_search_projection<true>: the per-stream work arrays in global memory (a frame with more keypoints than LDS holds)
     float minX, maxX, minY, maxY, wInv, hInv, fx, fy, cx, cy, th;
     float scale[16];
     int check_ori;
@@ -146,8 +147,12 @@ __host__ inline int search_slot_n(int cap) { return search_lds_bytes(cap, SEARCH
 // 1024 threads per stream: the kernel is a chain of LDS / L2 latencies per point (grid walk, descriptor fetch), so it wants every
 // point of a ~1000-point frame on its own thread and 16 waves per CU to hide them (256 threads: 0.32 ms per 256 streams)
 #define SEARCH_THREADS 1024
+// GW = false: the work arrays in LDS (every frame of up to viorb_frontend_search_capacity() keypoints); GW = true: the same arrays in a
+// per-stream slice of global memory — same code, same result, for frames LDS cannot hold (the reference has no limit)
+template <bool GW>
 __global__ __launch_bounds__(SEARCH_THREADS) void k_search_projection(SearchArgs A) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_lds[];
+    unsigned char* s_raw = GW ? A.work + (size_t)blockIdx.x * A.work_bytes : s_lds;
     const int b = blockIdx.x, cap = A.cap, t = threadIdx.x, lane = t & 63;
     if (A.skip_if_at_least > 0 && A.nmatches[b] >= A.skip_if_at_least) return;       // uniform per workgroup, before any barrier
     const int ncur = min(A.cur_count[b], cap), nlast = min(A.last_count[b], cap);
@@ -361,6 +366,7 @@ struct LocalSearchArgs {
     int* match; int* nmatches; int* status; float* frustum;
     uint32_t* cand; int* cand_n;
     int cap, pcap, slot_n;    // slot_n: candidates per point cached in LDS (LOCAL_SLOT or 0)
+    unsigned char* work; size_t work_bytes;   // k_search_local_points<true>: the per-stream work arrays in global memory
     float minX, maxX, minY, maxY, wInv, hInv, fx, fy, cx, cy, th, nnratio, log_sf;
     float scale[16];
     int nlevels;
@@ -369,8 +375,10 @@ __host__ __device__ inline size_t local_search_lds_bytes(int cap, int pcap, int 
     return (size_t)pcap * (slot_n * 4 + 4 + 4) + (size_t)cap * (4 + 8 + 2 + 1 + 1) + (size_t)(GRID_CELLS + 2) * 2 + 64;
 }
 
+template <bool GW>
 __global__ __launch_bounds__(SEARCH_THREADS) void k_search_local_points(LocalSearchArgs A) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_lds[];
+    unsigned char* s_raw = GW ? A.work + (size_t)blockIdx.x * A.work_bytes : s_lds;
     const int b = blockIdx.x, cap = A.cap, pcap = A.pcap, t = threadIdx.x, lane = t & 63;
     const int ncur = min(A.cur_count[b], cap), npts = min(A.pts_count[b], pcap);
     const int slot_n = A.slot_n;
@@ -2001,6 +2009,7 @@ struct viorb_frontend {
     float wInv = 0, hInv = 0;
     uint32_t* d_cand = nullptr; int* d_cand_n = nullptr;
     uint32_t* d_lcand = nullptr; int* d_lcand_n = nullptr; int lcand_pcap = 0;
+    unsigned char* d_search_work = nullptr; size_t search_work_bytes = 0;      // work arrays of the searches when a frame's keypoints do not fit LDS
     double *d_cam = nullptr, *d_gw = nullptr; float* d_inv_sigma2 = nullptr; float* d_scale = nullptr;
 };
 
@@ -2026,7 +2035,7 @@ int viorb_frontend_create(const viorb_frontend_config* cfg, int max_batch, int c
     {   // the projection search's LDS plan limits cap to ~4600 — checked where it is launched: the other calls of the handle (grid, IMU
         // prediction, pose solves: the host drop-in of PoseOptimization builds its handle for the number of edges) have no such limit
         const size_t lds = search_lds_bytes(cap, search_slot_n(cap));
-        if (lds > 64 * 1024 && lds <= 160 * 1024) VIORB_HIP_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(k_search_projection), lds));
+        if (lds > 64 * 1024 && lds <= 160 * 1024) VIORB_HIP_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(k_search_projection<false>), lds));
     }
     VIORB_HIP_TRY(hipMalloc(&h->d_cand, (size_t)max_batch * cap * CAND_CAP * sizeof(uint32_t)));
     VIORB_HIP_TRY(hipMalloc(&h->d_cand_n, (size_t)max_batch * cap * sizeof(int)));
@@ -2051,6 +2060,7 @@ int viorb_frontend_destroy(viorb_frontend* h) {
     (void)hipSetDevice(h->device);
     if (h->d_cand) (void)hipFree(h->d_cand);
     if (h->d_cand_n) (void)hipFree(h->d_cand_n);
+    if (h->d_search_work) (void)hipFree(h->d_search_work);
     if (h->d_lcand) (void)hipFree(h->d_lcand);
     if (h->d_lcand_n) (void)hipFree(h->d_lcand_n);
     if (h->d_cam) (void)hipFree(h->d_cam);
@@ -2169,8 +2179,20 @@ int viorb_frontend_search_projection_retry_device(viorb_frontend* h, const viorb
     A.cur_uright = g_stereo_args.cur_uright; A.last_pose12 = g_stereo_args.last_pose12; A.bf = g_stereo_args.bf; A.mb = g_stereo_args.mb;
     ProfScope ps("k_search_projection", (hipStream_t)stream);
     A.slot_n = search_slot_n(h->cap);
-    if (search_lds_bytes(h->cap, A.slot_n) > 160 * 1024) { set_error("cap %d needs %zu B of LDS for the projection search", h->cap, search_lds_bytes(h->cap, A.slot_n)); return VIORB_ERR_UNSUPPORTED; }
-    hipLaunchKernelGGL(k_search_projection, dim3(batch), dim3(SEARCH_THREADS), search_lds_bytes(h->cap, A.slot_n), (hipStream_t)stream, A);
+    A.work = nullptr; A.work_bytes = 0;
+    if (search_lds_bytes(h->cap, A.slot_n) > 160 * 1024) {               // more keypoints per frame than LDS holds: the work arrays in global memory
+        const size_t per = (search_lds_bytes(h->cap, 0) + 255) & ~(size_t)255;
+        if (h->search_work_bytes < per * h->max_batch) {
+            VIORB_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+            if (h->d_search_work) (void)hipFree(h->d_search_work);
+            h->d_search_work = nullptr; h->search_work_bytes = 0;
+            VIORB_HIP_TRY(hipMalloc(&h->d_search_work, per * h->max_batch));
+            h->search_work_bytes = per * h->max_batch;
+        }
+        A.slot_n = 0; A.work = h->d_search_work; A.work_bytes = per;
+        hipLaunchKernelGGL(k_search_projection<true>, dim3(batch), dim3(SEARCH_THREADS), 0, (hipStream_t)stream, A);
+    } else
+    hipLaunchKernelGGL(k_search_projection<false>, dim3(batch), dim3(SEARCH_THREADS), search_lds_bytes(h->cap, A.slot_n), (hipStream_t)stream, A);
     VIORB_HIP_TRY(hipGetLastError());
     return VIORB_OK;
 }
@@ -2210,7 +2232,7 @@ int viorb_frontend_search_local_points_device(viorb_frontend* h, const viorb_key
     VIORB_REQUIRE(pcap >= 1 && pcap <= 65535, "1 <= pcap <= 65535");
     const int lslot = local_search_lds_bytes(h->cap, pcap, LOCAL_SLOT) <= 160 * 1024 ? LOCAL_SLOT : 0;      // the slot cache only while it fits
     const size_t lds = local_search_lds_bytes(h->cap, pcap, lslot);
-    if (lds > 160 * 1024) { set_error("%d local points x %d keypoints need %zu B of LDS", pcap, h->cap, lds); return VIORB_ERR_UNSUPPORTED; }
+    const bool gw = lds > 160 * 1024;                                    // more keypoints / local points than LDS holds: work arrays in global memory
     if (h->lcand_pcap < pcap) {
         if (h->d_lcand) (void)hipFree(h->d_lcand);
         if (h->d_lcand_n) (void)hipFree(h->d_lcand_n);
@@ -2218,8 +2240,8 @@ int viorb_frontend_search_local_points_device(viorb_frontend* h, const viorb_key
         VIORB_HIP_TRY(hipMalloc(&h->d_lcand, (size_t)h->max_batch * pcap * CAND_CAP * sizeof(uint32_t)));
         VIORB_HIP_TRY(hipMalloc(&h->d_lcand_n, (size_t)h->max_batch * pcap * sizeof(int)));
         h->lcand_pcap = pcap;
-        if (lds > 64 * 1024)
-            VIORB_HIP_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(k_search_local_points), lds));
+        if (lds > 64 * 1024 && !gw)
+            VIORB_HIP_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(k_search_local_points<false>), lds));
     }
     LocalSearchArgs A;
     A.cur_kps = cur_kps; A.cur_desc = cur_desc; A.cur_count = cur_count; A.cell_start = cell_start; A.cell_idx = cell_idx; A.pose12 = pose12;
@@ -2233,7 +2255,20 @@ int viorb_frontend_search_local_points_device(viorb_frontend* h, const viorb_key
     A.nlevels = h->cfg.nlevels;
     VIORB_HIP_TRY(hipMemsetAsync(status, 0, sizeof(int32_t) * batch, (hipStream_t)stream));
     ProfScope ps("k_search_local_points", (hipStream_t)stream);
-    hipLaunchKernelGGL(k_search_local_points, dim3(batch), dim3(SEARCH_THREADS), lds, (hipStream_t)stream, A);
+    A.work = nullptr; A.work_bytes = 0;
+    if (gw) {
+        const size_t per = (lds + 255) & ~(size_t)255;
+        if (h->search_work_bytes < per * h->max_batch) {
+            VIORB_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+            if (h->d_search_work) (void)hipFree(h->d_search_work);
+            h->d_search_work = nullptr; h->search_work_bytes = 0;
+            VIORB_HIP_TRY(hipMalloc(&h->d_search_work, per * h->max_batch));
+            h->search_work_bytes = per * h->max_batch;
+        }
+        A.work = h->d_search_work; A.work_bytes = per;
+        hipLaunchKernelGGL(k_search_local_points<true>, dim3(batch), dim3(SEARCH_THREADS), 0, (hipStream_t)stream, A);
+    } else
+    hipLaunchKernelGGL(k_search_local_points<false>, dim3(batch), dim3(SEARCH_THREADS), lds, (hipStream_t)stream, A);
     VIORB_HIP_TRY(hipGetLastError());
     return VIORB_OK;
 }

@@ -202,10 +202,6 @@ int viorb_tracker_create(const viorb_tracker_config* cfg, viorb_tracker** out) {
         fc.min_x = b4[0]; fc.max_x = b4[1]; fc.min_y = b4[2]; fc.max_y = b4[3];
     }
     h->undistort = fc.dist_coef[0] != 0.0f;
-    if (h->cap > viorb_frontend_search_capacity()) {
-        set_error("%d keypoints per frame: the tracker's searches hold at most %d (viorb_frontend_search_capacity)", h->cap, viorb_frontend_search_capacity());
-        return VIORB_ERR_UNSUPPORTED;                                    // the guard above releases what was built
-    }
     TR_TRY(viorb_frontend_create(&fc, cfg->batch, h->cap, cfg->device, &h->fe));
     {
         int lo = 0, hi = 0;
