@@ -135,8 +135,8 @@ int viorb_extractor_level_download(viorb_extractor* h, int b, int level, int blu
  * after extraction (the reference runs two ORBextractor instances, src/Frame.cc:258-261): image left_index + p of L is
  * matched against image right_index + p of R (L and R may be the same batched handle). bf = Camera.bf, fx = Camera.fx.
  * Outputs per left keypoint: d_uright[p][cap], d_depth[p][cap] (-1 where unmatched, cap = viorb_extractor_max_keypoints)
- * and d_nmatched[p]. The row buckets of the right image and the per-keypoint work arrays live in LDS: up to ~4000 features per image
- * (KITTI's setting is 2000), more is refused with VIORB_ERR_UNSUPPORTED. */
+ * and d_nmatched[p]. The sort keys of the right image's rows and the per-keypoint work arrays live in LDS for up to ~4000 features per
+ * image (KITTI's setting is 2000) and in global memory beyond that (same result, slower). */
 int viorb_stereo_match_device(const viorb_extractor* L, int left_index, const viorb_extractor* R, int right_index, int pairs,
                               float bf, float fx, float* d_uright, float* d_depth, int32_t* d_nmatched, void* stream);
 /* Host-buffer form for the literal two-instance use: image 0 of both handles; uright/depth hold min(cap, max_keypoints). */

@@ -9,7 +9,8 @@ from viorb_amd.synth import make_stereo_pair, KITTI_K
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("seed,w,h,nf", [(100, 1241, 376, 2000), (101, 1241, 376, 2000), (7, 752, 480, 1000)])
+@pytest.mark.parametrize("seed,w,h,nf", [(100, 1241, 376, 2000), (101, 1241, 376, 2000), (7, 752, 480, 1000),
+                                         (102, 1241, 376, 5000)])      # 5000: more features than the sort / SAD arrays fit in LDS (k_stereo_match<true>)
 def test_stereo_matches_equal_oracle(oracle, seed, w, h, nf):
     if viorb_amd.lib().viorb_device_count() < 1:
         pytest.fail("no HIP device visible")

@@ -1682,11 +1682,14 @@ struct StereoArgs {
     int cap, sort_n, nlevels; float bf, fx;
     float scale[16], inv_scale[16];
     float* uright; float* depth; int* nmatched;
+    unsigned char* work; size_t work_bytes;      // k_stereo_match<true>: the sort / SAD arrays in global memory (more features than LDS holds)
 };
 __host__ __device__ inline size_t stereo_lds_bytes(int cap, int sort_n) { return (size_t)sort_n * (8 + 4 + 4 + 4) + (size_t)cap * 4 + 64; }
 
+template <bool GW>
 __global__ __launch_bounds__(1024) void k_stereo_match(StereoArgs A) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char s_st[];
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_st_lds[];
+    unsigned char* s_st = GW ? A.work + (size_t)blockIdx.x * A.work_bytes : s_st_lds;
     const int p = blockIdx.x, t = threadIdx.x, cap = A.cap, sn = A.sort_n;
     unsigned long long* keys = reinterpret_cast<unsigned long long*>(s_st);            // [sn] (ybits << 32 | iR)
     float* ry = reinterpret_cast<float*>(keys + sn);                                    // [sn] y of the sorted right keypoints
@@ -1853,6 +1856,7 @@ struct viorb_extractor {
     int fast3_tile_bytes = 0, fast3_score_bytes = 0;
     int oct_ncap = 0, oct_nodecap = 0, oct_sortcap = 0;
     int oct_big_cap = 0, oct_big_slots = 0; uint32_t* d_oct_big = nullptr; int* d_oct_big_next = nullptr; int* d_lvl_tot = nullptr;   // over-size levels (k_octree<true>)
+    unsigned char* d_stereo_work = nullptr; size_t stereo_work_bytes = 0;                // k_stereo_match<true>
     bool oct_huge = false; uint8_t* d_oct_nodes = nullptr; size_t oct_node_bytes = 0;     // a per-level quota whose node list does not fit LDS: nodes + sort keys in global scratch too
     std::vector<int> rs_pitch_dw, rs_rows;
     // second resize form (k_resize2): per-level tile table, LDS pitch, whether the level qualifies; whether level 1's kernel may also write level 0
@@ -2453,6 +2457,7 @@ int viorb_extractor_create(const viorb_extractor_params* params, int max_batch, 
 int viorb_extractor_destroy(viorb_extractor* h) {
     if (!h) return VIORB_OK;
     if (h->d_planes) { (void)hipSetDevice(h->device); free_device(h); }
+    if (h->d_stereo_work) (void)hipFree(h->d_stereo_work);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     if (h->aux_stream) (void)hipStreamDestroy(h->aux_stream);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
@@ -2603,10 +2608,24 @@ int viorb_stereo_match_device(const viorb_extractor* L, int left_index, const vi
     for (int i = 0; i < 16; i++) { A.scale[i] = L->scale[i < L->p.nlevels ? i : L->p.nlevels - 1]; A.inv_scale[i] = L->inv_scale[i < L->p.nlevels ? i : L->p.nlevels - 1]; }
     A.uright = d_uright; A.depth = d_depth; A.nmatched = d_nmatched;
     const size_t lds = stereo_lds_bytes(cap, sn);
-    if (lds > 160 * 1024) { set_error("stereo matcher needs %zu B of LDS", lds); return VIORB_ERR_UNSUPPORTED; }
-    if (lds > 64 * 1024) VIORB_HIP_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(k_stereo_match), lds));
+    A.work = nullptr; A.work_bytes = 0;
     ProfScope ps("k_stereo_match", (hipStream_t)stream);
-    hipLaunchKernelGGL(k_stereo_match, dim3(pairs), dim3(1024), lds, (hipStream_t)stream, A);
+    if (lds > 160 * 1024) {                                            // more features per image (> ~4000) than the sort / SAD arrays fit in LDS
+        viorb_extractor* Lm = const_cast<viorb_extractor*>(L);
+        const size_t per = (lds + 255) & ~(size_t)255;
+        if (Lm->stereo_work_bytes < per * pairs) {
+            VIORB_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+            if (Lm->d_stereo_work) (void)hipFree(Lm->d_stereo_work);
+            Lm->d_stereo_work = nullptr; Lm->stereo_work_bytes = 0;
+            VIORB_HIP_TRY(hipMalloc(&Lm->d_stereo_work, per * pairs));
+            Lm->stereo_work_bytes = per * pairs;
+        }
+        A.work = Lm->d_stereo_work; A.work_bytes = per;
+        hipLaunchKernelGGL(k_stereo_match<true>, dim3(pairs), dim3(1024), 0, (hipStream_t)stream, A);
+    } else {
+        if (lds > 64 * 1024) VIORB_HIP_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(k_stereo_match<false>), lds));
+        hipLaunchKernelGGL(k_stereo_match<false>, dim3(pairs), dim3(1024), lds, (hipStream_t)stream, A);
+    }
     VIORB_HIP_TRY(hipGetLastError());
     return VIORB_OK;
 }
