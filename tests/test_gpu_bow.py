@@ -57,7 +57,8 @@ def _pair(oracle, voc, seed, nK, nF, n_common, noise):
 
 
 @pytest.mark.parametrize("seed,k,L,nK,nF,ori", [(0, 6, 5, 300, 340, True), (1, 6, 5, 1000, 1000, False), (2, 10, 6, 1000, 970, True),
-                                                 (3, 10, 4, 500, 600, True), (4, 10, 6, 2000, 2000, True), (5, 4, 5, 64, 1, True)])
+                                                 (3, 10, 4, 500, 600, True), (4, 10, 6, 2000, 2000, True), (5, 4, 5, 64, 1, True),
+                                                 (6, 8, 5, 8000, 7600, True)])      # more keypoints than the work arrays fit in LDS (k_search_by_bow<true>)
 def test_search_by_bow_bit_exact(oracle, seed, k, L, nK, nF, ori):
     """(k=10, L=4: levelsup 4 puts every feature under the root, the search degenerates to greedy brute force.)"""
     from viorb_amd import SearchByBoW

@@ -58,11 +58,14 @@ struct BowSearchArgs {
     const viorb_keypoint* f_kps; const uint8_t* f_desc; const int* f_node; const int* f_count;
     int* match; int* nmatches;
     int cap; float nnratio; int check_ori;
+    unsigned char* work; size_t work_bytes;      // k_search_by_bow<true>: the work arrays in global memory (more than ~7100 keypoints)
 };
 __host__ __device__ inline size_t bow_search_lds_bytes(int cap) { return (size_t)cap * (4 + 4 + 4 + 2 + 4 * 2 + 1) + 256; }
 
+template <bool GW>
 __global__ __launch_bounds__(256) void k_search_by_bow(BowSearchArgs A) {
-    extern __shared__ __align__(16) unsigned char smem[];
+    extern __shared__ __align__(16) unsigned char smem_lds[];
+    unsigned char* smem = GW ? A.work + (size_t)blockIdx.x * A.work_bytes : smem_lds;
     const int cap = A.cap, b = blockIdx.x, t = threadIdx.x, lane = t & 63, wv = t >> 6;
     int* s_knode = reinterpret_cast<int*>(smem);                       // [cap]
     int* s_fnode = s_knode + cap;                                      // [cap]
@@ -369,14 +372,31 @@ int viorb_search_by_bow_device(const viorb_keypoint* kf_kps, const uint8_t* kf_d
     VIORB_REQUIRE(kf_kps && kf_desc && kf_node && kf_has_point && kf_count && f_kps && f_desc && f_node && f_count && match && nmatches, "null array");
     VIORB_REQUIRE(cap >= 1 && cap <= 65535 && batch >= 1, "1 <= cap <= 65535");
     const size_t lds = bow_search_lds_bytes(cap);
-    if (lds > 160 * 1024) { set_error("cap %d needs %zu B of LDS for SearchByBoW", cap, lds); return VIORB_ERR_UNSUPPORTED; }
-    if (lds > 64 * 1024) VIORB_HIP_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(k_search_by_bow), lds));
+    const bool gw = lds > 160 * 1024;                                    // more keypoints than the work arrays fit in LDS (~7100): global memory
+    if (!gw && lds > 64 * 1024) VIORB_HIP_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(k_search_by_bow<false>), lds));
     BowSearchArgs A;
     A.kf_kps = kf_kps; A.kf_desc = kf_desc; A.kf_node = kf_node; A.kf_has_point = kf_has_point; A.kf_count = kf_count;
     A.f_kps = f_kps; A.f_desc = f_desc; A.f_node = f_node; A.f_count = f_count; A.match = match; A.nmatches = nmatches;
     A.cap = cap; A.nnratio = nnratio; A.check_ori = check_orientation;
+    A.work = nullptr; A.work_bytes = 0;
     ProfScope ps("k_search_by_bow", (hipStream_t)stream);
-    hipLaunchKernelGGL(k_search_by_bow, dim3(batch), dim3(256), lds, (hipStream_t)stream, A);
+    if (gw) {
+        // grow-only scratch of the calling thread (this entry point has no handle to keep it in)
+        struct Scratch { unsigned char* p = nullptr; size_t bytes = 0; int device = -1; ~Scratch() { if (p) (void)hipFree(p); } };
+        static thread_local Scratch sc;
+        int dev = 0; VIORB_HIP_TRY(hipGetDevice(&dev));
+        const size_t per = (lds + 255) & ~(size_t)255;
+        if (sc.device != dev || sc.bytes < per * batch) {
+            VIORB_HIP_TRY(hipDeviceSynchronize());
+            if (sc.p) (void)hipFree(sc.p);
+            sc.p = nullptr; sc.bytes = 0; sc.device = dev;
+            VIORB_HIP_TRY(hipMalloc(&sc.p, per * batch));
+            sc.bytes = per * batch;
+        }
+        A.work = sc.p; A.work_bytes = per;
+        hipLaunchKernelGGL(k_search_by_bow<true>, dim3(batch), dim3(256), 0, (hipStream_t)stream, A);
+    } else
+    hipLaunchKernelGGL(k_search_by_bow<false>, dim3(batch), dim3(256), lds, (hipStream_t)stream, A);
     VIORB_HIP_TRY(hipGetLastError());
     return VIORB_OK;
 }
