@@ -169,8 +169,10 @@ def run_tracking(args, cfg, rank, dev_index, dev, world):
     # through that lens and the tracker undistorts the keypoints ahead of the grid (Frame::UndistortKeyPoints) with bounds from the undistorted corners
     from viorb_amd.synth import EUROC_DIST
     lens = EUROC_DIST if (args.config == "euroc" and not args.no_distortion) else None
-    pre = getattr(args, "pregenerated", None)               # the pinhole pass's streams, generated before anything touched the GPU (main)
-    base = pre if (pre is not None and lens is None) else generate_streams(stream_seeds(rank, distinct), W_IMG, H_IMG, args.gen_procs, lens)
+    # the synthetic streams come from main(), generated before the process group and the GPU were touched (a pool forked after RCCL / HIP
+    # initialisation is not something to rely on); keyed by the camera model so that the pinhole pass finds its own
+    pre = getattr(args, "pregenerated", {}).get("lens" if lens else "pinhole")
+    base = pre if pre is not None else generate_streams(stream_seeds(rank, distinct), W_IMG, H_IMG, args.gen_procs, lens)
     streams = [base[i % distinct] for i in range(S)]
     up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     frames = up(np.stack([s["frames"] for s in streams], 1))                   # [F, S, h, w] u8
@@ -366,7 +368,7 @@ def run_tracking(args, cfg, rank, dev_index, dev, world):
                 out["config"]["hbm_resident_frames_per_s"] = other["frames_per_s"]
         if not (res["status"] == 0).all():
             raise SystemExit("a stream reported a capacity / status error: %s" % res["status"])
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:          # the CPU baseline is timed on rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline_tracking(base, W_IMG, H_IMG, NFEAT, 200 if args.config == "euroc" else 60, 20 if args.config == "euroc" else 8, lens)
     out["metric"] = "frames/sec ORB extract+match+pose-opt, EuRoC 752x480, 1/2/4/8 GPUs" if args.config == "euroc" else \
         "frames/sec ORB extract+match+pose-opt, synthetic 1280x720 / 1500 features, batched streams"
@@ -421,7 +423,7 @@ def run_dropin(args, cfg, rank, dev_index, dev, world):
                          "frames_per_s_inside_the_calls": round(args.steps / in_calls, 1),
                          "tracked_frames": int(sum(1 for x in states if x == 0)), "frames": len(states)}
         out["roofline"] = None
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:          # the CPU baseline is timed on rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline_tracking([s], cfg["w"], cfg["h"], cfg["nfeat"], 100, 10, dist)
     out["metric"] = "frames/sec ORB extract+match+pose-opt, EuRoC 752x480, single stream through the host-buffer drop-ins"
     out["unit"] = "frames/s"; out["dtype"] = "u8"
@@ -490,7 +492,7 @@ def run_stereo(args, cfg, rank, dev_index, dev, world):
                                      "(one batched handle) + Frame::ComputeStereoMatches (row buckets, Hamming, 11x11 SAD, sub-pixel, median rejection)",
                          "baseline_config": cfg["baseline_config"], "pairs_per_gpu_per_step": Pn, "pairs_per_step": Pn * world,
                          "mean_stereo_matches_per_pair": round(float(n.float().mean().item()), 1), "keypoint_capacity": ex.cap}
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:          # the CPU baseline is timed on rank 0 at N = 1 only
             from oracle import binding as ora
             exo = [ora.Extractor(NFEAT, 1.2, 8, 20, 7), ora.Extractor(NFEAT, 1.2, 8, 20, 7)]
             times = []
@@ -552,7 +554,7 @@ def run_local_ba(args, cfg, rank, dev_index, dev, world):
                                      "and out (its caller is the LocalMapping thread)" % ne,
                          "baseline_config": cfg["baseline_config"], "windows_per_gpu_per_step": nwin, "windows_in_flight": fl,
                          "lm_iterations_first_second": [res[0]["its_first"], res[0]["its_second"]], "final_chi2": round(float(res[0]["chi2_final"]), 3)}
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:          # the CPU baseline is timed on rank 0 at N = 1 only
             q = probs[0]; a = (q["kfs"], q["n_local"], q["prev_kf"], q["preint"], q["points"], q["edge_idx"], q["edge_obs"], q["gw"], q["cam"])
             ora.local_ba(*a)
             times = []
@@ -625,10 +627,17 @@ def main():
             dist.barrier(); dist.destroy_process_group()
         return
     pinhole_pass = args.config == "euroc" and world == 1 and not args.no_distortion and not args.no_host_input_pass
-    if pinhole_pass:
-        # the streams of the pinhole-camera pass (after the timed region) are generated here, before anything touches the GPU: a process pool
-        # forked from a process that has initialised HIP is not something to rely on (under rocprofv3 its workers have been seen not to exit)
-        args.pregenerated = generate_streams(stream_seeds(rank, min(args.streams, args.distinct or 256)), cfg["w"], cfg["h"], args.gen_procs, None)
+    args.pregenerated = {}
+    if args.config in ("euroc", "synth720p"):
+        # Every rank's synthetic streams are generated HERE, before the process group (RCCL initialises the device eagerly with device_id=)
+        # and before anything else touches the GPU: a process pool forked from a process that has initialised HIP / RCCL is not something to
+        # rely on (under rocprofv3 --pmc such workers have been seen not to exit). The pinhole pass (N = 1, after the timed region) too.
+        from viorb_amd.synth import EUROC_DIST
+        seeds = stream_seeds(rank, min(args.streams, args.distinct or 256))
+        lens = EUROC_DIST if (args.config == "euroc" and not args.no_distortion) else None
+        args.pregenerated["lens" if lens else "pinhole"] = generate_streams(seeds, cfg["w"], cfg["h"], args.gen_procs, lens)
+        if pinhole_pass:
+            args.pregenerated["pinhole"] = generate_streams(seeds, cfg["w"], cfg["h"], args.gen_procs, None)
     if viorb_amd.lib().viorb_device_count() < 1:
         raise SystemExit("bench.py needs a HIP device (viorb_amd has no CPU fallback)")
     # VIORB_BENCH_REHEARSAL=1: run the N > 1 code path on a box with fewer GPUs than ranks (ranks share devices, gloo instead of
