@@ -260,6 +260,17 @@ int viorb_frontend_search_local_points_device(viorb_frontend* h, const viorb_key
                                               float nnratio, const uint8_t* cur_owner_obs, int batch, int32_t* match,
                                               int32_t* nmatches, float* frustum, int32_t* status, void* stream);
 
+/* The same search for a stereo / RGB-D frame (reference src/ORBmatcher.cc:91-97): cur_uright[b][cap] = F.mvuRight (<= 0: no right match), bf = F.mbf.
+ * A candidate keypoint with a right coordinate is skipped when |mTrackProjXR - mvuRight| exceeds the window radius r * mvScaleFactors[level],
+ * with mTrackProjXR = u - mbf * invz as Frame::isInFrustum stores it (src/Frame.cc:499). frustum_xr (may be NULL) [b][pcap] receives mTrackProjXR
+ * (0 for a point that is not in view). KITTI-shaped TrackLocalMap goes through this entry. */
+int viorb_frontend_search_local_points_stereo_device(viorb_frontend* h, const viorb_keypoint* cur_kps, const uint8_t* cur_desc,
+                                                     const int32_t* cur_count, const float* cur_uright, float bf, const int32_t* cell_start,
+                                                     const int32_t* cell_idx, const float* pose12, const float* pts_f, const uint8_t* pts_flags,
+                                                     const uint8_t* pts_desc, const int32_t* pts_count, int pcap, float th, float nnratio,
+                                                     const uint8_t* cur_owner_obs, int batch, int32_t* match, int32_t* nmatches, float* frustum,
+                                                     float* frustum_xr, int32_t* status, void* stream);
+
 /* Edge construction of PoseOptimization: one observation per matched keypoint, in keypoint order.
  * match[b][i] >= 0 selects point match_Pw[b][match[b][i]]. obs_index[b][k] = keypoint of obs k. */
 int viorb_frontend_build_observations_device(viorb_frontend* h, const viorb_keypoint* kps, const int32_t* count,
@@ -450,6 +461,12 @@ int viorb_search_by_projection_points(const viorb_keypoint* cur_kps, const uint8
                                       const float pose12[12], const float intr4[4], const float* scale_factors, int nlevels,
                                       const float* pts_f, const uint8_t* pts_flags, const uint8_t* pts_desc, int npts, float th,
                                       float nnratio, const uint8_t* cur_owner_obs, int32_t* match, int* nmatches, float* frustum5);
+/* ... for a frame with right coordinates (stereo / RGB-D): cur_uright = F.mvuRight, bf = F.mbf, proj_xr (may be NULL) [npts] = mTrackProjXR; see
+ * viorb_frontend_search_local_points_stereo_device. With cur_uright all <= 0 the matches equal viorb_search_by_projection_points'. */
+int viorb_search_by_projection_points_stereo(const viorb_keypoint* cur_kps, const uint8_t* cur_desc, const float* cur_uright, float bf, int ncur,
+                                             const float bounds4[4], const float pose12[12], const float intr4[4], const float* scale_factors, int nlevels,
+                                             const float* pts_f, const uint8_t* pts_flags, const uint8_t* pts_desc, int npts, float th, float nnratio,
+                                             const uint8_t* cur_owner_obs, int32_t* match, int* nmatches, float* frustum5, float* proj_xr);
 /* ... and with bMono = false (stereo / RGB-D, Tracking.cc:432 with mSensor != MONOCULAR): see viorb_frontend_search_projection_stereo_device. */
 int viorb_search_by_projection_frame_stereo(const viorb_keypoint* cur_kps, const uint8_t* cur_desc, const float* cur_uright, int ncur,
                                             const float bounds4[4], const float pose12[12], const float last_pose12[12], const float intr4[4],

@@ -324,6 +324,7 @@ def _match():
         L.ora_search_by_projection_frame.argtypes = [vp, vp, i, vp, vp, vp, vp, i, vp, vp, vp, vp, vp, f, i, vp]
         L.ora_search_by_projection_frame_stereo.argtypes = [vp, vp, vp, i, vp, vp, vp, vp, f, f, vp, i, vp, vp, vp, vp, vp, f, i, vp]
         L.ora_search_local_points.argtypes = [vp, vp, i, vp, vp, vp, vp, i, f, i, vp, vp, vp, f, f, vp, vp, vp]
+        L.ora_search_local_points_stereo.argtypes = [vp, vp, vp, f, i, vp, vp, vp, vp, i, f, i, vp, vp, vp, f, f, vp, vp, vp, vp]
         _match_ready = True
     return L
 
@@ -388,9 +389,10 @@ def search_by_projection_frame_stereo(cur_kps, cur_desc, cur_uright, bounds, pos
 
 
 def search_local_points(cur_kps, cur_desc, bounds, pose12, intr4, scale_factors, log_scale_factor, pts_f, pts_flags, pts_desc,
-                        th, nnratio, cur_owner_obs):
+                        th, nnratio, cur_owner_obs, cur_uright=None, bf=0.0):
     """Tracking::SearchLocalPoints (isInFrustum per point) + ORBmatcher::SearchByProjection(F, vpMapPoints, th).
-    pts_f [n,8] = Pw3 normal3 minDist maxDist. Returns (nmatches, match[Ncur], frustum[n,5])."""
+    pts_f [n,8] = Pw3 normal3 minDist maxDist. Returns (nmatches, match[Ncur], frustum[n,5]); with cur_uright (mvuRight of a
+    stereo / RGB-D frame) and bf (mbf) the right-coordinate gate of ORBmatcher.cc:91-97 applies and a fourth value, mTrackProjXR [n], is returned."""
     cur_kps = np.ascontiguousarray(cur_kps, KP_DTYPE)
     n = len(cur_kps)
     f32 = lambda a: np.ascontiguousarray(a, np.float32)
@@ -398,6 +400,13 @@ def search_local_points(cur_kps, cur_desc, bounds, pose12, intr4, scale_factors,
     m = np.full(max(n, 1), -1, np.int32)
     fr = np.zeros((max(len(pts_f), 1), 5), np.float32)
     sf = f32(scale_factors)
+    if cur_uright is not None:
+        xr = np.zeros(max(len(pts_f), 1), np.float32)
+        nm = _match().ora_search_local_points_stereo(_p(cur_kps), _p(np.ascontiguousarray(cur_desc, np.uint8)), _p(f32(cur_uright)), float(bf), n, _p(f32(bounds)),
+                                                     _p(f32(pose12)), _p(f32(intr4)), _p(sf), len(sf), float(log_scale_factor), len(pts_f), _p(pts_f),
+                                                     _p(np.ascontiguousarray(pts_flags, np.uint8)), _p(np.ascontiguousarray(pts_desc, np.uint8)),
+                                                     float(th), float(nnratio), _p(np.ascontiguousarray(cur_owner_obs, np.uint8)), _p(m), _p(fr), _p(xr))
+        return nm, m[:n], fr[:len(pts_f)], xr[:len(pts_f)]
     nm = _match().ora_search_local_points(_p(cur_kps), _p(np.ascontiguousarray(cur_desc, np.uint8)), n, _p(f32(bounds)), _p(f32(pose12)),
                                           _p(f32(intr4)), _p(sf), len(sf), float(log_scale_factor), len(pts_f), _p(pts_f),
                                           _p(np.ascontiguousarray(pts_flags, np.uint8)), _p(np.ascontiguousarray(pts_desc, np.uint8)),

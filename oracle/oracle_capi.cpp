@@ -298,7 +298,7 @@ int ora_search_by_projection_frame_stereo(const KeyPoint* cur_kps, const uint8_t
 extern "C" {
 // pts_f[n][8] = Pw3 normal3 minDist maxDist; pts_flags[n] bit0 valid, bit1 skip, bit2 has observations.
 // frustum_out[n][5] = in_view projx projy viewcos level (may be NULL).
-int ora_search_local_points(const KeyPoint* cur_kps, const uint8_t* cur_desc, int ncur, const float* bounds4, const float* pose12,
+static int search_local_points_impl(const float* cur_uright, float bf, float* proj_xr_out, const KeyPoint* cur_kps, const uint8_t* cur_desc, int ncur, const float* bounds4, const float* pose12,
                             const float* intr4, const float* scale_factors, int nlevels, float log_scale_factor, int npts,
                             const float* pts_f, const uint8_t* pts_flags, const uint8_t* pts_desc, float th, float nnratio,
                             const uint8_t* cur_owner_obs, int* match, float* frustum_out) {
@@ -312,13 +312,29 @@ int ora_search_local_points(const KeyPoint* cur_kps, const uint8_t* cur_desc, in
         pts[i].min_dist = pts_f[8 * i + 6]; pts[i].max_dist = pts_f[8 * i + 7]; pts[i].desc = pts_desc + (size_t)32 * i;
     }
     std::vector<int> m; std::vector<FrustumResult> fr;
-    int n = search_local_points(g, T, scale_factors, nlevels, log_scale_factor, pts, th, nnratio, cur_owner_obs, m, &fr);
+    int n = search_local_points(g, T, scale_factors, nlevels, log_scale_factor, pts, th, nnratio, cur_owner_obs, m, &fr, cur_uright, bf);
+    if (proj_xr_out) for (int i = 0; i < npts; i++) proj_xr_out[i] = fr[i].proj_xr;
     for (int i = 0; i < ncur; i++) match[i] = m[i];
     if (frustum_out) for (int i = 0; i < npts; i++) {
         frustum_out[5 * i] = fr[i].in_view; frustum_out[5 * i + 1] = fr[i].proj_x; frustum_out[5 * i + 2] = fr[i].proj_y;
         frustum_out[5 * i + 3] = fr[i].view_cos; frustum_out[5 * i + 4] = (float)fr[i].level;
     }
     return n;
+}
+int ora_search_local_points(const KeyPoint* cur_kps, const uint8_t* cur_desc, int ncur, const float* bounds4, const float* pose12,
+                            const float* intr4, const float* scale_factors, int nlevels, float log_scale_factor, int npts,
+                            const float* pts_f, const uint8_t* pts_flags, const uint8_t* pts_desc, float th, float nnratio,
+                            const uint8_t* cur_owner_obs, int* match, float* frustum_out) {
+    return search_local_points_impl(nullptr, 0.0f, nullptr, cur_kps, cur_desc, ncur, bounds4, pose12, intr4, scale_factors, nlevels, log_scale_factor, npts, pts_f, pts_flags,
+                                    pts_desc, th, nnratio, cur_owner_obs, match, frustum_out);
+}
+// the same with a stereo / RGB-D current frame: cur_uright = mvuRight, bf = mbf; proj_xr_out[n] = mTrackProjXR (may be NULL)
+int ora_search_local_points_stereo(const KeyPoint* cur_kps, const uint8_t* cur_desc, const float* cur_uright, float bf, int ncur, const float* bounds4,
+                                   const float* pose12, const float* intr4, const float* scale_factors, int nlevels, float log_scale_factor, int npts,
+                                   const float* pts_f, const uint8_t* pts_flags, const uint8_t* pts_desc, float th, float nnratio,
+                                   const uint8_t* cur_owner_obs, int* match, float* frustum_out, float* proj_xr_out) {
+    return search_local_points_impl(cur_uright, bf, proj_xr_out, cur_kps, cur_desc, ncur, bounds4, pose12, intr4, scale_factors, nlevels, log_scale_factor, npts, pts_f,
+                                    pts_flags, pts_desc, th, nnratio, cur_owner_obs, match, frustum_out);
 }
 } // extern "C"
 

@@ -160,8 +160,8 @@ void camera_centre(const PoseF& T, float* Ow) {
 
 // Frame.cc:449-505
 FrustumResult is_in_frustum(const PoseF& T, const float* Ow, float min_x, float max_x, float min_y, float max_y,
-                            float log_scale_factor, int nlevels, const LocalPoint& p, float viewingCosLimit) {
-    FrustumResult R{0, 0, 0, 0, 0};
+                            float log_scale_factor, int nlevels, const LocalPoint& p, float viewingCosLimit, float bf) {
+    FrustumResult R{0, 0, 0, 0, 0, 0};
     float Pc[3]; transform_point(T, p.Pw, Pc);
     const float PcX = Pc[0], PcY = Pc[1], PcZ = Pc[2];
     if (PcZ < 0.0f) return R;
@@ -184,23 +184,24 @@ FrustumResult is_in_frustum(const PoseF& T, const float* Ow, float min_x, float 
     int nScale = (int)std::ceil((float)std::log((double)ratio) / log_scale_factor);
     if (nScale < 0) nScale = 0; else if (nScale >= nlevels) nScale = nlevels - 1;
     R.in_view = 1; R.proj_x = u; R.proj_y = v; R.level = nScale; R.view_cos = viewCos;
+    R.proj_xr = u - bf * invz;                                   // pMP->mTrackProjXR = u - mbf*invz (Frame.cc:499), float
     return R;
 }
 
 // Tracking.cc:1922-1937 + ORBmatcher.cc:45-129
 int search_local_points(const FrameGrid& cur, const PoseF& T, const float* sf, int nlevels, float log_scale_factor,
                         const std::vector<LocalPoint>& pts, float th, float nnratio, const uint8_t* cur_owner_obs,
-                        std::vector<int>& match, std::vector<FrustumResult>* frustum) {
+                        std::vector<int>& match, std::vector<FrustumResult>* frustum, const float* cur_uright, float bf) {
     float Ow[3]; camera_centre(T, Ow);
     int nmatches = 0;
     const bool bFactor = th != 1.0f;
     match.assign(cur.N, -1);
     std::vector<uint8_t> owner_obs(cur_owner_obs, cur_owner_obs + cur.N);
-    if (frustum) frustum->assign(pts.size(), FrustumResult{0, 0, 0, 0, 0});
+    if (frustum) frustum->assign(pts.size(), FrustumResult{0, 0, 0, 0, 0, 0});
     for (size_t i = 0; i < pts.size(); i++) {
         const LocalPoint& p = pts[i];
         if (p.skip || !p.valid) continue;                         // mnLastFrameSeen == id / isBad(): isInFrustum is not called
-        const FrustumResult fr = is_in_frustum(T, Ow, cur.minX, cur.maxX, cur.minY, cur.maxY, log_scale_factor, nlevels, p, 0.5f);
+        const FrustumResult fr = is_in_frustum(T, Ow, cur.minX, cur.maxX, cur.minY, cur.maxY, log_scale_factor, nlevels, p, 0.5f, bf);
         if (frustum) (*frustum)[i] = fr;
         if (!fr.in_view) continue;
         float r = fr.view_cos > 0.998 ? 2.5f : 4.0f;              // RadiusByViewingCos
@@ -210,6 +211,10 @@ int search_local_points(const FrameGrid& cur, const PoseF& T, const float* sf, i
         int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
         for (int idx : cand) {
             if (owner_obs[idx]) continue;
+            if (cur_uright && cur_uright[idx] > 0) {               // ORBmatcher.cc:91-97
+                const float er = std::fabs(fr.proj_xr - cur_uright[idx]);
+                if (er > r * sf[fr.level]) continue;
+            }
             const int dist = descriptor_distance(p.desc, cur.desc + (size_t)32 * idx);
             if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestLevel2 = bestLevel; bestLevel = cur.kps[idx].octave; bestIdx = idx; }
             else if (dist < bestDist2) { bestLevel2 = cur.kps[idx].octave; bestDist2 = dist; }

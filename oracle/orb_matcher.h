@@ -56,11 +56,11 @@ struct LocalPoint {
     float min_dist, max_dist; // mfMinDistance, mfMaxDistance (the 0.8 / 1.2 invariance factors are applied inside)
     const uint8_t* desc;      // GetDescriptor()
 };
-struct FrustumResult { uint8_t in_view; float proj_x, proj_y, view_cos; int level; };
+struct FrustumResult { uint8_t in_view; float proj_x, proj_y, view_cos; int level; float proj_xr; };   // proj_xr = mTrackProjXR (Frame.cc:499)
 // Frame::isInFrustum(pMP, viewingCosLimit) + MapPoint::PredictScale, reference src/Frame.cc:449-505,
 // src/MapPoint.cc:408-424. Ow = -Rcw^T tcw (mOw), log_scale_factor = log(scaleFactor) as float.
 FrustumResult is_in_frustum(const PoseF& T, const float* Ow, float min_x, float max_x, float min_y, float max_y,
-                            float log_scale_factor, int nlevels, const LocalPoint& p, float viewing_cos_limit);
+                            float log_scale_factor, int nlevels, const LocalPoint& p, float viewing_cos_limit, float bf = 0.0f);
 // mOw of Frame::UpdatePoseMatrices (src/Frame.cc:441-447) in cv::gemm float order.
 void camera_centre(const PoseF& T, float* Ow);
 
@@ -70,7 +70,8 @@ void camera_centre(const PoseF& T, float* Ow);
 // here, or -1. frustum (optional) receives the per-point isInFrustum fields.
 int search_local_points(const FrameGrid& cur, const PoseF& T, const float* scale_factors, int nlevels, float log_scale_factor,
                         const std::vector<LocalPoint>& pts, float th, float nnratio, const uint8_t* cur_owner_obs,
-                        std::vector<int>& match, std::vector<FrustumResult>* frustum);
+                        std::vector<int>& match, std::vector<FrustumResult>* frustum,
+                        const float* cur_uright = nullptr, float bf = 0.0f);   // stereo / RGB-D frame: mvuRight + mbf (the gate of ORBmatcher.cc:91-97)
 
 // reference src/ORBmatcher.cc:1602-1643
 void compute_three_maxima(const std::vector<int>* histo, int L, int& ind1, int& ind2, int& ind3);

@@ -52,7 +52,7 @@ struct KeyFrame;
 struct MapPoint {                                   // include/MapPoint.h: the members the matchers / window solves touch
     cv::Mat Pw, Pn, desc; int nobs = 1; bool bad = false; float minD = 0.5f, maxD = 30.f;
     long mnLastFrameSeen = -1; unsigned long mnBALocalForKF = 0, mnId = 0;
-    bool mbTrackInView = false; float mTrackProjX = 0, mTrackProjY = 0, mTrackViewCos = 0; int mnTrackScaleLevel = 0, visible = 0, replaced = 0, updates = 0;
+    bool mbTrackInView = false; float mTrackProjX = 0, mTrackProjY = 0, mTrackProjXR = 0, mTrackViewCos = 0; int mnTrackScaleLevel = 0, visible = 0, replaced = 0, updates = 0;
     std::map<KeyFrame*, size_t> obs;
     MapPoint() : Pw(3, 1, CV_32F), Pn(3, 1, CV_32F), desc(1, 32, CV_8U) {}
     cv::Mat GetWorldPos() const { return Pw; } cv::Mat GetNormal() const { return Pn; } cv::Mat GetDescriptor() const { return desc; }
@@ -193,6 +193,23 @@ int main() {
             for (int i = 0; i < N; i++) EXPECT(F.mvpMapPoints[i] == (m[i] >= 0 ? vp[m[i]] : nullptr));
             int inview = 0; for (int p = 0; p < np; p++) { inview += fr[(size_t)p * 5] != 0; EXPECT(vp[p]->mbTrackInView == (fr[(size_t)p * 5] != 0 && !(fl[p] & 2))); }
             EXPECT(inview > 100 && pts[1].visible == 1 && pts[0].visible == 0);
+            // mTrackProjXR = u - mbf * invz for every point in view (Frame.cc:499), also on a monocular frame
+            for (int p = 0; p < np; p++) if (vp[p]->mbTrackInView) { const float z = vp[p]->Pw.at<float>(2); EXPECT(std::fabs(vp[p]->mTrackProjXR - (vp[p]->mTrackProjX - F.mbf * (1.0f / z))) < 1e-3f); }
+        }
+        // 2b. the same call site with a stereo frame (KITTI-shaped TrackLocalMap): a keypoint with a right coordinate is only a candidate when
+        // it agrees with mTrackProjXR within the window radius (ORBmatcher.cc:91-97). Every third keypoint gets the right coordinate its
+        // point projects to, every ninth one that is 40 px off: the shim must return what the stereo entry point returns, and fewer
+        // matches than the monocular call above.
+        if (gpu) {
+            Frame G = Cur; G.mvpMapPoints.assign(N, nullptr);
+            for (int i = 0; i < N; i++) if (Last.mvpMapPoints[i] && i % 3 == 0) { const float z = pts[i].Pw.at<float>(2); G.mvuRight[i] = G.mvKeysUn[i].pt.x - G.mbf / z + (i % 9 == 0 ? 40.f : 0.f); }
+            for (int p = 0; p < np; p++) vp[p]->mbTrackInView = false;
+            std::vector<int32_t> ms(N, -1); std::vector<float> xr(np, 0.f); int nms = 0, gots = -1;
+            const int rcs = viorb_search_by_projection_points_stereo(ck.data(), G.mDescriptors.data, G.mvuRight.data(), G.mbf, N, bounds, pose, intr, sf.data(), 8, pf.data(), fl.data(), pd.data(), np, 3.f, 0.8f, own.data(), ms.data(), &nms, fr.data(), xr.data());
+            const bool ths = throws([&] { gots = viorb_shim::search_by_projection_points(G, vp, 3.f, 0.8f); });
+            EXPECT(rcs == VIORB_OK && !ths && gots == nms && nms > 50 && nms < nm);
+            for (int i = 0; i < N; i++) EXPECT(G.mvpMapPoints[i] == (ms[i] >= 0 ? vp[ms[i]] : nullptr));
+            for (int p = 0; p < np; p++) if (vp[p]->mbTrackInView) EXPECT(vp[p]->mTrackProjXR == xr[p]);
         }
     }
     // ---------------------------------------------------------------- two key frames (bag-of-words searches, Fuse)

@@ -293,6 +293,42 @@ def test_host_dropin_search_by_projection(torch_cuda, oracle, streams):
     assert nm == 0 and len(match) == 0
 
 
+def test_host_dropin_search_when_the_scratch_arena_grows_mid_call(torch_cuda, oracle, streams):
+    """A host-buffer drop-in stages its inputs in a page-locked mirror of the calling thread's device arena. A thread whose arena is
+    still the initial 4 MiB block and whose frame has more than 16384 keypoints (scratch ~4.75 MB) makes the arena grow in the middle
+    of the call, after buffers have been zero-staged in the first block and before their data is put(): the data must still arrive
+    (round-3 advisor finding: flush() copied the staged zeros over it and the search returned VIORB_OK with wrong matches).
+    Run on a fresh thread (fresh thread-local arena): a small call first, then the large one, both against the oracle."""
+    from concurrent.futures import ThreadPoolExecutor
+    s = streams[0]
+    Rcw, tcw = cam_pose_from_navstate(s["s"]["ns_true"][1], s["s"]["cam"])
+    pose = np.concatenate([Rcw.ravel(), tcw]).astype(np.float32)
+    rng = np.random.default_rng(3)
+    reps = 17000 // len(s["k1"]) + 1
+    kbig = np.tile(s["k1"], reps)[:17000].copy()
+    kbig["x"] = np.clip(kbig["x"] + rng.uniform(-6, 6, len(kbig)).astype(np.float32), 1, 750)
+    kbig["y"] = np.clip(kbig["y"] + rng.uniform(-6, 6, len(kbig)).astype(np.float32), 1, 478)
+    dbig = np.tile(s["d1"], (reps, 1))[:17000].copy()
+    flip = rng.random(dbig.shape) < 0.15
+    dbig[flip] ^= rng.integers(1, 256, flip.sum(), dtype=np.uint8)
+    intr, sf = s["s"]["cam"][:4], s["tables"]["scale"]
+
+    def on_a_fresh_thread():
+        m = viorb_amd.ORBmatcher(0.9, True)
+        small = m.SearchByProjection(s["k1"], s["d1"], BOUNDS, pose, intr, sf, s["k0"], s["flags"], s["Pw"], s["d0"], 15.0)
+        big = m.SearchByProjection(kbig, dbig, BOUNDS, pose, intr, sf, s["k0"], s["flags"], s["Pw"], s["d0"], 15.0)
+        again = m.SearchByProjection(kbig, dbig, BOUNDS, pose, intr, sf, s["k0"], s["flags"], s["Pw"], s["d0"], 15.0)     # arena already large: the plain path
+        return small, big, again
+    with ThreadPoolExecutor(max_workers=1) as exr:
+        small, big, again = exr.submit(on_a_fresh_thread).result()
+    onm, om = oracle.search_by_projection_frame(s["k1"], s["d1"], BOUNDS, pose, intr, sf, s["flags"], s["Pw"], s["d0"], s["k0"]["octave"], s["k0"]["angle"], 15.0)
+    assert small[0] == onm; np.testing.assert_array_equal(small[1], om)
+    bnm, bm = oracle.search_by_projection_frame(kbig, dbig, BOUNDS, pose, intr, sf, s["flags"], s["Pw"], s["d0"], s["k0"]["octave"], s["k0"]["angle"], 15.0)
+    assert bnm > 100
+    assert big[0] == bnm; np.testing.assert_array_equal(big[1], bm)
+    assert again[0] == bnm; np.testing.assert_array_equal(again[1], bm)
+
+
 @pytest.mark.parametrize("motion", [0.0, 0.5, -0.5])
 def test_host_dropin_search_by_projection_stereo_branch(torch_cuda, oracle, motion):
     """SearchByProjection(CurrentFrame, LastFrame, th, bMono=false): forward / backward octave windows and the mvuRight gate
@@ -370,6 +406,97 @@ def test_search_local_points_matches_oracle(torch_cuda, oracle, th, nnratio):
     n0, m0 = viorb_amd.SearchLocalPoints(scenes[0]["k2"][:0], scenes[0]["d2"][:0], BOUNDS, scenes[0]["pose"], scenes[0]["s"]["cam"][:4], sf,
                                          scenes[0]["pts_f"], scenes[0]["flags"], scenes[0]["pts_desc"])
     assert n0 == 0 and len(m0) == 0
+
+
+@pytest.mark.parametrize("shape", [(752, 480, 1000), (1241, 376, 2000)])
+def test_search_local_points_stereo_gate_matches_oracle(torch_cuda, oracle, shape):
+    """a12 with a stereo / RGB-D current frame (reference src/ORBmatcher.cc:91-97, src/Frame.cc:499): a candidate keypoint that has a right
+    coordinate is skipped when |mTrackProjXR - mvuRight| exceeds the window radius. EuRoC-sized and KITTI-shaped (1241x376, 2000 features)
+    frames; right coordinates from the true depth for 60 % of the keypoints (+- 0.5 px), 5-60 px off for 20 %, none for the rest. Device
+    entry and host-buffer drop-in against the oracle: matches, nmatches, the five isInFrustum fields and mTrackProjXR, bit for bit; the gate
+    must change the result (fewer matches than the monocular search of the same frame)."""
+    torch = torch_cuda
+    from viorb_amd.synth import make_vi_stream, make_local_map, plane_points_f32
+    w, h, nfeat = shape
+    bounds = (0.0, float(w), 0.0, float(h))
+    bf = np.float32(386.1448)
+    ex = oracle.Extractor(nfeat, 1.2, 8, 20, 7)
+    sf = ex.tables()["scale"]
+    scenes = []
+    for seed in (5, 9):
+        s = make_vi_stream(seed, 3, w=w, h=h)
+        feats = [ex(f) for f in s["frames"]]
+        pts, descs = [], []
+        for j in (0, 1):
+            k, d = feats[j]
+            Rcw, tcw = cam_pose_from_navstate(s["ns_true"][j], s["cam"])
+            Pw = plane_points_f32(np.stack([k["x"], k["y"]], 1), np.concatenate([Rcw.ravel(), tcw]), s["cam"])
+            pts.append(make_local_map(k, Pw, s["ns_true"][j], s["cam"], sf)); descs.append(d)
+        rng = np.random.default_rng(seed + 77)
+        pts_f, pts_desc = np.concatenate(pts), np.concatenate(descs)
+        flags = np.full(len(pts_f), 1 | 4, np.uint8)
+        flags[rng.random(len(flags)) < 0.05] &= ~np.uint8(1); flags[rng.random(len(flags)) < 0.2] |= 2; flags[rng.random(len(flags)) < 0.1] &= ~np.uint8(4)
+        k2, d2 = feats[2]
+        owner = (rng.random(len(k2)) < 0.2).astype(np.uint8)
+        Rcw, tcw = cam_pose_from_navstate(s["ns_true"][2], s["cam"])
+        pose = np.concatenate([Rcw.ravel(), tcw]).astype(np.float32)
+        # mvuRight of the current frame from the true depth of every keypoint
+        Pw2 = plane_points_f32(np.stack([k2["x"], k2["y"]], 1), np.concatenate([Rcw.ravel(), tcw]), s["cam"]).astype(np.float64)
+        z = (Pw2 @ Rcw.T + tcw)[:, 2]
+        ur = (k2["x"].astype(np.float64) - float(bf) / z + rng.uniform(-0.5, 0.5, len(k2)))
+        u = rng.random(len(k2))
+        off = u < 0.2
+        ur[off] += rng.choice([-1.0, 1.0], off.sum()) * rng.uniform(5, 60, off.sum())
+        ur[(u >= 0.2) & (u < 0.4)] = -1.0
+        scenes.append(dict(s=s, k2=k2, d2=d2, pose=pose, pts_f=pts_f, pts_desc=pts_desc, flags=flags, owner=owner, ur=ur.astype(np.float32)))
+    B = len(scenes)
+    cap = max(len(c["k2"]) for c in scenes) + 16
+    pcap = max(len(c["pts_f"]) for c in scenes) + 40
+    t = ex.tables()
+    fe = viorb_amd.Frontend(scenes[0]["s"]["cam"], scenes[0]["s"]["gw"], t["scale"], t["inv_sigma2"], bounds, max_batch=B, cap=cap)
+    ck = pad(torch, [c["k2"] for c in scenes], cap, viorb_amd.KP_DTYPE); cd = pad(torch, [c["d2"] for c in scenes], cap, np.uint8, (32,))
+    cc = torch.tensor([len(c["k2"]) for c in scenes], dtype=torch.int32, device="cuda")
+    cs = torch.zeros((B, 3073), dtype=torch.int32, device="cuda"); ci = torch.zeros((B, cap), dtype=torch.int32, device="cuda")
+    fe.grid(ck.data_ptr(), cc.data_ptr(), B, cs, ci)
+    pf = pad(torch, [c["pts_f"] for c in scenes], pcap, np.float32, (8,)); pfl = pad(torch, [c["flags"] for c in scenes], pcap, np.uint8)
+    pd = pad(torch, [c["pts_desc"] for c in scenes], pcap, np.uint8, (32,))
+    pc = torch.tensor([len(c["pts_f"]) for c in scenes], dtype=torch.int32, device="cuda")
+    own = pad(torch, [c["owner"] for c in scenes], cap, np.uint8); cur_ur = pad(torch, [c["ur"] for c in scenes], cap, np.float32)
+    pose = torch.from_numpy(np.stack([c["pose"] for c in scenes])).cuda()
+    log_sf = np.float32(np.log(np.float64(np.float32(1.2))))
+    for th, nnratio in ((1.0, 0.8), (3.0, 0.8)):
+        match = torch.full((B, cap), -7, dtype=torch.int32, device="cuda"); nm = torch.zeros(B, dtype=torch.int32, device="cuda")
+        fr = torch.zeros((B, pcap, 5), dtype=torch.float32, device="cuda"); xr = torch.full((B, pcap), -3.0, dtype=torch.float32, device="cuda")
+        status = torch.zeros(B, dtype=torch.int32, device="cuda")
+        fe.search_local_points(ck.data_ptr(), cd.data_ptr(), cc.data_ptr(), cs, ci, pose, pf, pfl, pd, pc, th, nnratio, own, B, match, nm, fr, status,
+                               cur_uright=cur_ur, bf=float(bf), frustum_xr=xr)
+        torch.cuda.synchronize()
+        assert (status.cpu().numpy() == 0).all()
+        for b, c in enumerate(scenes):
+            cam4 = c["s"]["cam"][:4]
+            onm, om, ofr, oxr = oracle.search_local_points(c["k2"], c["d2"], bounds, c["pose"], cam4, sf, log_sf, c["pts_f"], c["flags"], c["pts_desc"], th, nnratio,
+                                                           c["owner"], cur_uright=c["ur"], bf=float(bf))
+            mono_nm, mono_m, _ = oracle.search_local_points(c["k2"], c["d2"], bounds, c["pose"], cam4, sf, log_sf, c["pts_f"], c["flags"], c["pts_desc"], th, nnratio,
+                                                            c["owner"])
+            assert onm > 100 and onm < mono_nm and (om != mono_m).any(), "the right-coordinate gate must bite on this scene"
+            np.testing.assert_array_equal(fr[b, :len(ofr)].cpu().numpy(), ofr)
+            called = ((c["flags"] & 1) != 0) & ((c["flags"] & 2) == 0)               # isInFrustum runs for these only
+            np.testing.assert_array_equal(xr[b, :len(oxr)].cpu().numpy()[called], oxr[called])
+            assert nm[b].item() == onm
+            np.testing.assert_array_equal(match[b, :len(om)].cpu().numpy(), om)
+            # mTrackProjXR is what Frame::isInFrustum stores: u - mbf * invz in float
+            inview = ofr[:, 0] != 0
+            assert inview.sum() > 100 and (oxr[inview] < ofr[inview, 1]).all()
+            hn, hm, hfr, hxr = viorb_amd.SearchLocalPoints(c["k2"], c["d2"], bounds, c["pose"], cam4, sf, c["pts_f"], c["flags"], c["pts_desc"], th, nnratio, c["owner"],
+                                                           want_frustum=True, cur_uright=c["ur"], bf=float(bf))
+            assert hn == onm
+            np.testing.assert_array_equal(hm, om); np.testing.assert_array_equal(hfr, ofr); np.testing.assert_array_equal(hxr, oxr)
+    # a frame whose right coordinates are all "none" is the monocular search
+    c = scenes[0]
+    hn, hm = viorb_amd.SearchLocalPoints(c["k2"], c["d2"], bounds, c["pose"], c["s"]["cam"][:4], sf, c["pts_f"], c["flags"], c["pts_desc"], 1.0, 0.8, c["owner"],
+                                         cur_uright=np.full(len(c["k2"]), -1.0, np.float32), bf=float(bf))
+    mn, mm = viorb_amd.SearchLocalPoints(c["k2"], c["d2"], bounds, c["pose"], c["s"]["cam"][:4], sf, c["pts_f"], c["flags"], c["pts_desc"], 1.0, 0.8, c["owner"])
+    assert hn == mn and (hm == mm).all()
 
 
 @pytest.mark.parametrize("stereo_frac", [0.0, 0.6, 1.0])

@@ -256,7 +256,7 @@ def local_scene(oracle):
     return dict(s=s, sf=sf, k2=k2, d2=d2, pose=pose, pts_f=pts_f, pts_desc=pts_desc, flags=flags, owner=owner)
 
 
-def literal_local_search(oracle, L, th, nnratio):
+def literal_local_search(oracle, L, th, nnratio, uright=None, bf=0.0):
     f = np.float32
     k2, d2, pose, sf = L["k2"], L["d2"], L["pose"], L["sf"]
     intr = L["s"]["cam"][:4].astype(np.float32)
@@ -264,7 +264,7 @@ def literal_local_search(oracle, L, th, nnratio):
     Ow = np.array([-f(f(f(R[0, r] * t[0]) + f(R[1, r] * t[1])) + f(R[2, r] * t[2])) for r in range(3)], np.float32)
     logsf = f(np.log(np.float64(f(1.2))))
     match = np.full(len(k2), -1, np.int32); owner = L["owner"].copy(); nm = 0
-    fr = np.zeros((len(L["pts_f"]), 5), np.float32)
+    fr = np.zeros((len(L["pts_f"]), 5), np.float32); xrs = np.zeros(len(L["pts_f"]), np.float32)
     for i, (p, fl) in enumerate(zip(L["pts_f"], L["flags"])):
         if (fl & 2) or not (fl & 1):
             continue
@@ -286,6 +286,7 @@ def literal_local_search(oracle, L, th, nnratio):
         lvl = int(np.ceil(f(f(np.log(np.float64(f(maxd / dist)))) / logsf)))
         lvl = min(max(lvl, 0), 7)
         fr[i] = (1, u, v, vc, lvl)
+        xr = f(u - f(f(bf) * invz)); xrs[i] = xr                  # pMP->mTrackProjXR = u - mbf*invz (Frame.cc:499)
         r = f(2.5) if vc > 0.998 else f(4.0)
         if th != 1.0:
             r = f(r * f(th))
@@ -294,6 +295,9 @@ def literal_local_search(oracle, L, th, nnratio):
         for idx in cand:
             if owner[idx]:
                 continue
+            if uright is not None and uright[idx] > 0:            # ORBmatcher.cc:91-97
+                if f(abs(f(xr - f(uright[idx])))) > f(r * sf[lvl]):
+                    continue
             dd = oracle.descriptor_distance(L["pts_desc"][i], d2[idx])
             if dd < b1:
                 b2, b1, l2, l1, bi = b1, dd, l1, int(k2["octave"][idx]), idx
@@ -303,7 +307,7 @@ def literal_local_search(oracle, L, th, nnratio):
             if l1 == l2 and b1 > f(nnratio) * b2:
                 continue
             match[bi] = i; owner[bi] = 1 if (fl & 4) else 0; nm += 1
-    return nm, match, fr
+    return (nm, match, fr) if uright is None else (nm, match, fr, xrs)
 
 
 @pytest.mark.parametrize("th,nnratio", [(1.0, 0.8), (5.0, 0.8), (3.0, 0.6)])
@@ -319,3 +323,37 @@ def test_search_local_points_equals_literal_restatement(oracle, local_scene, th,
     # frustum geometry against float64: projections agree, predicted level within the pyramid
     inv = fr[:, 0] > 0
     assert inv.sum() > 500 and ((fr[inv, 4] >= 0) & (fr[inv, 4] <= 7)).all() and (fr[inv, 3] >= 0.5).all()
+
+
+@pytest.mark.parametrize("th", [1.0, 3.0])
+def test_search_local_points_stereo_gate_equals_literal_restatement(oracle, local_scene, th):
+    """The mvuRight gate of ORBmatcher::SearchByProjection(F, vpMapPoints, th) (reference src/ORBmatcher.cc:91-97) with mTrackProjXR of
+    Frame::isInFrustum (src/Frame.cc:499): right coordinates from the true depth (60 %), 5-60 px off (20 %), none (20 %)."""
+    from viorb_amd.synth import plane_points_f32
+    L = local_scene
+    Rcw, tcw = L["pose"][:9].reshape(3, 3).astype(np.float64), L["pose"][9:].astype(np.float64)
+    Pw2 = plane_points_f32(np.stack([L["k2"]["x"], L["k2"]["y"]], 1), L["pose"].astype(np.float64), L["s"]["cam"]).astype(np.float64)
+    z = (Pw2 @ Rcw.T + tcw)[:, 2]
+    rng = np.random.default_rng(11); bf = np.float32(386.1448)
+    ur = L["k2"]["x"].astype(np.float64) - float(bf) / z + rng.uniform(-0.5, 0.5, len(z))
+    u = rng.random(len(z)); off = u < 0.2
+    ur[off] += rng.choice([-1.0, 1.0], off.sum()) * rng.uniform(5, 60, off.sum()); ur[(u >= 0.2) & (u < 0.4)] = -1.0
+    ur = ur.astype(np.float32)
+    args = (L["k2"], L["d2"], BOUNDS, L["pose"], L["s"]["cam"][:4], L["sf"], np.float32(np.log(np.float64(np.float32(1.2)))), L["pts_f"], L["flags"], L["pts_desc"], th, 0.8,
+            L["owner"])
+    nm, m, fr, xr = oracle.search_local_points(*args, cur_uright=ur, bf=float(bf))
+    wn, wm, wfr, wxr = literal_local_search(oracle, L, th, 0.8, uright=ur, bf=bf)
+    np.testing.assert_array_equal(fr, wfr); np.testing.assert_array_equal(xr, wxr)
+    assert nm == wn and nm > 100
+    np.testing.assert_array_equal(m, wm)
+    mono_nm, mono_m, mono_fr = oracle.search_local_points(*args)
+    np.testing.assert_array_equal(mono_fr, fr)                       # the frustum test does not depend on the right coordinates
+    assert nm < mono_nm and (m != mono_m).any()                      # the gate removes candidates
+    # no keypoint with a right coordinate was matched to a point whose projection disagrees with it by more than the largest window
+    got = m >= 0
+    has = got & (ur > 0)
+    assert has.sum() > 50
+    assert (np.abs(xr[m[has]] - ur[has]) <= 4.0 * th * L["sf"][fr[m[has], 4].astype(int)] + 1e-3).all()
+    # all right coordinates absent: the monocular result
+    nm0, m0, _, _ = oracle.search_local_points(*args, cur_uright=np.full(len(z), -1.0, np.float32), bf=float(bf))
+    assert nm0 == mono_nm and (m0 == mono_m).all()

@@ -110,6 +110,7 @@ SIGNATURES = {
     "viorb_frontend_search_projection_device": (i32, [vp] * 12 + [f32, i32, vp, vp, vp, vp]),
     "viorb_frontend_search_projection_retry_device": (i32, [vp] * 12 + [f32, i32, i32, vp, vp, vp, vp]),
     "viorb_frontend_search_local_points_device": (i32, [vp] * 11 + [i32, f32, f32, vp, i32, vp, vp, vp, vp, vp]),
+    "viorb_frontend_search_local_points_stereo_device": (i32, [vp] * 5 + [f32] + [vp] * 7 + [i32, f32, f32, vp, i32, vp, vp, vp, vp, vp, vp]),
     "viorb_frontend_build_observations_device": (i32, [vp, vp, vp, vp, vp, i32, vp, vp, vp, vp]),
     "viorb_frontend_pose_opt_device": (i32, [vp, i32, i32] + [vp] * 9 + [i32] + [vp] * 7),
     "viorb_frontend_pose_opt_se3_device": (i32, [vp, vp, vp, vp, C.c_double, i32, vp, vp, vp, vp]),
@@ -167,6 +168,7 @@ SIGNATURES = {
     "viorb_search_by_projection_frame_stereo": (i32, [vp, vp, vp, i32, vp, vp, vp, vp, f32, f32, vp, i32, vp, i32, vp, vp, vp, f32, i32, vp, PP(i32)]),
     "viorb_frontend_search_projection_stereo_device": (i32, [vp] * 14 + [f32, f32, f32, i32, i32, vp, vp, vp, vp]),
     "viorb_search_by_projection_points": (i32, [vp, vp, i32, vp, vp, vp, vp, i32, vp, vp, vp, i32, f32, f32, vp, vp, PP(i32), vp]),
+    "viorb_search_by_projection_points_stereo": (i32, [vp, vp, vp, f32, i32, vp, vp, vp, vp, i32, vp, vp, vp, i32, f32, f32, vp, vp, PP(i32), vp, vp]),
     "viorb_preintegrate": (i32, [vp, i32, vp, vp, C.c_double, C.c_double, vp]),
     "viorb_pose_opt_vi": (i32, [i32, i32] + [vp] * 8 + [i32, vp, i32] + [vp] * 6),
     "viorb_debug_pvr_edge": (None, [vp] * 7),

@@ -363,6 +363,8 @@ struct LocalSearchArgs {
     const int* cell_start; const int* cell_idx; const float* pose12;
     const float* pts_f; const uint8_t* pts_flags; const uint8_t* pts_desc; const int* pts_count;
     const uint8_t* cur_owner_obs;
+    const float* cur_uright; float bf;   // stereo / RGB-D frames (mvuRight, mbf): the right-coordinate gate of ORBmatcher.cc:91-97; NULL = monocular
+    float* frustum_xr;                    // optional [batch][pcap]: mTrackProjXR = u - mbf * invz (Frame.cc:499)
     int* match; int* nmatches; int* status; float* frustum;
     uint32_t* cand; int* cand_n;
     int cap, pcap, slot_n;    // slot_n: candidates per point cached in LDS (LOCAL_SLOT or 0)
@@ -418,10 +420,11 @@ __global__ __launch_bounds__(SEARCH_THREADS) void k_search_local_points(LocalSea
     // isInFrustum + the candidates of local point i in the reference's order: f(k, dist << 16 | index); fr (when not null) receives
     // mbTrackInView, mTrackProjX, mTrackProjY, mTrackViewCos, mnTrackScaleLevel. Phase A stores the first CAND_CAP candidates; a point
     // with more is enumerated again by every sweep of phase B (no capacity limit).
+    const float* cur_ur = A.cur_uright ? A.cur_uright + (size_t)b * cap : nullptr;
     auto enumerate = [&](int i, float* fr, auto&& f) -> int {
         int nc = 0;
         const int fl = pf[i];
-        float fr_in = 0, fr_u = 0, fr_v = 0, fr_cos = 0, fr_lvl = 0;
+        float fr_in = 0, fr_u = 0, fr_v = 0, fr_cos = 0, fr_lvl = 0, fr_xr = 0;
         if ((fl & 1) && !(fl & 2)) {
             const float* X = A.pts_f + ((size_t)b * pcap + i) * 8;
             float pc[3];
@@ -441,7 +444,8 @@ __global__ __launch_bounds__(SEARCH_THREADS) void k_search_local_points(LocalSea
                 const float ratio = X[7] / dist;
                 int lvl = (int)ceilf(viorb_logf(ratio) / A.log_sf);
                 lvl = lvl < 0 ? 0 : (lvl >= A.nlevels ? A.nlevels - 1 : lvl);
-                fr_in = 1; fr_u = u; fr_v = v; fr_cos = viewCos; fr_lvl = (float)lvl;
+                const float xr = u - A.bf * invz;               // mTrackProjXR (Frame.cc:499); bf = 0 for a monocular frame
+                fr_in = 1; fr_u = u; fr_v = v; fr_cos = viewCos; fr_lvl = (float)lvl; fr_xr = xr;
                 float rr = viewCos > 0.998 ? 2.5f : 4.0f;
                 if (bFactor) rr *= A.th;
                 const float radius = rr * A.scale[lvl];
@@ -463,6 +467,10 @@ __global__ __launch_bounds__(SEARCH_THREADS) void k_search_local_points(LocalSea
                             const float2 q = cxy[i2];
                             if (!(fabsf(q.x - u) < radius && fabsf(q.y - v) < radius)) continue;
                             if (cown[i2]) continue;                 // held by a point with observations: never available
+                            if (cur_ur) {                            // "if(F.mvuRight[idx]>0) { er = fabs(mTrackProjXR - mvuRight[idx]); if(er > r*sf) continue; }"
+                                const float ur = cur_ur[i2];
+                                if (ur > 0 && fabsf(xr - ur) > radius) continue;
+                            }
                             const uint4* dc = reinterpret_cast<const uint4*>(A.cur_desc + ((size_t)b * cap + i2) * 32);
                             const uint4 ea = dc[0], eb = dc[1];
                             const int dist2 = __popc(da.x ^ ea.x) + __popc(da.y ^ ea.y) + __popc(da.z ^ ea.z) + __popc(da.w ^ ea.w) +
@@ -474,12 +482,13 @@ __global__ __launch_bounds__(SEARCH_THREADS) void k_search_local_points(LocalSea
                 }
             }
         }
-        if (fr) { fr[0] = fr_in; fr[1] = fr_u; fr[2] = fr_v; fr[3] = fr_cos; fr[4] = fr_lvl; }
+        if (fr) { fr[0] = fr_in; fr[1] = fr_u; fr[2] = fr_v; fr[3] = fr_cos; fr[4] = fr_lvl; if (A.frustum_xr) A.frustum_xr[(size_t)b * pcap + i] = fr_xr; }
         return nc;
     };
     // ---- phase A: frustum + candidates
     for (int i = t; i < npts; i += blockDim.x) {
-        cand_n[i] = enumerate(i, A.frustum ? A.frustum + ((size_t)b * pcap + i) * 5 : nullptr, [&](int k, uint32_t e) {
+        float fr_tmp[5];
+        cand_n[i] = enumerate(i, A.frustum ? A.frustum + ((size_t)b * pcap + i) * 5 : (A.frustum_xr ? fr_tmp : nullptr), [&](int k, uint32_t e) {
             if (k < slot_n) slot[(size_t)i * slot_n + k] = e;
             else if (k < CAND_CAP) cand[(size_t)i * CAND_CAP + k] = e;
         });                                                            // the true count, also beyond CAND_CAP
@@ -2221,6 +2230,10 @@ int viorb_frontend_search_projection_stereo_device(viorb_frontend* h, const vior
     return rc;
 }
 
+// the stereo arguments of the local-points search in progress on this thread (set by viorb_frontend_search_local_points_stereo_device only)
+struct StereoLocalArgs { const float* cur_uright = nullptr; float bf = 0; float* frustum_xr = nullptr; };
+static thread_local StereoLocalArgs g_stereo_local;
+
 int viorb_frontend_search_local_points_device(viorb_frontend* h, const viorb_keypoint* cur_kps, const uint8_t* cur_desc, const int32_t* cur_count,
                                               const int32_t* cell_start, const int32_t* cell_idx, const float* pose12, const float* pts_f,
                                               const uint8_t* pts_flags, const uint8_t* pts_desc, const int32_t* pts_count, int pcap, float th,
@@ -2247,6 +2260,7 @@ int viorb_frontend_search_local_points_device(viorb_frontend* h, const viorb_key
     A.cur_kps = cur_kps; A.cur_desc = cur_desc; A.cur_count = cur_count; A.cell_start = cell_start; A.cell_idx = cell_idx; A.pose12 = pose12;
     A.pts_f = pts_f; A.pts_flags = pts_flags; A.pts_desc = pts_desc; A.pts_count = pts_count; A.cur_owner_obs = cur_owner_obs;
     A.match = match; A.nmatches = nmatches; A.status = status; A.frustum = frustum; A.cand = h->d_lcand; A.cand_n = h->d_lcand_n;
+    A.cur_uright = g_stereo_local.cur_uright; A.bf = g_stereo_local.bf; A.frustum_xr = g_stereo_local.frustum_xr;
     A.cap = h->cap; A.pcap = pcap; A.slot_n = lslot;
     A.minX = h->cfg.min_x; A.maxX = h->cfg.max_x; A.minY = h->cfg.min_y; A.maxY = h->cfg.max_y; A.wInv = h->wInv; A.hInv = h->hInv;
     A.fx = h->cfg.fx; A.fy = h->cfg.fy; A.cx = h->cfg.cx; A.cy = h->cfg.cy; A.th = th; A.nnratio = nnratio;
@@ -2271,6 +2285,20 @@ int viorb_frontend_search_local_points_device(viorb_frontend* h, const viorb_key
     hipLaunchKernelGGL(k_search_local_points<false>, dim3(batch), dim3(SEARCH_THREADS), lds, (hipStream_t)stream, A);
     VIORB_HIP_TRY(hipGetLastError());
     return VIORB_OK;
+}
+
+int viorb_frontend_search_local_points_stereo_device(viorb_frontend* h, const viorb_keypoint* cur_kps, const uint8_t* cur_desc, const int32_t* cur_count,
+                                                     const float* cur_uright, float bf, const int32_t* cell_start, const int32_t* cell_idx,
+                                                     const float* pose12, const float* pts_f, const uint8_t* pts_flags, const uint8_t* pts_desc,
+                                                     const int32_t* pts_count, int pcap, float th, float nnratio, const uint8_t* cur_owner_obs,
+                                                     int batch, int32_t* match, int32_t* nmatches, float* frustum, float* frustum_xr, int32_t* status,
+                                                     void* stream) {
+    VIORB_REQUIRE(cur_uright, "null stereo array");
+    g_stereo_local.cur_uright = cur_uright; g_stereo_local.bf = bf; g_stereo_local.frustum_xr = frustum_xr;
+    const int rc = viorb_frontend_search_local_points_device(h, cur_kps, cur_desc, cur_count, cell_start, cell_idx, pose12, pts_f, pts_flags, pts_desc, pts_count,
+                                                             pcap, th, nnratio, cur_owner_obs, batch, match, nmatches, frustum, status, stream);
+    g_stereo_local = StereoLocalArgs();
+    return rc;
 }
 
 int viorb_frontend_build_observations_device(viorb_frontend* h, const viorb_keypoint* kps, const int32_t* count, const int32_t* match,
@@ -2494,16 +2522,20 @@ static thread_local HostArena g_host_arena;
 int current_device();
 // Per-call view of the arena. Inputs are staged in the page-locked mirror and go to the device in one asynchronous copy (flush); outputs
 // are registered (down) and come back in one copy + one synchronisation (fetch). A call used to issue ~15 small pageable copies and
-// five or six blocking downloads: 0.2 ms of the 0.5 ms a host-buffer pose solve cost. A buffer that does not lie in the mirrored
-// block (the arena grew during this very call) falls back to direct copies.
+// five or six blocking downloads: 0.2 ms of the 0.5 ms a host-buffer pose solve cost. The mirror covers the block the arena held when
+// the call began (base0: it stays allocated until the next call's reset()); a buffer taken after the arena grew during this very call
+// lies in a newer block and falls back to direct copies. Whether a buffer is mirrored is decided by its ADDRESS alone, so that a buffer
+// of the first block keeps going through the mirror after the arena has grown (a zero-staged buffer followed by a put() of the real
+// data would otherwise be overwritten by flush()'s copy of the staged zeros).
 struct DevBuf {
     struct Out { void* dst; const void* src; size_t bytes; };
-    std::vector<Out> outs; size_t lo = (size_t)-1, hi = 0; void* base0 = nullptr;
-    DevBuf() { g_host_arena.reset(current_device()); base0 = g_host_arena.blocks.empty() ? nullptr : g_host_arena.blocks.back().p; }
+    std::vector<Out> outs; size_t lo = (size_t)-1, hi = 0; void* base0 = nullptr; size_t base0_bytes = 0;
+    DevBuf() {
+        g_host_arena.reset(current_device());
+        if (!g_host_arena.blocks.empty()) { base0 = g_host_arena.blocks.back().p; base0_bytes = std::min(g_host_arena.blocks.back().bytes, g_host_arena.pin_bytes); }
+    }
     bool mirrored(const void* d, size_t bytes) const {
-        const HostArena& A = g_host_arena;
-        return A.pin && base0 && !A.blocks.empty() && A.blocks.back().p == base0 && (const char*)d >= (const char*)base0 &&
-               (const char*)d + bytes <= (const char*)base0 + A.pin_bytes;
+        return g_host_arena.pin && base0 && (const char*)d >= (const char*)base0 && (const char*)d + bytes <= (const char*)base0 + base0_bytes;
     }
     int put(void* d, const void* hsrc, size_t bytes) {       // host bytes -> the device buffer d (staged when d is mirrored)
         if (!bytes) return VIORB_OK;
@@ -2693,16 +2725,17 @@ int viorb_fuse(const viorb_keypoint* kps, const uint8_t* desc, const float* urig
     return VIORB_OK;
 }
 
-int viorb_search_by_projection_points(const viorb_keypoint* cur_kps, const uint8_t* cur_desc, int ncur, const float bounds4[4], const float pose12[12],
-                                      const float intr4[4], const float* scale_factors, int nlevels, const float* pts_f, const uint8_t* pts_flags,
-                                      const uint8_t* pts_desc, int npts, float th, float nnratio, const uint8_t* cur_owner_obs, int32_t* match,
-                                      int* nmatches, float* frustum5) {
+static int search_by_projection_points_host(const viorb_keypoint* cur_kps, const uint8_t* cur_desc, const float* cur_uright, float bf, int ncur,
+                                            const float bounds4[4], const float pose12[12], const float intr4[4], const float* scale_factors, int nlevels,
+                                            const float* pts_f, const uint8_t* pts_flags, const uint8_t* pts_desc, int npts, float th, float nnratio,
+                                            const uint8_t* cur_owner_obs, int32_t* match, int* nmatches, float* frustum5, float* proj_xr) {
     VIORB_REQUIRE(bounds4 && pose12 && intr4 && scale_factors && nmatches && ncur >= 0 && npts >= 0, "null array");
     VIORB_REQUIRE(nlevels >= 1 && nlevels <= 16, "nlevels must be 1..16");
     VIORB_REQUIRE(ncur == 0 || match, "match is NULL");
     *nmatches = 0;
     for (int i = 0; i < ncur; i++) match[i] = -1;
     if (frustum5) memset(frustum5, 0, sizeof(float) * 5 * (size_t)npts);
+    if (proj_xr) memset(proj_xr, 0, sizeof(float) * (size_t)npts);
     if (ncur == 0 || npts == 0) return VIORB_OK;
     VIORB_REQUIRE(cur_kps && cur_desc && pts_f && pts_flags && pts_desc && cur_owner_obs, "null array");
     viorb_frontend_config c = default_cfg();
@@ -2713,23 +2746,48 @@ int viorb_search_by_projection_points(const viorb_keypoint* cur_kps, const uint8
     viorb_frontend* h = nullptr;
     FE_TRY(host_frontend(c, ncur, &h, true));
     const size_t hc = (size_t)h->cap;
-    DevBuf B; viorb_keypoint* d_k; uint8_t *d_d, *d_pfl, *d_pd, *d_own; float *d_pose, *d_pf, *d_fr = nullptr; int *d_c, *d_cs, *d_ci, *d_pc, *d_m, *d_nm, *d_st;
+    DevBuf B; viorb_keypoint* d_k; uint8_t *d_d, *d_pfl, *d_pd, *d_own; float *d_pose, *d_pf, *d_fr = nullptr, *d_ur = nullptr, *d_xr = nullptr; int *d_c, *d_cs, *d_ci, *d_pc, *d_m, *d_nm, *d_st;
     FE_TRY(B.up(&d_k, (const viorb_keypoint*)nullptr, hc)); FE_TRY(B.up(&d_d, (const uint8_t*)nullptr, hc * 32)); FE_TRY(B.up(&d_own, (const uint8_t*)nullptr, hc));
+    if (cur_uright) FE_TRY(B.up(&d_ur, (const float*)nullptr, hc));
     FE_TRY(B.put(d_k, cur_kps, sizeof(viorb_keypoint) * ncur)); FE_TRY(B.put(d_d, cur_desc, (size_t)32 * ncur)); FE_TRY(B.put(d_own, cur_owner_obs, (size_t)ncur));
+    if (cur_uright) FE_TRY(B.put(d_ur, cur_uright, sizeof(float) * ncur));
     FE_TRY(B.up(&d_pose, pose12, 12)); FE_TRY(B.up(&d_c, &ncur, 1)); FE_TRY(B.up(&d_cs, (const int*)nullptr, GRID_CELLS + 1)); FE_TRY(B.up(&d_ci, (const int*)nullptr, hc));
     FE_TRY(B.up(&d_pf, pts_f, (size_t)npts * 8)); FE_TRY(B.up(&d_pfl, pts_flags, (size_t)npts)); FE_TRY(B.up(&d_pd, pts_desc, (size_t)npts * 32));
     FE_TRY(B.up(&d_pc, &npts, 1)); FE_TRY(B.up(&d_m, (const int*)nullptr, hc)); FE_TRY(B.up(&d_nm, (const int*)nullptr, 1)); FE_TRY(B.up(&d_st, (const int*)nullptr, 1));
     if (frustum5) FE_TRY(B.up(&d_fr, (const float*)nullptr, (size_t)npts * 5));
+    if (proj_xr) FE_TRY(B.up(&d_xr, (const float*)nullptr, (size_t)npts));
     FE_TRY(B.flush());
     FE_TRY(viorb_frontend_grid_device(h, d_k, d_c, 1, d_cs, d_ci, nullptr));
+    if (cur_uright)
+        FE_TRY(viorb_frontend_search_local_points_stereo_device(h, d_k, d_d, d_c, d_ur, bf, d_cs, d_ci, d_pose, d_pf, d_pfl, d_pd, d_pc, npts, th, nnratio, d_own, 1, d_m,
+                                                                d_nm, d_fr, d_xr, d_st, nullptr));
+    else
     FE_TRY(viorb_frontend_search_local_points_device(h, d_k, d_d, d_c, d_cs, d_ci, d_pose, d_pf, d_pfl, d_pd, d_pc, npts, th, nnratio, d_own, 1, d_m, d_nm, d_fr, d_st,
                                                      nullptr));
     int st = 0;
     B.down(match, d_m, sizeof(int) * ncur); B.down(nmatches, d_nm, sizeof(int)); B.down(&st, d_st, sizeof(int));
     if (frustum5) B.down(frustum5, d_fr, sizeof(float) * 5 * (size_t)npts);
+    if (proj_xr && d_xr) B.down(proj_xr, d_xr, sizeof(float) * (size_t)npts);
     FE_TRY(B.fetch());
     if (st != VIORB_OK) { set_error("SearchByProjection(Frame, MapPoints): device status %d", st); return st; }
     return VIORB_OK;
+}
+
+int viorb_search_by_projection_points(const viorb_keypoint* cur_kps, const uint8_t* cur_desc, int ncur, const float bounds4[4], const float pose12[12],
+                                      const float intr4[4], const float* scale_factors, int nlevels, const float* pts_f, const uint8_t* pts_flags,
+                                      const uint8_t* pts_desc, int npts, float th, float nnratio, const uint8_t* cur_owner_obs, int32_t* match,
+                                      int* nmatches, float* frustum5) {
+    return search_by_projection_points_host(cur_kps, cur_desc, nullptr, 0.f, ncur, bounds4, pose12, intr4, scale_factors, nlevels, pts_f, pts_flags, pts_desc, npts, th,
+                                            nnratio, cur_owner_obs, match, nmatches, frustum5, nullptr);
+}
+
+int viorb_search_by_projection_points_stereo(const viorb_keypoint* cur_kps, const uint8_t* cur_desc, const float* cur_uright, float bf, int ncur,
+                                             const float bounds4[4], const float pose12[12], const float intr4[4], const float* scale_factors, int nlevels,
+                                             const float* pts_f, const uint8_t* pts_flags, const uint8_t* pts_desc, int npts, float th, float nnratio,
+                                             const uint8_t* cur_owner_obs, int32_t* match, int* nmatches, float* frustum5, float* proj_xr) {
+    VIORB_REQUIRE(ncur == 0 || cur_uright, "cur_uright is NULL");
+    return search_by_projection_points_host(cur_kps, cur_desc, cur_uright, bf, ncur, bounds4, pose12, intr4, scale_factors, nlevels, pts_f, pts_flags, pts_desc, npts, th,
+                                            nnratio, cur_owner_obs, match, nmatches, frustum5, proj_xr);
 }
 
 int viorb_preintegrate(const double* imu, int n_imu, const double bg[3], const double ba[3], double t_last, double t_cur, double* preint142) {

@@ -79,15 +79,25 @@ class ORBmatcher:
 
 
 def SearchLocalPoints(cur_kps, cur_desc, bounds, pose12, intr4, scale_factors, pts_f, pts_flags, pts_desc, th=1.0, nnratio=0.8, cur_owner_obs=None,
-                      want_frustum=False):
+                      want_frustum=False, cur_uright=None, bf=0.0):
     """Tracking::SearchLocalPoints' matcher call: Frame::isInFrustum + ORBmatcher(nnratio).SearchByProjection(F, vpMapPoints, th)
-    (reference src/Tracking.cc:1904-1958, src/ORBmatcher.cc:45-129), host arrays. Returns (nmatches, match[N]) (+ frustum[npts,5])."""
+    (reference src/Tracking.cc:1904-1958, src/ORBmatcher.cc:45-129), host arrays. Returns (nmatches, match[N]) (+ frustum[npts,5]).
+    cur_uright (F.mvuRight) + bf (F.mbf): a stereo / RGB-D frame — the right-coordinate gate of ORBmatcher.cc:91-97 applies and the frustum
+    result gains mTrackProjXR as a third return value ((nmatches, match, frustum, proj_xr) with want_frustum)."""
     f32 = lambda a: np.ascontiguousarray(a, np.float32)
     ck = np.ascontiguousarray(cur_kps, capi.KP_DTYPE)
     pf = f32(pts_f).reshape(-1, 8); sf = f32(scale_factors)
     own = np.zeros(max(len(ck), 1), np.uint8) if cur_owner_obs is None else np.ascontiguousarray(cur_owner_obs, np.uint8)
     match = np.full(max(len(ck), 1), -1, np.int32); nm = C.c_int()
     fr = np.zeros((max(len(pf), 1), 5), np.float32) if want_frustum else None
+    if cur_uright is not None:
+        ur = f32(cur_uright); assert len(ur) >= len(ck)
+        xr = np.zeros(max(len(pf), 1), np.float32) if want_frustum else None
+        check(lib().viorb_search_by_projection_points_stereo(ptr(ck), ptr(np.ascontiguousarray(cur_desc, np.uint8)), ptr(ur), float(bf), len(ck), ptr(f32(bounds)),
+                                                             ptr(f32(pose12)), ptr(f32(intr4)), ptr(sf), len(sf), ptr(pf), ptr(np.ascontiguousarray(pts_flags, np.uint8)),
+                                                             ptr(np.ascontiguousarray(pts_desc, np.uint8)), len(pf), float(th), float(nnratio), ptr(own), ptr(match),
+                                                             C.byref(nm), ptr(fr) if fr is not None else None, ptr(xr) if xr is not None else None))
+        return (nm.value, match[:len(ck)], fr[:len(pf)], xr[:len(pf)]) if want_frustum else (nm.value, match[:len(ck)])
     check(lib().viorb_search_by_projection_points(ptr(ck), ptr(np.ascontiguousarray(cur_desc, np.uint8)), len(ck), ptr(f32(bounds)), ptr(f32(pose12)),
                                                   ptr(f32(intr4)), ptr(sf), len(sf), ptr(pf), ptr(np.ascontiguousarray(pts_flags, np.uint8)),
                                                   ptr(np.ascontiguousarray(pts_desc, np.uint8)), len(pf), float(th), float(nnratio), ptr(own), ptr(match),
@@ -374,8 +384,16 @@ class Frontend:
             ptr(status), self._st(stream)))
 
     def search_local_points(self, cur_kps_ptr, cur_desc_ptr, cur_count_ptr, cell_start, cell_idx, pose12, pts_f, pts_flags, pts_desc,
-                            pts_count, th, nnratio, cur_owner_obs, batch, match, nmatches, frustum, status, stream=None):
+                            pts_count, th, nnratio, cur_owner_obs, batch, match, nmatches, frustum, status, stream=None, cur_uright=None, bf=0.0,
+                            frustum_xr=None):
         p = lambda a: a if isinstance(a, C.c_void_p) else (C.c_void_p(a) if isinstance(a, int) else ptr(a))
+        if cur_uright is not None:                # stereo / RGB-D frame: the mvuRight gate of ORBmatcher.cc:91-97
+            check(self.L.viorb_frontend_search_local_points_stereo_device(
+                self.h, p(cur_kps_ptr), p(cur_desc_ptr), p(cur_count_ptr), ptr(cur_uright), float(bf), ptr(cell_start), ptr(cell_idx), ptr(pose12), ptr(pts_f),
+                ptr(pts_flags), ptr(pts_desc), ptr(pts_count), pts_f.shape[1], float(th), float(nnratio), ptr(cur_owner_obs), batch,
+                ptr(match), ptr(nmatches), ptr(frustum) if frustum is not None else None, ptr(frustum_xr) if frustum_xr is not None else None, ptr(status),
+                self._st(stream)))
+            return
         check(self.L.viorb_frontend_search_local_points_device(
             self.h, p(cur_kps_ptr), p(cur_desc_ptr), p(cur_count_ptr), ptr(cell_start), ptr(cell_idx), ptr(pose12), ptr(pts_f),
             ptr(pts_flags), ptr(pts_desc), ptr(pts_count), pts_f.shape[1], float(th), float(nnratio), ptr(cur_owner_obs), batch,

@@ -85,14 +85,14 @@ inline int search_by_projection_frame(FrameT& Cur, const FrameT& Last, float th,
 // are not already matched in this frame — which sets mbTrackInView, mTrackProjX, mTrackProjY, mTrackProjXR, mnTrackScaleLevel,
 // mTrackViewCos and calls IncreaseVisible() — followed by ORBmatcher(0.8).SearchByProjection(F, vpMapPoints, th). The caller keeps
 // the first loop of SearchLocalPoints (marking mnLastFrameSeen of the points the frame already holds). Returns the matcher's nmatches.
-// Monocular frames only (VIORB's mono-inertial path): the mvuRight gate of :91-97 (stereo / RGB-D keypoints against mTrackProjXR) is
-// not in the device search, so a frame with right coordinates is refused instead of being matched differently.
+// Monocular, stereo and RGB-D frames alike: F.mvuRight (all -1 for a monocular frame) and F.mbf go to the device, which applies the gate of
+// :91-97 (a keypoint with a right coordinate must lie within the window radius of mTrackProjXR) and returns mTrackProjXR = u - mbf * invz.
 template <class FrameT, class MapPointT>
 inline int search_by_projection_points(FrameT& F, const std::vector<MapPointT*>& vpMapPoints, float th, float nnratio) {
     const int np = (int)vpMapPoints.size();
-    for (int i = 0; i < F.N; i++) if (F.mvuRight[i] > 0) throw std::runtime_error("SearchByProjection(Frame, MapPoints): stereo keypoints are not supported by the device search");
     std::vector<viorb_keypoint> ck; flatten_keys(F.mvKeysUn, F.N, ck);
-    std::vector<float> pts_f((size_t)(np + 1) * 8, 0.f), frustum((size_t)(np + 1) * 5, 0.f);
+    std::vector<float> pts_f((size_t)(np + 1) * 8, 0.f), frustum((size_t)(np + 1) * 5, 0.f), proj_xr(np + 1, 0.f), uright(F.N + 1, -1.f);
+    for (int i = 0; i < F.N && i < (int)F.mvuRight.size(); i++) uright[i] = F.mvuRight[i];
     std::vector<unsigned char> flags(np + 1, 0), pdesc((size_t)(np + 1) * 32, 0), owner(F.N + 1, 0);
     for (int p = 0; p < np; p++) {
         MapPointT* pMP = vpMapPoints[p];
@@ -104,8 +104,9 @@ inline int search_by_projection_points(FrameT& F, const std::vector<MapPointT*>&
     float pose[12]; flatten_pose(F.mTcw, pose);
     const float bounds[4] = {F.mnMinX, F.mnMaxX, F.mnMinY, F.mnMaxY}, intr[4] = {F.fx, F.fy, F.cx, F.cy};
     std::vector<int32_t> match(F.N + 1, -1); int nmatches = 0;
-    check(viorb_search_by_projection_points(&ck[0], F.mDescriptors.data, F.N, bounds, pose, intr, &F.mvScaleFactors[0], F.mnScaleLevels, &pts_f[0], &flags[0],
-                                            &pdesc[0], np, th, nnratio, &owner[0], &match[0], &nmatches, &frustum[0]), "SearchByProjection(Frame, MapPoints)");
+    check(viorb_search_by_projection_points_stereo(&ck[0], F.mDescriptors.data, &uright[0], F.mbf, F.N, bounds, pose, intr, &F.mvScaleFactors[0], F.mnScaleLevels,
+                                                   &pts_f[0], &flags[0], &pdesc[0], np, th, nnratio, &owner[0], &match[0], &nmatches, &frustum[0], &proj_xr[0]),
+          "SearchByProjection(Frame, MapPoints)");
     for (int p = 0; p < np; p++) {
         MapPointT* pMP = vpMapPoints[p];
         if (!(flags[p] & 1) || (flags[p] & 2)) continue;                    // isInFrustum is not called for these (:1929-1932)
@@ -113,6 +114,7 @@ inline int search_by_projection_points(FrameT& F, const std::vector<MapPointT*>&
         pMP->mbTrackInView = f[0] != 0.f;
         if (pMP->mbTrackInView) {
             pMP->mTrackProjX = f[1]; pMP->mTrackProjY = f[2]; pMP->mTrackViewCos = f[3]; pMP->mnTrackScaleLevel = (int)f[4];
+            pMP->mTrackProjXR = proj_xr[p];
             pMP->IncreaseVisible();
         }
     }
