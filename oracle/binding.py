@@ -279,7 +279,8 @@ def edge_prior(pvr, bias, prior, jac=True):
 
 
 def _result(ns, ns_last, oc, ol, marg, info, trace):
-    return dict(ns=ns, ns_last=ns_last, outlier_cur=oc, outlier_last=ol, marg_cov_inv=marg.reshape(12, 12),
+    d = (C.c_int * 2)(); _vio().ora_pose_opt_diagnostics(d)
+    return dict(rejected_rounds=int(d[0]), stale_verdicts=int(d[1]), ns=ns, ns_last=ns_last, outlier_cur=oc, outlier_last=ol, marg_cov_inv=marg.reshape(12, 12),
                 n_inliers=int(info[0]), final_chi2=float(info[1]), lm_iterations=int(info[2]),
                 chi2_trace=trace[:int(info[3])].copy())
 
@@ -420,7 +421,9 @@ def pose_opt_se3(pose12, intr5, obs7):
     obs7 = _f64(obs7).reshape(-1, 7)
     out, fl, info = np.zeros(12, np.float32), np.zeros(max(len(obs7), 1), np.uint8), np.zeros(3)
     _vio().ora_pose_opt_se3(_p(np.ascontiguousarray(pose12, np.float32)), _p(_f64(intr5, 5)), _p(obs7), len(obs7), _p(out), _p(fl), _p(info))
-    return dict(pose12=out, outlier=fl[:len(obs7)], n_inliers=int(info[0]), final_chi2=float(info[1]), lm_iterations=int(info[2]))
+    d = (C.c_int * 2)(); _vio().ora_pose_opt_diagnostics(d)
+    return dict(pose12=out, outlier=fl[:len(obs7)], n_inliers=int(info[0]), final_chi2=float(info[1]), lm_iterations=int(info[2]),
+                rejected_rounds=int(d[0]), stale_verdicts=int(d[1]))
 
 
 def stereo_match(ex_left, ex_right, kl, dl, kr, dr, bf, fx):

@@ -154,6 +154,8 @@ void result_out(const PoseOptResult& R, double* ns_cur, double* ns_last, uint8_t
 
 extern "C" {
 
+void ora_pose_opt_diagnostics(int* out2) { pose_opt_diagnostics(out2, out2 + 1); }
+
 void ora_preintegrate(const double* samples7, int n, const double* bg, const double* ba, double t_last, double t_cur, double* out142) {
     std::vector<ImuSample> s(n);
     for (int i = 0; i < n; i++) { for (int k = 0; k < 3; k++) { s[i].g[k] = samples7[7 * i + k]; s[i].a[k] = samples7[7 * i + 3 + k]; } s[i].t = samples7[7 * i + 6]; }

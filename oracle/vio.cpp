@@ -204,6 +204,7 @@ struct Graph {
     int n = 0; Mat H; std::vector<double> b, x;
     double lambda = -1, ni = 2; int nBad = 0;
     std::vector<double> trace; int outer_its = 0; double last_chi = 0;
+    bool last_trial_rejected = false;   // the optimize() call in progress ended on a rejected trial: inlier edges keep the rejected state's errors
     void index() { n = 0; for (auto& v : V) { v.hidx = v.fixed ? -1 : n; if (!v.fixed) n += v.dim; } }
     void compute_active_errors() { for (auto& e : E) if (e.level == 0) e.compute_error(e); }
     double active_robust_chi2() {
@@ -273,6 +274,7 @@ struct Graph {
             qmax++;
         } while (rho < 0 && qmax < 10);
         last_chi = currentChi; trace.push_back(currentChi); outer_its++;
+        last_trial_rejected = !(rho > 0 && std::isfinite(tempChi));
         if (qmax == 10 || rho == 0) return false;
         if ((iniChi - currentChi) * 1e3 < iniChi) nBad++; else nBad = 0;
         if (nBad >= 3) return false;
@@ -324,19 +326,30 @@ static Edge make_prior_edge(Graph* g, int vp, int vb, const NavState& prior, con
 }
 
 // the 4-round outlier scheme shared by both overloads (Optimizer.cc:599-692 / :979-1029)
+// Diagnostics of the last run_rounds() on this thread (tests only): rounds whose optimize() ended on a rejected trial — g2o then leaves the
+// errors of the REJECTED state on the active edges (optimization_algorithm_levenberg.cpp:143-147 pops the vertices, nothing recomputes
+// the errors) and Optimizer.cc:629-634 / :659-664 classify inliers by that stored chi2 —, and edges whose verdict by the stored error
+// differs from the verdict by the error at the restored estimate.
+thread_local int g_diag_rejected_rounds = 0, g_diag_stale_verdicts = 0;
 static int run_rounds(Graph& g, const std::vector<std::pair<int, NavState>>& resets,
                       std::vector<int>& edges_cur, std::vector<uint8_t>& out_cur,
                       std::vector<int>& edges_last, std::vector<uint8_t>& out_last) {
+    g_diag_rejected_rounds = 0; g_diag_stale_verdicts = 0;
     const float chi2Mono[4] = {5.991f, 5.991f, 5.991f, 5.991f};
     int nBad = 0;
     for (int it = 0; it < 4; it++) {
         for (auto& r : resets) g.V[r.first].est = r.second;
         g.optimize(10);
+        if (g.last_trial_rejected) g_diag_rejected_rounds++;
         auto classify = [&](std::vector<int>& ed, std::vector<uint8_t>& out) {
             int bad = 0;
             for (size_t i = 0; i < ed.size(); i++) {
                 Edge& e = g.E[ed[i]];
                 if (out[i]) e.compute_error(e);
+                else if (g.last_trial_rejected) {                     // diagnostic only: what a recomputation at the restored estimate would say
+                    Edge f = e; f.compute_error(f);
+                    if (((float)f.chi2() > chi2Mono[it]) != ((float)e.chi2() > chi2Mono[it])) g_diag_stale_verdicts++;
+                }
                 const float chi2 = (float)e.chi2();
                 if (chi2 > chi2Mono[it]) { out[i] = 1; e.level = 1; bad++; } else { out[i] = 0; e.level = 0; }
                 if (it == 2) e.delta = 0;
@@ -350,6 +363,7 @@ static int run_rounds(Graph& g, const std::vector<std::pair<int, NavState>>& res
     return nBad;
 }
 } // namespace
+void pose_opt_diagnostics(int* rejected_rounds, int* stale_verdicts) { *rejected_rounds = g_diag_rejected_rounds; *stale_verdicts = g_diag_stale_verdicts; }
 
 PoseOptResult pose_opt_vi_kf(const NavState& cur, const NavState& kf, const Preint& preint, V3 gw, const Camera& cam,
                              const std::vector<Observation>& obs, bool marg) {
@@ -470,9 +484,11 @@ Se3Result pose_opt_se3(const float* pose12, double fx, double fy, double cx, dou
     auto active_chi = [&]() { double c = 0; for (auto& e : E) if (e.level == 0) { if (e.delta > 0) { double r[3]; huber(chi2(e), e.delta, r); c += r[0]; } else c += chi2(e); } return c; };
     const float chi2Mono = 5.991f, chi2Stereo = 7.815f;
     int nBad = 0; double lambda = 0, ni = 2; int its_total = 0; double last_chi = 0;
+    g_diag_rejected_rounds = 0; g_diag_stale_verdicts = 0;
     for (int round = 0; round < 4; round++) {
         est = from_pose();
         int nBadLM = 0;
+        bool last_rejected = false;
         for (int it = 0; it < 10; it++) {
             for (auto& e : E) if (e.level == 0) compute_error(e);
             double currentChi = active_chi(); const double iniChi = currentChi;
@@ -504,7 +520,8 @@ Se3Result pose_opt_se3(const float* pose12, double fx, double fy, double cx, dou
                 if (rho > 0 && std::isfinite(tempChi)) {
                     double alpha = 1. - std::pow((2 * rho - 1), 3); alpha = std::min(alpha, 2. / 3.);
                     lambda *= std::max(1. / 3., alpha); ni = 2; currentChi = tempChi;
-                } else { lambda *= ni; ni *= 2; est = backup; }
+                    last_rejected = false;
+                } else { lambda *= ni; ni *= 2; est = backup; last_rejected = true; }
                 qmax++;
             } while (rho < 0 && qmax < 10);
             its_total++; last_chi = currentChi;
@@ -513,9 +530,11 @@ Se3Result pose_opt_se3(const float* pose12, double fx, double fy, double cx, dou
             if (nBadLM >= 3) break;
         }
         nBad = 0;
+        if (last_rejected) g_diag_rejected_rounds++;
         for (size_t i = 0; i < E.size(); i++) {
             Se3Edge& e = E[i];
-            if (R.outlier[i]) compute_error(e);
+            if (R.outlier[i]) compute_error(e);            // an inlier keeps the error of the last computeActiveErrors (the last trial state, also when it was rejected)
+            else if (last_rejected) { Se3Edge f = e; compute_error(f); if (((float)chi2(f) > (e.stereo ? chi2Stereo : chi2Mono)) != ((float)chi2(e) > (e.stereo ? chi2Stereo : chi2Mono))) g_diag_stale_verdicts++; }
             const float c2 = (float)chi2(e);
             if (c2 > (e.stereo ? chi2Stereo : chi2Mono)) { R.outlier[i] = 1; e.level = 1; nBad++; } else { R.outlier[i] = 0; e.level = 0; }
             if (round == 2) e.delta = 0;

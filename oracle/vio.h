@@ -78,6 +78,10 @@ PoseOptResult pose_opt_vi_frame(const NavState& cur, const NavState& last, const
                                 const std::vector<Observation>& obs_cur, const std::vector<Observation>& obs_last,
                                 bool compute_marg);
 
+// Diagnostics of the last pose_opt_vi_* call on this thread (tests): rounds whose optimize() ended on a rejected trial, and inlier edges whose
+// verdict by g2o's stored (stale) error differs from the verdict at the restored estimate.
+void pose_opt_diagnostics(int* rejected_rounds, int* stale_verdicts);
+
 // ---- vision-only pose optimisation, Optimizer::PoseOptimization(Frame*), reference src/Optimizer.cc:3749-3978,
 // edges Thirdparty/g2o/g2o/types/types_six_dof_expmap.cpp:266-364, SE3Quat::exp se3quat.h:223-257.
 struct Se3Obs { V3 Xw; double u, v, ur; double inv_sigma2; };     // ur < 0: monocular edge, else stereo edge

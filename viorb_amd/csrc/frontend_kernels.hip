@@ -1048,6 +1048,22 @@ __device__ bool wave_solve_reg(const double* __restrict__ H, const double* __res
     return ok;
 }
 
+// Quaternion normalisation by ONE reciprocal square root (v_rsq_f64 + two Newton steps, ~1 ulp) and four multiplications instead of sqrt and
+// four IEEE divisions (~150 dependent-ish f64 instructions): the scalar phases of the pose solver (IMU / prior factor pieces, state update) normalise
+// five to eight quaternions per evaluation on a single lane, which was 40 % of their length. Used where the parity bar is a tolerance
+// (solver state 1e-7, cost 1e-5), never in the bit-exact front-end arithmetic; DESIGN.md section 2, deviation 3.
+__device__ __forceinline__ quat qnorm_f(quat q) {
+    const double r = rsqrt_nr(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
+    return mkq(q.x * r, q.y * r, q.z * r, q.w * r);
+}
+__device__ __forceinline__ quat so3_mul_f(quat a, quat b) { return qnorm_f(qmul(qnorm_f(a), b)); }
+__device__ __forceinline__ quat so3_exp_f(d3 w) {
+    const double th = norm3(w), half = 0.5 * th;
+    double imag; const double real = cos(half);
+    if (th < 1e-10) { const double t2 = th * th, t4 = t2 * t2; imag = 0.5 - 0.0208333 * t2 + 0.000260417 * t4; }
+    else imag = sin(half) / th;
+    return qnorm_f(mkq(imag * w.x, imag * w.y, imag * w.z, real));
+}
 __device__ __forceinline__ pvr sh_pvr(const double* p) { pvr s; s.P = ld3(p); s.V = ld3(p + 3); s.q = mkq(p[6], p[7], p[8], p[9]); return s; }
 __device__ __forceinline__ void sh_put(double* p, const pvr& s) { st3(p, s.P); st3(p + 3, s.V); p[6] = s.q.x; p[7] = s.q.y; p[8] = s.q.z; p[9] = s.q.w; }
 
@@ -1122,7 +1138,7 @@ __device__ __forceinline__ void imu_piece_pv(const double* est_i, const double* 
     const double dT = pre[60], dT2 = dT * dT;
     LDS_READS_DONE();
     const pvr si = sh_pvr(ei); const d3 Pj = ld3(ej), Vj = ld3(ej + 3), gw = ld3(g3), dba_i = ld3(db);
-    const quat RiT = qnorm(qconj(si.q));
+    const quat RiT = qnorm_f(qconj(si.q));
     const d3 aP = qrot(RiT, Pj - si.P - si.V * dT - gw * (0.5 * dT2));
     const d3 aV = qrot(RiT, Vj - si.V - gw * dT);
     const m33 JPa = ldm(ja), JVa = ldm(jv);
@@ -1139,8 +1155,8 @@ __device__ __forceinline__ void imu_piece_rot(const double* est_i, const double*
     lds_get(est_i + 6, qa); lds_get(est_j + 6, qb); lds_get(corrT, ct);
     LDS_READS_DONE();
     const quat qi = mkq(qa[0], qa[1], qa[2], qa[3]), qj = mkq(qb[0], qb[1], qb[2], qb[3]);
-    const quat RiT = qnorm(qconj(qi));
-    const quat rR = so3_mul(so3_mul(mkq(ct[0], ct[1], ct[2], ct[3]), RiT), qj);
+    const quat RiT = qnorm_f(qconj(qi));
+    const quat rR = so3_mul_f(so3_mul_f(mkq(ct[0], ct[1], ct[2], ct[3]), RiT), qj);
     const d3 rPhi = so3_log(rR);
     e[6] = rPhi.x; e[7] = rPhi.y; e[8] = rPhi.z;
     if (!J) return;
@@ -1163,7 +1179,7 @@ __device__ __forceinline__ void prior_piece(const double* est, d3 ba_plus_dba, c
     LDS_READS_DONE();
     const pvr s = sh_pvr(es);
     const d3 eP = ld3(pr) - s.P, eV = ld3(pr + 3) - s.V;
-    const d3 eR = so3_log(so3_mul(mkq(pr[6], pr[7], pr[8], pr[9]), s.q));
+    const d3 eR = so3_log(so3_mul_f(mkq(pr[6], pr[7], pr[8], pr[9]), s.q));
     const d3 eB = ld3(pr + 10) - ba_plus_dba;
     e[0] = eP.x; e[1] = eP.y; e[2] = eP.z; e[3] = eV.x; e[4] = eV.y; e[5] = eV.z; e[6] = eR.x; e[7] = eR.y; e[8] = eR.z; e[9] = eB.x; e[10] = eB.y; e[11] = eB.z;
     if (!J) return;
@@ -1712,7 +1728,7 @@ __global__ __launch_bounds__(POSE_THREADS, 2) void k_pose_opt_vi(PoseOptArgs A) 
                     LDS_READS_DONE();
                     const quat q0 = mkq(old[6], old[7], old[8], old[9]);
                     if (wave < 2) {
-                        const quat r = so3_mul(q0, so3_exp(mk3(u[6], u[7], u[8])));
+                        const quat r = so3_mul_f(q0, so3_exp_f(mk3(u[6], u[7], u[8])));
                         S.est[side][6] = r.x; S.est[side][7] = r.y; S.est[side][8] = r.z; S.est[side][9] = r.w;
                     } else {
                         st3(S.est[side], ld3(old) + mulv(qmat(q0), mk3(u[0], u[1], u[2])));
@@ -1839,6 +1855,8 @@ __global__ __launch_bounds__(POSE_THREADS, 2) void k_pose_opt_vi(PoseOptArgs A) 
     }
 }
 
+#include "pose_opt_mp.inc"
+
 // ---------------------------------------------------------------------------------------------
 // Vision-only pose optimisation, Optimizer::PoseOptimization(Frame*) (reference src/Optimizer.cc:3749-3978):
 // one 6-DoF SE3 vertex (left-multiplicative update), mono and stereo only-pose edges, the same 4 x optimize(10)
@@ -1849,7 +1867,7 @@ struct Se3Args {
     double fx, fy, cx, cy, bf;
     float* out_pose12; uint8_t* outlier; double* info;
 };
-struct Se3Shared { double H[36], Lm[36], b[6], x[6]; double red[4][28]; double est[7], bak[7]; double sc[8]; int flag[4]; };
+struct Se3Shared { double H[36], Lm[36], b[6], x[6]; double red[4][28]; double est[7], bak[7], ev[7]; double sc[8]; int flag[4]; };   // ev: the estimate of the last computeActiveErrors
 
 __global__ __launch_bounds__(256) void k_pose_opt_se3(Se3Args A) {
     __shared__ Se3Shared S;
@@ -1936,6 +1954,7 @@ __global__ __launch_bounds__(256) void k_pose_opt_se3(Se3Args A) {
         }
         __syncthreads();
         double lambda = 0, ni = 2; int nBadLM = 0;
+        bool last_rejected = false;
         for (int it = 0; it < 10; it++) {
             double currentChi = evaluate(true);
             const double iniChi = currentChi;
@@ -1955,12 +1974,14 @@ __global__ __launch_bounds__(256) void k_pose_opt_se3(Se3Args A) {
                     S.est[0] = nw.r.x; S.est[1] = nw.r.y; S.est[2] = nw.r.z; S.est[3] = nw.r.w; S.est[4] = nw.t.x; S.est[5] = nw.t.y; S.est[6] = nw.t.z;
                 }
                 __syncthreads();
+                if (t < 7) S.ev[t] = S.est[t];
                 double tempChi = evaluate(false);
                 if (!ok2) tempChi = 1.7976931348623157e308;
                 double scale = 0; for (int j = 0; j < 6; j++) scale += S.x[j] * (lambda * S.x[j] + S.b[j]);
                 scale += 1e-3;
                 rho = (currentChi - tempChi) / scale;
-                if (rho > 0 && isfinite(tempChi)) { double alpha = 1. - pow(2 * rho - 1, 3); alpha = fmin(alpha, 2. / 3.); lambda *= fmax(1. / 3., alpha); ni = 2; currentChi = tempChi; }
+                last_rejected = !(rho > 0 && isfinite(tempChi));
+                if (!last_rejected) { double alpha = 1. - pow(2 * rho - 1, 3); alpha = fmin(alpha, 2. / 3.); lambda *= fmax(1. / 3., alpha); ni = 2; currentChi = tempChi; }
                 else { lambda *= ni; ni *= 2; if (t < 7) S.est[t] = S.bak[t]; }
                 __syncthreads();
                 qmax++;
@@ -1972,11 +1993,16 @@ __global__ __launch_bounds__(256) void k_pose_opt_se3(Se3Args A) {
         }
         __syncthreads();
         {
-            const se3q s = ld_est();
+            // Optimizer.cc:3880-3940: an edge flagged as outlier is re-evaluated at the new estimate ("if(pFrame->mvbOutlier[idx]) e->computeError()"),
+            // an inlier is classified by its STORED error — the error of the last computeActiveErrors, i.e. of the last trial state, which is
+            // not the estimate when that trial was rejected (optimization_algorithm_levenberg.cpp:143-147 restores the vertices only)
+            const se3q s_est = ld_est();
+            se3q s_ev; s_ev.r = mkq(S.ev[0], S.ev[1], S.ev[2], S.ev[3]); s_ev.t = mk3(S.ev[4], S.ev[5], S.ev[6]);
             int bad_local = 0;
             for (int i = t; i < n; i += blockDim.x) {
                 const double* o = ob + 7 * i;
                 double e[3];
+                const se3q s = (last_rejected && !ol[i]) ? s_ev : s_est;
                 const int dim = se3_edge(s, ld3(o), o[3], o[4], o[5], A.fx, A.fy, A.cx, A.cy, A.bf, false, e, nullptr);
                 const float chi2 = (float)(o[6] * (e[0] * e[0] + e[1] * e[1] + e[2] * e[2]));
                 const int bad = chi2 > (dim == 3 ? 7.815f : 5.991f);
@@ -2021,6 +2047,37 @@ struct viorb_frontend {
     unsigned char* d_search_work = nullptr; size_t search_work_bytes = 0;      // work arrays of the searches when a frame's keypoints do not fit LDS
     double *d_cam = nullptr, *d_gw = nullptr; float* d_inv_sigma2 = nullptr; float* d_scale = nullptr;
 };
+
+// Launch of the visual-inertial pose solve. VIORB_POSE_MP="P,WPP" selects an instantiation of k_pose_opt_vi_mp (problems per workgroup,
+// wavefronts per problem; "0" = the round-3 kernel, one 256-thread workgroup per problem); the default is POSE_MP_DEFAULT.
+#ifndef POSE_MP_DEFAULT_P
+#define POSE_MP_DEFAULT_P 2
+#define POSE_MP_DEFAULT_WPP 2
+#endif
+template <int P, int WPP> static int launch_pose_mp(const PoseOptArgs& A, int batch, hipStream_t st) {
+    const size_t lds = sizeof(PoseMpShared<P, WPP>);
+    if (lds > 64 * 1024) VIORB_HIP_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(k_pose_opt_vi_mp<P, WPP>), lds));
+    hipLaunchKernelGGL((k_pose_opt_vi_mp<P, WPP>), dim3((batch + P - 1) / P), dim3(64 * P * WPP), lds, st, A, batch);
+    return VIORB_OK;
+}
+static int launch_pose_opt_vi(const PoseOptArgs& A, int batch, hipStream_t st) {
+    static int cfg = -1;
+    if (cfg < 0) {
+        int P = POSE_MP_DEFAULT_P, W = POSE_MP_DEFAULT_WPP;
+        if (const char* e = getenv("VIORB_POSE_MP")) { P = 0; W = 0; sscanf(e, "%d,%d", &P, &W); }
+        cfg = P * 16 + W;
+    }
+    switch (cfg) {
+        case 0: hipLaunchKernelGGL(k_pose_opt_vi, dim3(batch), dim3(POSE_THREADS), 0, st, A); return VIORB_OK;
+        case 1 * 16 + 4: return launch_pose_mp<1, 4>(A, batch, st);
+        case 1 * 16 + 2: return launch_pose_mp<1, 2>(A, batch, st);
+        case 2 * 16 + 2: return launch_pose_mp<2, 2>(A, batch, st);
+        case 2 * 16 + 4: return launch_pose_mp<2, 4>(A, batch, st);
+        case 4 * 16 + 1: return launch_pose_mp<4, 1>(A, batch, st);
+        case 4 * 16 + 2: return launch_pose_mp<4, 2>(A, batch, st);
+        default: set_error("VIORB_POSE_MP: unsupported (P, WPP)"); return VIORB_ERR_UNSUPPORTED;
+    }
+}
 
 extern "C" {
 
@@ -2421,7 +2478,7 @@ int viorb_frontend_pose_opt_device(viorb_frontend* h, int variant, int compute_m
     A.outlier_cur = outlier_cur; A.outlier_last = variant ? outlier_last : nullptr; A.acc_bias_rw2 = h->cfg.acc_bias_rw2;
     A.variant_arr = nullptr; A.skip = nullptr;
     ProfScope ps("k_pose_opt_vi", (hipStream_t)stream);
-    hipLaunchKernelGGL(k_pose_opt_vi, dim3(batch), dim3(POSE_THREADS), 0, (hipStream_t)stream, A);
+    { const int rc = launch_pose_opt_vi(A, batch, (hipStream_t)stream); if (rc != VIORB_OK) return rc; }
     VIORB_HIP_TRY(hipGetLastError());
     return VIORB_OK;
 }
@@ -2443,7 +2500,7 @@ int viorb_frontend_pose_opt_select_device(viorb_frontend* h, const uint8_t* vari
     A.outlier_cur = outlier_cur; A.outlier_last = outlier_last; A.acc_bias_rw2 = h->cfg.acc_bias_rw2;
     A.variant_arr = variant; A.skip = skip;
     ProfScope ps("k_pose_opt_vi", (hipStream_t)stream);
-    hipLaunchKernelGGL(k_pose_opt_vi, dim3(batch), dim3(POSE_THREADS), 0, (hipStream_t)stream, A);
+    { const int rc = launch_pose_opt_vi(A, batch, (hipStream_t)stream); if (rc != VIORB_OK) return rc; }
     VIORB_HIP_TRY(hipGetLastError());
     return VIORB_OK;
 }
