@@ -372,7 +372,8 @@ typedef struct viorb_tracker_config {
     viorb_frontend_config  frontend;      /* bounds (Frame::ComputeImageBounds from width / height / dist_coef), scale tables and nlevels are filled in */
     int32_t width, height, batch, device;
     float   th_projection;                /* SearchByProjection window: 15 mono, 7 stereo (src/Tracking.cc:427-431) */
-    int32_t track_local_map;              /* 0: TrackWithIMU only */
+    int32_t track_local_map;              /* > 0: TrackWithIMU + TrackLocalMapWithIMU; 0: TrackWithIMU only; < 0: extract + grid + IMU prediction + SearchByProjection
+                                             only ("ORB extract + match": no pose solve, the frame hands on its IMU prediction) */
     int32_t local_frames;                 /* local map = the points of this many frames before the last one (1..8) */
     int32_t compute_marg;                 /* bComputeMarg of the last solve of a frame */
     int32_t max_steps_ahead;              /* host runs at most this many steps in front of the device (<= 0: 8) */

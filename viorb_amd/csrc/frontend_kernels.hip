@@ -2061,15 +2061,22 @@ template <int P, int WPP> static int launch_pose_mp(const PoseOptArgs& A, int ba
     return VIORB_OK;
 }
 static int launch_pose_opt_vi(const PoseOptArgs& A, int batch, hipStream_t st) {
-    static int cfg = -1;
-    if (cfg < 0) {
-        int P = POSE_MP_DEFAULT_P, W = POSE_MP_DEFAULT_WPP;
-        if (const char* e = getenv("VIORB_POSE_MP")) { P = 0; W = 0; sscanf(e, "%d,%d", &P, &W); }
-        cfg = P * 16 + W;
+    static int cfg_env = -1, n_cu = 0;
+    if (cfg_env < 0) {
+        cfg_env = 0;
+        if (const char* e = getenv("VIORB_POSE_MP")) { int P = 0, W = 0; sscanf(e, "%d,%d", &P, &W); cfg_env = 0x100 | (P * 16 + W); }
+        int dev = 0; hipDeviceProp_t pr;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) n_cu = pr.multiProcessorCount;
+        if (n_cu <= 0) n_cu = 256;
     }
+    // Throughput shape <2, 2> (two problems share a 256-thread workgroup's scalar phases: fewest instructions and fewest resident wavefronts per
+    // problem) once there is a problem pair per CU; below that the chip is idle anyway and a solve's LATENCY is what a step waits for: four
+    // wavefronts per problem, eight when even a problem per two CUs is not there (a single stream).
+    int cfg = cfg_env & 0x100 ? (cfg_env & 0xff) : (batch >= 2 * n_cu ? POSE_MP_DEFAULT_P * 16 + POSE_MP_DEFAULT_WPP : (batch > n_cu / 2 ? 1 * 16 + 4 : 1 * 16 + 8));
     switch (cfg) {
         case 0: hipLaunchKernelGGL(k_pose_opt_vi, dim3(batch), dim3(POSE_THREADS), 0, st, A); return VIORB_OK;
         case 1 * 16 + 4: return launch_pose_mp<1, 4>(A, batch, st);
+        case 1 * 16 + 8: return launch_pose_mp<1, 8>(A, batch, st);
         case 1 * 16 + 2: return launch_pose_mp<1, 2>(A, batch, st);
         case 2 * 16 + 2: return launch_pose_mp<2, 2>(A, batch, st);
         case 2 * 16 + 4: return launch_pose_mp<2, 4>(A, batch, st);

@@ -163,7 +163,7 @@ struct viorb_tracker {
 
 static int tracker_roll(viorb_tracker* h, const viorb_keypoint* kps, const uint8_t* desc, const int* count, const double* ns_src, const double* t_src,
                         const double* marg_src, const double* synth_pose12, hipStream_t st) {
-    const bool tlm = h->cfg.track_local_map != 0;
+    const bool tlm = h->cfg.track_local_map > 0;
     TR_TRY(viorb_frontend_roll_device(h->fe, kps, desc, count, h->last_kps, h->last_desc, h->last_count, tlm ? h->last_pts_f : nullptr, h->last_flags,
                                       tlm ? h->loc_pts_f : nullptr, tlm ? h->loc_desc : nullptr, tlm ? h->loc_flags : nullptr, h->cfg.local_frames,
                                       (tlm && h->rolls > 0) ? 1 : 0, ns_src, h->last_ns, h->prior_ns, t_src, h->t_last, marg_src,
@@ -182,7 +182,7 @@ extern "C" {
 int viorb_tracker_create(const viorb_tracker_config* cfg, viorb_tracker** out) {
     VIORB_REQUIRE(cfg && out, "null cfg/out");
     VIORB_REQUIRE(cfg->batch >= 1 && cfg->width > 0 && cfg->height > 0, "batch >= 1, width, height > 0");
-    VIORB_REQUIRE(!cfg->track_local_map || (cfg->local_frames >= 1 && cfg->local_frames <= 8), "1 <= local_frames <= 8");
+    VIORB_REQUIRE(cfg->track_local_map <= 0 || (cfg->local_frames >= 1 && cfg->local_frames <= 8), "1 <= local_frames <= 8");
     if (viorb_device_count() < 1) { set_error("no HIP device: libviorb_hip has no CPU fallback"); return VIORB_ERR_NO_DEVICE; }
     VIORB_HIP_TRY(hipSetDevice(cfg->device));
     viorb_tracker* h = new viorb_tracker();
@@ -214,7 +214,7 @@ int viorb_tracker_create(const viorb_tracker_config* cfg, viorb_tracker** out) {
     }
     VIORB_HIP_TRY(hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming));
     for (int i = 0; i < 2; i++) { VIORB_HIP_TRY(hipEventCreateWithFlags(&h->ev_ex[i], hipEventDisableTiming)); VIORB_HIP_TRY(hipEventCreateWithFlags(&h->ev_tr[i], hipEventDisableTiming)); }
-    const size_t B = (size_t)h->B, cap = (size_t)h->cap, R = (size_t)(cfg->track_local_map ? cfg->local_frames : 1);
+    const size_t B = (size_t)h->B, cap = (size_t)h->cap, R = (size_t)(cfg->track_local_map > 0 ? cfg->local_frames : 1);
     DevArena& M = h->mem;
     h->last_kps = M.get<viorb_keypoint>(B * cap); h->last_desc = M.get<uint8_t>(B * cap * 32); h->last_count = M.get<int>(B);
     h->last_flags = M.get<uint8_t>(B * cap); h->last_Pw = M.get<float>(B * cap * 3); h->last_pts_f = M.get<float>(B * cap * 8); h->last_self = M.get<int>(B * cap);
@@ -331,7 +331,8 @@ int viorb_tracker_step(viorb_tracker* h, const viorb_tracker_inputs* in, void* c
         d_images = h->stage[sl]; ev_upload = h->ev_cp[sl];
         h->upload_bytes += (double)bytes;
     }
-    const bool tlm = h->cfg.track_local_map != 0;
+    const bool tlm = h->cfg.track_local_map > 0;
+    const bool match_only = h->cfg.track_local_map < 0;       // extraction + grid + IMU prediction + SearchByProjection only: the frame hands on its IMU prediction
     const int marg = h->cfg.compute_marg != 0;
     viorb_extractor* ex = h->ex[slot];
     // inputs were produced on the caller's stream
@@ -361,6 +362,16 @@ int viorb_tracker_step(viorb_tracker* h, const viorb_tracker_inputs* in, void* c
                                                          h->last_flags, h->last_Pw, h->last_desc, 2 * h->cfg.th_projection, 20, B, h->cur_match, h->nmatches,
                                                          h->status_s1, st));
     TR_TRY(viorb_frontend_build_observations_device(h->fe, kps, count, h->cur_match, h->last_Pw, B, h->obs_cur, h->idx_cur, h->n_cur, st));
+    if (match_only) {
+        // "ORB extract + match" (BASELINE north_star's single-stream figure): no pose solve; state = VIORB_TRACK_OK, the NavState handed on is the
+        // IMU prediction (what Tracking does while vision is lost, src/Tracking.cc:1036-1114), the prior information stays
+        VIORB_HIP_TRY(hipMemsetAsync(h->state, 0, sizeof(int32_t) * B, st));
+        VIORB_HIP_TRY(hipMemcpyAsync(h->final_ns, h->cur_ns, sizeof(double) * 22 * B, hipMemcpyDeviceToDevice, st));
+        hipLaunchKernelGGL(k_track_merge_status, dim3((B + 255) / 256), dim3(256), 0, st, ex_status, h->status_s1, (const int32_t*)nullptr, B, h->status);
+        VIORB_HIP_TRY(hipGetLastError());
+        TR_TRY(tracker_roll(h, kps, desc, count, in->d_reset_ns ? in->d_reset_ns : h->final_ns, in->d_t_next_last ? in->d_t_next_last : in->d_t_cur, nullptr,
+                            in->d_synth_pose12, st));
+    } else {
     hipLaunchKernelGGL(k_track_gate0, dim3((B + 255) / 256), dim3(256), 0, st, h->nmatches, B, h->skip1, in->d_map_updated, h->variant);
     TR_TRY(viorb_frontend_pose_opt_select_device(h->fe, h->variant, h->skip1, marg && !tlm, h->cur_ns, h->last_ns, h->prior_ns, h->marg_cov_inv, h->preint,
                                                  h->obs_cur, h->n_cur, h->obs_last, h->n_last, B, h->out_ns, h->out_last_ns, h->outlier_cur,
@@ -387,6 +398,7 @@ int viorb_tracker_step(viorb_tracker* h, const viorb_tracker_inputs* in, void* c
     VIORB_HIP_TRY(hipGetLastError());
     // ---- mLastFrame = Frame(mCurrentFrame)
     TR_TRY(tracker_roll(h, kps, desc, count, h->final_ns, in->d_t_next_last ? in->d_t_next_last : in->d_t_cur, h->final_marg, in->d_synth_pose12, st));
+    }
     VIORB_HIP_TRY(hipEventRecord(h->ev_tr[slot], st));
     h->ev_tr_valid[slot] = true;
     h->k++;

@@ -283,7 +283,7 @@ class NativeTracker:
         cap = C.c_int()
         check(lib().viorb_tracker_capacity(h, C.byref(cap)))
         self.cap = cap.value
-        self.track_local_map = bool(track_local_map)
+        self.track_local_map = int(track_local_map) > 0
         self._keep, self._pending = [], []
         self.max_steps_ahead = max_steps_ahead
 
