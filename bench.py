@@ -77,14 +77,25 @@ def _gen_stream(args):
     return dict(frames=s["frames"], imu=s["imu"], t=s["t"], ns_true=s["ns_true"], pose_true=s["pose_true"], period=s["period"], cam=s["cam"], gw=s["gw"])
 
 
+def generator_procs(n_seeds, procs=None):
+    """Worker processes of the synthetic-stream generator on this rank: the host's cores are shared by the ranks of the node (LOCAL_WORLD_SIZE)."""
+    nproc = max(1, min(n_seeds, (os.cpu_count() or 2) // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1"))), 16))
+    return max(1, min(nproc, procs)) if procs else nproc
+
+
+def host_memory_estimate(cfg, streams, distinct, world, host_pass):
+    """Bytes of host memory one rank of a tracking config holds at its peak: the generated distinct streams, the [F, S, h, w] stack that is
+    uploaded once, and (only when a live-feed pass reads it: N = 1 or --host-input) its page-locked copy."""
+    frame = cfg["w"] * cfg["h"]
+    return {"generated": distinct * N_FRAMES * frame, "upload_stack": streams * N_FRAMES * frame, "page_locked_copy": streams * N_FRAMES * frame if host_pass else 0}
+
+
 def generate_streams(seeds, w=752, h=480, procs=None, dist=None):
     """CPU-side synthetic data (before anything touches the GPU). `procs=1` generates in-process: under `rocprofv3 --pmc` the profiler's
     preloaded library has initialised the GPU before Python starts, and forked pool workers of such a process never exit (that, not a
     kernel-ordering bug, is why the round-2 bench "did not finish" under --pmc: profiles/README.md, round 3)."""
     import multiprocessing as mp
-    nproc = max(1, min(len(seeds), (os.cpu_count() or 2) // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1"))), 16))
-    if procs:
-        nproc = max(1, min(nproc, procs))
+    nproc = generator_procs(len(seeds), procs)
     jobs = [(s, w, h, dist) for s in seeds]
     if nproc == 1:
         return [_gen_stream(j) for j in jobs]
@@ -189,6 +200,8 @@ def run_tracking(args, cfg, rank, dev_index, dev, world):
     tr.bootstrap(frames[0], pose_true[0], t_frames[0], ns_true[0], mci0)
 
     # live feed: the same frames in page-locked host memory, uploaded by the tracker's copy stream inside the step (viorb_tracker_inputs.h_images)
+    if world > 1:
+        args.no_host_input_pass = True                                   # the context passes after the timed region are N = 1 only
     need_host = args.host_input or not args.no_host_input_pass       # 8 x S x frame bytes of page-locked memory: only when a pass reads it
     frames_host = torch.from_numpy(np.stack([s["frames"] for s in streams], 1)).pin_memory() if need_host else None
     feed = {"frames": frames_host if args.host_input else frames}
@@ -408,6 +421,16 @@ def run_tracking(args, cfg, rank, dev_index, dev, world):
                 out["config"]["single_stream"] = {"error": str(e)[:200]}
         if not (res["status"] == 0).all():
             raise SystemExit("a stream reported a capacity / status error: %s" % res["status"])
+        if args.config == "synth720p" and world == 1 and not args.no_host_input_pass and S < 128:
+            # BASELINE configs[4] gives every GPU 8 of the 64 streams: a latency-bound batch that any number of GPUs runs at the same per-GPU
+            # rate. What ONE GPU does with this workload when it has enough streams to fill it (the same 8 scenes replicated, own state each):
+            import copy
+            del tr, frames, frames_host
+            torch.cuda.empty_cache()
+            a2 = copy.copy(args); a2.streams = 128; a2.steps = 24; a2.warmup = 6; a2.no_host_input_pass = True; a2.no_cpu_baseline = True; a2.no_kernel_events = True
+            sat = run_tracking(a2, cfg, rank, dev_index, dev, world)
+            out["config"]["saturated_frames_per_s"] = round(sat["units"] / sat["elapsed"], 1)
+            out["config"]["saturated_note"] = "the same 1280x720 / 1500-feature sequence at 128 streams per GPU per step (the 8 scenes replicated, own tracker state each), 24 steps after the timed region"
         if not args.no_cpu_baseline and world == 1:          # the CPU baseline is timed on rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline_tracking(base, W_IMG, H_IMG, NFEAT, 200 if args.config == "euroc" else 60, 20 if args.config == "euroc" else 8, lens)
     out["metric"] = "frames/sec ORB extract+match+pose-opt, EuRoC 752x480, 1/2/4/8 GPUs" if args.config == "euroc" else \
@@ -556,25 +579,34 @@ def run_stereo(args, cfg, rank, dev_index, dev, world):
 # local_ba: Optimizer::LocalBundleAdjustmentNavState, 20-key-frame window (reference src/Optimizer.cc:1690-2241)
 # ------------------------------------------------------------------------------------------------------------------------------
 def run_local_ba(args, cfg, rank, dev_index, dev, world):
+    import ctypes as C
     import torch
     import torch.distributed as dist
-    from oracle import binding as ora                      # pre-integration of the synthetic problem's IMU blocks (input preparation) + baseline
+    import viorb_amd
     from viorb_amd.synth import make_local_ba_problem
     from viorb_amd import LocalBundleAdjustmentNavStateBatch
     nwin = args.streams
+    # DISTINCT windows (a lock-step group waits for its slowest window; replicas of a few windows all take the same Levenberg path, which is the
+    # best case): W in [10, 20] key frames, 1000-3000 points each seen by 3-8 key frames, one seed per window. The IMU blocks are pre-integrated
+    # by the library itself (viorb_preintegrate), as the reference's KeyFrame does before LocalMapping calls the solve.
+    n_distinct = min(nwin, args.distinct or 64)
+    rng = np.random.default_rng(1000 + rank)
     probs = []
-    for s in range(min(nwin, 4)):
-        p = make_local_ba_problem(3 + rank * 16 + s, W=20, n_points=2000)
+    for s in range(n_distinct):
+        W = int(rng.integers(10, 21)); npts = int(rng.integers(1000, 3001))
+        p = make_local_ba_problem(3 + rank * 4096 + s, W=W, n_points=npts)
         pre = []
         for i, (imu, t0, t1) in enumerate(p["imu"]):
             j = i - 1 if i > 0 else p["prev_kf"]
-            pre.append(ora.preintegrate(imu, p["kfs"][j][10:13], p["kfs"][j][13:16], t0, t1))
+            pre.append(viorb_amd.preintegrate(imu, p["kfs"][j][10:13], p["kfs"][j][13:16], t0, t1))
         probs.append(dict(kfs=p["kfs"], n_local=p["n_local"], prev_kf=p["prev_kf"], preint=np.stack(pre), points=p["points"], edge_idx=p["edge_idx"],
                           edge_obs=p["edge_obs"], gw=p["gw"], cam=p["cam"]))
     batch = [probs[i % len(probs)] for i in range(nwin)]
     fl = args.in_flight
     for _ in range(max(1, args.warmup)):
         LocalBundleAdjustmentNavStateBatch(batch[:max(fl, 2)], max_in_flight=fl)
+    L = viorb_amd.lib()
+    L.viorb_profile_select(None); L.viorb_profile_reset(); L.viorb_profile_enable(0 if args.no_kernel_events else 1)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -585,23 +617,62 @@ def run_local_ba(args, cfg, rank, dev_index, dev, world):
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    out = dict(units=nwin * args.steps, elapsed=elapsed, metric="windows/sec LocalBundleAdjustmentNavState, 20-key-frame window, 2000 points", unit="windows/s", dtype="f64")
+    L.viorb_profile_enable(0)
+    out = dict(units=nwin * args.steps, elapsed=elapsed, metric="windows/sec LocalBundleAdjustmentNavState, 10-20-key-frame windows, 1000-3000 points", unit="windows/s", dtype="f64")
     if rank == 0:
-        ne = int(np.mean([len(p["edge_idx"]) for p in probs]))
-        out["roofline"] = None
-        out["config"] = {"workload": "synthetic EuRoC-shaped local window: W = 20 key frames (12 unknowns each) + 3 fixed, 2000 points, ~%d mono edges, IMU + bias "
-                                     "factors; LocalBundleAdjustmentNavState = optimize(5), chi2 gate, optimize(10); viorb_local_ba_navstate_batch, host buffers in "
-                                     "and out (its caller is the LocalMapping thread)" % ne,
-                         "baseline_config": cfg["baseline_config"], "windows_per_gpu_per_step": nwin, "windows_in_flight": fl,
-                         "lm_iterations_first_second": [res[0]["its_first"], res[0]["its_second"]], "final_chi2": round(float(res[0]["chi2_final"]), 3)}
+        names = C.create_string_buffer(4096); ms = (C.c_double * 64)(); calls = (C.c_int * 64)(); n = C.c_int()
+        L.viorb_profile_read(names, 4096, ms, calls, 64, C.byref(n))
+        prof = {nm_: (ms[i], calls[i]) for i, nm_ in enumerate(names.value.decode().split("\n")[:n.value]) if nm_}
+        # FP64 FLOP model of ONE Levenberg trial of a window: two error passes (60 FLOP per edge each), linearisation with
+        # the W blocks and the Hpp / Hll / b sums (450 per edge), IMU + bias factors (10 k per key frame), 3 x 3 inverses (50 per point), the Schur
+        # complement gathered per key-frame pair (324 per (point, pair of its observing key frames) entry), the dense Cholesky + two triangular
+        # solves of the reduced 12 W system (n^3 / 3 + 2 n^2), back-substitution (36 per edge + 30 per point). Trials >= LM iterations (rejected
+        # trials are not reported), so the rate is a lower bound.
+        def trial_flop(q):
+            ne, npt, Wq = len(q["edge_idx"]), len(q["points"]), int(q["n_local"])
+            cnt = np.bincount(np.asarray(q["edge_idx"])[:, 0].astype(np.int64), minlength=npt)      # observations per point (edge_idx rows = (point, key frame))
+            pairs = float((cnt * (cnt + 1) / 2).sum())
+            nred = 12.0 * Wq
+            parts = {"errors": 120.0 * ne, "linearise": 450.0 * ne, "imu": 1.0e4 * Wq, "dinv": 50.0 * npt, "schur": 324.0 * pairs,
+                     "cholesky": nred ** 3 / 3 + 2 * nred ** 2, "backsub": 36.0 * ne + 30.0 * npt}
+            return parts
+        its = np.array([r["its_first"] + r["its_second"] for r in res], np.float64)
+        parts = [trial_flop(batch[i]) for i in range(nwin)]
+        flop_step = float(sum(sum(pp.values()) * its[i] for i, pp in enumerate(parts)))
+        chol_step = float(sum(pp["cholesky"] * its[i] for i, pp in enumerate(parts)))
+        ach = flop_step * args.steps / elapsed / 1e12
+        kern = {k: round(v[0] / args.steps, 3) for k, v in sorted(prof.items())}
+        roof = {"bound": "fp64_vector", "kernel": "viorb_local_ba_navstate_batch (whole lock-step solve)", "achieved": round(ach, 3), "peak": FP64_VECTOR_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(ach / FP64_VECTOR_PEAK_TFLOPS, 5), "traffic": None,
+                "flop_per_step": int(flop_step), "kernel_ms_per_step": kern,
+                "note": "FP64 FLOP of every LM iteration of every window of a step (model above; rejected trials not counted) over the step's wall time, host "
+                        "preparation and transfers included; v_mfma_f64_16x16x4_f64 runs at the FP64 vector rate on gfx950, so one peak serves both. "
+                        "MFMA-busy counters: profiles/r04_pmc_mfma_local_ba.txt"}
+        if prof.get("k_bab_chol_solve", (0, 0))[1]:
+            tms = prof["k_bab_chol_solve"][0]
+            roof["cholesky"] = {"kernel": "k_bab_chol_solve", "ms_per_step": round(tms / args.steps, 3), "launches_per_step": prof["k_bab_chol_solve"][1] // args.steps,
+                                "achieved": round(chol_step * args.steps / (tms * 1e-3) / 1e12, 3), "unit": "TFLOP/s",
+                                "frac": round(chol_step * args.steps / (tms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS, 5),
+                                "note": "n^3/3 + 2 n^2 of every iterating window over the kernel's HIP-event time (a launch factors the whole group; the MFMA trailing updates "
+                                        "and panel solves are the FLOPs, the diagonal blocks' dependent 1/sqrt chains are the time)"}
+        out["roofline"] = roof
+        Ws = [int(q["n_local"]) for q in probs]; nps = [len(q["points"]) for q in probs]; nes = [len(q["edge_idx"]) for q in probs]
+        out["config"] = {"workload": "synthetic EuRoC-shaped local windows, %d DISTINCT per step (W = %d..%d key frames of 12 unknowns + 4 fixed, %d..%d points seen by 3-8 key "
+                                     "frames, %d..%d mono edges, IMU + bias factors); LocalBundleAdjustmentNavState = optimize(5), chi2 gate, optimize(10); "
+                                     "viorb_local_ba_navstate_batch, host buffers in and out (its caller is the LocalMapping thread); IMU blocks pre-integrated by "
+                                     "viorb_preintegrate" % (n_distinct, min(Ws), max(Ws), min(nps), max(nps), min(nes), max(nes)),
+                         "baseline_config": cfg["baseline_config"], "windows_per_gpu_per_step": nwin, "distinct_windows": n_distinct, "windows_in_flight": fl,
+                         "lm_iterations_mean_min_max": [round(float(its.mean()), 2), int(its.min()), int(its.max())],
+                         "final_chi2_window0": round(float(res[0]["chi2_final"]), 3)}
         if not args.no_cpu_baseline and world == 1:          # the CPU baseline is timed on rank 0 at N = 1 only
-            q = probs[0]; a = (q["kfs"], q["n_local"], q["prev_kf"], q["preint"], q["points"], q["edge_idx"], q["edge_obs"], q["gw"], q["cam"])
-            ora.local_ba(*a)
-            times = []
-            while sum(times) < 10.0 and len(times) < 200:
-                t1 = time.perf_counter(); ora.local_ba(*a); times.append(time.perf_counter() - t1)
+            from oracle import binding as ora               # checker, used as the CPU baseline only
+            times, ti = [], 0
+            t_all = time.perf_counter()
+            while time.perf_counter() - t_all < 15.0 and ti < 4 * len(probs):
+                q = probs[ti % len(probs)]; a = (q["kfs"], q["n_local"], q["prev_kf"], q["preint"], q["points"], q["edge_idx"], q["edge_obs"], q["gw"], q["cam"])
+                t1 = time.perf_counter(); ora.local_ba(*a); times.append(time.perf_counter() - t1); ti += 1
             out["cpu_baseline"] = {"value": round(len(times) / sum(times), 3), "unit": "windows/s", "cores": 1, "kind": "port",
-                                   "sample": "%d solves of one window after 1 warm-up, oracle (C++ -O3, dense Cholesky of the reduced system) on 1 host thread: "
+                                   "sample": "%d of the step's distinct windows, one solve each, oracle (C++ -O3, dense Cholesky of the reduced system) on 1 host thread: "
                                              "median %.1f ms" % (len(times), np.median(times) * 1e3),
                                    "median_ms_per_window": round(float(np.median(times)) * 1e3, 2), "hardware_concurrency": os.cpu_count(), "cpu_model": cpu_model()}
     return out
@@ -653,16 +724,22 @@ def main():
         # rank plumbing, gloo rendezvous, stream ownership, and the {sum units, max time} reduction of a made-up measurement. Prints no metric.
         if world > 1:
             dist_init("gloo")
-        seeds = stream_seeds(rank, min(args.streams, 4))
+        full = bool(os.environ.get("VIORB_BENCH_PLUMBING_FULL"))      # the real number of distinct streams per rank instead of 4 (seed ownership at scale)
+        n_own = min(args.streams, (args.distinct or 256) if full else 4)
+        seeds = stream_seeds(rank, n_own)
         units, elapsed = reduce_throughput(args.streams * args.steps, 1.0 + 0.5 * rank)
+        host_pass = args.host_input or (world == 1 and not args.no_host_input_pass)
+        mine = {"rank": rank, "local_rank": local_rank, "seeds": seeds if not full else [seeds[0], seeds[-1], len(seeds)], "gen_procs": generator_procs(n_own, args.gen_procs),
+                "host_bytes": host_memory_estimate(cfg, args.streams, min(args.streams, args.distinct or 256), world, host_pass) if args.config in ("euroc", "synth720p") else None}
         owned = [None] * world
         if world > 1:
-            dist.all_gather_object(owned, seeds)
+            dist.all_gather_object(owned, mine)
         else:
-            owned = [seeds]
+            owned = [mine]
         if rank == 0:
             print(json.dumps({"plumbing_only": True, "config": args.config, "n_gpus": world, "local_rank": local_rank, "streams_per_gpu": args.streams,
-                              "steps": args.steps, "warmup": args.warmup, "units": units, "elapsed": elapsed, "seeds": owned}))
+                              "steps": args.steps, "warmup": args.warmup, "units": units, "elapsed": elapsed, "seeds": [o["seeds"] for o in owned],
+                              "ranks": owned, "host_cpus": os.cpu_count()}))
         if world > 1:
             dist.barrier(); dist.destroy_process_group()
         return

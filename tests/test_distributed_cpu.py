@@ -74,3 +74,36 @@ def test_bench_plumbing_on_two_gloo_ranks():
     bad = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "4"], capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
     assert bad.returncode != 0
+
+
+def test_bench_plumbing_on_eight_gloo_ranks():
+    """The driver's N = 8 launch of bench.py on CPU (gloo, VIORB_BENCH_PLUMBING_ONLY): eight ranks with the REAL number of distinct streams per rank
+    own disjoint, gap-free seed ranges; local ranks are 0..7; the synthetic-stream generators of the eight ranks together do not oversubscribe the
+    host (LOCAL_WORLD_SIZE-aware process counts); a rank's host memory stays bounded (no page-locked copy of the frames at N > 1)."""
+    import json
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", VIORB_BENCH_PLUMBING_ONLY="1", VIORB_BENCH_PLUMBING_FULL="1", OMP_NUM_THREADS="1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "3", "--warmup", "1"],
+                         capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stdout + out.stderr
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 8 and r["units"] == 8 * r["streams_per_gpu"] * 3 and abs(r["elapsed"] - (1.0 + 0.5 * 7)) < 1e-12     # sum of units, slowest rank's time
+    ranks = sorted(r["ranks"], key=lambda q: q["rank"])
+    assert [q["rank"] for q in ranks] == list(range(8)) and [q["local_rank"] for q in ranks] == list(range(8))
+    nxt = 1000
+    for q in ranks:                                               # [first, last, count] per rank: consecutive blocks of 256 seeds
+        first, last, cnt = q["seeds"]
+        assert first == nxt and cnt == 256 and last == first + cnt - 1
+        nxt = last + 1
+    cpus = r["host_cpus"]
+    assert all(q["gen_procs"] == max(1, min(256, cpus // 8, 16)) for q in ranks)
+    assert sum(q["gen_procs"] for q in ranks) <= max(cpus, 8)
+    for q in ranks:
+        hb = q["host_bytes"]
+        assert hb["page_locked_copy"] == 0
+        assert hb["generated"] + hb["upload_stack"] < 3 * 2 ** 30        # 256 distinct + the 512-stream upload stack of 752x480 frames: 2.2 GB

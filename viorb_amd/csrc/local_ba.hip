@@ -1736,19 +1736,21 @@ static int ba_run_lockstep(Win* w, int n, int max_in_flight, Prepare prepare) {
         for (int a = 0; a < na; a++) Sp[a] = S[act[a]].get();
         while (done < na && rounds < MAX_ROUNDS) {
             for (int r = 0; r < ROUNDS_PER_CHECK; r++, rounds++) {
+                // (ProfScope: HIP-event pairs around the heavy launches when viorb_profile_enable is on — bench.py --config local_ba; free otherwise)
                 hipLaunchKernelGGL(k_bab_round_begin, dim3(gw), dim3(64), 0, st, Dv, na);
-                hipLaunchKernelGGL(k_bab_errors_chi, YE, dim3(TB), 0, st, Dv);
+                { ProfScope ps("k_bab_errors_chi", st); hipLaunchKernelGGL(k_bab_errors_chi, YE, dim3(TB), 0, st, Dv); }
                 hipLaunchKernelGGL(k_bab_take_chi, dim3(gw), dim3(64), 0, st, Dv, na);
-                hipLaunchKernelGGL(k_bab_f_lin_clear, dim3((unsigned)gL + gC, na), dim3(TB), 0, st, Dv, gL, (int)gC);
-                hipLaunchKernelGGL(k_bab_f_hpp_imu_hll, dim3((unsigned)(2 * Wmax + gP), na), dim3(256), 0, st, Dv, Wmax);
+                { ProfScope ps("k_bab_f_lin_clear", st); hipLaunchKernelGGL(k_bab_f_lin_clear, dim3((unsigned)gL + gC, na), dim3(TB), 0, st, Dv, gL, (int)gC); }
+                { ProfScope ps("k_bab_f_hpp_imu_hll", st); hipLaunchKernelGGL(k_bab_f_hpp_imu_hll, dim3((unsigned)(2 * Wmax + gP), na), dim3(256), 0, st, Dv, Wmax); }
                 hipLaunchKernelGGL(k_bab_max_diag, dim3(8, na), dim3(256), 0, st, Dv);
                 hipLaunchKernelGGL(k_bab_lambda0, dim3(gw), dim3(64), 0, st, Dv, na);
-                hipLaunchKernelGGL(k_bab_f_init_dinv, dim3(gR + (unsigned)gP, na), dim3(TB), 0, st, Dv, (int)gR);
-                hipLaunchKernelGGL(k_bab_schur, dim3((unsigned)(Wmax * (Wmax + 1) / 2) * 8u * (unsigned)((na + 7) / 8)), dim3(64), 0, st, Dv, Wmax * (Wmax + 1) / 2, na);
+                { ProfScope ps("k_bab_f_init_dinv", st); hipLaunchKernelGGL(k_bab_f_init_dinv, dim3(gR + (unsigned)gP, na), dim3(TB), 0, st, Dv, (int)gR); }
+                { ProfScope ps("k_bab_schur", st);
+                  hipLaunchKernelGGL(k_bab_schur, dim3((unsigned)(Wmax * (Wmax + 1) / 2) * 8u * (unsigned)((na + 7) / 8)), dim3(64), 0, st, Dv, Wmax * (Wmax + 1) / 2, na); }
                 (void)raise_dynamic_lds(reinterpret_cast<const void*>(k_bab_chol_solve), BA_CHOL_LDS_BYTES);
-                hipLaunchKernelGGL(k_bab_chol_solve, Y1, dim3(BA_CHOL_THREADS), BA_CHOL_LDS_BYTES, st, Dv);
-                hipLaunchKernelGGL(k_bab_f_backsub8_update, dim3((unsigned)g8, na), dim3(TB), 0, st, Dv);
-                hipLaunchKernelGGL(k_bab_errors, YE, dim3(TB), 0, st, Dv);
+                { ProfScope ps("k_bab_chol_solve", st); hipLaunchKernelGGL(k_bab_chol_solve, Y1, dim3(BA_CHOL_THREADS), BA_CHOL_LDS_BYTES, st, Dv); }
+                { ProfScope ps("k_bab_f_backsub8_update", st); hipLaunchKernelGGL(k_bab_f_backsub8_update, dim3((unsigned)g8, na), dim3(TB), 0, st, Dv); }
+                { ProfScope ps("k_bab_errors", st); hipLaunchKernelGGL(k_bab_errors, YE, dim3(TB), 0, st, Dv); }
                 hipLaunchKernelGGL(k_bab_decide, dim3(gw), dim3(64), 0, st, Dv, na);
                 hipLaunchKernelGGL(k_bab_restore, YP, dim3(TB), 0, st, Dv);
                 hipLaunchKernelGGL(k_bab_gate, YE, dim3(TB), 0, st, Dv, Ev);
