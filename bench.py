@@ -425,9 +425,7 @@ def run_tracking(args, cfg, rank, dev_index, dev, world):
             # BASELINE configs[4] gives every GPU 8 of the 64 streams: a latency-bound batch that any number of GPUs runs at the same per-GPU
             # rate. What ONE GPU does with this workload when it has enough streams to fill it (the same 8 scenes replicated, own state each):
             import copy
-            del tr, frames, frames_host
-            torch.cuda.empty_cache()
-            a2 = copy.copy(args); a2.streams = 128; a2.steps = 24; a2.warmup = 6; a2.no_host_input_pass = True; a2.no_cpu_baseline = True; a2.no_kernel_events = True
+            a2 = copy.copy(args); a2.distinct = distinct; a2.streams = 128; a2.steps = 24; a2.warmup = 6; a2.no_host_input_pass = True; a2.no_cpu_baseline = True; a2.no_kernel_events = True
             sat = run_tracking(a2, cfg, rank, dev_index, dev, world)
             out["config"]["saturated_frames_per_s"] = round(sat["units"] / sat["elapsed"], 1)
             out["config"]["saturated_note"] = "the same 1280x720 / 1500-feature sequence at 128 streams per GPU per step (the 8 scenes replicated, own tracker state each), 24 steps after the timed region"
