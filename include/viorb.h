@@ -187,7 +187,9 @@ typedef struct viorb_frontend_config {
  * projection and local-point searches keep a frame's keypoints and their work arrays in LDS up to cap = viorb_frontend_search_capacity()
  * (~4600; the reference's settings files use 1000-2000 features): above 2400 they give up their LDS cache of the first candidates of every
  * point and take all candidates from the global list, above the capacity they keep the work arrays in global memory as well — same
- * result, slower each time. cap <= 65535 (16-bit keypoint indices). */
+ * result, slower each time. cap <= 65535 (16-bit keypoint indices). The global-memory work arrays of the over-size forms (searches,
+ * SearchByBoW above ~7100 keypoints, stereo association above ~4000 features) are ONE scratch per handle (per calling thread for the handle-less
+ * entry points): over-size calls on one handle / thread must be issued on one stream at a time; the LDS forms have no such restriction. */
 int viorb_frontend_create(const viorb_frontend_config* cfg, int max_batch, int cap, int device, viorb_frontend** out);
 int viorb_frontend_search_capacity(void);      /* largest cap whose search work arrays fit LDS (beyond it: global memory, slower) */
 int viorb_frontend_destroy(viorb_frontend* h);

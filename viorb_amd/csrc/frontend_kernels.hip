@@ -2090,7 +2090,7 @@ extern "C" {
 
 int viorb_frontend_create(const viorb_frontend_config* cfg, int max_batch, int cap, int device, viorb_frontend** out) {
     VIORB_REQUIRE(cfg && out, "null cfg/out");
-    VIORB_REQUIRE(max_batch >= 1 && cap >= 1 && cap <= 32768, "max_batch >= 1, 1 <= cap <= 32768");
+    VIORB_REQUIRE(max_batch >= 1 && cap >= 1 && cap <= 65535, "max_batch >= 1, 1 <= cap <= 65535 (16-bit keypoint indices)");
     VIORB_REQUIRE(cfg->nlevels >= 1 && cfg->nlevels <= 16, "nlevels must be 1..16");
     VIORB_REQUIRE(cfg->max_x > cfg->min_x && cfg->max_y > cfg->min_y, "empty image bounds");
     if (viorb_device_count() < 1) { set_error("no HIP device: libviorb_hip has no CPU fallback"); return VIORB_ERR_NO_DEVICE; }
@@ -2256,7 +2256,7 @@ int viorb_frontend_search_projection_retry_device(viorb_frontend* h, const viorb
     if (search_lds_bytes(h->cap, A.slot_n) > 160 * 1024) {               // more keypoints per frame than LDS holds: the work arrays in global memory
         const size_t per = (search_lds_bytes(h->cap, 0) + 255) & ~(size_t)255;
         if (h->search_work_bytes < per * h->max_batch) {
-            VIORB_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+            VIORB_HIP_TRY(hipDeviceSynchronize());               // the handle's scratch is shared by its searches: nothing may still walk the old allocation
             if (h->d_search_work) (void)hipFree(h->d_search_work);
             h->d_search_work = nullptr; h->search_work_bytes = 0;
             VIORB_HIP_TRY(hipMalloc(&h->d_search_work, per * h->max_batch));
@@ -2337,7 +2337,7 @@ int viorb_frontend_search_local_points_device(viorb_frontend* h, const viorb_key
     if (gw) {
         const size_t per = (lds + 255) & ~(size_t)255;
         if (h->search_work_bytes < per * h->max_batch) {
-            VIORB_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+            VIORB_HIP_TRY(hipDeviceSynchronize());               // the handle's scratch is shared by its searches: nothing may still walk the old allocation
             if (h->d_search_work) (void)hipFree(h->d_search_work);
             h->d_search_work = nullptr; h->search_work_bytes = 0;
             VIORB_HIP_TRY(hipMalloc(&h->d_search_work, per * h->max_batch));

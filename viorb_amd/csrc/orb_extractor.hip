@@ -2614,7 +2614,10 @@ int viorb_stereo_match_device(const viorb_extractor* L, int left_index, const vi
         viorb_extractor* Lm = const_cast<viorb_extractor*>(L);
         const size_t per = (lds + 255) & ~(size_t)255;
         if (Lm->stereo_work_bytes < per * pairs) {
-            VIORB_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+            // the scratch is the handle's: over-size stereo associations of one handle run on one stream at a time (include/viorb.h); a whole-
+            // device synchronisation before it is replaced, so that no kernel of another stream still walks the old allocation
+            VIORB_HIP_TRY(hipSetDevice(L->device));
+            VIORB_HIP_TRY(hipDeviceSynchronize());
             if (Lm->d_stereo_work) (void)hipFree(Lm->d_stereo_work);
             Lm->d_stereo_work = nullptr; Lm->stereo_work_bytes = 0;
             VIORB_HIP_TRY(hipMalloc(&Lm->d_stereo_work, per * pairs));
