@@ -32,7 +32,7 @@ HBM_PEAK_GBS = 8000.0                         # MI355X HBM3E spec peak (MI355X_M
 FP64_VECTOR_PEAK_TFLOPS = 78.6                # MI355X FP64 vector spec (AMD data sheet: 256 CUs x 128 FLOP/clk x 2.4 GHz; the guide has no FP64 row)
 CONFIGS = {
     # name: width, height, features, default units per GPU, BASELINE.json configs index
-    "euroc": dict(w=752, h=480, nfeat=1000, streams=512, baseline_config=1),
+    "euroc": dict(w=752, h=480, nfeat=1000, streams=1024, baseline_config=1),      # 1024 streams per GPU per step: two pose-solver workgroups per CU (512: 172 k, 768: 173 k, 1024: 177 k, 1536: 163 k frames/s)
     "synth720p": dict(w=1280, h=720, nfeat=1500, streams=8, baseline_config=4),
     "kitti_stereo": dict(w=1241, h=376, nfeat=2000, streams=256, baseline_config=2),
     "local_ba": dict(w=752, h=480, nfeat=1000, streams=256, baseline_config=3),
@@ -683,7 +683,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--config", choices=sorted(CONFIGS), default="euroc", help="BASELINE.json config: euroc = configs[1] (default), kitti_stereo = configs[2], "
                     "local_ba = configs[3], synth720p = configs[4]")
-    ap.add_argument("--streams", type=int, default=None, help="independent units per GPU per step: camera streams (euroc 512, synth720p 8), stereo pairs "
+    ap.add_argument("--streams", type=int, default=None, help="independent units per GPU per step: camera streams (euroc 1024, synth720p 8), stereo pairs "
                     "(kitti_stereo 256), windows (local_ba 64)")
     ap.add_argument("--distinct", type=int, default=None, help="tracking configs: distinct synthetic streams generated per rank (default min(streams, 256))")
     ap.add_argument("--gen-procs", type=int, default=None, help="worker processes of the synthetic-stream generator; 1 = in-process, no fork (needed under "

@@ -1057,12 +1057,37 @@ __device__ __forceinline__ quat qnorm_f(quat q) {
     return mkq(q.x * r, q.y * r, q.z * r, q.w * r);
 }
 __device__ __forceinline__ quat so3_mul_f(quat a, quat b) { return qnorm_f(qmul(qnorm_f(a), b)); }
+// sin and cos of the small angles of the solver's scalar phases (an LM step's rotation, a factor's rotation residual: |x| well below 0.5)
+// by their Taylor series to x^17 / x^16 in Horner form — truncation below 3e-20, rounding ~1 ulp — instead of the library routines with
+// their full argument reduction (~150 instructions each on one lane); any larger argument takes the library path.
+__device__ __forceinline__ void sincos_small(double x, double* sn, double* cs) {
+    if (fabs(x) < 0.5) {
+        const double z = x * x;
+        double ps = -1.0 / 355687428096000.0;                                            // -1/17!
+        ps = fma(ps, z, 1.0 / 1307674368000.0); ps = fma(ps, z, -1.0 / 6227020800.0); ps = fma(ps, z, 1.0 / 39916800.0);
+        ps = fma(ps, z, -1.0 / 362880.0); ps = fma(ps, z, 1.0 / 5040.0); ps = fma(ps, z, -1.0 / 120.0); ps = fma(ps, z, 1.0 / 6.0);
+        *sn = fma(-(x * z), ps, x);
+        double pc = 1.0 / 20922789888000.0;                                              // 1/16!
+        pc = fma(pc, z, -1.0 / 87178291200.0); pc = fma(pc, z, 1.0 / 479001600.0); pc = fma(pc, z, -1.0 / 3628800.0);
+        pc = fma(pc, z, 1.0 / 40320.0); pc = fma(pc, z, -1.0 / 720.0); pc = fma(pc, z, 1.0 / 24.0); pc = fma(pc, z, -0.5);
+        *cs = fma(pc, z, 1.0);
+    } else { *sn = sin(x); *cs = cos(x); }
+}
 __device__ __forceinline__ quat so3_exp_f(d3 w) {
     const double th = norm3(w), half = 0.5 * th;
-    double imag; const double real = cos(half);
+    double sh, real; sincos_small(half, &sh, &real);
+    double imag;
     if (th < 1e-10) { const double t2 = th * th, t4 = t2 * t2; imag = 0.5 - 0.0208333 * t2 + 0.000260417 * t4; }
-    else imag = sin(half) / th;
+    else imag = sh / th;
     return qnorm_f(mkq(imag * w.x, imag * w.y, imag * w.z, real));
+}
+// so3.cpp JacobianRInv with the small-angle sin / cos above
+__device__ __forceinline__ m33 so3_jr_inv_f(d3 w) {
+    const double th = norm3(w);
+    if (th < 0.00001) return eye3();
+    const m33 K = hat3(w * (1.0 / th));
+    double sn, cs; sincos_small(th, &sn, &cs);
+    return add(add(eye3(), scl(hat3(w), 0.5)), scl(mul(K, K), 1.0 - (1.0 + cs) * th / (2.0 * sn)));
 }
 __device__ __forceinline__ pvr sh_pvr(const double* p) { pvr s; s.P = ld3(p); s.V = ld3(p + 3); s.q = mkq(p[6], p[7], p[8], p[9]); return s; }
 __device__ __forceinline__ void sh_put(double* p, const pvr& s) { st3(p, s.P); st3(p + 3, s.V); p[6] = s.q.x; p[7] = s.q.y; p[8] = s.q.z; p[9] = s.q.w; }
@@ -1160,7 +1185,7 @@ __device__ __forceinline__ void imu_piece_rot(const double* est_i, const double*
     const d3 rPhi = so3_log(rR);
     e[6] = rPhi.x; e[7] = rPhi.y; e[8] = rPhi.z;
     if (!J) return;
-    const m33 JrInv = so3_jr_inv(rPhi);
+    const m33 JrInv = so3_jr_inv_f(rPhi);
     imu_put(J, 6, 15, JrInv, 1);
     imu_put(J, 6, 6, mul(mul(JrInv, tr(qmat(qj))), qmat(qi)), -1);
 }
@@ -1183,7 +1208,7 @@ __device__ __forceinline__ void prior_piece(const double* est, d3 ba_plus_dba, c
     const d3 eB = ld3(pr + 10) - ba_plus_dba;
     e[0] = eP.x; e[1] = eP.y; e[2] = eP.z; e[3] = eV.x; e[4] = eV.y; e[5] = eV.z; e[6] = eR.x; e[7] = eR.y; e[8] = eR.z; e[9] = eB.x; e[10] = eB.y; e[11] = eB.z;
     if (!J) return;
-    const m33 R = qmat(s.q), Ji = so3_jr_inv(eR);
+    const m33 R = qmat(s.q), Ji = so3_jr_inv_f(eR);
     const double rv[9] = {R.a00, R.a01, R.a02, R.a10, R.a11, R.a12, R.a20, R.a21, R.a22};
     const double jv[9] = {Ji.a00, Ji.a01, Ji.a02, Ji.a10, Ji.a11, Ji.a12, Ji.a20, Ji.a21, Ji.a22};
 #pragma unroll
@@ -2079,6 +2104,8 @@ static int launch_pose_opt_vi(const PoseOptArgs& A, int batch, hipStream_t st) {
         case 1 * 16 + 8: return launch_pose_mp<1, 8>(A, batch, st);
         case 1 * 16 + 2: return launch_pose_mp<1, 2>(A, batch, st);
         case 2 * 16 + 2: return launch_pose_mp<2, 2>(A, batch, st);
+        case 2 * 16 + 3: return launch_pose_mp<2, 3>(A, batch, st);
+        case 1 * 16 + 3: return launch_pose_mp<1, 3>(A, batch, st);
         case 2 * 16 + 4: return launch_pose_mp<2, 4>(A, batch, st);
         case 4 * 16 + 1: return launch_pose_mp<4, 1>(A, batch, st);
         case 4 * 16 + 2: return launch_pose_mp<4, 2>(A, batch, st);
