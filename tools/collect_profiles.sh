@@ -33,5 +33,5 @@ for c in synth720p kitti_stereo local_ba dropin; do echo "bench $c"; timeout -k 
 rm -rf $OUT/${TAG}_stats $OUT/${TAG}_bf $OUT/${TAG}_pmc_FETCH_SIZE $OUT/${TAG}_pmc_WRITE_SIZE $OUT/${TAG}_pmc_sq $OUT/${TAG}_pmc_step_FETCH_SIZE $OUT/${TAG}_pmc_step_WRITE_SIZE
 timeout -k 10 300 python3 $R/bench.py --no-cpu-baseline --steps 60 --all-kernel-events --timeline $OUT/${TAG}_timeline.txt > $OUT/${TAG}_bench256_all_events.json 2> /dev/null
 bash $R/tools/lba_profile.sh $TAG > /dev/null 2>&1
-bash $R/tools/pmc_step.sh $TAG 512 > /dev/null 2>&1
+bash $R/tools/pmc_step.sh $TAG 1024 > /dev/null 2>&1
 ls $OUT | grep ${TAG}

@@ -1,4 +1,4 @@
-"""profiles/r03_pmc_traffic.json from the FETCH_SIZE / WRITE_SIZE summaries of tools/collect_profiles.sh:
+"""profiles/<round>_pmc_traffic.json (round = the tag up to its first underscore) from the FETCH_SIZE / WRITE_SIZE summaries of tools/collect_profiles.sh:
    python tools/make_traffic_table.py <tag> [images]      (reads gpurun_out/<tag>_pmc_{FETCH,WRITE}_SIZE_ex<images>.txt)
 HBM bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024: both counters are in KiB, and FETCH_SIZE counts 64 of every 128 fetched bytes on
 gfx950 (tools/ubench/fetch_calib.hip, profiles/r02_a_fetch_calibration.txt). Values are means per dispatch; units_per_launch = images one
@@ -31,5 +31,6 @@ for k in sorted(F):
     tab["bytes_per_launch"][nm] = int((2 * F[k][0] + W[k][0]) * 1024)
     tab["launches_per_step"][nm] = round(per_step, 2)
     tab["units_per_launch"][nm] = images if nm in ("k_resize",) else int(round(images / per_step)) if per_step >= 1 else images
-json.dump(tab, open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json"), "w"), indent=1)
+rnd = tag.split("_")[0]                      # r04_a -> r04
+json.dump(tab, open(os.path.join(ROOT, "profiles", "%s_pmc_traffic.json" % rnd), "w"), indent=1)
 print(json.dumps(tab, indent=1))
