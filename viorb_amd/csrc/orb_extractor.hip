@@ -789,6 +789,15 @@ __host__ __device__ __forceinline__ uint32_t spread8(uint32_t x) {
 //     pass over the score map instead — same output, no list.
 #define F3_SURV_CAP (63 + 64 * 16 + 1)
 #define F3_CORN_CAP 512
+// Phase cycle counts for development (-DVIORB_FAST_TIMING): the kernel is bound by vector issue, so a phase's share of the s_memtime ticks is its
+// share of the instructions
+#ifdef VIORB_FAST_TIMING
+#define FT_DECL unsigned long long ft_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ft_t0 = __builtin_amdgcn_s_memtime(); int ft_cells = 0, ft_surv = 0, ft_corn = 0, ft_att2 = 0
+#define FT_LAP(k) do { const unsigned long long ft_now = __builtin_amdgcn_s_memtime(); ft_acc[k] += ft_now - ft_t0; ft_t0 = ft_now; } while (0)
+#else
+#define FT_DECL
+#define FT_LAP(k)
+#endif
 __global__ __launch_bounds__(64) void k_fast_cells3(const uint8_t* __restrict__ planes, size_t frame_bytes,
                                                     const CellDesc* __restrict__ cells, int ini_th, int min_th,
                                                     uint32_t* __restrict__ slots, int slot_cap,
@@ -827,7 +836,9 @@ __global__ __launch_bounds__(64) void k_fast_cells3(const uint8_t* __restrict__ 
     request_tile(c);
     const int lds_lane = __mul24(lrow, F3_TP) + 4 * lq;
     const unsigned long long lt = (1ull << lane) - 1ull;
+    FT_DECL;
     for (int kk = 0; kk < ncell; kk++) {
+    FT_LAP(7);
     const int cell = cell0 + kk;
     const int x0a = c.x0 & ~3, xoff = c.x0 - x0a;
     {
@@ -847,6 +858,7 @@ __global__ __launch_bounds__(64) void k_fast_cells3(const uint8_t* __restrict__ 
     }
     __syncthreads();
     if (has_next) request_tile(cn);
+    FT_LAP(0);
     uint32_t* my_slots = slots + ((size_t)img_b * ncells_total + cell) * slot_cap;
     int total = 0;
     if (dw > 0 && dh > 0) {
@@ -872,6 +884,10 @@ __global__ __launch_bounds__(64) void k_fast_cells3(const uint8_t* __restrict__ 
                 const int hi_last = min((G & 1) ? 4 : 8, dw - (8 * (G2 - 1) - sh0));
                 const uint32_t m8_first = (0xffu << sh0) & 0xffu, m8_last = (1u << hi_last) - 1u;
                 const uint32_t mask_first = spread8(m8_first) * 3u, mask_last = spread8(m8_last) * 3u;
+                FT_LAP(1);
+#ifdef VIORB_FAST_TIMING
+                if (attempt) ft_att2++;
+#endif
                 for (int trip = 0; trip < ntrip; trip++) {
                     const int rc = min(r, dh - 1);
                     const int ga = 2 * gp, gb = min(ga + 1, G - 1);
@@ -919,6 +935,10 @@ __global__ __launch_bounds__(64) void k_fast_cells3(const uint8_t* __restrict__ 
                     if (gp >= G2) { gp -= G2; r++; }
                     // ---- pass 2 on the full groups (after the last trip: on whatever is left)
                     const int need = trip + 1 < ntrip ? 64 : 1;
+                    FT_LAP(2);
+#ifdef VIORB_FAST_TIMING
+                    ft_surv += trip_total;
+#endif
                     if (pending >= need) {
                         __syncthreads();
                         int done = 0;
@@ -945,10 +965,15 @@ __global__ __launch_bounds__(64) void k_fast_cells3(const uint8_t* __restrict__ 
                         }
                         pending = left;
                         __syncthreads();
+                        FT_LAP(3);
                     }
                 }
             }
             __syncthreads();
+            FT_LAP(4);
+#ifdef VIORB_FAST_TIMING
+            ft_corn += ncorn;
+#endif
             // ---- pass 3: strict 3x3 NMS, over the corner list — or, for a cell with more corners than the list holds, over every pixel of the
             // score map in the same (row-major) order
             const bool dense = ncorn > F3_CORN_CAP;
@@ -977,12 +1002,22 @@ __global__ __launch_bounds__(64) void k_fast_cells3(const uint8_t* __restrict__ 
                 total += __popcll(m);
             }
             __syncthreads();
+            FT_LAP(5);
         }
     }
     if (lane == 0) cell_cnt[(size_t)img_b * ncells_total + cell] = min(total, slot_cap);
     __syncthreads();
     c = cn;
+    FT_LAP(6);
+#ifdef VIORB_FAST_TIMING
+    ft_cells++;
+#endif
     }
+#ifdef VIORB_FAST_TIMING
+    if (lane == 0 && (blockIdx.x % 997) == 3)
+        printf("fast3 block=%d cells=%d att2=%d surv=%d corn=%d | tile+clear=%llu setup=%llu pass1=%llu pass2=%llu tail=%llu nms=%llu end=%llu loop=%llu\n", (int)blockIdx.x, ft_cells, ft_att2, ft_surv, ft_corn,
+               ft_acc[0], ft_acc[1], ft_acc[2], ft_acc[3], ft_acc[4], ft_acc[5], ft_acc[6], ft_acc[7]);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
