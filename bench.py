@@ -84,10 +84,11 @@ def generator_procs(n_seeds, procs=None):
 
 
 def host_memory_estimate(cfg, streams, distinct, world, host_pass):
-    """Bytes of host memory one rank of a tracking config holds at its peak: the generated distinct streams, the [F, S, h, w] stack that is
-    uploaded once, and (only when a live-feed pass reads it: N = 1 or --host-input) its page-locked copy."""
+    """Bytes of host memory one rank of a tracking config holds at its peak: the generated distinct streams, their [F, distinct, h, w] stack that
+    is uploaded once (the replication to S streams happens on the device), and (only when a live-feed pass reads it: N = 1 or --host-input) the
+    page-locked copy of all S streams' frames."""
     frame = cfg["w"] * cfg["h"]
-    return {"generated": distinct * N_FRAMES * frame, "upload_stack": streams * N_FRAMES * frame, "page_locked_copy": streams * N_FRAMES * frame if host_pass else 0}
+    return {"generated": distinct * N_FRAMES * frame, "upload_stack": distinct * N_FRAMES * frame, "page_locked_copy": streams * N_FRAMES * frame if host_pass else 0}
 
 
 def generate_streams(seeds, w=752, h=480, procs=None, dist=None):
@@ -186,7 +187,11 @@ def run_tracking(args, cfg, rank, dev_index, dev, world):
     base = pre if pre is not None else generate_streams(stream_seeds(rank, distinct), W_IMG, H_IMG, args.gen_procs, lens)
     streams = [base[i % distinct] for i in range(S)]
     up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-    frames = up(np.stack([s["frames"] for s in streams], 1))                   # [F, S, h, w] u8
+    # the distinct streams' frames go up once and are replicated ON THE DEVICE (every stream its own copy of the images): the host never holds the
+    # [F, S, h, w] stack (3 GB at 1024 streams; 8 ranks share one host)
+    frames_d = up(np.stack([s["frames"] for s in base[:distinct]], 1))       # [F, distinct, h, w] u8
+    frames = frames_d[:, torch.arange(S, device=dev) % distinct].contiguous() if S != distinct else frames_d   # [F, S, h, w] u8
+    del frames_d
     imu = up(np.stack([s["imu"] for s in streams], 1))                         # [F, S, n, 7] f64
     t_frames = up(np.stack([s["t"] for s in streams], 1))                      # [F, S]
     t_period = up(np.array([s["period"] for s in streams]))                    # [S]

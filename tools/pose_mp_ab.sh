@@ -1,6 +1,6 @@
 #!/bin/bash
-# A/B of the pose-solver instantiations (VIORB_POSE_MP="P,WPP"; 0 = the round-3 kernel): parity tests, then the bench line. usage: tools/pose_mp_ab.sh OUTDIR "cfg cfg ..."
-out=${1:-gpurun_out/pose_mp}; cfgs=${2:-"0 1,4 2,2 4,2 4,1 2,4"}; mkdir -p $out
+# A/B of the pose-solver instantiations (VIORB_POSE_MP="P,WPP"): parity tests, then the bench line. usage: tools/pose_mp_ab.sh OUTDIR "cfg cfg ..."
+out=${1:-gpurun_out/pose_mp}; cfgs=${2:-"1,4 2,2 4,2 4,1 2,4"}; mkdir -p $out
 for c in $cfgs; do
   n=$(echo $c | tr ',' '_')
   VIORB_POSE_MP=$c timeout -k 10 600 python -m pytest tests/test_gpu_frontend.py tests/test_gpu_tracker.py tests/test_gpu_native_tracker.py -x -q -m gpu -k "pose_opt or tracker or batched" > $out/test_$n.txt 2>&1

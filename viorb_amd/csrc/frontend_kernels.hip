@@ -5,7 +5,7 @@
 //   k_imu_predict         IMUPreintegrator::update xN, Converter::updateNS, Frame::UpdatePoseFromNS
 //                         reference src/IMU/IMUPreintegrator.cpp:86-153, src/Frame.cc:41-105
 //   k_build_observations  the edge-construction loops of PoseOptimization  src/Optimizer.cc:493-589
-//   k_pose_opt_vi         Optimizer::PoseOptimization(Frame*, KeyFrame*|Frame*, ...) with g2o's LM
+//   k_pose_opt_vi_mp      Optimizer::PoseOptimization(Frame*, KeyFrame*|Frame*, ...) with g2o's LM (pose_opt_mp.inc)
 //                         reference src/Optimizer.cc:323-1112 + Thirdparty/g2o (see vio_core.h)
 #include <hip/hip_runtime.h>
 #include <vector>
@@ -929,24 +929,6 @@ struct PoseOptArgs {
     const uint8_t* skip;         // optional: problems with skip[b] != 0 return at once like "fewer than 3 correspondences"
 };
 
-struct PoseOptShared {
-    double Hb[2][24 * 24], Lm[24 * 24], bb[2][24], x[24], y[24];   // two normal-equation buffers: current system / speculative next
-    double J1[9 * 21], OJ1[9 * 21], e1[12];            // IMU factor
-    double J2[12 * 12], OJ2[12 * 12], e2[12];          // prior factor
-    double q[32];                                       // per-row terms of the quadratic forms
-    double info_pvr[81], info_prior[144];
-    double red[8][2][28];                               // per wave, per side: 21 H + 6 b + chi
-    double est[2][10], bias[2][3];                      // PVR (P V q) and dBias_acc of cur / last
-    double bak[2][10], bakb[2][3];
-    double base_ba[2][3];                               // BiasAcc of cur / last (constant)
-    double sc[16];                                      // 0 chi total, 1 w_imu, 2 w_prior, 3 ok, 7 last chi
-    double pre[64];                                     // dP dV dR JPg JPa JVg JVa JRg (60) + dT: what the IMU factor reads every evaluation
-    double gw[3], dbg[3];                               // gravity, the last frame's gyro-bias delta
-    double cpv[6], corrT[4], pri[13];                   // constant parts of the IMU and prior factors (imu_constants, prior_constants)
-    double T6[36], GT[2][36], b6[2][6];                 // edge-Jacobian transform (see evaluate()), G*T and T^T g of both frames
-    uint32_t tab[324][2];                               // where each lower-triangle H entry / b entry gets its terms from (built once per solve)
-    int flag[4];
-};
 
 // hipcc's scheduler keeps register pressure low by pairing every LDS read with its use: a dot product fed from LDS becomes
 // read -> s_waitcnt lgkmcnt(0) -> fma, once per term (a 27-term H entry took 2.6 k cycles). Where a phase is a handful of short chains
@@ -1093,46 +1075,6 @@ __device__ __forceinline__ pvr sh_pvr(const double* p) { pvr s; s.P = ld3(p); s.
 __device__ __forceinline__ void sh_put(double* p, const pvr& s) { st3(p, s.P); st3(p + 3, s.V); p[6] = s.q.x; p[7] = s.q.y; p[8] = s.q.z; p[9] = s.q.w; }
 
 
-// Reprojection edge of the pose solver's linearisation pass: proj_edge()'s error and the two 6-entry Jacobian rows over
-// (dP, dPhi), written with explicit fma and without the products by hat()'s structural zeros — 106 instead of ~170 f64 instructions
-// per edge. Same formulas, fewer roundings; the solver's parity bar is the 1e-5 relative cost tolerance, not bit-exactness.
-__device__ __forceinline__ d3 mulv_fma(const m33& a, d3 v) {
-    return mk3(fma(a.a02, v.z, fma(a.a01, v.y, a.a00 * v.x)), fma(a.a12, v.z, fma(a.a11, v.y, a.a10 * v.x)), fma(a.a22, v.z, fma(a.a21, v.y, a.a20 * v.x)));
-}
-__device__ __forceinline__ void proj_edge_lin(const cam_t& k, const m33& RwbT, d3 Pwb, d3 Pw, double u, double v, double& e0, double& e1,
-                                              double* __restrict__ j0, double* __restrict__ j1) {
-    const d3 Paux = mulv_fma(k.Rcb, mulv_fma(RwbT, Pw - Pwb));
-    const d3 Pc = Paux - k.RcbPbc;
-    const double iz = 1.0 / Pc.z, xz = Pc.x * iz, yz = Pc.y * iz;
-    e0 = u - fma(xz, k.fx, k.cx);
-    e1 = v - fma(yz, k.fy, k.cy);
-    const double j00 = k.fx * iz, j02 = -xz * j00, j11 = k.fy * iz, j12 = -yz * j11;
-    const m33& R = k.Rcb;
-    j0[0] = fma(j02, R.a20, j00 * R.a00); j0[1] = fma(j02, R.a21, j00 * R.a01); j0[2] = fma(j02, R.a22, j00 * R.a02);
-    j1[0] = fma(j12, R.a20, j11 * R.a10); j1[1] = fma(j12, R.a21, j11 * R.a11); j1[2] = fma(j12, R.a22, j11 * R.a12);
-    // HR = hat(Paux) * Rcb, row by row
-    const double x = Paux.x, y = Paux.y, z = Paux.z;
-    const double h00 = fma(y, R.a20, -z * R.a10), h01 = fma(y, R.a21, -z * R.a11), h02 = fma(y, R.a22, -z * R.a12);
-    const double h10 = fma(z, R.a00, -x * R.a20), h11 = fma(z, R.a01, -x * R.a21), h12 = fma(z, R.a02, -x * R.a22);
-    const double h20 = fma(x, R.a10, -y * R.a00), h21 = fma(x, R.a11, -y * R.a01), h22 = fma(x, R.a12, -y * R.a02);
-    j0[3] = -fma(j02, h20, j00 * h00); j0[4] = -fma(j02, h21, j00 * h01); j0[5] = -fma(j02, h22, j00 * h02);
-    j1[3] = -fma(j12, h20, j11 * h10); j1[4] = -fma(j12, h21, j11 * h11); j1[5] = -fma(j12, h22, j11 * h12);
-}
-
-// Phase timing for development (-DVIORB_POSE_TIMING, VIORB_HIPCC_FLAGS in viorb_amd/build.py): workgroup 0 prints its accumulated
-// s_memtime ticks per phase.
-#ifdef VIORB_POSE_TIMING
-#define PT_DECL unsigned long long pt_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, pt_t0 = 0; int pt_n = 0
-#define PT_START() pt_t0 = __builtin_amdgcn_s_memtime()
-#define PT_LAP(k) do { const unsigned long long pt_now = __builtin_amdgcn_s_memtime(); pt_acc[k] += pt_now - pt_t0; pt_t0 = pt_now; } while (0)
-#define PT_COUNT() pt_n++
-#else
-#define PT_DECL
-#define PT_START()
-#define PT_LAP(k)
-#define PT_COUNT()
-#endif
-
 // The IMU factor of vio_core.h's pvr_edge() — same operations in the same order per value — cut into three independent pieces that
 // the solver runs on the first lanes of three different waves (a single lane took ~15 k cycles per evaluation, as long as its wave's
 // whole share of the reprojection edges). est_i / est_j: P V q (10 doubles); every operand is read from LDS where it is used.
@@ -1226,658 +1168,6 @@ __device__ __forceinline__ void imu_piece_blocks(const double* est_i, const doub
     const m33 RiTm = tr(qmat(qi));
     imu_put(J, 0, 0, eye3(), -1); imu_put(J, 0, 3, RiTm, -dT); imu_put(J, 3, 3, RiTm, -1); imu_put(J, 3, 12, RiTm, 1);
     imu_put(J, 0, 9, mul(RiTm, qmat(qj)), 1);
-}
-
-// 256 threads, one wave per SIMD, <= 200 registers per lane. Measured at 256 streams beside the extraction stream: 512 threads finish
-// one solve 9 % sooner but hold twice the register file while they run, and the step gets 8 % slower (90.6 k vs 98.3 k frames/s):
-// what this kernel costs the other stream is registers x time, so it stays small.
-#ifndef POSE_THREADS
-#define POSE_THREADS 256
-#endif
-#define POSE_WAVES (POSE_THREADS / 64)
-__global__ __launch_bounds__(POSE_THREADS, 2) void k_pose_opt_vi(PoseOptArgs A) {
-    __shared__ PoseOptShared S;
-#ifdef VIORB_POSE_TIMING
-    const unsigned long long pt_begin = __builtin_amdgcn_s_memtime();
-#endif
-    const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6, cap = A.cap;
-    const int variant = A.variant_arr ? (A.variant_arr[b] ? 1 : 0) : A.variant, n = variant ? 24 : 12;
-    const bool skipped = A.skip && A.skip[b];
-    const int ncur_all = min(A.n_cur[b], cap);                            // a skipped problem still clears its outlier flags
-    const int ncur = skipped ? 0 : ncur_all, nlast = variant ? min(A.n_last[b], cap) : 0;
-    const double* obs_c = A.obs_cur + (size_t)b * cap * 6;
-    const double* obs_l = A.obs_last ? A.obs_last + (size_t)b * cap * 6 : nullptr;
-    uint8_t* out_c = A.outlier_cur + (size_t)b * cap;
-    uint8_t* out_l = A.outlier_last ? A.outlier_last + (size_t)b * cap : nullptr;
-    const double* curns = A.cur_ns + (size_t)b * 22;
-    const double* lastns = A.last_ns + (size_t)b * 22;
-    const double* pre = A.preint + (size_t)b * 142;
-    const double* priorns = variant ? A.prior_ns + (size_t)b * 22 : nullptr;
-    const cam_t K = ld_cam(A.cam);
-    const double d_mono = (double)(float)sqrt(5.991), d_pvr = (double)(float)sqrt(21.666), d_bias = (double)(float)sqrt(16.812),
-                 d_prior = (double)(float)sqrt(30.5779);
-    const double bias_info = 1.0 / A.acc_bias_rw2 / pre[141];
-    // ---- setup
-    for (int i = t; i < ncur_all; i += blockDim.x) out_c[i] = 0;
-    for (int i = t; i < nlast; i += blockDim.x) out_l[i] = 0;
-    struct obs_t { d3 X; double u, v, is2; };
-    // Observations stay in global memory (L2): an LDS copy (24 B per edge as float) made one solve 4 % faster alone and the whole
-    // step 9 % slower, because 50 KB more LDS per workgroup keep the extraction stream's workgroups off the CU while this kernel runs.
-    auto load_obs = [&](const double* ob, int i) {
-        const double2* p = reinterpret_cast<const double2*>(ob) + 3 * i;      // 48-byte records of a 256-byte aligned array
-        const double2 q0 = p[0], q1 = p[1], q2 = p[2];
-        obs_t o; o.X = mk3(q0.x, q0.y, q1.x); o.u = q1.y; o.v = q2.x; o.is2 = q2.y;
-        return o;
-    };
-    // information of the IMU factor: cov^-1 + diag(1e2,1,1e2) (x) I3, by Gauss-Jordan over all threads
-    {
-        double* a = S.Lm; double* inv = S.Hb[0];              // scratch: [9x9 | 9x9]
-        for (int i = t; i < 81; i += blockDim.x) { a[i] = pre[60 + i]; inv[i] = (i / 9 == i % 9) ? 1.0 : 0.0; }
-        __syncthreads();
-        for (int col = 0; col < 9; col++) {
-            // the covariance is SPD: no pivoting needed. Barriers only in wave-uniform control flow.
-            const double piv = a[col * 9 + col];
-            __syncthreads();
-            if (t < 9) a[col * 9 + t] /= piv; else if (t >= 64 && t < 73) inv[col * 9 + t - 64] /= piv;
-            __syncthreads();
-            const int which = t / 81, el = t % 81, r = el / 9, c = el % 9;
-            double* M = which ? inv : a;
-            const double f = (t < 162) ? a[r * 9 + col] : 0.0;
-            __syncthreads();
-            if (t < 162 && r != col) M[r * 9 + c] -= f * M[col * 9 + c];
-            __syncthreads();
-        }
-        for (int i = t; i < 81; i += blockDim.x) {
-            const int r = i / 9, c = i % 9;
-            S.info_pvr[i] = inv[i] + ((r == c) ? ((r < 3 || r >= 6) ? 1e2 : 1.0) : 0.0);
-        }
-    }
-    if (variant) {
-        const double* mc = A.marg_cov_inv + (size_t)b * 144;
-        for (int i = t; i < 144; i += blockDim.x) {
-            const int r = i / 12, c = i % 12;
-            S.info_prior[i] = mc[i] + ((r == c && r < 9) ? ((r < 3 || r >= 6) ? 1e2 : 1.0) : 0.0);
-        }
-    }
-    for (int i = t; i < 189; i += blockDim.x) S.J1[i] = 0;          // the factors' Jacobians keep a static zero pattern
-    if (t < 61) S.pre[t] = t < 60 ? pre[t] : pre[141];
-    else if (t >= 64 && t < 67) { S.gw[t - 64] = A.gw[t - 64]; S.dbg[t - 64] = lastns[16 + t - 64]; }
-    for (int i = t; i < 144; i += blockDim.x) S.J2[i] = 0;
-    if (t == 0) {
-        for (int k = 0; k < 3; k++) { S.base_ba[0][k] = curns[13 + k]; S.base_ba[1][k] = lastns[13 + k]; }
-        S.flag[1] = 0;                                                   // LM iteration counter
-    }
-    __syncthreads();
-    // Assembly table: work item q < n(n+1)/2 is the lower-triangle entry (R, C), the next n items are b[R]. Word 0: R | C<<5 | isb<<10 |
-    // red index<<11 (31 = no reprojection term) | side<<16 | IMU column of R<<17 | IMU column of C<<22 (31 = none) | bias sign<<27
-    // (0 none, 1 +, 2 -) | bias component<<29; word 1: prior column of R | prior column of C<<4 (15 = none).
-    {
-        const int ntri = n * (n + 1) / 2;
-        for (int q = t; q < ntri + n; q += blockDim.x) {
-            const bool isb = q >= ntri;
-            int R, Cc;
-            if (isb) { R = q - ntri; Cc = 0; }
-            else {
-                R = (int)((sqrtf(8.0f * (float)q + 1.0f) - 1.0f) * 0.5f);
-                while (R * (R + 1) / 2 > q) R--;
-                while ((R + 1) * (R + 2) / 2 <= q) R++;
-                Cc = q - R * (R + 1) / 2;
-            }
-            auto six = [](int x) { const int r = x % 12; return r < 3 ? r : (r >= 6 && r < 9 ? r - 3 : -1); };
-            auto imu_col = [](int x) { return x < 9 ? 9 + x : (x >= 12 && x < 21 ? x - 12 : (x >= 21 ? 18 + x - 21 : 31)); };
-            auto bias_of = [](int x) { return (x >= 9 && x < 12) ? x - 9 : (x >= 21 ? x - 21 : -1); };
-            const int sideR = R / 12, r6 = six(R);
-            int redk = 31;
-            if (isb) { if (r6 >= 0) redk = 21 + r6; }
-            else {
-                const int c6 = six(Cc);
-                if (sideR == Cc / 12 && r6 >= 0 && c6 >= 0) { const int lo6 = min(r6, c6), hi6 = max(r6, c6); redk = lo6 * 6 - lo6 * (lo6 - 1) / 2 + (hi6 - lo6); }
-            }
-            const int mR = imu_col(R), mC = isb ? 31 : imu_col(Cc);
-            const int bR = bias_of(R);
-            int bsign = 0;
-            if (bR >= 0) {
-                if (isb) bsign = R < 12 ? 2 : 1;
-                else if (bias_of(Cc) == bR) bsign = ((Cc < 12) == (R < 12)) ? 1 : 2;
-            }
-            const int pR = (variant && R >= 12) ? R - 12 : 15, pC = (!isb && variant && Cc >= 12) ? Cc - 12 : 15;
-            S.tab[q][0] = (uint32_t)R | ((uint32_t)Cc << 5) | ((uint32_t)isb << 10) | ((uint32_t)redk << 11) | ((uint32_t)sideR << 16) | ((uint32_t)mR << 17) |
-                          ((uint32_t)mC << 22) | ((uint32_t)bsign << 27) | ((uint32_t)(bR < 0 ? 0 : bR) << 29);
-            const int c6t = isb ? 0 : six(Cc);
-            S.tab[q][1] = (uint32_t)pR | ((uint32_t)pC << 4) | ((uint32_t)(r6 < 0 ? 0 : r6) << 8) | ((uint32_t)(c6t < 0 ? 0 : c6t) << 11);
-        }
-    }
-    if (t == 128) {                                                       // T = [Rcb, -hat(Rcb Pbc) Rcb; 0, Rcb] (static indexing only)
-        const m33 HR = mul(hat3(K.RcbPbc), K.Rcb);
-        const double Rm[9] = {K.Rcb.a00, K.Rcb.a01, K.Rcb.a02, K.Rcb.a10, K.Rcb.a11, K.Rcb.a12, K.Rcb.a20, K.Rcb.a21, K.Rcb.a22};
-        const double Hm[9] = {HR.a00, HR.a01, HR.a02, HR.a10, HR.a11, HR.a12, HR.a20, HR.a21, HR.a22};
-#pragma unroll
-        for (int r = 0; r < 3; r++)
-#pragma unroll
-            for (int c = 0; c < 3; c++) {
-                S.T6[r * 6 + c] = Rm[r * 3 + c]; S.T6[r * 6 + 3 + c] = -Hm[r * 3 + c];
-                S.T6[(r + 3) * 6 + c] = 0; S.T6[(r + 3) * 6 + 3 + c] = Rm[r * 3 + c];
-            }
-    }
-    if (t == 0) imu_constants(S.pre, S.dbg, S.cpv, S.corrT);
-    else if (t == 64 && variant) {
-        prior_constants(priorns, S.pri);
-        for (int r = 0; r < 3; r++) { S.J2[(3 + r) * 12 + 3 + r] = -1; S.J2[(9 + r) * 12 + 9 + r] = -1; }
-    }
-    __syncthreads();
-    if (ncur < 3) {                                                      // "if(nInitialCorrespondences<3) return 0"
-        if (t == 0) {
-            double* o = A.out_ns + (size_t)b * 22; for (int k = 0; k < 22; k++) o[k] = curns[k];
-            if (A.out_last_ns) { double* ol = A.out_last_ns + (size_t)b * 22; for (int k = 0; k < 22; k++) ol[k] = lastns[k]; }
-            double* inf = A.info + (size_t)b * 4; inf[0] = 0; inf[1] = 0; inf[2] = 0; inf[3] = 0;
-        }
-        return;
-    }
-    const int n_edges_total = ncur + nlast + (variant ? 3 : 2);
-    int kernel_on = 1;           // mono edges keep their Huber kernel until the end of round 3
-    PT_DECL;
-    int hb_last = 0;
-    int nbad = 0;
-
-    // One pass over the active reprojection edges at the current estimate: robust chi2 and, when `lin`,
-    // the 6x6 (P, Phi) normal-equation blocks of both frames. Followed by the two dense factors (IMU on
-    // wave 0, prior on wave 1) and the bias factor. Leaves H, b (when lin) and the total robust chi2 in S.sc[0].
-    auto evaluate = [&](bool lin, double* Hm, double* bv) -> double {
-        PT_START();
-        // Reprojection edges go in chunks of 64 (one edge per lane); chunk j of a frame belongs to wave j % POSE_WAVES, and a wave takes its
-        // chunks two at a time (accumulate2 below). Pair q of a wave: q < np0 on the current frame, the rest on the last frame. The first
-        // pair's loads are issued here, under the dense factors, and every later pair's (across the change of frame too) under the
-        // arithmetic of the pair before it: a wave only has two or three trips per evaluation, so an exposed L2 round trip per frame was a
-        // third of the loop.
-        const int nch0 = (ncur + 63) >> 6, nch1 = (nlast + 63) >> 6;
-        const int cnt0 = nch0 > wave ? (nch0 - wave + POSE_WAVES - 1) / POSE_WAVES : 0, cnt1 = nch1 > wave ? (nch1 - wave + POSE_WAVES - 1) / POSE_WAVES : 0;
-        const int np0 = (cnt0 + 1) >> 1, npairs = np0 + ((cnt1 + 1) >> 1);
-        auto fetch_pair = [&](int q, obs_t (&o)[2], int (&f)[2]) {
-            const int sd = q >= np0 && q < npairs, pq = q >= npairs ? 0 : (sd ? q - np0 : q);   // beyond the last pair: any valid address
-            const double* ob = sd ? obs_l : obs_c; const uint8_t* ol = sd ? out_l : out_c; const int ne = sd ? nlast : ncur;
-            const int last = max(ne - 1, 0);
-#pragma unroll
-            for (int e = 0; e < 2; e++) {
-                const int i = (wave + POSE_WAVES * (2 * pq + e)) * 64 + lane, c = min(i, last);
-#if defined(POSE_EXP) && POSE_EXP == 2        /* timing experiment: no loads */
-                f[e] = 0; o[e].X = mk3(0.1 * lane, 0.2, 4.0 + c); o[e].u = 300; o[e].v = 200; o[e].is2 = 1;
-#else
-                f[e] = ol[c]; o[e] = load_obs(ob, c);
-#endif
-                if (i >= ne || q >= npairs) f[e] = 1;
-            }
-        };
-        obs_t oc[2]; int fc[2];
-        fetch_pair(0, oc, fc);
-        int qpos = 0;
-        // dense factors: residuals (+ Jacobians) by one lane each of the last four waves
-        const int dw = wave - (POSE_WAVES - 4);
-        if (lane == 0 && dw >= 0) {
-            if (dw == 0) imu_piece_pv(S.est[1], S.est[0], S.cpv, S.bias[1], S.pre, S.gw, S.e1, lin ? S.J1 : nullptr);
-            else if (dw == 1) {
-                if (variant) prior_piece(S.est[1], ld3(S.base_ba[1]) + ld3(S.bias[1]), S.pri, S.e2, lin ? S.J2 : nullptr);
-            }
-            else if (dw == 2) imu_piece_rot(S.est[1], S.est[0], S.corrT, S.e1, lin ? S.J1 : nullptr);
-            else if (lin) imu_piece_blocks(S.est[1], S.est[0], S.pre, S.J1);
-        }
-        PT_LAP(0);
-        for (int side = 0; side < (variant ? 2 : 1); side++) {
-            const pvr s = sh_pvr(S.est[side]);
-            const m33 Rcw = mul(K.Rcb, tr(qmat(s.q)));                     // Rcb * Rwb^T
-            // The edge Jacobian over (dP, dPhi) factors as J = Jc * T with Jc = Jproj * [I | -hat(Pc)] (the classic 2 x 6 camera-frame
-            // Jacobian, two structural zeros) and T = [Rcb, -hat(Rcb Pbc) Rcb; 0, Rcb], the same 6 x 6 matrix for every edge of every
-            // solve (camera extrinsics only). The lanes therefore accumulate G = sum w Jc^T Jc (20 entries, not 21: G[0][1] has no
-            // term) and -sum w Jc^T e — about 95 f64 instructions per edge instead of about 200 — and T^T G T, T^T g are formed once
-            // per evaluation after the reduction (assembly, step 1). a[0..20]: upper triangle of G row by row, a[21..26]: -g, a[27]: chi2.
-            double a[28];
-#pragma unroll
-            for (int k = 0; k < 28; k++) a[k] = 0;
-            const double dsq_mono = d_mono * d_mono;
-            // Two edges per trip, written stage by stage for both: a single edge is a dependent chain of ~26 f64 operations (point ->
-            // 1/z -> error -> chi2 -> Huber weight -> weighted rows) and a dependent v_fma_f64 issues every ~10 cycles against ~5 for
-            // independent ones (tools/ubench/f64_latency.hip); with one wave per SIMD nothing else fills those slots. A flagged
-            // (outlier / out-of-range) edge runs with weight 0 instead of a branch.
-            auto accumulate2 = [&](const obs_t (&o)[2], const int (&flag)[2]) {
-#if defined(POSE_EXP) && POSE_EXP == 1        /* timing experiment: loads only */
-                a[27] += o[0].X.x + o[0].X.y + o[0].X.z + o[0].u + o[0].v + o[0].is2 + o[1].X.x + o[1].X.y + o[1].X.z + o[1].u + o[1].v + o[1].is2; return;
-#endif
-                double pcx[2], pcy[2], pcz[2], iz[2], xz[2], yz[2], ea0[2], ea1[2], chi0[2], ra0[2], ra1[2];
-#pragma unroll
-                for (int e = 0; e < 2; e++) {
-                    const d3 dd = o[e].X - s.P;
-                    pcx[e] = fma(Rcw.a02, dd.z, fma(Rcw.a01, dd.y, fma(Rcw.a00, dd.x, -K.RcbPbc.x)));
-                    pcy[e] = fma(Rcw.a12, dd.z, fma(Rcw.a11, dd.y, fma(Rcw.a10, dd.x, -K.RcbPbc.y)));
-                    pcz[e] = fma(Rcw.a22, dd.z, fma(Rcw.a21, dd.y, fma(Rcw.a20, dd.x, -K.RcbPbc.z)));
-                }
-#pragma unroll
-                for (int e = 0; e < 2; e++) {                              // 1 / z: hardware estimate + two Newton steps
-                    iz[e] = __builtin_amdgcn_rcp(pcz[e]);
-                    iz[e] = fma(fma(-pcz[e], iz[e], 1.0), iz[e], iz[e]);
-                    iz[e] = fma(fma(-pcz[e], iz[e], 1.0), iz[e], iz[e]);
-                }
-#pragma unroll
-                for (int e = 0; e < 2; e++) {
-                    xz[e] = pcx[e] * iz[e]; yz[e] = pcy[e] * iz[e];
-                    ea0[e] = o[e].u - fma(xz[e], K.fx, K.cx); ea1[e] = o[e].v - fma(yz[e], K.fy, K.cy);
-                    chi0[e] = o[e].is2 * fma(ea0[e], ea0[e], ea1[e] * ea1[e]);
-                    ra0[e] = chi0[e]; ra1[e] = 1.0;
-                }
-                // Huber (robust_kernel_impl.cpp:78-91): rho = 2 sqrt(chi) d - d^2, rho' = d / sqrt(chi) beyond d^2; skipped by the
-                // whole wave when no lane is beyond it (always, once the kernel is dropped after round 2)
-                const bool h0 = kernel_on && chi0[0] > dsq_mono, h1 = kernel_on && chi0[1] > dsq_mono;
-                if (__builtin_amdgcn_ballot_w64(h0 || h1) != 0) {
-#pragma unroll
-                    for (int e = 0; e < 2; e++) {
-                        const double rs = rsqrt_nr(fmax(chi0[e], 1e-300));
-                        const bool hub = e ? h1 : h0;
-                        ra0[e] = hub ? fma(2.0 * d_mono, chi0[e] * rs, -dsq_mono) : chi0[e]; ra1[e] = hub ? d_mono * rs : 1.0;
-                    }
-                }
-#pragma unroll
-                for (int e = 0; e < 2; e++) a[27] += flag[e] ? 0.0 : ra0[e];
-                if (lin) {
-#pragma unroll
-                    for (int e = 0; e < 2; e++) {
-                        const double w0 = flag[e] ? 0.0 : ra1[e] * o[e].is2;
-                        const double A = K.fx * iz[e], B = K.fy * iz[e], fxp = K.fx * xz[e], fyq = K.fy * yz[e];
-                        // Jc row 0 = [A, 0, -A xz, -fx xz yz, fx (1 + xz^2), -fx yz], row 1 = [0, B, -B yz, -fy (1 + yz^2), fy xz yz, fy xz]
-                        const double r0[6] = {A, 0.0, -(A * xz[e]), -(fxp * yz[e]), fma(fxp, xz[e], K.fx), -(K.fx * yz[e])};
-                        const double r1[6] = {0.0, B, -(B * yz[e]), -fma(fyq, yz[e], K.fy), fyq * xz[e], K.fy * xz[e]};
-                        double w0r[6], w1r[6];
-#pragma unroll
-                        for (int r = 0; r < 6; r++) { w0r[r] = w0 * r0[r]; w1r[r] = w0 * r1[r]; }
-                        int k = 0;
-#pragma unroll
-                        for (int r = 0; r < 6; r++)
-#pragma unroll
-                            for (int c = r; c < 6; c++, k++) {
-                                if (r != 1 && c != 1) a[k] = fma(w0r[r], r0[c], a[k]);          // row 0 has no entry 1
-                                if (r != 0 && c != 0) a[k] = fma(w1r[r], r1[c], a[k]);          // row 1 has no entry 0
-                            }
-#pragma unroll
-                        for (int r = 0; r < 6; r++) {
-                            if (r != 1) a[21 + r] = fma(-w0r[r], ea0[e], a[21 + r]);
-                            if (r != 0) a[21 + r] = fma(-w1r[r], ea1[e], a[21 + r]);
-                        }
-                    }
-                }
-            };
-            const int qend = side ? npairs : np0;
-            while (qpos < qend) {
-                obs_t on[2]; int fn[2];
-                fetch_pair(qpos + 1, on, fn);                              // unconditional (clamped indices; beyond the last pair: flagged)
-                accumulate2(oc, fc);
-                oc[0] = on[0]; oc[1] = on[1]; fc[0] = fn[0]; fc[1] = fn[1];
-                qpos++;
-            }
-            PT_LAP(6);
-            if (lin) {
-                // transpose-reduce 32 padded values over the 64 lanes: 16+8+4+2+1 exchanges leave lane l with the
-                // wave total of value (l >> 1) & 31, one more exchange pairs the two copies
-                double v[32];
-#pragma unroll
-                for (int k = 0; k < 28; k++) v[k] = a[k];
-#pragma unroll
-                for (int k = 28; k < 32; k++) v[k] = 0;
-#pragma unroll
-                for (int half = 16, bit = 32; half >= 1; half >>= 1, bit >>= 1) {
-                    const bool up = (lane & bit) != 0;
-#pragma unroll
-                    for (int i = 0; i < half; i++) {
-                        const double keep = up ? v[half + i] : v[i];
-                        const double send = up ? v[i] : v[half + i];
-                        v[i] = keep + __shfl_xor(send, bit);
-                    }
-                }
-                const double tot = v[0] + __shfl_xor(v[0], 1);
-                // lane bits 5..1 selected the upper half at steps 16,8,4,2,1 -> value index
-                const int idx = ((lane >> 5) & 1) * 16 + ((lane >> 4) & 1) * 8 + ((lane >> 3) & 1) * 4 + ((lane >> 2) & 1) * 2 + ((lane >> 1) & 1);
-                if ((lane & 1) == 0 && idx < 28) S.red[wave][side][idx] = tot;
-            } else {
-                double vv = a[27];
-#pragma unroll
-                for (int d = 32; d > 0; d >>= 1) vv += __shfl_xor(vv, d);
-                if (lane == 0) S.red[wave][side][27] = vv;
-            }
-        }
-        PT_LAP(1);
-        __syncthreads();
-        PT_LAP(2);
-        // ---- assembly. Step 1 (parallel): quadratic forms q[r] = e_r (Omega e)_r of the dense factors, Omega*J of both, and the
-        // bias random-walk factor's weight; step 2: every thread derives the two Huber weights itself and builds complete H / b
-        // entries from all their sources (reprojection partials, IMU factor, prior factor, bias factor) — one pass, no zeroing.
-        if (t < 9) { double iv[9], ev[9]; lds_get(S.info_pvr + t * 9, iv); lds_get(S.e1, ev); const double et = S.e1[t]; LDS_READS_DONE();
-                     double sq = 0;
-#pragma unroll
-                     for (int c = 0; c < 9; c++) sq = fma(iv[c], ev[c], sq);
-                     S.q[t] = et * sq; }
-        else if (t >= 64 && t < 76 && variant) { const int r = t - 64; double iv[12], ev[12]; lds_get(S.info_prior + r * 12, iv); lds_get(S.e2, ev); const double et = S.e2[r]; LDS_READS_DONE();
-                     double sq = 0;
-#pragma unroll
-                     for (int c = 0; c < 12; c++) sq = fma(iv[c], ev[c], sq);
-                     S.q[12 + r] = et * sq; }
-        else if (t == 128) {
-            const d3 eb = (ld3(S.base_ba[0]) + ld3(S.bias[0])) - (ld3(S.base_ba[1]) + ld3(S.bias[1]));
-            double r0, r1; huber(bias_info * dot3(eb, eb), d_bias, &r0, &r1);
-            S.sc[3] = r1 * bias_info; S.sc[4] = eb.x; S.sc[5] = eb.y; S.sc[6] = eb.z; S.sc[8] = r0;
-        }
-        if (lin) {
-            for (int i = t; i < 189 + (variant ? 144 : 0); i += blockDim.x) {
-                // one code path for both factors (row of the information matrix x column of the Jacobian, 9 or 12 terms)
-                const bool f1 = i < 189; const int ii = f1 ? i : i - 189, nc = f1 ? 21 : 12, r = ii / nc, c = ii - r * nc, nk = f1 ? 9 : 12;
-                const double* ip = f1 ? S.info_pvr + r * 9 : S.info_prior + r * 12; const double* jp = (f1 ? S.J1 : S.J2) + c;
-                double iv[12], jvv[12];
-#pragma unroll
-                for (int kk = 0; kk < 12; kk++) { const int k2 = kk < nk ? kk : 0; iv[kk] = ip[k2]; jvv[kk] = jp[k2 * nc]; }
-                LDS_READS_DONE();
-                double sq = 0;
-#pragma unroll
-                for (int kk = 0; kk < 12; kk++) sq = kk < nk ? fma(iv[kk], jvv[kk], sq) : sq;
-                (f1 ? S.OJ1 : S.OJ2)[ii] = sq;
-            }
-        }
-        if (lin && t >= POSE_THREADS - 84) {
-            // reprojection blocks back in (dP, dPhi) coordinates: GT = G T (36 entries per frame), b6 = T^T (-g) (6 per frame)
-            const int i = t - (POSE_THREADS - 84), side = i >= 42, j = i - 42 * side;
-            if (side == 0 || variant) {
-                if (j < 36) {
-                    const int r = j / 6, c = j % 6;
-                    double gv[6][POSE_WAVES], tv[6];
-#pragma unroll
-                    for (int k = 0; k < 6; k++) {
-                        const int lo = min(r, k), hi = max(r, k), gi = lo * 6 - lo * (lo - 1) / 2 + (hi - lo);
-#pragma unroll
-                        for (int w = 0; w < POSE_WAVES; w++) gv[k][w] = S.red[w][side][gi];
-                        tv[k] = S.T6[k * 6 + c];
-                    }
-                    LDS_READS_DONE();
-                    double v = 0;
-#pragma unroll
-                    for (int k = 0; k < 6; k++) {
-                        double g = 0;
-#pragma unroll
-                        for (int w = 0; w < POSE_WAVES; w++) g += gv[k][w];
-                        v = fma(g, tv[k], v);
-                    }
-                    S.GT[side][j] = v;
-                } else {
-                    const int c = j - 36;
-                    double gv[6][POSE_WAVES], tv[6];
-#pragma unroll
-                    for (int k = 0; k < 6; k++) {
-#pragma unroll
-                        for (int w = 0; w < POSE_WAVES; w++) gv[k][w] = S.red[w][side][21 + k];
-                        tv[k] = S.T6[k * 6 + c];
-                    }
-                    LDS_READS_DONE();
-                    double v = 0;
-#pragma unroll
-                    for (int k = 0; k < 6; k++) {
-                        double g = 0;
-#pragma unroll
-                        for (int w = 0; w < POSE_WAVES; w++) g += gv[k][w];
-                        v = fma(tv[k], g, v);
-                    }
-                    S.b6[side][c] = v;
-                }
-            }
-        }
-        __syncthreads();
-        PT_LAP(7);
-        double w1, w2 = 0, rob1, rob2 = 0;
-        {
-            double qv[24];
-            lds_get(S.q, qv);
-            LDS_READS_DONE();
-            double chi = 0;
-#pragma unroll
-            for (int i = 0; i < 9; i++) chi += qv[i];
-            huber(chi, d_pvr, &rob1, &w1);
-            if (variant) {
-                double chi2 = 0;
-#pragma unroll
-                for (int i = 0; i < 12; i++) chi2 += qv[12 + i];
-                huber(chi2, d_prior, &rob2, &w2);
-            }
-        }
-        if (t == 0) {
-            double tot = 0;
-            for (int w = 0; w < POSE_WAVES; w++) { tot += S.red[w][0][27]; if (variant) tot += S.red[w][1][27]; }
-            tot += rob1; tot += S.sc[8];
-            if (variant) tot += rob2;
-            S.sc[0] = tot;
-        }
-        PT_LAP(10);
-        if (lin) {
-            const double wb = S.sc[3];
-            const int nitems = n * (n + 1) / 2 + n;
-            for (int q = t; q < nitems; q += blockDim.x) {
-                const uint32_t d0 = S.tab[q][0], d1 = S.tab[q][1];
-                const int R = d0 & 31, Cc = (d0 >> 5) & 31, redk = (d0 >> 11) & 31, sideR = (d0 >> 16) & 1, mR = (d0 >> 17) & 31, mC = (d0 >> 22) & 31;
-                const int bsign = (d0 >> 27) & 3, bR = d0 >> 29, pR = d1 & 15, pC = (d1 >> 4) & 15;
-                const bool isb = (d0 >> 10) & 1;
-                // branch-free: every source is read from a clamped index and masked afterwards, so that all LDS reads of an item are in
-                // flight together (one wait) instead of one dependent round trip per taken branch
-                double v = 0, s1 = 0, s2 = 0, scb;
-                {
-                    // reprojection term: H entry (r6, c6) = sum_k T[k][r6] GT[k][c6]; b entry r6 = b6[r6]
-                    const int r6 = (d1 >> 8) & 7, c6 = (d1 >> 11) & 7;
-                    const int mRc = mR == 31 ? 0 : mR, mCc = mC == 31 ? 0 : mC, pRc = pR == 15 ? 0 : pR, pCc = pC == 15 ? 0 : pC;
-                    const double* a1 = (isb ? S.OJ1 : S.J1) + mRc; const double* b1 = isb ? S.e1 : S.OJ1 + mCc; const int sb1 = isb ? 1 : 21;
-                    const double* a2 = (isb ? S.OJ2 : S.J2) + pRc; const double* b2 = isb ? S.e2 : S.OJ2 + pCc; const int sb2 = isb ? 1 : 12;
-                    double A1[9], B1[9], A2[12], B2[12], Tt[6], Gt[6];
-                    lds_get(a1, A1, 21); lds_get(b1, B1, sb1); lds_get(a2, A2, 12); lds_get(b2, B2, sb2);
-                    lds_get(S.T6 + r6, Tt, 6); lds_get(S.GT[sideR] + c6, Gt, 6);
-                    const double bb6 = S.b6[sideR][r6]; scb = S.sc[4 + bR];
-                    LDS_READS_DONE();
-                    double sr = 0;
-#pragma unroll
-                    for (int k = 0; k < 6; k++) sr = fma(Tt[k], Gt[k], sr);
-                    if (isb) sr = bb6;
-                    v = redk != 31 ? sr : 0.0;
-#pragma unroll
-                    for (int kk = 0; kk < 9; kk++) s1 = fma(A1[kk], B1[kk], s1);
-#pragma unroll
-                    for (int kk = 0; kk < 12; kk++) s2 = fma(A2[kk], B2[kk], s2);
-                }
-                const bool has1 = mR != 31 && (isb || mC != 31), has2 = pR != 15 && (isb || pC != 15);
-                if (isb) {
-                    if (has1) v -= w1 * s1;
-                    if (has2) v -= w2 * s2;
-                    if (bsign) v += (bsign == 2 ? -wb : wb) * scb;
-                    bv[R] = v;
-                } else {
-                    if (has1) v += w1 * s1;
-                    if (has2) v += w2 * s2;
-                    if (bsign) v += bsign == 1 ? wb : -wb;
-                    Hm[R * n + Cc] = v; Hm[Cc * n + R] = v;          // both triangles: the marginal at the end reads the full matrix
-                }
-            }
-        }
-        PT_LAP(11);
-        __syncthreads();
-        PT_LAP(3); PT_COUNT();
-        return S.sc[0];
-    };
-
-    // (H + lambda I) x = b on wave 0, matrix rows in registers (wave_solve_reg). S.flag[0] = success.
-    auto solve = [&](double lambda, const double* Hm, const double* bv) {
-        PT_START();
-        if (wave == 0) {
-            const bool ok = variant ? wave_solve_reg<24>(Hm, bv, lambda, S.Lm, S.x, lane) : wave_solve_reg<12>(Hm, bv, lambda, S.Lm, S.x, lane);
-            if (!ok && lane < n) S.x[lane] = 0;
-            if (lane == 0) S.flag[0] = ok ? 1 : 0;
-        }
-        __syncthreads();
-        PT_LAP(4);
-    };
-
-#ifdef VIORB_POSE_TIMING
-    const unsigned long long pt_setup = __builtin_amdgcn_s_memtime() - pt_begin;
-#endif
-    for (int round = 0; round < 4; round++) {
-        // reset the estimates to the frames' NavStates (Optimizer.cc:614-617 / :984-985)
-        if (t == 0) {
-            sh_put(S.est[0], ld_pvr(curns)); sh_put(S.est[1], ld_pvr(lastns));
-            for (int k = 0; k < 3; k++) { S.bias[0][k] = curns[19 + k]; S.bias[1][k] = lastns[19 + k]; }
-        }
-        __syncthreads();
-        // ---- optimize(10): g2o Levenberg
-        // Every trial state is linearised speculatively (errors + Jacobians in one pass into the other H/b buffer): an accepted trial
-        // is exactly the state g2o's next iteration re-evaluates and re-linearises, so that pass is skipped; a rejected trial leaves the
-        // current buffer untouched for the re-solve with a larger lambda. hb_last = buffer of the last buildSystem (what
-        // computeMarginals sees at the end).
-        double lambda = 0, ni = 2; int nBadLM = 0;
-        int cur = 0; bool have_lin = false; double chi_lin = 0;
-        for (int it = 0; it < 10; it++) {
-            double* Hc = S.Hb[cur]; double* bc = S.bb[cur];
-            double currentChi = have_lin ? chi_lin : evaluate(true, Hc, bc);   // computeActiveErrors + activeRobustChi2 + buildSystem
-            hb_last = cur;
-            const double iniChi = currentChi;
-            if (it == 0) {
-                double mx = 0; for (int i = 0; i < n; i++) mx = fmax(fabs(Hc[i * n + i]), mx);
-                lambda = 1e-5 * mx; ni = 2; nBadLM = 0;
-            }
-            double rho = 0; int qmax = 0;
-            bool accepted = false;
-            do {
-                if (t < 20) S.bak[t / 10][t % 10] = S.est[t / 10][t % 10]; else if (t < 26) S.bakb[(t - 20) / 3][(t - 20) % 3] = S.bias[(t - 20) / 3][(t - 20) % 3];
-                solve(lambda, Hc, bc);
-                const int ok2 = S.flag[0];
-                // NavState::IncSmallPVR + the bias increment, one frame per wave pair: the rotation (Exp, two normalisations) on one lane,
-                // position / velocity / bias on another; both read the pre-update state from the backup copy made above
-                if (lane == 0 && wave < 4 && ((wave & 1) == 0 || variant)) {
-                    const int side = wave & 1;
-                    double u[12], old[10];
-                    lds_get(S.x + 12 * side, u); lds_get(S.bak[side], old);
-                    LDS_READS_DONE();
-                    const quat q0 = mkq(old[6], old[7], old[8], old[9]);
-                    if (wave < 2) {
-                        const quat r = so3_mul_f(q0, so3_exp_f(mk3(u[6], u[7], u[8])));
-                        S.est[side][6] = r.x; S.est[side][7] = r.y; S.est[side][8] = r.z; S.est[side][9] = r.w;
-                    } else {
-                        st3(S.est[side], ld3(old) + mulv(qmat(q0), mk3(u[0], u[1], u[2])));
-                        st3(S.est[side] + 3, ld3(old + 3) + mk3(u[3], u[4], u[5]));
-                        const d3 bo = ld3(S.bias[side]);
-                        st3(S.bias[side], bo + mk3(u[9], u[10], u[11]));
-                    }
-                }
-                __syncthreads();
-                PT_LAP(8);
-                double tempChi = evaluate(true, S.Hb[cur ^ 1], S.bb[cur ^ 1]);
-                PT_START();
-                if (!ok2) tempChi = 1.7976931348623157e308;
-                double scale = 0;                                    // g2o computeScale(): sum_j x_j (lambda x_j + b_j), in order
-                {
-                    double xs[24], bs[24];
-#pragma unroll
-                    for (int j = 0; j < 24; j++) { xs[j] = S.x[j < n ? j : 0]; bs[j] = bc[j < n ? j : 0]; }
-                    LDS_READS_DONE();
-#pragma unroll
-                    for (int j = 0; j < 24; j++) if (j < n) scale += xs[j] * (lambda * xs[j] + bs[j]);
-                }
-                scale += 1e-3;
-                rho = (currentChi - tempChi) / scale;
-                accepted = rho > 0 && isfinite(tempChi);
-                if (accepted) {
-                    const double tr1 = 2 * rho - 1;
-                    double alpha = 1. - tr1 * tr1 * tr1;               // g2o: 1 - pow(2*rho-1, 3)
-                    alpha = fmin(alpha, 2. / 3.);
-                    lambda *= fmax(1. / 3., alpha); ni = 2; currentChi = tempChi;
-                } else {
-                    lambda *= ni; ni *= 2;
-                    if (t < 20) S.est[t / 10][t % 10] = S.bak[t / 10][t % 10]; else if (t < 26) S.bias[(t - 20) / 3][(t - 20) % 3] = S.bakb[(t - 20) / 3][(t - 20) % 3];
-                }
-                __syncthreads();
-                PT_LAP(9);
-                qmax++;
-            } while (rho < 0 && qmax < 10);
-            if (accepted) { cur ^= 1; have_lin = true; chi_lin = currentChi; }      // the speculative buffer is the next iteration's system
-            else have_lin = true, chi_lin = currentChi;                               // state restored: the current system is still its linearisation
-            if (t == 0) { S.flag[1]++; S.sc[7] = currentChi; }
-            if (qmax == 10 || rho == 0) break;
-            if ((iniChi - currentChi) * 1e3 < iniChi) nBadLM++; else nBadLM = 0;
-            if (nBadLM >= 3) break;
-        }
-        __syncthreads();
-        // ---- re-classify every mono edge by its chi2 at the new estimate (Optimizer.cc:622-688)
-        PT_START();
-        {
-            int bad_local = 0;
-            for (int side = 0; side < (variant ? 2 : 1); side++) {
-                const pvr s = sh_pvr(S.est[side]);
-                const m33 RT = tr(qmat(s.q));
-                const double* ob = side ? obs_l : obs_c; uint8_t* ol = side ? out_l : out_c; const int ne = side ? nlast : ncur;
-                for (int i = t; i < ne; i += blockDim.x) {
-                    const obs_t o = load_obs(ob, i);
-                    double e[2];
-                    proj_edge(K, RT, s.P, o.X, o.u, o.v, false, e, nullptr, nullptr);
-                    const float chi2 = (float)(o.is2 * (e[0] * e[0] + e[1] * e[1]));
-                    const int bad = chi2 > 5.991f;
-                    ol[i] = (uint8_t)bad;
-                    if (side == 0) bad_local += bad;
-                }
-            }
-#pragma unroll
-            for (int d = 32; d > 0; d >>= 1) bad_local += __shfl_xor(bad_local, d);
-            __syncthreads();
-            if (lane == 0) S.flag[2 + 0] = 0;
-            __syncthreads();
-            if (lane == 0) atomicAdd(&S.flag[2], bad_local);
-            __syncthreads();
-            nbad = S.flag[2];
-        }
-        if (round == 2) kernel_on = 0;
-        __syncthreads();
-        PT_LAP(5);
-        if (n_edges_total < 10) break;
-    }
-#ifdef VIORB_POSE_TIMING
-    if (b == 0 && lane == 0)
-        printf("pose_opt wave=%d total=%llu evals=%d dense=%llu edges=%llu wait=%llu asm=%llu solve=%llu classify=%llu loop=%llu setup=%llu asm1=%llu update=%llu post=%llu\n", wave,
-               __builtin_amdgcn_s_memtime() - pt_begin, pt_n, pt_acc[0], pt_acc[1], pt_acc[2], pt_acc[3], pt_acc[4], pt_acc[5], pt_acc[6], pt_setup, pt_acc[7], pt_acc[8], pt_acc[9]);
-    if (b == 0 && lane == 0) printf("pose_opt2 wave=%d asm_w=%llu asm_items=%llu\n", wave, pt_acc[10], pt_acc[11]);
-#endif
-    // ---- outputs
-    if (t == 0) {
-        double* o = A.out_ns + (size_t)b * 22;
-        for (int k = 0; k < 10; k++) o[k] = S.est[0][k];
-        for (int k = 10; k < 19; k++) o[k] = curns[k];
-        for (int k = 0; k < 3; k++) o[19 + k] = S.bias[0][k];
-        if (A.out_last_ns) {
-            double* ol = A.out_last_ns + (size_t)b * 22;
-            for (int k = 0; k < 10; k++) ol[k] = variant ? S.est[1][k] : lastns[k];
-            for (int k = 10; k < 19; k++) ol[k] = lastns[k];
-            for (int k = 0; k < 3; k++) ol[19 + k] = variant ? S.bias[1][k] : lastns[19 + k];
-        }
-        double* inf = A.info + (size_t)b * 4;
-        inf[0] = ncur - nbad; inf[1] = S.sc[7]; inf[2] = S.flag[1]; inf[3] = 0;
-    }
-    if (A.compute_marg) {
-        // mMargCovInv from the last linearised H (diagonal restored). The reference inverts H, takes the blocks of
-        // (cur PVR, cur bias) and inverts again; inverse-of-a-block-of-the-inverse is the Schur complement of the
-        // other block, which falls out of a partial Cholesky with the last-frame block ordered first.
-        double* mo = A.marg_out + (size_t)b * 144;
-        if (variant) {
-            for (int i = t; i < 576; i += blockDim.x) {
-                const int r = i / 24, c = i % 24;
-                S.Lm[i] = S.Hb[hb_last][((r + 12) % 24) * 24 + (c + 12) % 24];     // [last | cur] ordering
-            }
-            __syncthreads();
-            if (wave == 0) wave_cholesky(S.Lm, 24, 12, lane);
-            __syncthreads();
-            for (int i = t; i < 144; i += blockDim.x) {
-                const int r = i / 12, c = i % 12;
-                mo[i] = (c <= r) ? S.Lm[(12 + r) * 24 + 12 + c] : S.Lm[(12 + c) * 24 + 12 + r];
-            }
-        } else {
-            // H = diag(H_pp (9x9), H_bb (3x3)) exactly (no factor couples cur PVR and cur bias when the KF is fixed)
-            for (int i = t; i < 144; i += blockDim.x) {
-                const int r = i / 12, c = i % 12;
-                mo[i] = ((r < 9) == (c < 9)) ? S.Hb[hb_last][r * 12 + c] : 0.0;
-            }
-        }
-    }
 }
 
 #include "pose_opt_mp.inc"
@@ -2074,7 +1364,7 @@ struct viorb_frontend {
 };
 
 // Launch of the visual-inertial pose solve. VIORB_POSE_MP="P,WPP" selects an instantiation of k_pose_opt_vi_mp (problems per workgroup,
-// wavefronts per problem; "0" = the round-3 kernel, one 256-thread workgroup per problem); the default is POSE_MP_DEFAULT.
+// wavefronts per problem); the default depends on the batch size (below).
 #ifndef POSE_MP_DEFAULT_P
 #define POSE_MP_DEFAULT_P 2
 #define POSE_MP_DEFAULT_WPP 2
@@ -2099,7 +1389,6 @@ static int launch_pose_opt_vi(const PoseOptArgs& A, int batch, hipStream_t st) {
     // wavefronts per problem, eight when even a problem per two CUs is not there (a single stream).
     int cfg = cfg_env & 0x100 ? (cfg_env & 0xff) : (batch >= 2 * n_cu ? POSE_MP_DEFAULT_P * 16 + POSE_MP_DEFAULT_WPP : (batch > n_cu / 2 ? 1 * 16 + 4 : 1 * 16 + 8));
     switch (cfg) {
-        case 0: hipLaunchKernelGGL(k_pose_opt_vi, dim3(batch), dim3(POSE_THREADS), 0, st, A); return VIORB_OK;
         case 1 * 16 + 4: return launch_pose_mp<1, 4>(A, batch, st);
         case 1 * 16 + 8: return launch_pose_mp<1, 8>(A, batch, st);
         case 1 * 16 + 2: return launch_pose_mp<1, 2>(A, batch, st);
