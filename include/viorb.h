@@ -292,6 +292,11 @@ int viorb_frontend_pose_opt_device(viorb_frontend* h, int variant, int compute_m
                                    double* out_last_ns, uint8_t* outlier_cur, uint8_t* outlier_last, double* marg_out,
                                    double* info, void* stream);
 
+/* Shape of the visual-inertial pose solver's launches for the rest of the process: P problems per workgroup (advanced in lock step), WPP wavefronts
+ * per problem; 0, 0 = chosen by batch size (default: 2, 2 from two problems per CU, 1, 4 / 1, 8 for small batches). A tuning / test hook: results are
+ * the same up to the grouping of floating-point sums. */
+int viorb_frontend_set_pose_shape(int problems_per_workgroup, int wavefronts_per_problem);
+
 /* Optimizer::PoseOptimization(Frame*) — vision-only 6-DoF solve (reference src/Optimizer.cc:3749-3978) for a batch.
  * pose12[b] = Rcw(9) tcw(3) of pFrame->mTcw (float), obs7[b][cap][7] = Xw3 u v uRight invSigma2 in keypoint order
  * (uRight < 0: monocular edge, else stereo edge with baseline*fx = bf). Intrinsics are the handle's fx fy cx cy.

@@ -600,3 +600,62 @@ def test_search_projection_retry_only_touches_streams_below_the_limit(oracle):
     r_n, r_m = oracle.search_by_projection_frame(ck, cd, (0.0, 752.0, 0.0, 480.0), streams[1]["pose_true"][1].astype(np.float32), streams[1]["cam"][:4],
                                                  tab["scale"], lf[1, :lc[1]], lP[1, :lc[1]], ld[1, :lc[1]], lk[1, :lc[1]]["octave"], lk[1, :lc[1]]["angle"], 30.0)
     assert n2[1] == r_n and np.array_equal(m2[1, :len(ck)], r_m) and (st.cpu().numpy() == 0).all()
+
+
+@pytest.fixture
+def pose_shape():
+    """Sets the VI pose solver's launch shape for one test and restores the automatic choice afterwards."""
+    L = viorb_amd.lib()
+    def set_shape(P, W):
+        assert L.viorb_frontend_set_pose_shape(int(P), int(W)) == 0
+    yield set_shape
+    L.viorb_frontend_set_pose_shape(0, 0)
+
+
+@pytest.mark.parametrize("shape", [(2, 2), (1, 4), (1, 8), (4, 2), (2, 3)])
+def test_pose_solver_shapes_equal_the_oracle(torch_cuda, oracle, pose_shape, shape):
+    """k_pose_opt_vi_mp<P, WPP>: the shape a deployment's batch size selects — <2, 2> from two problems per CU (the benchmark's), <1, 4> / <1, 8>
+    for small batches — and two more of the instantiated ones. Small test batches would only ever run <1, 8>, so the shape is forced: a batch of
+    5 problems of different sizes and BOTH overloads in one launch (per-problem `variant`, uneven lock-step partners, a last workgroup that is
+    only partly filled, a problem with < 3 correspondences that returns at once) against the oracle: flags, inlier counts, LM iteration counts
+    exact, cost 1e-5, state 1e-7, marginal 1e-4."""
+    torch = torch_cuda
+    pose_shape(*shape)
+    probs = [make_vio_problem(40 + i, n_points=n) for i, n in enumerate((300, 90, 650, 2, 420))]
+    variants = [1, 0, 1, 1, 0]
+    B, cap = len(probs), 700
+    fe = viorb_amd.Frontend(probs[0]["cam"], probs[0]["gw"], np.float32(1.2) ** np.arange(8), 1.0 / (np.float32(1.2) ** np.arange(8)) ** 2, BOUNDS, max_batch=B, cap=cap)
+    cur, last, pre, oc, ol = [], [], [], [], []
+    for p in probs:
+        l = p["ns_last"]; pr = oracle.preintegrate(p["imu"], l[10:13], l[13:16], p["t_last"], p["t_cur"])
+        cur.append(oracle.update_ns(l, pr, p["gw"])); last.append(l); pre.append(pr)
+        a = np.zeros((cap, 6)); a[:len(p["obs_cur"])] = p["obs_cur"]; oc.append(a)
+        b = np.zeros((cap, 6)); b[:len(p["obs_last"])] = p["obs_last"]; ol.append(b)
+    up = lambda a, dt=np.float64: torch.from_numpy(np.ascontiguousarray(np.asarray(a, dt))).cuda()
+    d = dict(cur=up(cur), last=up(last), prior=up([p["prior"] for p in probs]), mci=up([p["marg_cov_inv"].ravel() for p in probs]), pre=up(pre), oc=up(oc), ol=up(ol),
+             nc=up([len(p["obs_cur"]) for p in probs], np.int32), nl=up([len(p["obs_last"]) for p in probs], np.int32), var=up(variants, np.uint8), skip=up([0] * B, np.uint8))
+    out = dict(ns=torch.zeros((B, 22), dtype=torch.float64, device="cuda"), nsl=torch.zeros((B, 22), dtype=torch.float64, device="cuda"),
+               fc=torch.zeros((B, cap), dtype=torch.uint8, device="cuda"), fl=torch.zeros((B, cap), dtype=torch.uint8, device="cuda"),
+               marg=torch.zeros((B, 144), dtype=torch.float64, device="cuda"), info=torch.zeros((B, 4), dtype=torch.float64, device="cuda"))
+    from viorb_amd.capi import check, ptr
+    check(viorb_amd.lib().viorb_frontend_pose_opt_select_device(fe.h, ptr(d["var"]), ptr(d["skip"]), 1, ptr(d["cur"]), ptr(d["last"]), ptr(d["prior"]), ptr(d["mci"]), ptr(d["pre"]),
+                                                                ptr(d["oc"]), ptr(d["nc"]), ptr(d["ol"]), ptr(d["nl"]), B, ptr(out["ns"]), ptr(out["nsl"]), ptr(out["fc"]), ptr(out["fl"]),
+                                                                ptr(out["marg"]), ptr(out["info"]), None))
+    torch.cuda.synchronize()
+    g = {k: v.cpu().numpy() for k, v in out.items()}
+    for i, (p, var) in enumerate(zip(probs, variants)):
+        o = (oracle.pose_opt_vi_frame(cur[i], last[i], p["prior"], p["marg_cov_inv"], pre[i], p["gw"], p["cam"], p["obs_cur"], p["obs_last"], marg=True) if var else
+             oracle.pose_opt_vi_kf(cur[i], last[i], pre[i], p["gw"], p["cam"], p["obs_cur"], marg=True))
+        n = len(p["obs_cur"])
+        assert int(g["info"][i, 0]) == o["n_inliers"] and int(g["info"][i, 2]) == o["lm_iterations"], (shape, i)
+        if n < 3:
+            np.testing.assert_array_equal(g["ns"][i], cur[i])
+            continue
+        assert abs(g["info"][i, 1] - o["final_chi2"]) <= 1e-5 * abs(o["final_chi2"]), (shape, i)
+        np.testing.assert_array_equal(g["fc"][i, :n], o["outlier_cur"])
+        np.testing.assert_allclose(g["ns"][i], o["ns"], rtol=0, atol=1e-7)
+        if var:
+            np.testing.assert_array_equal(g["fl"][i, :len(p["obs_last"])], o["outlier_last"])
+            np.testing.assert_allclose(g["nsl"][i], o["ns_last"], rtol=0, atol=1e-7)
+        M = o["marg_cov_inv"]
+        np.testing.assert_allclose(g["marg"][i].reshape(12, 12), M, rtol=1e-4, atol=1e-6 * np.abs(M).max())

@@ -219,3 +219,19 @@ def test_native_tracker_carries_its_estimate_across_keyframe_boundaries_for_40_f
     assert first_diff is None, "first discrete difference at (frame, stream) %s" % (first_diff,)
     assert max(w["ns"] for w in log) <= 1e-7 and max(w["chi"] for w in log) <= 1e-5, [(w["frame"], w["ns"], w["chi"]) for w in log if w["ns"] > 1e-7 or w["chi"] > 1e-5]
     assert all(st == 0 for w in log for st in w["states"]), "every frame of the chained run is tracked"
+
+
+@pytest.mark.parametrize("shape", [(2, 2), (1, 4)])
+def test_native_tracker_under_the_throughput_solver_shapes(shape):
+    """The test batches are small, so the library would run every pose solve of this file under the single-stream shape <1, 8>. The same chained
+    comparison (3 streams: the second workgroup of <2, 2> is half empty; mbMapUpdated every 3rd frame mixes both overloads in one launch) under the
+    shape the benchmark's 1024 streams select and under <1, 4>."""
+    import viorb_amd
+    L = viorb_amd.lib()
+    assert L.viorb_frontend_set_pose_shape(*shape) == 0
+    try:
+        first_diff, log = _chained_run(10, seeds=[311, 312, 313], map_updated_every=3)
+    finally:
+        L.viorb_frontend_set_pose_shape(0, 0)
+    assert first_diff is None, "first discrete difference at (frame, stream) %s" % (first_diff,)
+    assert max(w["ns"] for w in log) <= 1e-7 and max(w["chi"] for w in log) <= 1e-5

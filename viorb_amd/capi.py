@@ -109,6 +109,7 @@ SIGNATURES = {
     "viorb_frontend_imu_predict_device": (i32, [vp, vp, i32, vp, vp, vp, i32, vp, vp, vp, vp]),
     "viorb_frontend_search_projection_device": (i32, [vp] * 12 + [f32, i32, vp, vp, vp, vp]),
     "viorb_frontend_search_projection_retry_device": (i32, [vp] * 12 + [f32, i32, i32, vp, vp, vp, vp]),
+    "viorb_frontend_set_pose_shape": (i32, [i32, i32]),
     "viorb_frontend_search_local_points_device": (i32, [vp] * 11 + [i32, f32, f32, vp, i32, vp, vp, vp, vp, vp]),
     "viorb_frontend_search_local_points_stereo_device": (i32, [vp] * 5 + [f32] + [vp] * 7 + [i32, f32, f32, vp, i32, vp, vp, vp, vp, vp, vp]),
     "viorb_frontend_build_observations_device": (i32, [vp, vp, vp, vp, vp, i32, vp, vp, vp, vp]),

@@ -9,6 +9,7 @@
 //                         reference src/Optimizer.cc:323-1112 + Thirdparty/g2o (see vio_core.h)
 #include <hip/hip_runtime.h>
 #include <vector>
+#include <atomic>
 #include <algorithm>
 #include "viorb_common.h"
 #include "orb_math.h"
@@ -1375,6 +1376,7 @@ template <int P, int WPP> static int launch_pose_mp(const PoseOptArgs& A, int ba
     hipLaunchKernelGGL((k_pose_opt_vi_mp<P, WPP>), dim3((batch + P - 1) / P), dim3(64 * P * WPP), lds, st, A, batch);
     return VIORB_OK;
 }
+static std::atomic<int> g_pose_shape_override{0};          // viorb_frontend_set_pose_shape: P * 16 + WPP, 0 = automatic
 static int launch_pose_opt_vi(const PoseOptArgs& A, int batch, hipStream_t st) {
     static int cfg_env = -1, n_cu = 0;
     if (cfg_env < 0) {
@@ -1388,6 +1390,7 @@ static int launch_pose_opt_vi(const PoseOptArgs& A, int batch, hipStream_t st) {
     // problem) once there is a problem pair per CU; below that the chip is idle anyway and a solve's LATENCY is what a step waits for: four
     // wavefronts per problem, eight when even a problem per two CUs is not there (a single stream).
     int cfg = cfg_env & 0x100 ? (cfg_env & 0xff) : (batch >= 2 * n_cu ? POSE_MP_DEFAULT_P * 16 + POSE_MP_DEFAULT_WPP : (batch > n_cu / 2 ? 1 * 16 + 4 : 1 * 16 + 8));
+    if (const int ov = g_pose_shape_override.load()) cfg = ov;
     switch (cfg) {
         case 1 * 16 + 4: return launch_pose_mp<1, 4>(A, batch, st);
         case 1 * 16 + 8: return launch_pose_mp<1, 8>(A, batch, st);
@@ -1781,6 +1784,18 @@ int viorb_frontend_fuse_device(viorb_frontend* h, const viorb_keypoint* kps, con
     hipLaunchKernelGGL(k_fuse, dim3(batch), dim3(1024), 0, (hipStream_t)stream, A);
     VIORB_HIP_TRY(hipGetLastError());
     return VIORB_OK;
+}
+
+// Shape of the VI pose solver for every later launch of this process: P problems per workgroup, WPP wavefronts per problem (one of 1,2 1,3 1,4
+// 1,8 2,2 2,3 2,4 4,1 4,2); 0, 0 = by batch size (the default). The solver's results do not depend on it beyond the grouping of floating-point
+// sums; the test-suite runs every parity test of the solver under the shapes the batch sizes of a deployment select.
+int viorb_frontend_set_pose_shape(int problems_per_workgroup, int wavefronts_per_problem) {
+    if (problems_per_workgroup == 0 && wavefronts_per_problem == 0) { g_pose_shape_override.store(0); return VIORB_OK; }
+    const int c = problems_per_workgroup * 16 + wavefronts_per_problem;
+    const int ok[] = {1 * 16 + 2, 1 * 16 + 3, 1 * 16 + 4, 1 * 16 + 8, 2 * 16 + 2, 2 * 16 + 3, 2 * 16 + 4, 4 * 16 + 1, 4 * 16 + 2};
+    for (int v : ok) if (v == c) { g_pose_shape_override.store(c); return VIORB_OK; }
+    set_error("viorb_frontend_set_pose_shape: unsupported (P, WPP) = (%d, %d)", problems_per_workgroup, wavefronts_per_problem);
+    return VIORB_ERR_INVALID_ARG;
 }
 
 int viorb_frontend_pose_opt_device(viorb_frontend* h, int variant, int compute_marg, const double* cur_ns, const double* last_ns,
