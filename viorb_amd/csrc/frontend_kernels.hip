@@ -147,7 +147,9 @@ __host__ inline int search_slot_n(int cap) { return search_lds_bytes(cap, SEARCH
 
 // 1024 threads per stream: the kernel is a chain of LDS / L2 latencies per point (grid walk, descriptor fetch), so it wants every
 // point of a ~1000-point frame on its own thread and 16 waves per CU to hide them (256 threads: 0.32 ms per 256 streams)
+#ifndef SEARCH_THREADS
 #define SEARCH_THREADS 1024
+#endif
 // GW = false: the work arrays in LDS (every frame of up to viorb_frontend_search_capacity() keypoints); GW = true: the same arrays in a
 // per-stream slice of global memory — same code, same result, for frames LDS cannot hold (the reference has no limit)
 template <bool GW>
