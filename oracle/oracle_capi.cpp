@@ -283,7 +283,8 @@ int ora_search_by_projection_frame_stereo(const KeyPoint* cur_kps, const uint8_t
     PoseF T; for (int i = 0; i < 9; i++) T.Rcw[i] = pose12[i]; for (int i = 0; i < 3; i++) T.tcw[i] = pose12[9 + i];
     T.fx = intr4[0]; T.fy = intr4[1]; T.cx = intr4[2]; T.cy = intr4[3];
     StereoSearch st; st.mb = mb; st.bf = bf; st.uright = cur_uright; st.last = T;
-    for (int i = 0; i < 9; i++) st.last.Rcw[i] = last_pose12[i]; for (int i = 0; i < 3; i++) st.last.tcw[i] = last_pose12[9 + i];
+    for (int i = 0; i < 9; i++) st.last.Rcw[i] = last_pose12[i];
+    for (int i = 0; i < 3; i++) st.last.tcw[i] = last_pose12[9 + i];
     std::vector<LastFramePoint> last(nlast);
     for (int i = 0; i < nlast; i++) {
         last[i].has_point = last_flags[i] & 1; last[i].outlier = (last_flags[i] >> 1) & 1; last[i].has_observations = (last_flags[i] >> 2) & 1;
