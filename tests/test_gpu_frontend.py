@@ -216,7 +216,7 @@ def test_pose_optimisation_edge_counts_around_the_thread_count(torch_cuda, oracl
     np.testing.assert_allclose(g["ns"], o["ns"], rtol=0, atol=1e-7)
 
 
-@pytest.mark.parametrize("n_points,variant", [(4700, 0), (9000, 1)])
+@pytest.mark.parametrize("n_points,variant", [(5200, 0), (9000, 1)])
 def test_pose_optimisation_more_edges_than_the_searches_hold_keypoints(torch_cuda, oracle, n_points, variant):
     """The host drop-in builds its handle for the number of edges; the keypoint limit of the projection search (LDS plan,
     viorb_frontend_search_capacity) must not apply to a handle that only solves."""

@@ -135,7 +135,7 @@ def test_native_tracker_3000_features_equals_twin():
 
 
 def test_native_tracker_5000_features_equals_twin():
-    """More keypoints per frame than the searches' work arrays fit in LDS (viorb_frontend_search_capacity, ~4600): they then live in global
+    """More keypoints per frame than the searches' work arrays fit in LDS (viorb_frontend_search_capacity, ~4900): they then live in global
     memory (k_search_projection<true>, k_search_local_points<true>); same matches, same solves."""
     import viorb_amd
     assert 5000 > viorb_amd.lib().viorb_frontend_search_capacity()

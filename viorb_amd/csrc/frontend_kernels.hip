@@ -118,7 +118,7 @@ struct SearchArgs {
     const float* pose12; const viorb_keypoint* last_kps; const int* last_count; const uint8_t* last_flags;
     const float* last_Pw; const uint8_t* last_desc;
     int* cur_match; int* nmatches; int* status;
-    uint32_t* cand;           // [B][cap][CAND_CAP] = dist<<16 | idx
+    uint32_t* cand;           // [B][CAND_CAP][cap] = dist<<16 | idx (SearchByProjection; entry k of point i at k * cap + i), [B][CAND_CAP][pcap] = dist << 20 | level << 16 | idx (SearchLocalPoints)
     int* cand_n;              // [B][cap]
     int cap;
     int slot_n;               // candidates per point cached in LDS: SEARCH_SLOT, or 0 when the frame's arrays leave no room (cap > ~2400)
@@ -137,10 +137,10 @@ struct SearchArgs {
 // SLOT candidates of every last-frame point, and the four per-keypoint work arrays. Candidates beyond SLOT
 // spill to the global scratch list.
 #ifndef SEARCH_SLOT
-#define SEARCH_SLOT 8
+#define SEARCH_SLOT 8       // a multiple of 4 (the candidate lists are read four entries at a time, from one address space)
 #endif
 __host__ __device__ inline size_t search_lds_bytes(int cap, int slot_n = SEARCH_SLOT) {
-    return (size_t)(GRID_CELLS + 1) * 2 + 2 /*pad*/ + (size_t)cap * (2 + 8 + 4 + 1 + 3 /*pad to 4*/) + (size_t)cap * slot_n * 4 + (size_t)cap * 4 * 4 + 64;
+    return (size_t)(GRID_CELLS + 1) * 2 + 2 /*pad*/ + (size_t)cap * (8 + 4 + 4) + (size_t)cap * slot_n * 4 + (size_t)cap * 4 * 4 + 64;
 }
 // the slot cache is dropped (every candidate goes through the global list) when the arrays would not fit LDS with it
 __host__ inline int search_slot_n(int cap) { return search_lds_bytes(cap, SEARCH_SLOT) <= 160 * 1024 ? SEARCH_SLOT : 0; }
@@ -149,6 +149,19 @@ __host__ inline int search_slot_n(int cap) { return search_lds_bytes(cap, SEARCH
 // point of a ~1000-point frame on its own thread and 16 waves per CU to hide them (256 threads: 0.32 ms per 256 streams)
 #ifndef SEARCH_THREADS
 #define SEARCH_THREADS 1024
+#endif
+#ifndef SCAN_W
+#define SCAN_W 4            // entries of a grid column tested per step of the window scan
+#endif
+// -DVIORB_SEARCH_TIMING: thread 0 of workgroup 0 prints the s_memtime ticks (100 MHz) of each phase of the two projection searches
+#ifdef VIORB_SEARCH_TIMING
+#define SPT_DECL unsigned long long spt_acc[6] = {0, 0, 0, 0, 0, 0}, spt_t0 = __builtin_amdgcn_s_memtime(); int spt_sweeps = 0
+#define SPT_LAP(k) do { const unsigned long long spt_now = __builtin_amdgcn_s_memtime(); spt_acc[k] += spt_now - spt_t0; spt_t0 = spt_now; } while (0)
+#define SPT_PRINT(name) do { if (threadIdx.x == 0 && blockIdx.x == 0) printf("SPT %s stage %llu walk %llu dist %llu sweeps %llu out %llu nsweeps %d\n", name, spt_acc[0], spt_acc[4], spt_acc[1], spt_acc[2], spt_acc[3], spt_sweeps); } while (0)
+#else
+#define SPT_DECL
+#define SPT_LAP(k)
+#define SPT_PRINT(name)
 #endif
 // GW = false: the work arrays in LDS (every frame of up to viorb_frontend_search_capacity() keypoints); GW = true: the same arrays in a
 // per-stream slice of global memory — same code, same result, for frames LDS cannot hold (the reference has no limit)
@@ -159,38 +172,29 @@ __global__ __launch_bounds__(SEARCH_THREADS) void k_search_projection(SearchArgs
     const int b = blockIdx.x, cap = A.cap, t = threadIdx.x, lane = t & 63;
     if (A.skip_if_at_least > 0 && A.nmatches[b] >= A.skip_if_at_least) return;       // uniform per workgroup, before any barrier
     const int ncur = min(A.cur_count[b], cap), nlast = min(A.last_count[b], cap);
+    SPT_DECL;
     // carve LDS (4-byte aligned sections first)
     const int slot_n = A.slot_n;
-    uint32_t* slot = reinterpret_cast<uint32_t*>(s_raw);                 // [cap][slot_n] dist<<16 | idx
-    int* choice = reinterpret_cast<int*>(slot + (size_t)cap * slot_n);   // [cap] chosen current keypoint of last point i, or -1
+    uint32_t* slot = reinterpret_cast<uint32_t*>(s_raw);                 // [slot_n][cap] dist<<16 | idx: entry k of point i at k * cap + i (lanes = points: conflict-free)
+    int* choice = reinterpret_cast<int*>(slot + (size_t)cap * slot_n);   // [cap] chosen current keypoint of last point i, or -1 (touched by the thread of point i only, until phase C)
     int* taken = choice + cap;            // [cap] per current keypoint: smallest i (with observations) that chose it
-    int* owner = taken + cap;             // [cap] per current keypoint: largest i that chose it
-    int* rej = owner + cap;               // [cap] scratch / per current keypoint: chosen by a point of a rejected bin
-    float2* cxy = reinterpret_cast<float2*>(rej + cap);                  // [cap]
-    float* cang = reinterpret_cast<float*>(cxy + cap);                   // [cap]
-    uint16_t* cs = reinterpret_cast<uint16_t*>(cang + cap);              // [GRID_CELLS + 1] (+1 pad)
-    uint16_t* ci = cs + GRID_CELLS + 2;                                   // [cap]
-    uint8_t* coct = reinterpret_cast<uint8_t*>(ci + cap);                // [cap]
-    __shared__ int s_changed, s_hist[HISTO_LENGTH], s_keep[HISTO_LENGTH], s_nm;
+    int* owner = taken + cap;             // [cap] the second buffer of `taken` during the sweeps; phase C: largest i that chose the keypoint
+    int* rej = owner + cap;               // [cap] phase C: per current keypoint, chosen by a point of a rejected bin
+    float2* pxy = reinterpret_cast<float2*>(rej + cap);                  // [cap] position of the keypoint at CSR entry p (the walk reads entries, not keypoints: no index hop)
+    float* cang = reinterpret_cast<float*>(pxy + cap);                   // [cap] by keypoint index
+    uint32_t* pio = reinterpret_cast<uint32_t*>(cang + cap);             // [cap] keypoint index | octave << 16 of CSR entry p
+    uint16_t* cs = reinterpret_cast<uint16_t*>(pio + cap);               // [GRID_CELLS + 1] (+1 pad)
+    __shared__ int s_changed[2], s_hist[HISTO_LENGTH], s_keep[HISTO_LENGTH], s_nm;
+#ifdef VIORB_SEARCH_TIMING
+    __shared__ int s_spt[4];        // [2], [3]: the slowest and the fastest wave's ticks in the walk
+    if (t < 4) s_spt[t] = t == 3 ? 0x7fffffff : 0;
+#endif
     const float* P = A.pose12 + (size_t)b * 12;
     const viorb_keypoint* ck = A.cur_kps + (size_t)b * cap;
     const viorb_keypoint* lk = A.last_kps + (size_t)b * cap;
     const uint8_t* lf = A.last_flags + (size_t)b * cap;
     uint32_t* cand = A.cand + (size_t)b * cap * CAND_CAP;
     int* cand_n = A.cand_n + (size_t)b * cap;
-    {
-        const int* gcs = A.cell_start + (size_t)b * (GRID_CELLS + 1);
-        const int* gci = A.cell_idx + (size_t)b * cap;
-        for (int i = t; i <= GRID_CELLS; i += blockDim.x) cs[i] = (uint16_t)gcs[i];
-        for (int i = t; i < ncur; i += blockDim.x) {
-            ci[i] = (uint16_t)gci[i];
-            const viorb_keypoint k = ck[i];
-            cxy[i] = make_float2(k.x, k.y); cang[i] = k.angle; coct[i] = (uint8_t)k.octave;
-        }
-    }
-    if (t == 0) s_nm = 0;
-    for (int i = t; i < HISTO_LENGTH; i += blockDim.x) { s_hist[i] = 0; s_keep[i] = 0; }
-    __syncthreads();
     // stereo: does the camera move forward / backward by more than the baseline? (tlc = Rlw * twc + tlw, twc = -Rcw^T tcw; :1339-1349)
     int motion = 0;
     const float* cur_ur = A.cur_uright ? A.cur_uright + (size_t)b * cap : nullptr;
@@ -202,11 +206,13 @@ __global__ __launch_bounds__(SEARCH_THREADS) void k_search_projection(SearchArgs
         const float tz = (Lp[6] * twc[0] + Lp[7] * twc[1] + Lp[8] * twc[2]) + Lp[11];
         motion = tz > A.mb ? 1 : (-tz > A.mb ? 2 : 0);
     }
-    // Candidates of last-frame point i in the reference's order (GetFeaturesInArea: columns outer, rows inner, insertion order inside a
-    // cell), each with its Hamming distance: f(k, dist << 16 | index). Phase A stores the first CAND_CAP of them; a point with more
-    // (a window of half the image) is enumerated again by every sweep of phase B instead of being cut short — no capacity limit.
-    auto enumerate = [&](int i, auto&& f) -> int {
-        int nc = 0;
+    // The search window of last-frame point i (:1351-1395): projection, radius by octave, level range, grid window. Needs no LDS: the
+    // window of a thread's first point is computed BEFORE the frame is staged, so its chain of dependent global loads (flags ->
+    // position -> octave -> scale factor) runs beside the staging loads instead of after the barrier.
+    struct Window { float u, v, invz, radius; int x0, x1, y0, y1, minL, maxL; bool ok; };
+    auto project = [&](int i) -> Window {
+        Window W; W.ok = false;
+        W.u = W.v = W.invz = W.radius = 0.0f; W.x0 = W.y0 = 0; W.x1 = W.y1 = -1; W.minL = 0; W.maxL = -1;
         const int fl = lf[i];
         if ((fl & 1) && !(fl & 2)) {
             const float* X = A.last_Pw + ((size_t)b * cap + i) * 3;
@@ -219,57 +225,155 @@ __global__ __launch_bounds__(SEARCH_THREADS) void k_search_projection(SearchArgs
                 const int oct = lk[i].octave;
                 const float radius = A.th * A.scale[oct];
                 // bForward: levels >= octave; bBackward: levels <= octave; else octave +- 1 (:1385-1390)
-                const int minL = motion == 1 ? oct : (motion == 2 ? 0 : oct - 1), maxL = motion == 1 ? -1 : (motion == 2 ? oct : oct + 1);
-                const int x0 = max(0, (int)floorf((u - A.minX - radius) * A.wInv));
-                const int x1 = min((int)GRID_COLS - 1, (int)ceilf((u - A.minX + radius) * A.wInv));
-                const int y0 = max(0, (int)floorf((v - A.minY - radius) * A.hInv));
-                const int y1 = min((int)GRID_ROWS - 1, (int)ceilf((v - A.minY + radius) * A.hInv));
-                if (x0 < GRID_COLS && x1 >= 0 && y0 < GRID_ROWS && y1 >= 0) {
-                    const uint4* dl = reinterpret_cast<const uint4*>(A.last_desc + ((size_t)b * cap + i) * 32);
-                    const uint4 da = dl[0], db = dl[1];
-                    const bool check_levels = (minL > 0) || (maxL >= 0);
-                    for (int ix = x0; ix <= x1; ix++) {
-                        // cells (ix, y0..y1) are contiguous in the CSR: one range per column
-                        const int pbeg = cs[ix * GRID_ROWS + y0], pend = cs[ix * GRID_ROWS + y1 + 1];
-                        for (int p = pbeg; p < pend; p++) {
-                            const int i2 = ci[p];
-                            const int o2 = coct[i2];
-                            if (check_levels) { if (o2 < minL) continue; if (maxL >= 0 && o2 > maxL) continue; }
-                            const float2 q = cxy[i2];
-                            if (!(fabsf(q.x - u) < radius && fabsf(q.y - v) < radius)) continue;
-                            if (cur_ur) {                                  // "if(CurrentFrame.mvuRight[i2]>0)" (:1404-1410)
-                                const float r2 = cur_ur[i2];
-                                if (r2 > 0) { const float ur = u - A.bf * invz; if (fabsf(ur - r2) > radius) continue; }
-                            }
-                            const uint4* dc = reinterpret_cast<const uint4*>(A.cur_desc + ((size_t)b * cap + i2) * 32);
-                            const uint4 ea = dc[0], eb = dc[1];
-                            const int dist = __popc(da.x ^ ea.x) + __popc(da.y ^ ea.y) + __popc(da.z ^ ea.z) + __popc(da.w ^ ea.w) +
-                                             __popc(db.x ^ eb.x) + __popc(db.y ^ eb.y) + __popc(db.z ^ eb.z) + __popc(db.w ^ eb.w);
-                            f(nc, ((uint32_t)dist << 16) | (uint32_t)i2);
-                            nc++;
-                        }
-                    }
-                }
+                W.minL = motion == 1 ? oct : (motion == 2 ? 0 : oct - 1); W.maxL = motion == 1 ? -1 : (motion == 2 ? oct : oct + 1);
+                W.x0 = max(0, (int)floorf((u - A.minX - radius) * A.wInv));
+                W.x1 = min((int)GRID_COLS - 1, (int)ceilf((u - A.minX + radius) * A.wInv));
+                W.y0 = max(0, (int)floorf((v - A.minY - radius) * A.hInv));
+                W.y1 = min((int)GRID_ROWS - 1, (int)ceilf((v - A.minY + radius) * A.hInv));
+                W.u = u; W.v = v; W.invz = invz; W.radius = radius;
+                W.ok = W.x0 < GRID_COLS && W.x1 >= 0 && W.y0 < GRID_ROWS && W.y1 >= 0;
             }
+        }
+        return W;
+    };
+    Window W0; W0.ok = false;
+    if (t < nlast) W0 = project(t);
+    {
+        const int* gcs = A.cell_start + (size_t)b * (GRID_CELLS + 1);
+        const int* gci = A.cell_idx + (size_t)b * cap;
+        for (int i = t; i <= GRID_CELLS; i += blockDim.x) cs[i] = (uint16_t)gcs[i];
+        for (int i = t; i < ncur; i += blockDim.x) cang[i] = ck[i].angle;
+        const int ngrid = min(gcs[GRID_CELLS], ncur);                    // entries of the CSR (keypoints outside the grid have none)
+        for (int p = t; p < ngrid; p += blockDim.x) {
+            const int i2 = gci[p];
+            const viorb_keypoint k = ck[i2];
+            pxy[p] = make_float2(k.x, k.y); pio[p] = (uint32_t)i2 | ((uint32_t)(k.octave & 0xff) << 16);
+        }
+        for (int p = ngrid + t; p < cap; p += blockDim.x) { pxy[p] = make_float2(0.0f, 0.0f); pio[p] = 0; }   // read (and masked) by the clamped loads of the walk
+    }
+    if (t == 0) s_nm = 0;
+    for (int i = t; i < HISTO_LENGTH; i += blockDim.x) { s_hist[i] = 0; s_keep[i] = 0; }
+    __syncthreads();
+    SPT_LAP(0);
+    // Candidates of the window in the reference's order (GetFeaturesInArea: columns outer, rows inner, insertion order inside a cell):
+    // g(k, index). Cells (ix, y0..y1) of a column are contiguous in the CSR, so a column is one range of entries. ONE loop with a
+    // straight-line body: a step tests up to FOUR entries of the current column and reads the bounds of the next; every LDS read of
+    // the step is issued up front (clamped addresses, results masked), the state moves by selects — a wave-step costs one LDS round
+    // trip whatever its lanes are doing, and a column of <= 4 entries is one step. (Written as column loop / entry loop, each entry
+    // cost three dependent LDS reads and the wave ran the sum over columns of the per-column maxima.)
+    auto scan = [&](const Window& W, auto&& g) -> int {
+        int nc = 0;
+        if (!W.ok) return 0;
+        const float u = W.u, v = W.v, radius = W.radius;
+        const int x1 = W.x1, y0 = W.y0, y1 = W.y1, minL = W.minL, maxL = W.maxL;
+        const bool check_levels = (minL > 0) || (maxL >= 0);
+        int ix = W.x0, p = 0, pend = 0;
+        for (;;) {
+            const int col = min(ix, x1) * GRID_ROWS;
+            const int cbeg = cs[col + y0], cend = cs[col + y1 + 1];
+            uint32_t e[SCAN_W]; float2 q[SCAN_W];
+#pragma unroll
+            for (int j = 0; j < SCAN_W; j++) { const int pp = min(p + j, cap - 1); e[j] = pio[pp]; q[j] = pxy[pp]; }
+#pragma unroll
+            for (int j = 0; j < SCAN_W; j++) {
+                const int i2 = (int)(e[j] & 0xffff), o2 = (int)(e[j] >> 16);
+                bool pass = p + j < pend && fabsf(q[j].x - u) < radius && fabsf(q[j].y - v) < radius;
+                if (check_levels) pass = pass && !(o2 < minL) && !(maxL >= 0 && o2 > maxL);
+                if (cur_ur && pass) {                                      // "if(CurrentFrame.mvuRight[i2]>0)" (:1404-1410)
+                    const float r2 = cur_ur[i2];
+                    if (r2 > 0) { const float ur = u - A.bf * W.invz; if (fabsf(ur - r2) > radius) pass = false; }
+                }
+                if (pass) { g(nc, i2); nc++; }
+            }
+            const bool adv = p + SCAN_W >= pend;                                // the column is done: enter the next, or stop after the last
+            if (adv && ix > x1) break;
+            p = adv ? cbeg : p + SCAN_W;
+            pend = adv ? cend : pend;
+            ix += adv ? 1 : 0;
         }
         return nc;
     };
-    // ---- phase A
+    // the same with each candidate's Hamming distance, f(k, dist << 16 | index): only for a point with more than CAND_CAP candidates
+    // (a window of half the image), which every sweep of phase B enumerates again instead of cutting the list short — no capacity limit
+    auto enumerate = [&](int i, auto&& f) -> int {
+        const uint4* dl = reinterpret_cast<const uint4*>(A.last_desc + ((size_t)b * cap + i) * 32);
+        const uint4 da = dl[0], db = dl[1];
+        return scan(project(i), [&](int k, int i2) {
+            const uint4* dc = reinterpret_cast<const uint4*>(A.cur_desc + ((size_t)b * cap + i2) * 32);
+            const uint4 ea = dc[0], eb = dc[1];
+            const int dist = __popc(da.x ^ ea.x) + __popc(da.y ^ ea.y) + __popc(da.z ^ ea.z) + __popc(da.w ^ ea.w) +
+                             __popc(db.x ^ eb.x) + __popc(db.y ^ eb.y) + __popc(db.z ^ eb.z) + __popc(db.w ^ eb.w);
+            f(k, ((uint32_t)dist << 16) | (uint32_t)i2);
+        });
+    };
+    // stored candidate k of point i: the first slot_n in LDS, the rest in the stream's global list; both with lanes (= points) adjacent
+    auto set_entry = [&](int i, int k, uint32_t e) { if (k < slot_n) slot[(size_t)k * cap + i] = e; else cand[(size_t)k * cap + i] = e; };
+    // four of them from k0 (a multiple of 4, like slot_n: one address space per call), indices clamped to n - 1
+    auto entries4 = [&](int i, int k0, int n, uint32_t* e) {
+        if (k0 < slot_n) {
+#pragma unroll
+            for (int u = 0; u < 4; u++) e[u] = slot[(size_t)min(k0 + u, n - 1) * cap + i];
+        } else {
+#pragma unroll
+            for (int u = 0; u < 4; u++) e[u] = cand[(size_t)min(k0 + u, n - 1) * cap + i];
+        }
+    };
+    // ---- phase A, in two passes per point: (1) the scan collects the candidates' indices (LDS reads only); (2) their descriptors are
+    // fetched EIGHT at a time (sixteen 16-byte loads in flight) and the Hamming distances written beside the indices
+#ifdef VIORB_SEARCH_TIMING
+    const unsigned long long spt_w0 = __builtin_amdgcn_s_memtime();
+#endif
     for (int i = t; i < nlast; i += blockDim.x) {
-        cand_n[i] = enumerate(i, [&](int k, uint32_t e) {
-            if (k < slot_n) slot[(size_t)i * slot_n + k] = e;
-            else if (k < CAND_CAP) cand[(size_t)i * CAND_CAP + k] = e;
-        });                                                            // the true count, also beyond CAND_CAP
+        const Window W = i == t ? W0 : project(i);
+        const int nc = scan(W, [&](int k, int i2) { if (k < CAND_CAP) set_entry(i, k, (uint32_t)i2); });   // the true count, also beyond CAND_CAP
+        cand_n[i] = nc;
         choice[i] = -1;
     }
+#ifdef VIORB_SEARCH_TIMING
+    { const int dt = (int)(__builtin_amdgcn_s_memtime() - spt_w0); if (lane == 0) { atomicMax(&s_spt[2], dt); atomicMin(&s_spt[3], dt); } }
     __syncthreads();
-    // ---- phase B: fixed-point sweeps
-    for (int sweep = 0; sweep <= nlast; sweep++) {
-        for (int c = t; c < ncur; c += blockDim.x) taken[c] = 0x7fffffff;
-        if (t == 0) s_changed = 0;
-        __syncthreads();
+    SPT_LAP(4);
+#endif
+    for (int i = t; i < nlast; i += blockDim.x) {                    // (every thread reads back its own points' lists: no barrier)
+        const int nc = cand_n[i];
+        const int ns = min(nc, (int)CAND_CAP);
+        if (ns > 0) {
+            const uint4* dl = reinterpret_cast<const uint4*>(A.last_desc + ((size_t)b * cap + i) * 32);
+            const uint4 da = dl[0], db = dl[1];
+            for (int k0 = 0; k0 < ns; k0 += 8) {
+                uint32_t id[8]; uint4 ea[8], eb[8];
+                entries4(i, k0, ns, id);
+                if (k0 + 4 < ns) entries4(i, k0 + 4, ns, id + 4);       // (never an index from a list position that was not written)
+                else { id[4] = id[0]; id[5] = id[0]; id[6] = id[0]; id[7] = id[0]; }
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const uint4* dc = reinterpret_cast<const uint4*>(A.cur_desc + ((size_t)b * cap + (id[u] & 0xffff)) * 32);
+                    ea[u] = dc[0]; eb[u] = dc[1];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    if (k0 + u >= ns) break;
+                    const int dist = __popc(da.x ^ ea[u].x) + __popc(da.y ^ ea[u].y) + __popc(da.z ^ ea[u].z) + __popc(da.w ^ ea[u].w) +
+                                     __popc(db.x ^ eb[u].x) + __popc(db.y ^ eb[u].y) + __popc(db.z ^ eb[u].z) + __popc(db.w ^ eb[u].w);
+                    set_entry(i, k0 + u, ((uint32_t)dist << 16) | id[u]);
+                }
+            }
+        }
+    }
+    SPT_LAP(1);
+    // ---- phase B: fixed-point sweeps. `taken` is double-buffered (one buffer holds this sweep's owners, the other is cleared for the
+    // next while this one is read) and choice[i] belongs to thread i: two barriers per sweep.
+    for (int c = t; c < ncur; c += blockDim.x) taken[c] = 0x7fffffff;
+    if (t < 2) s_changed[t] = 0;
+    __syncthreads();
+    int cur = 0;
+    for (int sweep = 0; sweep <= nlast; sweep++, cur ^= 1) {
+#ifdef VIORB_SEARCH_TIMING
+        spt_sweeps++;
+#endif
+        int* tkc = cur ? owner : taken; int* tkn = cur ? taken : owner;
         for (int i = t; i < nlast; i += blockDim.x)
-            if (choice[i] >= 0 && (lf[i] & 4)) atomicMin(&taken[choice[i]], i);
+            if (choice[i] >= 0 && (lf[i] & 4)) atomicMin(&tkc[choice[i]], i);
         __syncthreads();
         bool changed = false;
         for (int i = t; i < nlast; i += blockDim.x) {
@@ -277,22 +381,33 @@ __global__ __launch_bounds__(SEARCH_THREADS) void k_search_projection(SearchArgs
             int best = 256, bidx = -1;
             auto consider = [&](int, uint32_t e) {
                 const int i2 = (int)(e & 0xffff), dist = (int)(e >> 16);
-                if (taken[i2] < i) return;                        // owned by an earlier point that has observations
+                if (tkc[i2] < i) return;                          // owned by an earlier point that has observations
                 if (dist < best) { best = dist; bidx = i2; }
             };
             if (nc <= CAND_CAP) {
-                for (int k = 0; k < nc; k++) consider(k, k < slot_n ? slot[(size_t)i * slot_n + k] : cand[(size_t)i * CAND_CAP + k]);
+                for (int k0 = 0; k0 < nc; k0 += 4) {               // four entries, then their four owners, in flight together; the
+                    uint32_t e[4]; int ow[4];                      // repeats of the last entry past nc change nothing (strict <)
+                    entries4(i, k0, nc, e);
+#pragma unroll
+                    for (int u = 0; u < 4; u++) ow[u] = tkc[e[u] & 0xffff];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const int dist = (int)(e[u] >> 16);
+                        if (!(ow[u] < i) && dist < best) { best = dist; bidx = (int)(e[u] & 0xffff); }
+                    }
+                }
             } else enumerate(i, consider);                        // more candidates than the stored list holds: walk the grid again
             const int nw = best <= TH_HIGH ? bidx : -1;
             changed = changed || (nw != choice[i]);
-            rej[i] = nw;                                           // committed after every thread has read `taken`
+            choice[i] = nw;
         }
-        if (__any(changed) && lane == 0) s_changed = 1;
+        for (int c = t; c < ncur; c += blockDim.x) tkn[c] = 0x7fffffff;
+        if (t == 0) s_changed[cur ^ 1] = 0;
+        if (__any(changed) && lane == 0) s_changed[cur] = 1;
         __syncthreads();
-        for (int i = t; i < nlast; i += blockDim.x) choice[i] = rej[i];
-        __syncthreads();
-        if (!s_changed) break;
+        if (!s_changed[cur]) break;
     }
+    SPT_LAP(2);
     // ---- phase C: histogram, maxima, final ownership
     for (int c = t; c < ncur; c += blockDim.x) { owner[c] = -1; rej[c] = 0; }
     __syncthreads();
@@ -350,6 +465,11 @@ __global__ __launch_bounds__(SEARCH_THREADS) void k_search_projection(SearchArgs
     int* out = A.cur_match + (size_t)b * cap;
     for (int c = t; c < cap; c += blockDim.x) out[c] = (c < ncur && !rej[c]) ? owner[c] : -1;
     if (t == 0) { A.nmatches[b] = s_nm; A.status[b] = VIORB_OK; }
+    SPT_LAP(3);
+    SPT_PRINT("projection");
+#ifdef VIORB_SEARCH_TIMING
+    if (t == 0 && b == 0) printf("SPT walk: %d wave-iterations %d lane-iterations, slowest wave %d fastest %d ticks, nlast %d ncur %d\n", s_spt[0], s_spt[1], s_spt[2], s_spt[3], nlast, ncur);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -377,7 +497,7 @@ struct LocalSearchArgs {
     int nlevels;
 };
 __host__ __device__ inline size_t local_search_lds_bytes(int cap, int pcap, int slot_n = LOCAL_SLOT) {
-    return (size_t)pcap * (slot_n * 4 + 4 + 4) + (size_t)cap * (4 + 8 + 2 + 1 + 1) + (size_t)(GRID_CELLS + 2) * 2 + 64;
+    return (size_t)pcap * (slot_n * 4 + 4) + (size_t)cap * (4 + 4 + 8 + 4) + (size_t)(GRID_CELLS + 2) * 2 + 64;
 }
 
 template <bool GW>
@@ -387,45 +507,33 @@ __global__ __launch_bounds__(SEARCH_THREADS) void k_search_local_points(LocalSea
     const int b = blockIdx.x, cap = A.cap, pcap = A.pcap, t = threadIdx.x, lane = t & 63;
     const int ncur = min(A.cur_count[b], cap), npts = min(A.pts_count[b], pcap);
     const int slot_n = A.slot_n;
-    uint32_t* slot = reinterpret_cast<uint32_t*>(s_raw);                       // [pcap][slot_n]
-    int* choice = reinterpret_cast<int*>(slot + (size_t)pcap * slot_n);         // [pcap]
-    int* nchoice = choice + pcap;                                                // [pcap]
-    int* taken = nchoice + pcap;                                                 // [cap]
-    float2* cxy = reinterpret_cast<float2*>(taken + cap);                        // [cap]
-    uint16_t* cs = reinterpret_cast<uint16_t*>(cxy + cap);                       // [GRID_CELLS + 2]
-    uint16_t* ci = cs + GRID_CELLS + 2;                                          // [cap]
-    uint8_t* coct = reinterpret_cast<uint8_t*>(ci + cap);                        // [cap]
-    uint8_t* cown = coct + cap;                                                  // [cap]
-    __shared__ int s_changed, s_nm;
+    SPT_DECL;
+    float2* pxy = reinterpret_cast<float2*>(s_raw);                              // [cap] position of the keypoint at CSR entry p (8-byte entries first: pcap may be odd)
+    uint32_t* slot = reinterpret_cast<uint32_t*>(pxy + cap);                     // [slot_n][pcap] dist << 20 | level << 16 | idx: entry k of point i at k * pcap + i
+    int* choice = reinterpret_cast<int*>(slot + (size_t)pcap * slot_n);         // [pcap] (touched by the thread of point i only, until the output)
+    int* taken = choice + pcap;                                                  // [cap]
+    int* taken2 = taken + cap;                                                   // [cap] the second buffer of `taken` during the sweeps
+    uint32_t* pio = reinterpret_cast<uint32_t*>(taken2 + cap);                   // [cap] keypoint index | octave << 16 | (holds a point with observations) << 24 of CSR entry p
+    uint16_t* cs = reinterpret_cast<uint16_t*>(pio + cap);                       // [GRID_CELLS + 2]
+    __shared__ int s_changed[2], s_nm;
     const float* P = A.pose12 + (size_t)b * 12;
     const viorb_keypoint* ck = A.cur_kps + (size_t)b * cap;
     const uint8_t* pf = A.pts_flags + (size_t)b * pcap;
     uint32_t* cand = A.cand + (size_t)b * pcap * CAND_CAP;
     int* cand_n = A.cand_n + (size_t)b * pcap;
-    {
-        const int* gcs = A.cell_start + (size_t)b * (GRID_CELLS + 1);
-        const int* gci = A.cell_idx + (size_t)b * cap;
-        for (int i = t; i <= GRID_CELLS; i += blockDim.x) cs[i] = (uint16_t)gcs[i];
-        for (int i = t; i < ncur; i += blockDim.x) {
-            ci[i] = (uint16_t)gci[i];
-            const viorb_keypoint k = ck[i];
-            cxy[i] = make_float2(k.x, k.y); coct[i] = (uint8_t)k.octave;
-            cown[i] = A.cur_owner_obs[(size_t)b * cap + i] ? 1 : 0;
-        }
-    }
-    if (t == 0) s_nm = 0;
-    __syncthreads();
     // mOw = -Rcw^T tcw
     float Ow[3];
 #pragma unroll
     for (int r = 0; r < 3; r++) { const float tt = P[r] * P[9] + P[3 + r] * P[10] + P[6 + r] * P[11]; Ow[r] = -tt; }
     const bool bFactor = A.th != 1.0f;
-    // isInFrustum + the candidates of local point i in the reference's order: f(k, dist << 16 | index); fr (when not null) receives
-    // mbTrackInView, mTrackProjX, mTrackProjY, mTrackViewCos, mnTrackScaleLevel. Phase A stores the first CAND_CAP candidates; a point
-    // with more is enumerated again by every sweep of phase B (no capacity limit).
     const float* cur_ur = A.cur_uright ? A.cur_uright + (size_t)b * cap : nullptr;
-    auto enumerate = [&](int i, float* fr, auto&& f) -> int {
-        int nc = 0;
+    // Frame::isInFrustum of local point i and its search window (ORBmatcher.cc:60-75); fr (when not null) receives mbTrackInView,
+    // mTrackProjX, mTrackProjY, mTrackViewCos, mnTrackScaleLevel. Needs no LDS: a thread's first point is done BEFORE the frame is
+    // staged, its chain of dependent global loads beside the staging loads (see k_search_projection).
+    struct Window { float u, v, xr, radius; int x0, x1, y0, y1, minL, maxL; bool ok; };
+    auto frustum = [&](int i, float* fr) -> Window {
+        Window W; W.ok = false;
+        W.u = W.v = W.xr = W.radius = 0.0f; W.x0 = W.y0 = 0; W.x1 = W.y1 = -1; W.minL = 0; W.maxL = -1;
         const int fl = pf[i];
         float fr_in = 0, fr_u = 0, fr_v = 0, fr_cos = 0, fr_lvl = 0, fr_xr = 0;
         if ((fl & 1) && !(fl & 2)) {
@@ -452,84 +560,179 @@ __global__ __launch_bounds__(SEARCH_THREADS) void k_search_local_points(LocalSea
                 float rr = viewCos > 0.998 ? 2.5f : 4.0f;
                 if (bFactor) rr *= A.th;
                 const float radius = rr * A.scale[lvl];
-                const int minL = lvl - 1, maxL = lvl;
-                const int x0 = max(0, (int)floorf((u - A.minX - radius) * A.wInv));
-                const int x1 = min((int)GRID_COLS - 1, (int)ceilf((u - A.minX + radius) * A.wInv));
-                const int y0 = max(0, (int)floorf((v - A.minY - radius) * A.hInv));
-                const int y1 = min((int)GRID_ROWS - 1, (int)ceilf((v - A.minY + radius) * A.hInv));
-                if (x0 < GRID_COLS && x1 >= 0 && y0 < GRID_ROWS && y1 >= 0) {
-                    const uint4* dl = reinterpret_cast<const uint4*>(A.pts_desc + ((size_t)b * pcap + i) * 32);
-                    const uint4 da = dl[0], db = dl[1];
-                    const bool check_levels = (minL > 0) || (maxL >= 0);
-                    for (int ix = x0; ix <= x1; ix++) {
-                        const int pbeg = cs[ix * GRID_ROWS + y0], pend = cs[ix * GRID_ROWS + y1 + 1];
-                        for (int p = pbeg; p < pend; p++) {
-                            const int i2 = ci[p];
-                            const int o2 = coct[i2];
-                            if (check_levels) { if (o2 < minL) continue; if (maxL >= 0 && o2 > maxL) continue; }
-                            const float2 q = cxy[i2];
-                            if (!(fabsf(q.x - u) < radius && fabsf(q.y - v) < radius)) continue;
-                            if (cown[i2]) continue;                 // held by a point with observations: never available
-                            if (cur_ur) {                            // "if(F.mvuRight[idx]>0) { er = fabs(mTrackProjXR - mvuRight[idx]); if(er > r*sf) continue; }"
-                                const float ur = cur_ur[i2];
-                                if (ur > 0 && fabsf(xr - ur) > radius) continue;
-                            }
-                            const uint4* dc = reinterpret_cast<const uint4*>(A.cur_desc + ((size_t)b * cap + i2) * 32);
-                            const uint4 ea = dc[0], eb = dc[1];
-                            const int dist2 = __popc(da.x ^ ea.x) + __popc(da.y ^ ea.y) + __popc(da.z ^ ea.z) + __popc(da.w ^ ea.w) +
-                                              __popc(db.x ^ eb.x) + __popc(db.y ^ eb.y) + __popc(db.z ^ eb.z) + __popc(db.w ^ eb.w);
-                            f(nc, ((uint32_t)dist2 << 16) | (uint32_t)i2);
-                            nc++;
-                        }
-                    }
-                }
+                W.minL = lvl - 1; W.maxL = lvl;
+                W.x0 = max(0, (int)floorf((u - A.minX - radius) * A.wInv));
+                W.x1 = min((int)GRID_COLS - 1, (int)ceilf((u - A.minX + radius) * A.wInv));
+                W.y0 = max(0, (int)floorf((v - A.minY - radius) * A.hInv));
+                W.y1 = min((int)GRID_ROWS - 1, (int)ceilf((v - A.minY + radius) * A.hInv));
+                W.u = u; W.v = v; W.xr = xr; W.radius = radius;
+                W.ok = W.x0 < GRID_COLS && W.x1 >= 0 && W.y0 < GRID_ROWS && W.y1 >= 0;
             }
         }
         if (fr) { fr[0] = fr_in; fr[1] = fr_u; fr[2] = fr_v; fr[3] = fr_cos; fr[4] = fr_lvl; if (A.frustum_xr) A.frustum_xr[(size_t)b * pcap + i] = fr_xr; }
+        return W;
+    };
+    float fr_tmp[5];
+    auto fr_of = [&](int i) -> float* { return A.frustum ? A.frustum + ((size_t)b * pcap + i) * 5 : (A.frustum_xr ? fr_tmp : nullptr); };
+    Window W0; W0.ok = false;
+    if (t < npts) W0 = frustum(t, fr_of(t));
+    {
+        const int* gcs = A.cell_start + (size_t)b * (GRID_CELLS + 1);
+        const int* gci = A.cell_idx + (size_t)b * cap;
+        for (int i = t; i <= GRID_CELLS; i += blockDim.x) cs[i] = (uint16_t)gcs[i];
+        const int ngrid = min(gcs[GRID_CELLS], ncur);                    // entries of the CSR (keypoints outside the grid have none)
+        for (int p = t; p < ngrid; p += blockDim.x) {
+            const int i2 = gci[p];
+            const viorb_keypoint k = ck[i2];
+            pxy[p] = make_float2(k.x, k.y);
+            pio[p] = (uint32_t)i2 | ((uint32_t)(k.octave & 0xff) << 16) | (A.cur_owner_obs[(size_t)b * cap + i2] ? 1u << 24 : 0u);
+        }
+        for (int p = ngrid + t; p < cap; p += blockDim.x) { pxy[p] = make_float2(0.0f, 0.0f); pio[p] = 0; }   // read (and masked) by the clamped loads of the scan
+    }
+    if (t == 0) s_nm = 0;
+    __syncthreads();
+    SPT_LAP(0);
+    // Candidates of the window in the reference's order, g(k, level << 16 | index): the single-loop scan of k_search_projection (four entries
+    // of the current column and the bounds of the next per step, every LDS read issued up front, state moved by selects)
+    auto scan = [&](const Window& W, auto&& g) -> int {
+        int nc = 0;
+        if (!W.ok) return 0;
+        const float u = W.u, v = W.v, radius = W.radius;
+        const int x1 = W.x1, y0 = W.y0, y1 = W.y1, minL = W.minL, maxL = W.maxL;
+        const bool check_levels = (minL > 0) || (maxL >= 0);
+        int ix = W.x0, p = 0, pend = 0;
+        for (;;) {
+            const int col = min(ix, x1) * GRID_ROWS;
+            const int cbeg = cs[col + y0], cend = cs[col + y1 + 1];
+            uint32_t e[SCAN_W]; float2 q[SCAN_W];
+#pragma unroll
+            for (int j = 0; j < SCAN_W; j++) { const int pp = min(p + j, cap - 1); e[j] = pio[pp]; q[j] = pxy[pp]; }
+#pragma unroll
+            for (int j = 0; j < SCAN_W; j++) {
+                const int i2 = (int)(e[j] & 0xffff), o2 = (int)((e[j] >> 16) & 0xff);
+                bool pass = p + j < pend && fabsf(q[j].x - u) < radius && fabsf(q[j].y - v) < radius;
+                if (check_levels) pass = pass && !(o2 < minL) && !(maxL >= 0 && o2 > maxL);
+                pass = pass && !(e[j] >> 24);                              // held by a point with observations: never available
+                if (cur_ur && pass) {                  // "if(F.mvuRight[idx]>0) { er = fabs(mTrackProjXR - mvuRight[idx]); if(er > r*sf) continue; }"
+                    const float ur = cur_ur[i2];
+                    if (ur > 0 && fabsf(W.xr - ur) > radius) pass = false;
+                }
+                if (pass) { g(nc, e[j] & 0xfffffu); nc++; }
+            }
+            const bool adv = p + SCAN_W >= pend;                                // the column is done: enter the next, or stop after the last
+            if (adv && ix > x1) break;
+            p = adv ? cbeg : p + SCAN_W;
+            pend = adv ? cend : pend;
+            ix += adv ? 1 : 0;
+        }
         return nc;
     };
-    // ---- phase A: frustum + candidates
+    // the same with each candidate's Hamming distance, f(k, dist << 20 | level << 16 | index): only for a point with more than CAND_CAP
+    // candidates, which every sweep of phase B enumerates again instead of cutting the list short — no capacity limit
+    auto enumerate = [&](int i, auto&& f) -> int {
+        const uint4* dl = reinterpret_cast<const uint4*>(A.pts_desc + ((size_t)b * pcap + i) * 32);
+        const uint4 da = dl[0], db = dl[1];
+        return scan(frustum(i, nullptr), [&](int k, uint32_t li) {
+            const uint4* dc = reinterpret_cast<const uint4*>(A.cur_desc + ((size_t)b * cap + (li & 0xffff)) * 32);
+            const uint4 ea = dc[0], eb = dc[1];
+            const int dist2 = __popc(da.x ^ ea.x) + __popc(da.y ^ ea.y) + __popc(da.z ^ ea.z) + __popc(da.w ^ ea.w) +
+                              __popc(db.x ^ eb.x) + __popc(db.y ^ eb.y) + __popc(db.z ^ eb.z) + __popc(db.w ^ eb.w);
+            f(k, ((uint32_t)dist2 << 20) | li);
+        });
+    };
+    auto set_entry = [&](int i, int k, uint32_t e) { if (k < slot_n) slot[(size_t)k * pcap + i] = e; else cand[(size_t)k * pcap + i] = e; };
+    // four stored candidates from k0 (a multiple of 4, like slot_n: one address space per call), indices clamped to n - 1
+    auto entries4 = [&](int i, int k0, int n, uint32_t* e) {
+        if (k0 < slot_n) {
+#pragma unroll
+            for (int u = 0; u < 4; u++) e[u] = slot[(size_t)min(k0 + u, n - 1) * pcap + i];
+        } else {
+#pragma unroll
+            for (int u = 0; u < 4; u++) e[u] = cand[(size_t)min(k0 + u, n - 1) * pcap + i];
+        }
+    };
+    // ---- phase A: frustum + candidate indices, then the Hamming distances eight candidates at a time
     for (int i = t; i < npts; i += blockDim.x) {
-        float fr_tmp[5];
-        cand_n[i] = enumerate(i, A.frustum ? A.frustum + ((size_t)b * pcap + i) * 5 : (A.frustum_xr ? fr_tmp : nullptr), [&](int k, uint32_t e) {
-            if (k < slot_n) slot[(size_t)i * slot_n + k] = e;
-            else if (k < CAND_CAP) cand[(size_t)i * CAND_CAP + k] = e;
-        });                                                            // the true count, also beyond CAND_CAP
+        const Window W = i == t ? W0 : frustum(i, fr_of(i));
+        const int nc = scan(W, [&](int k, uint32_t li) { if (k < CAND_CAP) set_entry(i, k, li); });       // the true count, also beyond CAND_CAP
+        cand_n[i] = nc;
         choice[i] = -1;
     }
+#ifdef VIORB_SEARCH_TIMING
     __syncthreads();
-    // ---- phase B: fixed-point sweeps over the greedy ownership
-    for (int sweep = 0; sweep <= npts; sweep++) {
-        for (int c = t; c < ncur; c += blockDim.x) taken[c] = 0x7fffffff;
-        if (t == 0) s_changed = 0;
-        __syncthreads();
+    SPT_LAP(4);
+#endif
+    for (int i = t; i < npts; i += blockDim.x) {                     // (every thread reads back its own points' lists: no barrier)
+        const int ns = min(cand_n[i], (int)CAND_CAP);
+        if (ns > 0) {
+            const uint4* dl = reinterpret_cast<const uint4*>(A.pts_desc + ((size_t)b * pcap + i) * 32);
+            const uint4 da = dl[0], db = dl[1];
+            for (int k0 = 0; k0 < ns; k0 += 8) {
+                uint32_t id[8]; uint4 ea[8], eb[8];
+                entries4(i, k0, ns, id);
+                if (k0 + 4 < ns) entries4(i, k0 + 4, ns, id + 4);       // (never an index from a list position that was not written)
+                else { id[4] = id[0]; id[5] = id[0]; id[6] = id[0]; id[7] = id[0]; }
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const uint4* dc = reinterpret_cast<const uint4*>(A.cur_desc + ((size_t)b * cap + (id[u] & 0xffff)) * 32);
+                    ea[u] = dc[0]; eb[u] = dc[1];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    if (k0 + u >= ns) break;
+                    const int dist2 = __popc(da.x ^ ea[u].x) + __popc(da.y ^ ea[u].y) + __popc(da.z ^ ea[u].z) + __popc(da.w ^ ea[u].w) +
+                                      __popc(db.x ^ eb[u].x) + __popc(db.y ^ eb[u].y) + __popc(db.z ^ eb[u].z) + __popc(db.w ^ eb[u].w);
+                    set_entry(i, k0 + u, ((uint32_t)dist2 << 20) | (id[u] & 0xfffffu));
+                }
+            }
+        }
+    }
+    SPT_LAP(1);
+    // ---- phase B: fixed-point sweeps over the greedy ownership; `taken` double-buffered, choice[i] owned by thread i: two barriers a sweep
+    for (int c = t; c < ncur; c += blockDim.x) taken[c] = 0x7fffffff;
+    if (t < 2) s_changed[t] = 0;
+    __syncthreads();
+    int cur = 0;
+    for (int sweep = 0; sweep <= npts; sweep++, cur ^= 1) {
+#ifdef VIORB_SEARCH_TIMING
+        spt_sweeps++;
+#endif
+        int* tkc = cur ? taken2 : taken; int* tkn = cur ? taken : taken2;
         for (int i = t; i < npts; i += blockDim.x)
-            if (choice[i] >= 0 && (pf[i] & 4)) atomicMin(&taken[choice[i]], i);
+            if (choice[i] >= 0 && (pf[i] & 4)) atomicMin(&tkc[choice[i]], i);
         __syncthreads();
         bool changed = false;
         for (int i = t; i < npts; i += blockDim.x) {
             const int nc = cand_n[i];
             int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
-            auto consider = [&](int, uint32_t e) {
-                const int i2 = (int)(e & 0xffff), dist = (int)(e >> 16);
-                if (taken[i2] < i) return;
-                if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestLevel2 = bestLevel; bestLevel = coct[i2]; bestIdx = i2; }
-                else if (dist < bestDist2) { bestLevel2 = coct[i2]; bestDist2 = dist; }
+            auto rank = [&](uint32_t e, int ow) {
+                const int i2 = (int)(e & 0xffff), dist = (int)(e >> 20), lv = (int)((e >> 16) & 0xf);
+                if (ow < i) return;
+                if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestLevel2 = bestLevel; bestLevel = lv; bestIdx = i2; }
+                else if (dist < bestDist2) { bestLevel2 = lv; bestDist2 = dist; }
             };
             if (nc <= CAND_CAP) {
-                for (int k = 0; k < nc; k++) consider(k, k < slot_n ? slot[(size_t)i * slot_n + k] : cand[(size_t)i * CAND_CAP + k]);
-            } else enumerate(i, nullptr, consider);               // more candidates than the stored list holds: walk the grid again
+                for (int k0 = 0; k0 < nc; k0 += 4) {               // four entries, then their four owners, in flight together
+                    uint32_t e[4]; int ow[4];
+                    entries4(i, k0, nc, e);
+#pragma unroll
+                    for (int u = 0; u < 4; u++) ow[u] = tkc[e[u] & 0xffff];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) if (k0 + u < nc) rank(e[u], ow[u]);
+                }
+            } else enumerate(i, [&](int, uint32_t e) { rank(e, tkc[e & 0xffff]); });      // more candidates than the stored list holds: walk the grid again
             int nw = -1;
             if (bestDist <= TH_HIGH && !(bestLevel == bestLevel2 && (float)bestDist > A.nnratio * (float)bestDist2)) nw = bestIdx;
             changed = changed || (nw != choice[i]);
-            nchoice[i] = nw;
+            choice[i] = nw;
         }
-        if (__any(changed) && lane == 0) s_changed = 1;
+        for (int c = t; c < ncur; c += blockDim.x) tkn[c] = 0x7fffffff;
+        if (t == 0) s_changed[cur ^ 1] = 0;
+        if (__any(changed) && lane == 0) s_changed[cur] = 1;
         __syncthreads();
-        for (int i = t; i < npts; i += blockDim.x) choice[i] = nchoice[i];
-        __syncthreads();
-        if (!s_changed) break;
+        if (!s_changed[cur]) break;
     }
+    SPT_LAP(2);
     // ---- output: last assigner of every keypoint
     for (int c = t; c < ncur; c += blockDim.x) taken[c] = -1;
     __syncthreads();
@@ -544,6 +747,8 @@ __global__ __launch_bounds__(SEARCH_THREADS) void k_search_local_points(LocalSea
     int* out = A.match + (size_t)b * cap;
     for (int c = t; c < cap; c += blockDim.x) out[c] = c < ncur ? taken[c] : -1;
     if (t == 0) A.nmatches[b] = s_nm;
+    SPT_LAP(3);
+    SPT_PRINT("local points");
 }
 
 // ---------------------------------------------------------------------------------------------
