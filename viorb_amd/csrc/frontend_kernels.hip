@@ -1578,7 +1578,9 @@ struct viorb_frontend {
 #define POSE_MP_DEFAULT_WPP 2
 #endif
 template <int P, int WPP> static int launch_pose_mp(const PoseOptArgs& A, int batch, hipStream_t st) {
-    const size_t lds = sizeof(PoseMpShared<P, WPP>);
+    // VIORB_POSE_LDS_MIN (bytes, experiment switch): a larger LDS request than the solver needs limits the workgroups resident per CU
+    static const size_t lds_min = [] { const char* e = getenv("VIORB_POSE_LDS_MIN"); return e ? (size_t)atol(e) : (size_t)0; }();
+    const size_t lds = std::max(sizeof(PoseMpShared<P, WPP>), lds_min);
     if (lds > 64 * 1024) VIORB_HIP_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(k_pose_opt_vi_mp<P, WPP>), lds));
     hipLaunchKernelGGL((k_pose_opt_vi_mp<P, WPP>), dim3((batch + P - 1) / P), dim3(64 * P * WPP), lds, st, A, batch);
     return VIORB_OK;
