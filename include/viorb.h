@@ -185,7 +185,7 @@ typedef struct viorb_frontend_config {
 
 /* cap = keypoints per frame the handle's arrays are pitched for (viorb_extractor_max_keypoints of the extractor that feeds it). The
  * projection and local-point searches keep a frame's keypoints and their work arrays in LDS up to cap = viorb_frontend_search_capacity()
- * (~4600; the reference's settings files use 1000-2000 features): above 2400 they give up their LDS cache of the first candidates of every
+ * (~4900; the reference's settings files use 1000-2000 features): above ~2460 they give up their LDS cache of the first candidates of every
  * point and take all candidates from the global list, above the capacity they keep the work arrays in global memory as well — same
  * result, slower each time. cap <= 65535 (16-bit keypoint indices). The global-memory work arrays of the over-size forms (searches,
  * SearchByBoW above ~7100 keypoints, stereo association above ~4000 features) are ONE scratch per handle (per calling thread for the handle-less

@@ -1633,7 +1633,7 @@ int viorb_frontend_create(const viorb_frontend_config* cfg, int max_batch, int c
     h->hInv = static_cast<float>(GRID_ROWS) / static_cast<float>(cfg->max_y - cfg->min_y);
     int s = 64; while (s < cap) s <<= 1;
     h->sort_n = s;
-    {   // the projection search's LDS plan limits cap to ~4600 — checked where it is launched: the other calls of the handle (grid, IMU
+    {   // the projection search's LDS plan limits cap to ~4900 — checked where it is launched: the other calls of the handle (grid, IMU
         // prediction, pose solves: the host drop-in of PoseOptimization builds its handle for the number of edges) have no such limit
         const size_t lds = search_lds_bytes(cap, search_slot_n(cap));
         if (lds > 64 * 1024 && lds <= 160 * 1024) VIORB_HIP_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(k_search_projection<false>), lds));
