@@ -1132,6 +1132,7 @@ struct PoseOptArgs {
     const double *obs_cur, *obs_last; const int *n_cur, *n_last;
     double *out_ns, *out_last_ns, *marg_out, *info;
     uint8_t *outlier_cur, *outlier_last;
+    float* chi_store;            // [batch][2][cap] scratch of the VI solver: every mono edge's chi2 at the last evaluation (g2o's stored edge error)
     double acc_bias_rw2;
     const uint8_t* variant_arr;  // optional per-problem variant (overrides `variant`)
     const uint8_t* skip;         // optional: problems with skip[b] != 0 return at once like "fewer than 3 correspondences"
@@ -1566,6 +1567,7 @@ struct viorb_frontend {
     int max_batch = 0, cap = 0, device = 0, sort_n = 0;
     float wInv = 0, hInv = 0;
     uint32_t* d_cand = nullptr; int* d_cand_n = nullptr;
+    float* d_pose_chi = nullptr;                              // k_pose_opt_vi_mp's per-edge chi2 scratch [max_batch][2][cap]
     uint32_t* d_lcand = nullptr; int* d_lcand_n = nullptr; int lcand_pcap = 0;
     unsigned char* d_search_work = nullptr; size_t search_work_bytes = 0;      // work arrays of the searches when a frame's keypoints do not fit LDS
     double *d_cam = nullptr, *d_gw = nullptr; float* d_inv_sigma2 = nullptr; float* d_scale = nullptr;
@@ -1639,6 +1641,7 @@ int viorb_frontend_create(const viorb_frontend_config* cfg, int max_batch, int c
         if (lds > 64 * 1024 && lds <= 160 * 1024) VIORB_HIP_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(k_search_projection<false>), lds));
     }
     VIORB_HIP_TRY(hipMalloc(&h->d_cand, (size_t)max_batch * cap * CAND_CAP * sizeof(uint32_t)));
+    VIORB_HIP_TRY(hipMalloc(&h->d_pose_chi, (size_t)max_batch * 2 * cap * sizeof(float)));
     VIORB_HIP_TRY(hipMalloc(&h->d_cand_n, (size_t)max_batch * cap * sizeof(int)));
     VIORB_HIP_TRY(hipMalloc(&h->d_cam, 16 * sizeof(double)));
     VIORB_HIP_TRY(hipMalloc(&h->d_gw, 3 * sizeof(double)));
@@ -1660,6 +1663,7 @@ int viorb_frontend_destroy(viorb_frontend* h) {
     if (!h) return VIORB_OK;
     (void)hipSetDevice(h->device);
     if (h->d_cand) (void)hipFree(h->d_cand);
+    if (h->d_pose_chi) (void)hipFree(h->d_pose_chi);
     if (h->d_cand_n) (void)hipFree(h->d_cand_n);
     if (h->d_search_work) (void)hipFree(h->d_search_work);
     if (h->d_lcand) (void)hipFree(h->d_lcand);
@@ -2022,7 +2026,7 @@ int viorb_frontend_pose_opt_device(viorb_frontend* h, int variant, int compute_m
     A.cur_ns = cur_ns; A.last_ns = last_ns; A.prior_ns = prior_ns; A.marg_cov_inv = marg_cov_inv; A.preint = preint;
     A.gw = h->d_gw; A.cam = h->d_cam; A.obs_cur = obs_cur; A.obs_last = variant ? obs_last : nullptr; A.n_cur = n_cur; A.n_last = n_last;
     A.out_ns = out_ns; A.out_last_ns = out_last_ns; A.marg_out = marg_out; A.info = info;
-    A.outlier_cur = outlier_cur; A.outlier_last = variant ? outlier_last : nullptr; A.acc_bias_rw2 = h->cfg.acc_bias_rw2;
+    A.outlier_cur = outlier_cur; A.outlier_last = variant ? outlier_last : nullptr; A.acc_bias_rw2 = h->cfg.acc_bias_rw2; A.chi_store = h->d_pose_chi;
     A.variant_arr = nullptr; A.skip = nullptr;
     ProfScope ps("k_pose_opt_vi", (hipStream_t)stream);
     { const int rc = launch_pose_opt_vi(A, batch, (hipStream_t)stream); if (rc != VIORB_OK) return rc; }
@@ -2044,7 +2048,7 @@ int viorb_frontend_pose_opt_select_device(viorb_frontend* h, const uint8_t* vari
     A.cur_ns = cur_ns; A.last_ns = last_ns; A.prior_ns = prior_ns; A.marg_cov_inv = marg_cov_inv; A.preint = preint;
     A.gw = h->d_gw; A.cam = h->d_cam; A.obs_cur = obs_cur; A.obs_last = obs_last; A.n_cur = n_cur; A.n_last = n_last;
     A.out_ns = out_ns; A.out_last_ns = out_last_ns; A.marg_out = marg_out; A.info = info;
-    A.outlier_cur = outlier_cur; A.outlier_last = outlier_last; A.acc_bias_rw2 = h->cfg.acc_bias_rw2;
+    A.outlier_cur = outlier_cur; A.outlier_last = outlier_last; A.acc_bias_rw2 = h->cfg.acc_bias_rw2; A.chi_store = h->d_pose_chi;
     A.variant_arr = variant; A.skip = skip;
     ProfScope ps("k_pose_opt_vi", (hipStream_t)stream);
     { const int rc = launch_pose_opt_vi(A, batch, (hipStream_t)stream); if (rc != VIORB_OK) return rc; }
