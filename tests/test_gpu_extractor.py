@@ -296,3 +296,16 @@ def test_uniform_noise_images_have_no_candidate_cap(gpu, oracle, w, h, nf):
         wantk = np.stack([ok["x"], ok["y"], ok["response"]], 1).astype(np.int32).reshape(-1, 3)
         np.testing.assert_array_equal(ex.debug_level_points(l, kept=True), wantk, err_msg="quadtree level %d" % l)
     assert len(kps) == len(okps) and (kps == okps).all() and (desc == odesc).all()
+
+
+@pytest.mark.parametrize("tiers", ["0", "1:512,2:256", "3:2048,5:1280"])
+def test_quadtree_level_tiers_fall_through_to_the_full_capacity_launch(gpu, oracle, monkeypatch, tiers):
+    """The higher pyramid levels take their own first quadtree launches with smaller LDS plans (VIORB_OCT_TIERS, default "3:2048"); a level with
+    more candidates than its plan holds must fall through to the full-capacity launch with the same result. "1:512,2:256" puts every level of a
+    752x480 frame above its plan, "0" is the single first launch."""
+    monkeypatch.setenv("VIORB_OCT_TIERS", tiers)
+    img, ex, kps, desc, ox, okps, odesc = run_pair(oracle, 3, 752, 480, 1000)
+    assert len(kps) == len(okps) and len(kps) > 900
+    for f in ("x", "y", "angle", "response", "octave"):
+        np.testing.assert_array_equal(kps[f], okps[f], err_msg=f)
+    np.testing.assert_array_equal(desc, odesc)

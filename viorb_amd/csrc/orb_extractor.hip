@@ -116,7 +116,7 @@ struct LevelDev {
     float kp_size;             // (float)(int)(31 * scale)
     int xtab_off, ytab_off;    // resize tables (level >= 1): index of first entry
     int kp_off;                // offset of this level inside the per-image level-keypoint buffer
-    int pad;
+    int oct_tier_cap;          // candidates the level's own first quadtree launch holds (0: the common first launch), see launch_all
 };
 struct CellDesc {              // one FAST cell = sub-image [x0,x0+cw) x [y0,y0+ch) of its level
     int32_t level, x0, y0, cw, ch, shx, shy, pitch;   // pitch = bytes per row of the cell's LDS tile (multiple of 4: cw + alignment slack + one spare dword). 32-bit fields: the wave-uniform descriptor then arrives by scalar loads (16-bit fields took a vector-memory round trip)
@@ -1214,6 +1214,7 @@ __global__ __launch_bounds__(64) void k_octree(const LevelDev* __restrict__ lv, 
                                                uint32_t* __restrict__ lvl_kp, int kp_pitch, int* __restrict__ lvl_cnt,
                                                int* __restrict__ lvl_ncand, int nlevels, int* __restrict__ status,
                                                int ncap, int nodecap, int sortcap, int n_above, int n_upto,
+                                               int level0, int use_tier_cap,
                                                uint32_t* __restrict__ big_scratch, int* __restrict__ big_next, int big_slots, int* __restrict__ lvl_tot,
                                                uint8_t* __restrict__ node_scratch = nullptr, size_t node_bytes = 0) {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_oct[];
@@ -1233,9 +1234,13 @@ __global__ __launch_bounds__(64) void k_octree(const LevelDev* __restrict__ lv, 
     // grid = (image, level): with the level in x and 8 levels, the round-robin deal of workgroups to the 8 XCDs would send every
     // level-0 quadtree (the longest) to XCD 0 and every level-7 one to XCD 7; image-major order spreads each level over all XCDs
     // and starts the long ones first
-    const int lane = threadIdx.x, level = blockIdx.y, b = blockIdx.x;
+    // A launch may cover the levels from level0 on only (gridDim.y of them): the higher levels have their own first launches with smaller LDS
+    // plans (fewer candidates, smaller quota: more workgroups per CU), and the full-capacity launch takes what exceeded a level's plan there
+    // (use_tier_cap: count above the level's oct_tier_cap instead of n_above)
+    const int lane = threadIdx.x, level = blockIdx.y + level0, b = blockIdx.x;
     const LevelDev L = lv[level];
     const int N = L.quota;
+    if (use_tier_cap && L.oct_tier_cap > 0) n_above = L.oct_tier_cap;
     // ---- 0. this launch only takes the (image, level) pairs with n_above < candidates <= n_upto: the common case runs
     //         with a smaller LDS footprint (3 workgroups per CU), a second launch with the full capacity takes the rest
     const int* cc = cell_cnt + (size_t)b * ncells_total + L.cell_base;
@@ -1890,6 +1895,7 @@ struct viorb_extractor {
     bool fast_v3 = false;            // every cell fits k_fast_cells3's compile-time LDS geometry
     int fast3_tile_bytes = 0, fast3_score_bytes = 0;
     int oct_ncap = 0, oct_nodecap = 0, oct_sortcap = 0;
+    std::vector<std::pair<int, int>> oct_tiers;            // (first level, candidates) of the higher levels' own first quadtree launches
     int oct_big_cap = 0, oct_big_slots = 0; uint32_t* d_oct_big = nullptr; int* d_oct_big_next = nullptr; int* d_lvl_tot = nullptr;   // over-size levels (k_octree<true>)
     unsigned char* d_stereo_work = nullptr; size_t stereo_work_bytes = 0;                // k_stereo_match<true>
     bool oct_huge = false; uint8_t* d_oct_nodes = nullptr; size_t oct_node_bytes = 0;     // a per-level quota whose node list does not fit LDS: nodes + sort keys in global scratch too
@@ -2163,6 +2169,25 @@ static int configure(viorb_extractor* h, int w, int hgt) {
         if (lds_big > 160 * 1024) h->oct_huge = true;
         else if (lds_big > 64 * 1024) VIORB_HIP_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(k_octree<true>), lds_big));
     }
+    {   // the higher levels' own first quadtree launches (see launch_all): "level:candidates,level:candidates", levels ascending, candidates
+        // descending and below OCT_NCAP_SMALL; VIORB_OCT_TIERS overrides ("0" = none)
+        const char* e = getenv("VIORB_OCT_TIERS");
+        std::string spec = e ? e : "3:2048";
+        h->oct_tiers.clear();
+        for (int l = 0; l < nl; l++) h->lv[l].oct_tier_cap = 0;
+        int prev_l = 0, prev_c = std::min(h->oct_ncap, (int)OCT_NCAP_SMALL);
+        size_t pos = 0;
+        while (!h->oct_huge && pos < spec.size()) {
+            int l = 0, c = 0, used = 0;
+            if (sscanf(spec.c_str() + pos, "%d:%d%n", &l, &c, &used) != 2 || l <= prev_l || l >= nl || c < 64 || c >= prev_c) break;
+            h->oct_tiers.push_back(std::make_pair(l, c)); prev_l = l; prev_c = c;
+            pos += (size_t)used; if (pos < spec.size() && spec[pos] == ',') pos++;
+        }
+        for (size_t ti = 0; ti < h->oct_tiers.size(); ti++) {
+            const int l1 = ti + 1 < h->oct_tiers.size() ? h->oct_tiers[ti + 1].first : nl;
+            for (int l = h->oct_tiers[ti].first; l < l1; l++) h->lv[l].oct_tier_cap = h->oct_tiers[ti].second;
+        }
+    }
     const size_t B = (size_t)h->max_batch;
     VIORB_HIP_TRY(hipMalloc(&h->d_planes, B * h->frame_bytes));
     VIORB_HIP_TRY(hipMalloc(&h->d_blur, B * h->frame_bytes));
@@ -2361,17 +2386,33 @@ static int launch_all(viorb_extractor* h, const uint8_t* d_images, int batch, in
         // launch and the pair took twice as long (DESIGN.md "Round 3 measurements")
         const size_t fixed = (size_t)h->oct_nodecap * sizeof(OctNode) + (size_t)h->oct_sortcap * 4;
         const int small = std::min(h->oct_ncap, (int)OCT_NCAP_SMALL);
+        // Beside the tracking stream's kernels the launch is slot-bound: 3 workgroups of 51 KB per CU (one beside two pose-solver workgroups),
+        // every slot sized for level 0 (4096 candidates, 5 x quota(0) + 64 nodes) although candidates and quota fall with the level (lens
+        // frames: 2404 2040 1710 1417 1200 972 757 560 candidates on levels 0..7). The higher levels therefore get their own first launches
+        // (h->oct_tiers: first level, candidates) with the LDS plan of THEIR largest quota; what exceeds a level's plan goes to the full-capacity
+        // launch like an over-size level 0 (LevelDev::oct_tier_cap). Alone the quadtree is not faster for it (latency of the longest tree),
+        // in the step it is: 186.1 -> 189.4 k frames/s with {3: 2048}.
+        const int ntier = h->oct_huge ? 0 : (int)h->oct_tiers.size();
         if (!h->oct_huge) {
             ProfScope ps("k_octree", st);
-            hipLaunchKernelGGL(k_octree<false>, dim3(batch, nl), dim3(64), (size_t)small * 8 + fixed, st, h->d_lv, h->d_slots, h->slot_cap, h->d_cell_cnt,
+            const int l_end0 = ntier ? h->oct_tiers[0].first : nl;
+            hipLaunchKernelGGL(k_octree<false>, dim3(batch, l_end0), dim3(64), (size_t)small * 8 + fixed, st, h->d_lv, h->d_slots, h->slot_cap, h->d_cell_cnt,
                                ncells, h->d_lvl_kp, h->kp_pitch, h->d_lvl_cnt, h->d_lvl_ncand, nl, h->d_status, small, h->oct_nodecap,
-                               h->oct_sortcap, -1, small, nullptr, nullptr, 0, h->d_lvl_tot);
+                               h->oct_sortcap, -1, small, 0, 0, nullptr, nullptr, 0, h->d_lvl_tot);
+            for (int ti = 0; ti < ntier; ti++) {
+                const int l0 = h->oct_tiers[ti].first, l1 = ti + 1 < ntier ? h->oct_tiers[ti + 1].first : nl, nc = h->oct_tiers[ti].second;
+                int mq = 1; for (int l = l0; l < l1; l++) mq = std::max(mq, h->quota[l]);
+                const int ndc = 5 * mq + 64;
+                hipLaunchKernelGGL(k_octree<false>, dim3(batch, l1 - l0), dim3(64), (size_t)nc * 8 + (size_t)ndc * sizeof(OctNode) + (size_t)h->oct_sortcap * 4,
+                                   st, h->d_lv, h->d_slots, h->slot_cap, h->d_cell_cnt, ncells, h->d_lvl_kp, h->kp_pitch, h->d_lvl_cnt, h->d_lvl_ncand, nl, h->d_status,
+                                   nc, ndc, h->oct_sortcap, -1, nc, l0, 0, nullptr, nullptr, 0, h->d_lvl_tot);
+            }
         }
-        if (!h->oct_huge && small < h->oct_ncap) {
+        if (!h->oct_huge && (small < h->oct_ncap || ntier)) {
             ProfScope ps("k_octree_large", st);
             hipLaunchKernelGGL(k_octree<false>, dim3(batch, nl), dim3(64), (size_t)h->oct_ncap * 8 + fixed, st, h->d_lv, h->d_slots, h->slot_cap,
                                h->d_cell_cnt, ncells, h->d_lvl_kp, h->kp_pitch, h->d_lvl_cnt, h->d_lvl_ncand, nl, h->d_status, h->oct_ncap,
-                               h->oct_nodecap, h->oct_sortcap, small, h->oct_ncap, nullptr, nullptr, 0, h->d_lvl_tot);
+                               h->oct_nodecap, h->oct_sortcap, small, h->oct_ncap, 0, ntier ? 1 : 0, nullptr, nullptr, 0, h->d_lvl_tot);
         }
         {   // levels with more candidates than the LDS form holds (none on camera images; their workgroups read one count and return)
             const size_t lds_big = h->oct_huge ? 0 : (size_t)h->oct_sortcap * 8 + (size_t)h->oct_nodecap * sizeof(OctNodeBig);
@@ -2380,7 +2421,7 @@ static int launch_all(viorb_extractor* h, const uint8_t* d_images, int batch, in
             // huge quota: this launch takes EVERY level (n_above = -1: it counts the candidates itself), one scratch slot per (image, level)
             hipLaunchKernelGGL(k_octree<true>, dim3(batch, nl), dim3(64), lds_big, st, h->d_lv, h->d_slots, h->slot_cap, h->d_cell_cnt, ncells, h->d_lvl_kp,
                                h->kp_pitch, h->d_lvl_cnt, h->d_lvl_ncand, nl, h->d_status, h->oct_big_cap, h->oct_nodecap, h->oct_sortcap,
-                               h->oct_huge ? -1 : std::max(h->oct_ncap, (int)small), 0x7fffffff, h->d_oct_big, h->d_oct_big_next, h->oct_big_slots, h->d_lvl_tot,
+                               h->oct_huge ? -1 : std::max(h->oct_ncap, (int)small), 0x7fffffff, 0, 0, h->d_oct_big, h->d_oct_big_next, h->oct_big_slots, h->d_lvl_tot,
                                h->oct_huge ? h->d_oct_nodes : (uint8_t*)nullptr, h->oct_node_bytes);
         }
     }
