@@ -298,12 +298,15 @@ def test_uniform_noise_images_have_no_candidate_cap(gpu, oracle, w, h, nf):
     assert len(kps) == len(okps) and (kps == okps).all() and (desc == odesc).all()
 
 
-@pytest.mark.parametrize("tiers", ["0", "1:512,2:256", "3:2048,5:1280"])
-def test_quadtree_level_tiers_fall_through_to_the_full_capacity_launch(gpu, oracle, monkeypatch, tiers):
+@pytest.mark.parametrize("tiers,node_x10", [("0", 50), ("1:512,2:256", 25), ("3:2048,5:1280", 25), ("0:3072,3:2048", 10), ("3:2048", 12)])
+def test_quadtree_level_tiers_fall_through_to_the_full_capacity_launch(gpu, oracle, monkeypatch, tiers, node_x10):
     """The higher pyramid levels take their own first quadtree launches with smaller LDS plans (VIORB_OCT_TIERS, default "3:2048"); a level with
     more candidates than its plan holds must fall through to the full-capacity launch with the same result. "1:512,2:256" puts every level of a
-    752x480 frame above its plan, "0" is the single first launch."""
+    752x480 frame above its plan, "0" is the single first launch. The first launches' node lists are sized VIORB_OCT_NODE_X10 / 10 x quota + 64
+    (default 2.5 x; 5 x can never run out): a level that runs out of node slots is left to the full-capacity launch before anything of it
+    is written — 1.0 x and 1.2 x make most levels do that."""
     monkeypatch.setenv("VIORB_OCT_TIERS", tiers)
+    monkeypatch.setenv("VIORB_OCT_NODE_X10", str(node_x10))
     img, ex, kps, desc, ox, okps, odesc = run_pair(oracle, 3, 752, 480, 1000)
     assert len(kps) == len(okps) and len(kps) > 900
     for f in ("x", "y", "angle", "response", "octave"):

@@ -1214,7 +1214,7 @@ __global__ __launch_bounds__(64) void k_octree(const LevelDev* __restrict__ lv, 
                                                uint32_t* __restrict__ lvl_kp, int kp_pitch, int* __restrict__ lvl_cnt,
                                                int* __restrict__ lvl_ncand, int nlevels, int* __restrict__ status,
                                                int ncap, int nodecap, int sortcap, int n_above, int n_upto,
-                                               int level0, int use_tier_cap,
+                                               int level0, int use_tier_cap, int defer_nodes,
                                                uint32_t* __restrict__ big_scratch, int* __restrict__ big_next, int big_slots, int* __restrict__ lvl_tot,
                                                uint8_t* __restrict__ node_scratch = nullptr, size_t node_bytes = 0) {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_oct[];
@@ -1258,7 +1258,11 @@ __global__ __launch_bounds__(64) void k_octree(const LevelDev* __restrict__ lv, 
             for (int d = 32; d > 0; d >>= 1) tot += __shfl_xor(tot, d);
             if (lane == 0) lvl_tot[b * nlevels + level] = tot;
         } else tot = lvl_tot[b * nlevels + level];
-        if (tot <= n_above || tot > n_upto) return;
+        // bit 30: a first launch ran out of NODE slots on this level (its node list is sized for the common case, defer_nodes) and left it to the
+        // full-capacity launch, whatever its candidate count
+        const bool deferred = (tot & 0x40000000) != 0;
+        tot &= 0x3fffffff;
+        if (!(deferred && !BIG && !defer_nodes) && (tot <= n_above || tot > n_upto)) return;
         if (BIG) {
             // one scratch slot of 3 * ncap words per over-size (image, level); when more levels than slots overflow in one call the rest
             // report VIORB_ERR_CAPACITY (big_slots = min(batch * levels, 64): every level of a small batch of pure-noise images fits)
@@ -1452,6 +1456,10 @@ __global__ __launch_bounds__(64) void k_octree(const LevelDev* __restrict__ lv, 
                 if (live >= N || live == prev2) finish = true;
             }
         }
+    }
+    if (defer_nodes && overflow) {                                      // nothing of this level has been written yet: the full-capacity launch does it all
+        if (lane == 0) lvl_tot[b * nlevels + level] |= 0x40000000;
+        return;
     }
     // ---- 4. best response per node (first maximum), output in list order = array descending
     for (int base = 0; base < nn; base += 64) {
@@ -1896,6 +1904,7 @@ struct viorb_extractor {
     int fast3_tile_bytes = 0, fast3_score_bytes = 0;
     int oct_ncap = 0, oct_nodecap = 0, oct_sortcap = 0;
     std::vector<std::pair<int, int>> oct_tiers;            // (first level, candidates) of the higher levels' own first quadtree launches
+    int oct_first_cap = 0, oct_node_x10 = 50;              // candidates of the common first launch; node slots of the first launches in tenths of the quota (50 = never short)
     int oct_big_cap = 0, oct_big_slots = 0; uint32_t* d_oct_big = nullptr; int* d_oct_big_next = nullptr; int* d_lvl_tot = nullptr;   // over-size levels (k_octree<true>)
     unsigned char* d_stereo_work = nullptr; size_t stereo_work_bytes = 0;                // k_stereo_match<true>
     bool oct_huge = false; uint8_t* d_oct_nodes = nullptr; size_t oct_node_bytes = 0;     // a per-level quota whose node list does not fit LDS: nodes + sort keys in global scratch too
@@ -2176,11 +2185,15 @@ static int configure(viorb_extractor* h, int w, int hgt) {
         h->oct_tiers.clear();
         for (int l = 0; l < nl; l++) h->lv[l].oct_tier_cap = 0;
         int prev_l = 0, prev_c = std::min(h->oct_ncap, (int)OCT_NCAP_SMALL);
+        h->oct_first_cap = prev_c;                                  // candidates of the common first launch ("0:candidates" lowers it)
+        { const char* e2 = getenv("VIORB_OCT_NODE_X10"); h->oct_node_x10 = e2 ? atoi(e2) : 25; if (h->oct_node_x10 < 10 || h->oct_node_x10 > 50) h->oct_node_x10 = 50; }
         size_t pos = 0;
         while (!h->oct_huge && pos < spec.size()) {
             int l = 0, c = 0, used = 0;
-            if (sscanf(spec.c_str() + pos, "%d:%d%n", &l, &c, &used) != 2 || l <= prev_l || l >= nl || c < 64 || c >= prev_c) break;
-            h->oct_tiers.push_back(std::make_pair(l, c)); prev_l = l; prev_c = c;
+            if (sscanf(spec.c_str() + pos, "%d:%d%n", &l, &c, &used) != 2) break;
+            if (l == 0 && h->oct_tiers.empty() && c >= 64 && c <= prev_c) { h->oct_first_cap = c; prev_c = c + 1; }
+            else if (l <= prev_l || l >= nl || c < 64 || c >= prev_c) break;
+            else { h->oct_tiers.push_back(std::make_pair(l, c)); prev_l = l; prev_c = c; }
             pos += (size_t)used; if (pos < spec.size() && spec[pos] == ',') pos++;
         }
         for (size_t ti = 0; ti < h->oct_tiers.size(); ti++) {
@@ -2385,7 +2398,7 @@ static int launch_all(viorb_extractor* h, const uint8_t* d_images, int batch, in
         // of a feature-rich frame: with 2048 (4 per CU) the level-0 trees of EuRoC-lens frames (~2400 candidates) all fell to the second
         // launch and the pair took twice as long (DESIGN.md "Round 3 measurements")
         const size_t fixed = (size_t)h->oct_nodecap * sizeof(OctNode) + (size_t)h->oct_sortcap * 4;
-        const int small = std::min(h->oct_ncap, (int)OCT_NCAP_SMALL);
+        const int small = h->oct_first_cap > 0 ? h->oct_first_cap : std::min(h->oct_ncap, (int)OCT_NCAP_SMALL);
         // Beside the tracking stream's kernels the launch is slot-bound: 3 workgroups of 51 KB per CU (one beside two pose-solver workgroups),
         // every slot sized for level 0 (4096 candidates, 5 x quota(0) + 64 nodes) although candidates and quota fall with the level (lens
         // frames: 2404 2040 1710 1417 1200 972 757 560 candidates on levels 0..7). The higher levels therefore get their own first launches
@@ -2393,26 +2406,35 @@ static int launch_all(viorb_extractor* h, const uint8_t* d_images, int batch, in
         // launch like an over-size level 0 (LevelDev::oct_tier_cap). Alone the quadtree is not faster for it (latency of the longest tree),
         // in the step it is: 186.1 -> 189.4 k frames/s with {3: 2048}.
         const int ntier = h->oct_huge ? 0 : (int)h->oct_tiers.size();
+        // Node slots of the first launches: 5 x quota + 64 can never run out (every node of a round expanding into four slots); a round in
+        // bulk mode needs <= 4/3 quota and the one-at-a-time tail typically ends below 2.5 x quota, so the first launches are sized
+        // oct_node_x10 / 10 x quota + 64 and a level that runs out of slots is left — before anything of it is written — to the
+        // full-capacity launch (bit 30 of its candidate count)
+        const bool defer = h->oct_node_x10 < 50;
+        auto first_nodes = [&](int mq) { return std::min(5 * mq + 64, (h->oct_node_x10 * mq) / 10 + 64); };
         if (!h->oct_huge) {
             ProfScope ps("k_octree", st);
             const int l_end0 = ntier ? h->oct_tiers[0].first : nl;
-            hipLaunchKernelGGL(k_octree<false>, dim3(batch, l_end0), dim3(64), (size_t)small * 8 + fixed, st, h->d_lv, h->d_slots, h->slot_cap, h->d_cell_cnt,
-                               ncells, h->d_lvl_kp, h->kp_pitch, h->d_lvl_cnt, h->d_lvl_ncand, nl, h->d_status, small, h->oct_nodecap,
-                               h->oct_sortcap, -1, small, 0, 0, nullptr, nullptr, 0, h->d_lvl_tot);
+            int mq0 = 1; for (int l = 0; l < l_end0; l++) mq0 = std::max(mq0, h->quota[l]);
+            const int ndc0 = defer ? first_nodes(mq0) : h->oct_nodecap;
+            hipLaunchKernelGGL(k_octree<false>, dim3(batch, l_end0), dim3(64), (size_t)small * 8 + (size_t)ndc0 * sizeof(OctNode) + (size_t)h->oct_sortcap * 4, st,
+                               h->d_lv, h->d_slots, h->slot_cap, h->d_cell_cnt,
+                               ncells, h->d_lvl_kp, h->kp_pitch, h->d_lvl_cnt, h->d_lvl_ncand, nl, h->d_status, small, ndc0,
+                               h->oct_sortcap, -1, small, 0, 0, defer ? 1 : 0, nullptr, nullptr, 0, h->d_lvl_tot);
             for (int ti = 0; ti < ntier; ti++) {
                 const int l0 = h->oct_tiers[ti].first, l1 = ti + 1 < ntier ? h->oct_tiers[ti + 1].first : nl, nc = h->oct_tiers[ti].second;
                 int mq = 1; for (int l = l0; l < l1; l++) mq = std::max(mq, h->quota[l]);
-                const int ndc = 5 * mq + 64;
+                const int ndc = defer ? first_nodes(mq) : 5 * mq + 64;
                 hipLaunchKernelGGL(k_octree<false>, dim3(batch, l1 - l0), dim3(64), (size_t)nc * 8 + (size_t)ndc * sizeof(OctNode) + (size_t)h->oct_sortcap * 4,
                                    st, h->d_lv, h->d_slots, h->slot_cap, h->d_cell_cnt, ncells, h->d_lvl_kp, h->kp_pitch, h->d_lvl_cnt, h->d_lvl_ncand, nl, h->d_status,
-                                   nc, ndc, h->oct_sortcap, -1, nc, l0, 0, nullptr, nullptr, 0, h->d_lvl_tot);
+                                   nc, ndc, h->oct_sortcap, -1, nc, l0, 0, defer ? 1 : 0, nullptr, nullptr, 0, h->d_lvl_tot);
             }
         }
-        if (!h->oct_huge && (small < h->oct_ncap || ntier)) {
+        if (!h->oct_huge && (small < h->oct_ncap || ntier || defer)) {
             ProfScope ps("k_octree_large", st);
             hipLaunchKernelGGL(k_octree<false>, dim3(batch, nl), dim3(64), (size_t)h->oct_ncap * 8 + fixed, st, h->d_lv, h->d_slots, h->slot_cap,
                                h->d_cell_cnt, ncells, h->d_lvl_kp, h->kp_pitch, h->d_lvl_cnt, h->d_lvl_ncand, nl, h->d_status, h->oct_ncap,
-                               h->oct_nodecap, h->oct_sortcap, small, h->oct_ncap, 0, ntier ? 1 : 0, nullptr, nullptr, 0, h->d_lvl_tot);
+                               h->oct_nodecap, h->oct_sortcap, small, h->oct_ncap, 0, ntier ? 1 : 0, 0, nullptr, nullptr, 0, h->d_lvl_tot);
         }
         {   // levels with more candidates than the LDS form holds (none on camera images; their workgroups read one count and return)
             const size_t lds_big = h->oct_huge ? 0 : (size_t)h->oct_sortcap * 8 + (size_t)h->oct_nodecap * sizeof(OctNodeBig);
@@ -2421,7 +2443,7 @@ static int launch_all(viorb_extractor* h, const uint8_t* d_images, int batch, in
             // huge quota: this launch takes EVERY level (n_above = -1: it counts the candidates itself), one scratch slot per (image, level)
             hipLaunchKernelGGL(k_octree<true>, dim3(batch, nl), dim3(64), lds_big, st, h->d_lv, h->d_slots, h->slot_cap, h->d_cell_cnt, ncells, h->d_lvl_kp,
                                h->kp_pitch, h->d_lvl_cnt, h->d_lvl_ncand, nl, h->d_status, h->oct_big_cap, h->oct_nodecap, h->oct_sortcap,
-                               h->oct_huge ? -1 : std::max(h->oct_ncap, (int)small), 0x7fffffff, 0, 0, h->d_oct_big, h->d_oct_big_next, h->oct_big_slots, h->d_lvl_tot,
+                               h->oct_huge ? -1 : std::max(h->oct_ncap, (int)small), 0x7fffffff, 0, 0, 0, h->d_oct_big, h->d_oct_big_next, h->oct_big_slots, h->d_lvl_tot,
                                h->oct_huge ? h->d_oct_nodes : (uint8_t*)nullptr, h->oct_node_bytes);
         }
     }
