@@ -284,7 +284,8 @@ int viorb_frontend_build_observations_device(viorb_frontend* h, const viorb_keyp
  * marg_cov_inv[b][144], reprojection edges of both frames. Outputs: out_ns (optimised current NavState),
  * out_last_ns (may be NULL), outlier_cur[b][cap] / outlier_last (mvbOutlier per observation),
  * info[b][4] = {return value nInitialCorrespondences - nBad, final robust chi2, LM iterations, 0},
- * marg_out[b][144] = mMargCovInv when compute_marg != 0. */
+ * marg_out[b][144] = mMargCovInv when compute_marg != 0. The solver keeps every edge's chi2 of its last evaluation (g2o's stored edge
+ * errors) in a scratch of the handle: the solves of ONE handle go to one stream at a time (like its searches' work arrays). */
 int viorb_frontend_pose_opt_device(viorb_frontend* h, int variant, int compute_marg, const double* cur_ns,
                                    const double* last_ns, const double* prior_ns, const double* marg_cov_inv,
                                    const double* preint, const double* obs_cur, const int32_t* n_cur,
